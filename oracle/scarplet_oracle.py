@@ -1,0 +1,362 @@
+"""CPU oracle for the scarplet template-matching hot path.
+
+TEST INFRASTRUCTURE ONLY.  This module is the float64 numpy restatement of the
+reference algorithm that the HIP path is checked against.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it.  Nothing under ``scarplet_amd/`` imports it and the product path
+has no CPU fallback.
+
+Parity status: PINNED.  ``oracle/gen_golden.py`` (run in the build container
+only) imports the unmodified reference from ``/root/reference`` and checks this
+restatement against it and against the reference's own golden files
+(``scarplet/tests/results/*.npy``); the resulting fixtures live in
+``tests/golden/`` and ``tests/test_oracle.py`` re-checks the oracle against
+them on every run.
+
+Every function cites the reference lines it restates (paths relative to
+``/root/reference/scarplet``).  Arithmetic is float64 / complex128 like the
+reference; the FFT backend is ``scipy.fft`` (pocketfft) because pyfftw/FFTW
+is not in this image - the reference's goldens are reproduced to ~1e-14
+either way.
+"""
+
+import numpy as np
+import scipy.fft as _fft
+from scipy.special import erfinv
+
+EPS = float(np.spacing(1))          # core.py:340
+
+SCARP = "scarp"
+RICKER = "ricker"
+RIGHT_UPPER = "right_upper_break"
+LEFT_UPPER = "left_upper_break"
+
+
+# ----------------------------------------------------------------------------
+# curvature                                                   dem.py:68-107
+# ----------------------------------------------------------------------------
+def curvature_components(z, dx, dy):
+    """The three alpha-independent finite-difference planes of dem.py:88-101.
+
+    A = d2z/dx2 (zero in the first/last column), B = d2z/dxdy (zero in the
+    first row and first column; note the reference divides by dx twice,
+    dem.py:88-89), C = d2z/dy2 (zero in the first/last row, divided by dy**2).
+    """
+    z = np.asarray(z, dtype=float)
+    ny, nx = z.shape
+    B = np.zeros((ny, nx))
+    B[1:, 1:] = np.diff(np.diff(z, 1, 1) / dx, 1, 0) / dx
+    A = np.zeros((ny, nx))
+    A[:, 1:-1] = np.diff(z, 2, 1) / dx ** 2
+    C = np.zeros((ny, nx))
+    C[1:-1, :] = np.diff(z, 2, 0) / dy ** 2
+    return A, B, C
+
+
+def directional_curvature(z, dx, dy, alpha):
+    """dem.py:68-107 ``_calculate_directional_laplacian`` (NaNs zeroed before
+    differencing, restored afterwards: dem.py:85-86,105)."""
+    z = np.array(z, dtype=float)
+    nan_idx = np.isnan(z)
+    z[nan_idx] = 0
+    A, B, C = curvature_components(z, dx, dy)
+    out = A * np.cos(alpha) ** 2 - 2 * B * np.sin(alpha) * np.cos(alpha) \
+        + C * np.sin(alpha) ** 2
+    out[nan_idx] = np.nan
+    return out
+
+
+# ----------------------------------------------------------------------------
+# template geometry                              WindowedTemplate.py:49-84
+# ----------------------------------------------------------------------------
+def grid_axes(nx, ny, de):
+    """Centred coordinate axes, WindowedTemplate.py:50-53 / 168-171."""
+    x = de * np.linspace(1, nx, num=nx)
+    y = de * np.linspace(1, ny, num=ny)
+    return x - np.mean(x), y - np.mean(y)
+
+
+def rotated_coords(nx, ny, de, alpha):
+    """WindowedTemplate.py:49-59.  ``alpha`` is the template's own alpha,
+    i.e. MINUS the orientation passed to the constructor (l.151, 489)."""
+    x, y = grid_axes(nx, ny, de)
+    x, y = np.meshgrid(x, y)
+    xr = x * np.cos(alpha) + y * np.sin(alpha)
+    yr = -x * np.sin(alpha) + y * np.cos(alpha)
+    return xr, yr
+
+
+def window_mask(nx, ny, de, alpha, c, d):
+    """WindowedTemplate.py:61-64."""
+    xr, yr = rotated_coords(nx, ny, de, alpha)
+    return (abs(xr) < c) & (abs(yr) < d)
+
+
+def scarp_c(kt):
+    """WindowedTemplate.py:156-157."""
+    return abs(2 * np.sqrt(kt) * erfinv(0.9))
+
+
+def window_limits(nx, ny, de, alpha, c, d):
+    """WindowedTemplate.py:66-84 (base class; Ricker overrides with all-False,
+    l.495-496)."""
+    x4 = d * np.cos(alpha - np.pi / 2)
+    y4 = d * np.sin(alpha - np.pi / 2)
+    x1 = d * np.cos(alpha)
+    y1 = d * np.sin(alpha)
+    an_y = abs((x4 - x1) + 2 * c * np.cos(alpha - np.pi / 2))
+    an_x = abs((y1 - y4) + 2 * c * np.sin(alpha - np.pi / 2))
+    x, y = grid_axes(nx, ny, de)
+    X, Y = np.meshgrid(x, y)
+    return ((X < (min(x) + an_x)) | (X > (max(x) - an_x))
+            | (Y < (min(y) + an_y)) | (Y > (max(y) - an_y)))
+
+
+def scarp_template(d, kt, angle, nx, ny, de):
+    """Scarp.template(), WindowedTemplate.py:159-183 (alpha = -angle, l.151)."""
+    alpha = -angle
+    xr, _ = rotated_coords(nx, ny, de, alpha)
+    W = (-xr / (2. * kt ** (3 / 2.) * np.sqrt(np.pi))) \
+        * np.exp(-xr ** 2. / (4. * kt))
+    return W * window_mask(nx, ny, de, alpha, scarp_c(kt), d)
+
+
+def ricker_template(d, f, angle, nx, ny, de):
+    """Ricker.template(), WindowedTemplate.py:498-520 (c = nx, l.492)."""
+    alpha = -angle
+    xr, _ = rotated_coords(nx, ny, de, alpha)
+    u2 = (np.pi * f * xr) ** 2.
+    W = (1. - 2. * u2) * np.exp(-u2)
+    return W * window_mask(nx, ny, de, alpha, nx, d)
+
+
+def template_arrays(kind, scale, age, angle, nx, ny, de):
+    """Returns (W, window_limit_mask, err_mask_or_None) for a built-in
+    template class, i.e. what match_template pulls out of the plugin object
+    (core.py:345-346, 369-375)."""
+    alpha = -angle
+    if kind == SCARP:
+        W = scarp_template(scale, age, angle, nx, ny, de)
+        lim = window_limits(nx, ny, de, alpha, scarp_c(age), scale)
+        return W, lim, None
+    if kind == RICKER:
+        W = ricker_template(scale, age, angle, nx, ny, de)
+        return W, np.zeros((ny, nx), dtype=bool), None
+    if kind in (RIGHT_UPPER, LEFT_UPPER):
+        # WindowedTemplate.py:246-267 / 294-304
+        W = scarp_template(scale, age, angle, nx, ny, de)
+        xr, _ = rotated_coords(nx, ny, de, alpha)
+        if kind == RIGHT_UPPER:
+            W, err = -W, xr <= 0
+        else:
+            err = xr >= 0
+        lim = window_limits(nx, ny, de, alpha, scarp_c(age), scale)
+        return W, lim, err
+    raise ValueError(kind)
+
+
+# ----------------------------------------------------------------------------
+# per-template kernel                                      core.py:297-377
+# ----------------------------------------------------------------------------
+def match_arrays(curv, W, lim, err=None, workers=1, details=False):
+    """core.py:348-375 given the curvature and the plugin's arrays."""
+    M = (W != 0)
+    fm2 = _fft.fft2(M.astype(float), workers=workers)
+    n = np.sum(M) + EPS
+    fc = _fft.fft2(curv, workers=workers)
+    ft = _fft.fft2(W, workers=workers)
+    fc2 = _fft.fft2(curv ** 2, workers=workers)
+    template_sum = np.sum(W ** 2)
+    xcorr = np.real(_fft.fftshift(_fft.ifft2(ft * fc, workers=workers)))
+    amp = xcorr / template_sum
+    T1 = template_sum * (amp ** 2)
+    T3 = _fft.fftshift(_fft.ifft2(fc2 * fm2, workers=workers))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        error = (1 / n) * np.real(T1 - 2 * amp * xcorr + T3) + EPS
+        snr = np.abs(T1 / error)
+    if err is not None:
+        snr[err] = 0
+    amp[lim] = 0
+    snr[lim] = 0
+    if details:
+        return amp, snr, dict(n=float(n), template_sum=float(template_sum),
+                              xcorr=xcorr, T3=np.real(T3))
+    return amp, snr
+
+
+def match_template(z, dx, dy, kind, scale, age, angle, workers=1,
+                   details=False):
+    """core.py:297-377 for a built-in template ``kind``.
+
+    Returns (amp, age, angle, snr) like the reference (core.py:377)."""
+    curv = directional_curvature(z, dx, dy, angle)
+    ny, nx = curv.shape
+    W, lim, err = template_arrays(kind, scale, age, angle, nx, ny, dx)
+    out = match_arrays(curv, W, lim, err, workers=workers, details=details)
+    if details:
+        return out[0], age, angle, out[1], out[2]
+    return out[0], age, angle, out[1]
+
+
+# ----------------------------------------------------------------------------
+# search grids and the running-best fold          core.py:139-243, 266-294
+# ----------------------------------------------------------------------------
+def angle_grid(ang_min=-np.pi / 2, ang_max=np.pi / 2):
+    """core.py:173-175."""
+    num = int((180 / np.pi) * (ang_max - ang_min) / 1 + 1)
+    return np.linspace(ang_min, ang_max, num)
+
+
+def age_grid():
+    """core.py:286 (same as l.107)."""
+    return 10 ** np.arange(0, 3.5, 0.1)
+
+
+def fold_step(best, this):
+    """One iteration of compare(), core.py:228-240.  ``best`` and ``this`` are
+    (amp, age, angle, snr); snr is updated last."""
+    b_amp, b_age, b_ang, b_snr = best
+    t_amp, t_age, t_ang, t_snr = this
+    with np.errstate(invalid="ignore"):
+        keep = (b_snr > t_snr)
+        take = (b_snr < t_snr)
+        b_amp = keep * b_amp + take * t_amp
+        b_age = keep * b_age + take * t_age
+        b_ang = keep * b_ang + take * t_ang
+        b_snr = keep * b_snr + take * t_snr
+    return b_amp, b_age, b_ang, b_snr
+
+
+def compare(results, ny, nx):
+    """core.py:198-243."""
+    best = (np.zeros((ny, nx)), np.zeros((ny, nx)),
+            np.zeros((ny, nx)), np.zeros((ny, nx)))
+    for r in results:
+        best = fold_step(best, r)
+    return best
+
+
+def best_fit_one_age(z, dx, dy, kind, scale, age, ang_max=np.pi / 2,
+                     ang_min=-np.pi / 2, workers=1):
+    """core.py:139-195 without the process pool (the pool only changes where
+    match_template runs; imap keeps the order)."""
+    ny, nx = np.shape(z)
+    res = (match_template(z, dx, dy, kind, scale, age, a, workers=workers)
+           for a in angle_grid(ang_min, ang_max))
+    return np.stack(compare(res, ny, nx))
+
+
+def match(z, dx, dy, kind, workers=1, ages=None, **kwargs):
+    """core.py:266-294.  With ``age`` in kwargs: (4,ny,nx) array; otherwise
+    the two-level fold over the 35-age grid, returned as a 4-tuple."""
+    if 'age' in kwargs:
+        return best_fit_one_age(z, dx, dy, kind, workers=workers, **kwargs)
+    ages = age_grid() if ages is None else ages
+    ny, nx = np.shape(z)
+    res = (best_fit_one_age(z, dx, dy, kind, age=age, workers=workers,
+                            **kwargs) for age in ages)
+    return compare(res, ny, nx)
+
+
+def match_serial(z, dx, dy, kind, scale, ang_max=np.pi / 2,
+                 ang_min=-np.pi / 2):
+    """core.py:65-136: angle-outer / age-inner flat fold."""
+    ny, nx = np.shape(z)
+    res = (match_template(z, dx, dy, kind, scale, age, a)
+           for a in angle_grid(ang_min, ang_max) for age in age_grid())
+    return compare(res, ny, nx)
+
+
+# ----------------------------------------------------------------------------
+# helpers for the parity tests (not in the reference)
+# ----------------------------------------------------------------------------
+def snr_stack(z, dx, dy, kind, scale, ages, angles, workers=1):
+    """Per-template (amp, snr) for a whole parameter grid, shape
+    (n_ages, n_angles, ny, nx) each.  Used by the tests to apply the
+    near-tie policy when comparing argmax indices."""
+    ny, nx = np.shape(z)
+    amp = np.empty((len(ages), len(angles), ny, nx))
+    snr = np.empty_like(amp)
+    for ia, age in enumerate(ages):
+        for ib, ang in enumerate(angles):
+            a, _, _, s = match_template(z, dx, dy, kind, scale, age, ang,
+                                        workers=workers)
+            amp[ia, ib], snr[ia, ib] = a, s
+    return amp, snr
+
+
+def xcorr_direct(curv, W):
+    """Real-space closed form of core.py:359 (and l.363 with W -> M,
+    curv -> curv**2), SURVEY.md section 7:
+
+        xcorr[i,j] = sum_{k,l} W[k,l] * curv[(i - ny//2 - k) % ny,
+                                             (j - nx//2 - l) % nx]
+
+    O(taps * ny * nx); only for small grids in the tests."""
+    ny, nx = curv.shape
+    out = np.zeros((ny, nx))
+    ks, ls = np.nonzero(W)
+    for k, l in zip(ks, ls):
+        out += W[k, l] * np.roll(np.roll(curv, ny // 2 + k, axis=0),
+                                 nx // 2 + l, axis=1)
+    return out
+
+
+def synthetic_dem(n, seed=20260101, kt0=10.0, b=0.01, sigma=0.05,
+                  dtype=np.float32):
+    """Synthetic erf-scarp + ramp + noise DEM of BASELINE.md section 3,
+    following generate_synthetic_scarp (tests/test_core.py:85-101) with
+    theta = 0.2 (so the rotation used is pi/2 - 0.2)."""
+    from scipy.special import erf
+    x = np.linspace(-n / 2, n / 2, num=n)
+    x, y = np.meshgrid(x, x)
+    theta = np.pi / 2 - 0.2
+    yrot = -x * np.sin(theta) + y * np.cos(theta)
+    z = -erf(yrot / (2 * np.sqrt(kt0))) + b * yrot
+    z = z + sigma * np.random.default_rng(seed).standard_normal((n, n))
+    return z.astype(dtype)
+
+
+def check_fold(res, amp_stack, snr_stack, ages, angles, tie_rtol=1e-6,
+               amp_tol=(1e-5, 1e-9), snr_tol=(1e-5, 1e-9)):
+    """Near-tie aware check of a folded result against per-template stacks.
+
+    The reference's fold (core.py:230-240) is an argmax by SNR whose outcome
+    on (near-)ties is decided by FFT rounding noise: e.g. a template that is
+    even in xr (Ricker), or Scarp at -pi/2 vs +pi/2, gives two SNRs equal to
+    ~1e-16, and the reference itself returns either candidate, or the all-zero
+    record when the two round to the same float (strict compares, tie -> 0).
+    So a folded result is accepted at a pixel when
+
+      (a) its (age, angle) equals those of a template t whose oracle SNR is
+          within ``tie_rtol`` (relative) of the per-pixel maximum, and its
+          amp / snr match that template's within (rtol, atol); or
+      (b) it is the all-zero record and either every oracle SNR there is 0
+          (masked) or at least two templates are within ``tie_rtol`` of the
+          maximum (an exact tie is possible).
+
+    ``amp_stack``/``snr_stack``: (T, ny, nx) in any order; ``ages``/``angles``:
+    length-T parameter values.  Returns a dict with the boolean ``ok`` map and
+    counts; ``n_strict`` is the number of pixels decided without the tie rule.
+    """
+    amp, age, ang, snr = [np.asarray(a, dtype=float) for a in res]
+    snr_stack = np.asarray(snr_stack)
+    T = snr_stack.shape[0]
+    smax = np.max(snr_stack, axis=0)
+    thr = smax * (1.0 - tie_rtol)
+    ncand = np.sum(snr_stack >= thr, axis=0)
+    ok = np.zeros(smax.shape, dtype=bool)
+    strict = np.zeros(smax.shape, dtype=bool)
+    for t in range(T):
+        s_t = snr_stack[t]
+        a_t = amp_stack[t]
+        hit = (age == ages[t]) & (ang == angles[t]) & (s_t >= thr) & (s_t > 0)
+        hit &= np.abs(snr - s_t) <= snr_tol[0] * np.abs(s_t) + snr_tol[1]
+        hit &= np.abs(amp - a_t) <= amp_tol[0] * np.abs(a_t) + amp_tol[1]
+        ok |= hit
+        strict |= hit & (ncand == 1)
+    zero = (amp == 0) & (age == 0) & (ang == 0) & (snr == 0)
+    ok |= zero & ((smax == 0) | (ncand >= 2))
+    strict |= zero & (smax == 0)
+    return dict(ok=ok, n_bad=int(np.sum(~ok)), n_strict=int(np.sum(strict)),
+                n_tie=int(np.sum(ok & ~strict)), n=int(ok.size))

@@ -1,0 +1,295 @@
+"""Template plugins for windowed template matching (host side).
+
+Drop-in for the reference's ``scarplet/WindowedTemplate.py`` plugin API: a
+template class is callable as ``Template(scale, age, angle, nx, ny, de)`` and
+offers ``template()``, ``get_window_limits()`` and optionally
+``get_err_mask()`` (the contract ``match_template`` relies on,
+reference core.py:345-346, 369-375).
+
+The numpy methods here exist for API compatibility and for user code that
+inspects templates; the matcher itself never calls them for the built-in
+classes.  Built-ins additionally describe themselves to the HIP library
+through ``_device_descriptor()``: a handful of float64 scalars (evaluated
+with numpy exactly as the reference evaluates them, so that the support
+``W != 0`` decided on the device in float64 is the reference's support) from
+which the kernels synthesise W, the window and the masks on the GPU.  Any
+other subclass of ``WindowedTemplate`` is handled generically: its numpy
+``template()`` is evaluated on the host and uploaded (see core.py).
+
+Reference lines are cited as WT.py:<line> (= scarplet/WindowedTemplate.py).
+"""
+
+import numpy as np
+from scipy.special import erfinv
+
+# kinds understood by the device library (include/scarplet_hip.h)
+KIND_SCARP = 0
+KIND_RICKER = 1
+KIND_WINDOW = 2          # explicit W window uploaded from the host
+
+FLAG_NEGATE = 1          # W -> -W (RightFacingUpperBreakScarp, WT.py:254-255)
+FLAG_ERR_XR_LE0 = 2      # snr = 0 where xr <= 0 (WT.py:265-267)
+FLAG_ERR_XR_GE0 = 4      # snr = 0 where xr >= 0 (WT.py:302-304)
+FLAG_NO_LIMITS = 8       # get_window_limits() is all-False (WT.py:495-496)
+
+# float64 exp(-u) is non-zero iff u < 1075*ln(2); this is what bounds the
+# support of a Ricker template (W != 0), SURVEY.md section 7.
+EXP_UNDERFLOW = 745.1332191019412
+
+
+def centred_axis(n, de):
+    """Cell-centre coordinates of one grid axis, mean removed (WT.py:50-53).
+
+    Evaluated with the same numpy operations as the reference so that the
+    values (and therefore every ``< c`` / ``!= 0`` decision taken on them)
+    are bit-identical."""
+    a = de * np.linspace(1, n, num=n)
+    return a - np.mean(a)
+
+
+class WindowedTemplate(object):
+    """Base class: rotated rectangular window of half-widths ``c`` (along xr)
+    and ``d`` (along yr) on an ``ny`` x ``nx`` grid of spacing ``de``."""
+
+    d = None
+    alpha = None
+    c = None
+    nx = None
+    ny = None
+    de = None
+
+    def _axes(self):
+        return centred_axis(self.nx, self.de), centred_axis(self.ny, self.de)
+
+    def get_coordinates(self):
+        """Rotated coordinates (xr, yr) of every grid cell (WT.py:49-59)."""
+        x, y = self._axes()
+        x = x[np.newaxis, :]
+        y = y[:, np.newaxis]
+        ca, sa = np.cos(self.alpha), np.sin(self.alpha)
+        return x * ca + y * sa, -x * sa + y * ca
+
+    def get_mask(self):
+        """Cells inside the template window (WT.py:61-64)."""
+        xr, yr = self.get_coordinates()
+        return (abs(xr) < self.c) & (abs(yr) < self.d)
+
+    def _limit_margins(self):
+        """(an_x, an_y) of WT.py:68-73."""
+        a, d, c = self.alpha, self.d, self.c
+        x4 = d * np.cos(a - np.pi / 2)
+        y4 = d * np.sin(a - np.pi / 2)
+        x1 = d * np.cos(a)
+        y1 = d * np.sin(a)
+        an_y = abs((x4 - x1) + 2 * c * np.cos(a - np.pi / 2))
+        an_x = abs((y1 - y4) + 2 * c * np.sin(a - np.pi / 2))
+        return an_x, an_y
+
+    def _limit_axes(self):
+        """1-D form of get_window_limits(): boolean 'masked' vectors for the
+        columns and rows (WT.py:75-82)."""
+        an_x, an_y = self._limit_margins()
+        x, y = self._axes()
+        mx = (x < (min(x) + an_x)) | (x > (max(x) - an_x))
+        my = (y < (min(y) + an_y)) | (y > (max(y) - an_y))
+        return mx, my
+
+    def get_window_limits(self):
+        """Mask of cells too close to the grid edge for the window to fit
+        (WT.py:66-84)."""
+        mx, my = self._limit_axes()
+        return mx[np.newaxis, :] | my[:, np.newaxis]
+
+    # -- device description -------------------------------------------------
+    def _kept_bounds(self):
+        """Window limits as index bounds: a cell (i, j) is kept iff
+        ilo <= i <= ihi and jlo <= j <= jhi (empty when lo > hi)."""
+        mx, my = self._limit_axes()
+
+        def bounds(m):
+            keep = np.nonzero(~m)[0]
+            if keep.size == 0:
+                return 0, -1
+            if keep[-1] - keep[0] + 1 != keep.size:
+                raise ValueError("window limits are not an index interval")
+            return int(keep[0]), int(keep[-1])
+
+        (jlo, jhi), (ilo, ihi) = bounds(mx), bounds(my)
+        return ilo, ihi, jlo, jhi
+
+    def _support_bbox(self, c_eff=None):
+        """Conservative bounding box of the support in centred offsets
+        p = k - ny//2, q = l - nx//2 (clipped to the grid)."""
+        c = self.c if c_eff is None else min(self.c, c_eff)
+        ca, sa = abs(np.cos(self.alpha)), abs(np.sin(self.alpha))
+        bx = c * ca + self.d * sa
+        by = c * sa + self.d * ca
+        x, y = self._axes()
+
+        def rng(a, b, n):
+            idx = np.nonzero(np.abs(a) <= b * (1 + 1e-12) + 1e-300)[0]
+            if idx.size == 0:
+                return 0, -1
+            return int(idx[0]) - n // 2, int(idx[-1]) - n // 2
+
+        (qmin, qmax), (pmin, pmax) = rng(x, bx, self.nx), rng(y, by, self.ny)
+        return pmin, pmax, qmin, qmax
+
+
+class Scarp(WindowedTemplate):
+    """Curvature template of a vertical scarp of morphologic age ``kt``
+    (Hanks 2000; Hilley et al. 2010), WT.py:87-183."""
+
+    _kind = KIND_SCARP
+    _flags = 0
+
+    def __init__(self, d, kt, alpha, nx, ny, de):
+        self.d = d
+        self.kt = kt
+        self.alpha = -alpha                        # WT.py:151
+        self.nx = nx
+        self.ny = ny
+        self.de = de
+        self.c = abs(2 * np.sqrt(self.kt) * erfinv(0.9))   # WT.py:156-157
+
+    def _profile(self, xr):
+        return (-xr / (2. * self.kt ** (3 / 2.) * np.sqrt(np.pi))) \
+            * np.exp(-xr ** 2. / (4. * self.kt))
+
+    def template(self):
+        """W = profile(xr) inside the window, 0 outside (WT.py:159-183)."""
+        xr, yr = self.get_coordinates()
+        inside = (abs(xr) < self.c) & (abs(yr) < self.d)
+        return self._profile(xr) * inside
+
+    def template_numexpr(self):
+        """Same values as template(); kept for API compatibility
+        (WT.py:185-215 differs from template() only in the evaluator)."""
+        return self.template()
+
+    def _device_descriptor(self):
+        kt = self.kt
+        return dict(kind=self._kind, flags=self._flags,
+                    cos_a=float(np.cos(self.alpha)),
+                    sin_a=float(np.sin(self.alpha)),
+                    c=float(self.c), d=float(self.d),
+                    p0=float(2. * kt ** (3 / 2.) * np.sqrt(np.pi)),
+                    p1=float(4. * kt),
+                    limits=self._kept_bounds(), bbox=self._support_bbox())
+
+
+class RightFacingUpperBreakScarp(Scarp):
+    """Upper slope break of a right-facing scarp: sign-flipped template and
+    an error mask over the lower half (WT.py:218-267)."""
+
+    _flags = FLAG_NEGATE | FLAG_ERR_XR_LE0
+
+    def template(self):
+        return -Scarp.template(self)
+
+    def get_err_mask(self):
+        xr, _ = self.get_coordinates()
+        return xr <= 0
+
+
+class LeftFacingUpperBreakScarp(Scarp):
+    """Upper slope break of a left-facing scarp (WT.py:270-304)."""
+
+    _flags = FLAG_ERR_XR_GE0
+
+    def get_err_mask(self):
+        xr, _ = self.get_coordinates()
+        return xr >= 0
+
+
+class ShiftedTemplateMixin(WindowedTemplate):
+    """Template offset from the window centre by (dx, dy) cells
+    (WT.py:307-421).  Only reachable through
+    calculate_best_fit_parameters_serial, which forwards **kwargs."""
+
+    _kind = KIND_WINDOW
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args)
+        self.set_offset(kwargs['dx'], kwargs['dy'])
+
+    def set_offset(self, dx, dy):
+        self.dx = dx
+        self.dy = dy
+
+    def shift_template(self, W, dx, dy):
+        """Shift W right by dx and down by dy cells, zero filling
+        (WT.py:368-408; dx <= 0 / dy <= 0 shift the other way)."""
+        ny, nx = W.shape
+        out = np.zeros_like(W)
+        if dx > 0:
+            out[:, dx:] = W[:, :nx - dx]
+        else:
+            out[:, :nx + dx] = W[:, -dx:]
+        W, out = out, np.zeros_like(W)
+        if dy > 0:
+            # reference quirk kept: dy > 0 drops the LAST dy rows and pads
+            # at the bottom, i.e. the content does not move (WT.py:398-401)
+            out[:ny - dy, :] = W[:ny - dy, :]
+        else:
+            out[-dy:, :] = W[-dy:, :]           # WT.py:403-406, likewise
+        return out
+
+    def template(self):
+        W = super().template()
+        return self.shift_template(W, self.dx, self.dy)
+
+    def _device_descriptor(self):
+        return None                              # generic (host window) path
+
+
+class ShiftedLeftFacingUpperBreakScarp(ShiftedTemplateMixin,
+                                       LeftFacingUpperBreakScarp):
+    pass
+
+
+class ShiftedRightFacingUpperBreakScarp(ShiftedTemplateMixin,
+                                        RightFacingUpperBreakScarp):
+    pass
+
+
+class Ricker(WindowedTemplate):
+    """2-D Ricker wavelet of frequency ``f`` (Lashermes et al. 2007),
+    WT.py:434-520.  The second constructor argument (the matcher's ``age``)
+    is the wavelet frequency."""
+
+    _kind = KIND_RICKER
+    _flags = FLAG_NO_LIMITS
+
+    def __init__(self, d, f, alpha, nx, ny, de):
+        self.d = d
+        self.f = f
+        self.alpha = -alpha                        # WT.py:489
+        self.nx = nx
+        self.ny = ny
+        self.c = nx                                # WT.py:492
+        self.de = de
+
+    def get_window_limits(self):
+        return np.zeros((self.ny, self.nx), dtype=bool)     # WT.py:495-496
+
+    def template(self):
+        xr, yr = self.get_coordinates()
+        u2 = (np.pi * self.f * xr) ** 2.
+        W = (1. - 2. * u2) * np.exp(-u2)
+        return W * ((abs(xr) < self.c) & (abs(yr) < self.d))
+
+    def _device_descriptor(self):
+        pif = float(np.pi * self.f)
+        c_eff = np.sqrt(EXP_UNDERFLOW) / abs(pif) if pif != 0 else np.inf
+        return dict(kind=self._kind, flags=self._flags,
+                    cos_a=float(np.cos(self.alpha)),
+                    sin_a=float(np.sin(self.alpha)),
+                    c=float(self.c), d=float(self.d), p0=pif, p1=0.0,
+                    limits=(0, self.ny - 1, 0, self.nx - 1),
+                    bbox=self._support_bbox(c_eff=c_eff))
+
+
+class Channel(Ricker):
+    """Ricker wavelet used for fluvial channels (WT.py:523-525)."""
+    pass

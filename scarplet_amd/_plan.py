@@ -1,0 +1,165 @@
+"""Host-side planning for the device matcher: search grids, template
+descriptors and the overlap-save tiling of the FFT path.
+
+Pure numpy; no device access here, so this is what the CPU test-suite
+exercises (tests/test_plan.py checks the tiling against the oracle through a
+numpy model of the kernels).
+
+Index conventions (verified against the reference in oracle/gen_golden.py):
+
+    xcorr[i, j] = sum_{p,q} W[ny//2 + p, nx//2 + q]
+                      * curv[(i - p + oy) % ny, (j - q + ox) % nx]
+
+with oy = ny % 2, ox = nx % 2: the reference's fft2/ifft2/fftshift sequence
+(core.py:349-363) is a circular convolution with the template centred at
+(ny//2, nx//2); for odd sizes the centre pixel and the fftshift disagree by
+one cell.  T3 is the same sum with W -> (W != 0) and curv -> curv**2.
+"""
+
+import math
+
+import numpy as np
+
+METHOD_DIRECT = 0
+METHOD_FFT = 1
+METHOD_AUTO = 2
+
+T_MIN = 64
+T_MAX = 4096
+
+
+def angle_grid(ang_min=-np.pi / 2, ang_max=np.pi / 2):
+    """Orientation grid of the reference search driver (core.py:173-175):
+    one-degree steps, both ends included."""
+    num = int((180 / np.pi) * (ang_max - ang_min) / 1 + 1)
+    return np.linspace(ang_min, ang_max, num)
+
+
+def age_grid():
+    """Morphologic-age grid of the reference (core.py:107, 286): 35 values,
+    10**0 ... 10**3.4 m2."""
+    return 10 ** np.arange(0, 3.5, 0.1)
+
+
+def curvature_coefficients(angle):
+    """(cc, sc2, ss) with curv = cc*A - sc2*B + ss*C (dem.py:103-104)."""
+    s, c = np.sin(angle), np.cos(angle)
+    return float(c ** 2), float(2 * s * c), float(s ** 2)
+
+
+def bbox_union(bboxes):
+    """Union of (pmin, pmax, qmin, qmax) boxes; empty boxes are skipped."""
+    pmin = qmin = 0
+    pmax = qmax = 0
+    for (a, b, c, d) in bboxes:
+        if b >= a:
+            pmin, pmax = min(pmin, a), max(pmax, b)
+        if d >= c:
+            qmin, qmax = min(qmin, c), max(qmax, d)
+    return pmin, pmax, qmin, qmax
+
+
+def halo_for(bbox, ny, nx):
+    """Rows/columns of DEM a tile needs beyond its core on each side, for a
+    support box in centred offsets: (lo_y, hi_y, lo_x, hi_x).  Output pixel i
+    reads curvature rows i - pmax + oy ... i - pmin + oy."""
+    pmin, pmax, qmin, qmax = bbox
+    oy, ox = ny % 2, nx % 2
+    return (max(pmax - oy, 0), max(-pmin + oy, 0),
+            max(qmax - ox, 0), max(-qmin + ox, 0))
+
+
+def _is_pow2(n):
+    return n > 0 and (n & (n - 1)) == 0
+
+
+def choose_tile(n_core, span, n_global, whole_axis, t_max=T_MAX):
+    """Pick the FFT length for one axis.
+
+    n_core     -- output cells this device owns along the axis
+    span       -- pmax - pmin of the batch (support extent minus one)
+    n_global   -- DEM size along the axis
+    whole_axis -- True when the device holds the whole periodic axis
+
+    Returns (T, V, ntiles, circular).  Overlap-save: a length-T circular
+    convolution yields V = T - span valid outputs.  When the axis itself is a
+    power of two (and we own all of it) the DEM's own periodicity is used and
+    nothing is wasted."""
+    best = None
+    if whole_axis and _is_pow2(n_global) and T_MIN <= n_global <= t_max \
+            and span < n_global:
+        best = (n_global * (math.log2(n_global) + 4.0), n_global, n_global, 1,
+                True)
+    t = T_MIN
+    while t <= t_max:
+        if t > span:
+            v = t - span
+            nt = -(-n_core // v)
+            cost = nt * t * (math.log2(t) + 4.0)
+            if best is None or cost < best[0]:
+                best = (cost, t, v, nt, False)
+        t *= 2
+    if best is None:
+        raise ValueError("template support (%d cells) exceeds the largest "
+                         "FFT tile (%d)" % (span + 1, t_max))
+    return best[1:]
+
+
+class Plan(object):
+    """Geometry of one sc_match call (mirrors struct sc_plan)."""
+
+    def __init__(self, ny, nx, core, bbox, whole=True, method=METHOD_FFT,
+                 group=1, t_max=T_MAX):
+        cy0, cy1, cx0, cx1 = core
+        pmin, pmax, qmin, qmax = bbox
+        self.ny, self.nx = ny, nx
+        self.core = core
+        self.bbox = bbox
+        self.oy, self.ox = ny % 2, nx % 2
+        self.method = method
+        self.group = group
+        self.Py, self.Qx = pmax, qmax
+        if method == METHOD_FFT:
+            self.Ty, self.Vy, self.nty, self.circ_y = choose_tile(
+                cy1 - cy0, pmax - pmin, ny, whole and (cy1 - cy0) == ny, t_max)
+            self.Tx, self.Vx, self.ntx, self.circ_x = choose_tile(
+                cx1 - cx0, qmax - qmin, nx, whole and (cx1 - cx0) == nx, t_max)
+        else:
+            self.Ty = self.Tx = self.Vy = self.Vx = 0
+            self.nty = self.ntx = 0
+            self.circ_y = self.circ_x = False
+
+    def tiles(self):
+        """[(i0, j0, vy, vx, gi0, gj0)]: core origin, valid extent and the
+        global origin of the tile's input window."""
+        cy0, cy1, cx0, cx1 = self.core
+        out = []
+        for ty in range(self.nty):
+            i0 = cy0 + ty * self.Vy
+            vy = min(self.Vy, cy1 - i0)
+            for tx in range(self.ntx):
+                j0 = cx0 + tx * self.Vx
+                vx = min(self.Vx, cx1 - j0)
+                out.append((i0, j0, vy, vx, i0 + self.oy - self.Py,
+                            j0 + self.ox - self.Qx))
+        return out
+
+    def padded_cells(self):
+        return self.nty * self.ntx * self.Ty * self.Tx
+
+    def __repr__(self):
+        return ("Plan(T=%dx%d V=%dx%d tiles=%dx%d circ=%s/%s bbox=%s)"
+                % (self.Ty, self.Tx, self.Vy, self.Vx, self.nty, self.ntx,
+                   self.circ_y, self.circ_x, (self.bbox,)))
+
+
+def direct_cost(n_taps):
+    """Relative cost per output cell of the real-space path."""
+    return 2.0 * n_taps
+
+
+def fft_cost(plan, n_cells):
+    """Relative cost per output cell of the FFT path (same units as
+    direct_cost; the constant is calibrated on MI355X)."""
+    return 24.0 * (math.log2(plan.Ty) + math.log2(plan.Tx)) \
+        * plan.padded_cells() / float(n_cells)
