@@ -1,0 +1,236 @@
+/*
+ * scarplet_hip.h - C ABI of libscarplet_hip.so, the MI355X (gfx950) engine
+ * behind scarplet's template-matching hot path.
+ *
+ * The reference (stgl/scarplet) is pure Python; the interface this library
+ * replaces is the body of
+ *
+ *     scarplet/core.py:297-377   match_template()      (per-template kernel)
+ *     scarplet/core.py:198-243   compare()             (running-best fold)
+ *     scarplet/dem.py:68-107     _calculate_directional_laplacian()
+ *     scarplet/WindowedTemplate.py:159-183, 498-520, 66-84, 257-304
+ *                                template() / get_window_limits() /
+ *                                get_err_mask() of the built-in plugins
+ *
+ * i.e. everything that runs once per (age, orientation) template.  The search
+ * drivers above it (core.py:139-195 calculate_best_fit_parameters,
+ * core.py:266-294 match) stay host code: they build the parameter grids,
+ * turn every template into an sc_template descriptor and make ONE call.
+ * INTEGRATION.md shows the ctypes binding a scarplet maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; all host buffers are caller-owned, C order;
+ *   - every call returns SC_OK (0) or a negative SC_ERR_* code and never
+ *     throws; sc_last_error() gives the message for the last failure;
+ *   - calls are synchronous unless the name ends in _async; an sc_ctx is
+ *     bound to one GPU and is not thread-safe; distinct contexts are
+ *     independent (one context per GPU / per process).
+ */
+#ifndef SCARPLET_HIP_H
+#define SCARPLET_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_ABI_VERSION 1
+
+#define SC_OK               0
+#define SC_ERR_INVALID     -1   /* bad argument                                */
+#define SC_ERR_HIP         -2   /* HIP runtime failure (see sc_last_error)     */
+#define SC_ERR_NO_DEM      -3   /* sc_set_dem has not been called              */
+#define SC_ERR_UNSUPPORTED -4   /* plan outside what the kernels are built for */
+#define SC_ERR_COMM        -5   /* RCCL failure                                */
+
+/* template kinds (WindowedTemplate.py classes) */
+#define SC_KIND_SCARP   0       /* Scarp and the UpperBreak variants (l.87-304) */
+#define SC_KIND_RICKER  1       /* Ricker / Channel (l.434-525)                 */
+#define SC_KIND_WINDOW  2       /* any other plugin: W window uploaded by host  */
+
+/* template flags */
+#define SC_FLAG_NEGATE      1   /* W -> -W            (WindowedTemplate.py:254) */
+#define SC_FLAG_ERR_XR_LE0  2   /* snr=0 where xr<=0  (WindowedTemplate.py:265) */
+#define SC_FLAG_ERR_XR_GE0  4   /* snr=0 where xr>=0  (WindowedTemplate.py:302) */
+#define SC_FLAG_NO_LIMITS   8   /* get_window_limits() all False (l.495-496)    */
+
+/* matching method */
+#define SC_METHOD_DIRECT 0      /* real-space sliding window                    */
+#define SC_METHOD_FFT    1      /* overlap-save tiles, LDS FFTs                 */
+
+#define SC_ID_NONE 0xFFFFFFFFu  /* best-id value of a cell no template has won  */
+
+typedef struct sc_ctx sc_ctx;
+
+/*
+ * One (scale, age, orientation) template = one call of match_template()
+ * in the reference (core.py:297).  All doubles are evaluated by the host with
+ * numpy exactly as the reference evaluates them, so that the support W != 0
+ * decided on the device in float64 is bit-for-bit the reference's.
+ */
+typedef struct sc_template {
+    int32_t  kind;            /* SC_KIND_*                                      */
+    int32_t  flags;           /* SC_FLAG_*                                      */
+    double   cos_a, sin_a;    /* cos/sin of the template's alpha = -orientation */
+    double   c, d;            /* window half-widths along xr / yr (l.61-64)     */
+    double   p0, p1;          /* SCARP: 2*kt**1.5*sqrt(pi), 4*kt (l.177-178)
+                                 RICKER: pi*f, unused (l.514-515)
+                                 WINDOW: n = count(W != 0), sum(W**2)           */
+    double   cc, sc2, ss;     /* curvature mix, dem.py:103-104:
+                                 curv = cc*d2z_dx2 - sc2*d2z_dxdy + ss*d2z_dy2  */
+    int32_t  ilo, ihi, jlo, jhi;     /* cells kept by get_window_limits()
+                                        (l.66-84): ilo<=i<=ihi && jlo<=j<=jhi   */
+    int32_t  pmin, pmax, qmin, qmax; /* support bounding box in offsets from
+                                        the template centre (ny//2, nx//2)      */
+    uint32_t id;              /* recorded in the best-id plane when it wins     */
+    int32_t  window;          /* SC_KIND_WINDOW: slot given to sc_upload_window */
+} sc_template;
+
+/* Geometry of one sc_match call (computed by the host planner). */
+typedef struct sc_plan {
+    int32_t method;           /* SC_METHOD_*                                    */
+    int32_t Ty, Tx;           /* FFT tile size (powers of two, 64..4096)        */
+    int32_t Vy, Vx;           /* valid outputs per tile = T - support span      */
+    int32_t nty, ntx;         /* tiles covering the core region                 */
+    int32_t circ_y, circ_x;   /* axis handled by its own periodicity (T == n)   */
+    int32_t Py, Qx;           /* max pmax / qmax over the batch                 */
+    int32_t group;            /* templates per inverse-transform launch (>= 1)  */
+} sc_plan;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int  sc_abi_version(void);
+int  sc_device_count(void);
+int  sc_create(int device, sc_ctx** out);
+void sc_destroy(sc_ctx* ctx);
+const char* sc_last_error(sc_ctx* ctx);
+
+/*
+ * Hand over the elevation block this context works on.
+ *   z            ly x lx float64, rows gy0.. / columns gx0.. of the ny x nx DEM
+ *                (global indices may lie outside [0,n): halo cells of a
+ *                periodic DEM); replaces DEMGrid._griddata (dem.py:84)
+ *   core         [cy0,cy1) x [cx0,cx1): global cells whose results this
+ *                context owns
+ *   wrap         1: the block IS the whole DEM (ly==ny, lx==nx, gy0==gx0==0)
+ *                and neighbours are found modulo the DEM size
+ *   xaxis,yaxis  centred cell coordinates (WindowedTemplate.py:50-53)
+ * Computes the three curvature stencils of dem.py:88-101 on the device.
+ */
+int sc_set_dem(sc_ctx* ctx, const double* z, int ly, int lx, int gy0, int gx0,
+               int ny, int nx, int cy0, int cy1, int cx0, int cx1,
+               double dx, double dy, int wrap,
+               const double* xaxis, const double* yaxis);
+
+/* Same, with z already in device memory (used after sc_halo_exchange). */
+int sc_set_dem_device(sc_ctx* ctx, const void* z_dev, int ly, int lx, int gy0,
+                      int gx0, int ny, int nx, int cy0, int cy1, int cx0,
+                      int cx1, double dx, double dy, int wrap,
+                      const double* xaxis, const double* yaxis);
+
+/* Explicit template window for SC_KIND_WINDOW (generic plugins): w is the
+ * h x w float64 block W[ny//2+pmin .., nx//2+qmin ..]; returns the slot. */
+int sc_upload_window(sc_ctx* ctx, const double* w, int h, int wd, int* slot);
+/* Optional per-cell masks for generic plugins (ny x nx uint8, global):
+ * get_window_limits() and get_err_mask() results; pass NULL to clear. */
+int sc_set_masks(sc_ctx* ctx, int slot, const uint8_t* limits,
+                 const uint8_t* err);
+int sc_clear_windows(sc_ctx* ctx);
+
+/* ---- the hot path ------------------------------------------------------ */
+/* Zero the running-best record (compare() start state, core.py:222-225). */
+int sc_reset_best(sc_ctx* ctx);
+
+/* Match n templates and fold them, in the order given, into the running
+ * best (core.py:227-240 semantics: strict compares, tie -> zero record,
+ * NaN sticky).  Templates with equal (cc, sc2, ss) share one curvature
+ * plane; send them adjacent. */
+int sc_match(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* plan);
+int sc_match_async(sc_ctx* ctx, const sc_template* t, int n,
+                   const sc_plan* plan);
+int sc_sync(sc_ctx* ctx);
+
+/* amp / snr maps of ONE template over the core region (match_template(),
+ * core.py:377), float32, (cy1-cy0) x (cx1-cx0). */
+int sc_match_template(sc_ctx* ctx, const sc_template* t, const sc_plan* plan,
+                      float* amp, float* snr);
+
+/* Copy the running best of the core region to the host. */
+int sc_get_best(sc_ctx* ctx, float* amp, float* snr, uint32_t* id);
+
+/*
+ * compare() for results that already sit on the host (core.py:198-243), e.g.
+ * user code that calls match_template() per orientation and folds itself.
+ * float64, literally best = (best_snr > snr)*best + (best_snr < snr)*this for
+ * the four planes, snr last.  Independent of the DEM state.
+ */
+int sc_compare_begin(sc_ctx* ctx, int ny, int nx);
+int sc_compare_fold(sc_ctx* ctx, const double* amp, const double* snr,
+                    double age, double angle);
+int sc_compare_end(sc_ctx* ctx, double* amp, double* age, double* angle,
+                   double* snr);
+
+/* Directional curvature of the block (dem.py:68-107), float32 ly x lx. */
+int sc_curvature(sc_ctx* ctx, double cc, double sc2, double ss, float* out);
+
+/* Per-template scalars of the last sc_match / sc_match_template call:
+ * n = count(W != 0) + eps (core.py:350) and sum(W**2) (core.py:356). */
+int sc_get_template_sums(sc_ctx* ctx, int n, double* n_out, double* ts_out);
+
+/* ---- measurement ------------------------------------------------------- */
+#define SC_K_CURV        0
+#define SC_K_WINDOWS     1
+#define SC_K_DIRECT      2
+#define SC_K_FWD_ROWS    3
+#define SC_K_FWD_COLS    4
+#define SC_K_INV_COLS    5
+#define SC_K_INV_ROWS    6
+#define SC_K_COUNT       7
+/* HIP-event timing of every launch on the context's stream. */
+int sc_profile(sc_ctx* ctx, int enable);
+int sc_profile_get(sc_ctx* ctx, int kernel, long long* launches,
+                   double* total_ms);
+const char* sc_kernel_name(int kernel);
+/* device memory currently held by the context, bytes */
+size_t sc_device_bytes(sc_ctx* ctx);
+
+/* ---- multi-GPU: RCCL halo exchange (one process per GPU) ---------------- */
+#define SC_COMM_ID_BYTES 128
+int sc_comm_unique_id(void* id_out /* SC_COMM_ID_BYTES */);
+int sc_comm_init(sc_ctx* ctx, const void* id, int rank, int nranks);
+/*
+ * One rectangle of the halo exchange, in cells of this rank's halo-extended
+ * block.  The host (scarplet_amd/dist.py) derives the list for every rank from
+ * the tile grid; all ranks walk the same global order, so sends and receives
+ * between a pair of ranks match up.
+ */
+#define SC_XFER_RECV  0   /* receive h x w cells from `peer` into (dy0, dx0)       */
+#define SC_XFER_SEND  1   /* send the h x w cells at (sy0, sx0) to `peer`          */
+#define SC_XFER_LOCAL 2   /* copy (sy0, sx0) -> (dy0, dx0) inside the block
+                             (periodic image of the rank's own core)              */
+typedef struct sc_xfer {
+    int32_t peer, kind;
+    int32_t sy0, sx0, dy0, dx0, h, w;
+} sc_xfer;
+
+/*
+ * Assemble this rank's halo-extended elevation block on the device.
+ *   core      this rank's own cells, core_h x core_w float64 (host)
+ *   h*_lo/hi  halo cells around the core; the block is
+ *             (hy_lo + core_h + hy_hi) x (hx_lo + core_w + hx_hi)
+ *   x, n      the rank's transfers; sends/receives run as one grouped
+ *             ncclSend/ncclRecv over xGMI, halo rectangles are packed into a
+ *             contiguous staging buffer first
+ * On return *z_dev is the float64 device block (owned by the context), ready
+ * for sc_set_dem_device.
+ */
+int sc_halo_exchange(sc_ctx* ctx, const double* core, int core_h, int core_w,
+                     int hy_lo, int hy_hi, int hx_lo, int hx_hi,
+                     const sc_xfer* x, int n, void** z_dev);
+int sc_comm_destroy(sc_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCARPLET_HIP_H */

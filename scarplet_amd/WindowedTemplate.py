@@ -37,14 +37,41 @@ FLAG_NO_LIMITS = 8       # get_window_limits() is all-False (WT.py:495-496)
 EXP_UNDERFLOW = 745.1332191019412
 
 
+_AXIS_CACHE = {}
+
+
 def centred_axis(n, de):
     """Cell-centre coordinates of one grid axis, mean removed (WT.py:50-53).
 
     Evaluated with the same numpy operations as the reference so that the
     values (and therefore every ``< c`` / ``!= 0`` decision taken on them)
-    are bit-identical."""
-    a = de * np.linspace(1, n, num=n)
-    return a - np.mean(a)
+    are bit-identical.  Cached: a search builds thousands of templates on the
+    same grid."""
+    key = (int(n), float(de))
+    a = _AXIS_CACHE.get(key)
+    if a is None:
+        a = de * np.linspace(1, n, num=n)
+        a = a - np.mean(a)
+        a.setflags(write=False)
+        if len(_AXIS_CACHE) > 64:
+            _AXIS_CACHE.clear()
+        _AXIS_CACHE[key] = a
+    return a
+
+
+def _interval_le(a, lo, hi):
+    """Indices [i0, i1] of the cells of the monotonic axis ``a`` with
+    lo <= a <= hi, found by bisection (same float compares as the elementwise
+    test, O(log n))."""
+    if a[0] <= a[-1]:
+        i0 = int(np.searchsorted(a, lo, side="left"))
+        i1 = int(np.searchsorted(a, hi, side="right")) - 1
+    else:
+        keep = np.nonzero((a >= lo) & (a <= hi))[0]
+        if keep.size == 0:
+            return 0, -1
+        i0, i1 = int(keep[0]), int(keep[-1])
+    return i0, i1
 
 
 class WindowedTemplate(object):
@@ -103,18 +130,13 @@ class WindowedTemplate(object):
     # -- device description -------------------------------------------------
     def _kept_bounds(self):
         """Window limits as index bounds: a cell (i, j) is kept iff
-        ilo <= i <= ihi and jlo <= j <= jhi (empty when lo > hi)."""
-        mx, my = self._limit_axes()
-
-        def bounds(m):
-            keep = np.nonzero(~m)[0]
-            if keep.size == 0:
-                return 0, -1
-            if keep[-1] - keep[0] + 1 != keep.size:
-                raise ValueError("window limits are not an index interval")
-            return int(keep[0]), int(keep[-1])
-
-        (jlo, jhi), (ilo, ihi) = bounds(mx), bounds(my)
+        ilo <= i <= ihi and jlo <= j <= jhi (empty when lo > hi).  Same float
+        compares as get_window_limits(): masked means x < min(x) + an_x or
+        x > max(x) - an_x (WT.py:81-82)."""
+        an_x, an_y = self._limit_margins()
+        x, y = self._axes()
+        jlo, jhi = _interval_le(x, min(x[0], x[-1]) + an_x, max(x[0], x[-1]) - an_x)
+        ilo, ihi = _interval_le(y, min(y[0], y[-1]) + an_y, max(y[0], y[-1]) - an_y)
         return ilo, ihi, jlo, jhi
 
     def _support_bbox(self, c_eff=None):
@@ -122,18 +144,13 @@ class WindowedTemplate(object):
         p = k - ny//2, q = l - nx//2 (clipped to the grid)."""
         c = self.c if c_eff is None else min(self.c, c_eff)
         ca, sa = abs(np.cos(self.alpha)), abs(np.sin(self.alpha))
-        bx = c * ca + self.d * sa
-        by = c * sa + self.d * ca
+        bx = (c * ca + self.d * sa) * (1 + 1e-12) + 1e-300
+        by = (c * sa + self.d * ca) * (1 + 1e-12) + 1e-300
         x, y = self._axes()
-
-        def rng(a, b, n):
-            idx = np.nonzero(np.abs(a) <= b * (1 + 1e-12) + 1e-300)[0]
-            if idx.size == 0:
-                return 0, -1
-            return int(idx[0]) - n // 2, int(idx[-1]) - n // 2
-
-        (qmin, qmax), (pmin, pmax) = rng(x, bx, self.nx), rng(y, by, self.ny)
-        return pmin, pmax, qmin, qmax
+        l0, l1 = _interval_le(x, -bx, bx)
+        k0, k1 = _interval_le(y, -by, by)
+        return (k0 - self.ny // 2, k1 - self.ny // 2,
+                l0 - self.nx // 2, l1 - self.nx // 2)
 
 
 class Scarp(WindowedTemplate):

@@ -1,0 +1,29 @@
+"""compare(): running-best fold of host-side results, on the GPU."""
+
+import ctypes as C
+
+import numpy as np
+
+from scarplet_amd import _lib
+
+
+def compare(results, ny, nx, device=0):
+    """Reference semantics (core.py:198-243): zeros start state, then for
+    every result ``best = (best_snr > snr)*best + (best_snr < snr)*this`` for
+    amp, age, angle and (last) snr."""
+    from scarplet_amd.core import _context
+    ctx = _context(device)
+    lib, h = ctx.lib, ctx._h
+    dp = C.POINTER(C.c_double)
+    ctx._check(lib.sc_compare_begin(h, int(ny), int(nx)), "sc_compare_begin")
+    for r in results:
+        amp, age, angle, snr = r
+        amp = np.ascontiguousarray(np.broadcast_to(np.asarray(amp, dtype=np.float64), (ny, nx)))
+        snr = np.ascontiguousarray(np.broadcast_to(np.asarray(snr, dtype=np.float64), (ny, nx)))
+        ctx._check(lib.sc_compare_fold(h, amp.ctypes.data_as(dp),
+                                       snr.ctypes.data_as(dp), float(age),
+                                       float(angle)), "sc_compare_fold")
+    out = [np.empty((ny, nx)) for _ in range(4)]
+    ctx._check(lib.sc_compare_end(h, *[o.ctypes.data_as(dp) for o in out]),
+               "sc_compare_end")
+    return tuple(out)

@@ -1,0 +1,317 @@
+"""ctypes binding of libscarplet_hip.so (include/scarplet_hip.h).
+
+The library is the only compute path: if it cannot be loaded, or no GPU is
+visible, the matcher raises - there is no CPU fallback in this package.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscarplet_hip.so")
+
+SC_OK = 0
+ABI_VERSION = 1
+ID_NONE = 0xFFFFFFFF
+COMM_ID_BYTES = 128
+
+K_NAMES = ("k_curv", "k_windows", "k_direct", "k_fwd_rows", "k_fwd_cols",
+           "k_inv_cols", "k_inv_rows")
+K_CURV, K_WINDOWS, K_DIRECT, K_FWD_ROWS, K_FWD_COLS, K_INV_COLS, K_INV_ROWS = range(7)
+
+XFER_RECV, XFER_SEND, XFER_LOCAL = 0, 1, 2
+
+
+class ScarpletHipError(RuntimeError):
+    pass
+
+
+class sc_template(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("flags", C.c_int32),
+                ("cos_a", C.c_double), ("sin_a", C.c_double),
+                ("c", C.c_double), ("d", C.c_double),
+                ("p0", C.c_double), ("p1", C.c_double),
+                ("cc", C.c_double), ("sc2", C.c_double), ("ss", C.c_double),
+                ("ilo", C.c_int32), ("ihi", C.c_int32),
+                ("jlo", C.c_int32), ("jhi", C.c_int32),
+                ("pmin", C.c_int32), ("pmax", C.c_int32),
+                ("qmin", C.c_int32), ("qmax", C.c_int32),
+                ("id", C.c_uint32), ("window", C.c_int32)]
+
+
+class sc_plan(C.Structure):
+    _fields_ = [("method", C.c_int32), ("Ty", C.c_int32), ("Tx", C.c_int32),
+                ("Vy", C.c_int32), ("Vx", C.c_int32), ("nty", C.c_int32),
+                ("ntx", C.c_int32), ("circ_y", C.c_int32),
+                ("circ_x", C.c_int32), ("Py", C.c_int32), ("Qx", C.c_int32),
+                ("group", C.c_int32)]
+
+
+class sc_xfer(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("kind", C.c_int32),
+                ("sy0", C.c_int32), ("sx0", C.c_int32),
+                ("dy0", C.c_int32), ("dx0", C.c_int32),
+                ("h", C.c_int32), ("w", C.c_int32)]
+
+
+_P = C.c_void_p
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_up = C.POINTER(C.c_uint32)
+_bp = C.POINTER(C.c_uint8)
+
+# every symbol include/scarplet_hip.h declares: (restype, argtypes)
+SIGNATURES = {
+    "sc_abi_version": (C.c_int, []),
+    "sc_device_count": (C.c_int, []),
+    "sc_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "sc_destroy": (None, [_P]),
+    "sc_last_error": (C.c_char_p, [_P]),
+    "sc_set_dem": (C.c_int, [_P, _dp] + [C.c_int] * 10 + [C.c_double] * 2
+                   + [C.c_int, _dp, _dp]),
+    "sc_set_dem_device": (C.c_int, [_P, _P] + [C.c_int] * 10
+                          + [C.c_double] * 2 + [C.c_int, _dp, _dp]),
+    "sc_upload_window": (C.c_int, [_P, _dp, C.c_int, C.c_int,
+                                   C.POINTER(C.c_int)]),
+    "sc_set_masks": (C.c_int, [_P, C.c_int, _bp, _bp]),
+    "sc_clear_windows": (C.c_int, [_P]),
+    "sc_reset_best": (C.c_int, [_P]),
+    "sc_match": (C.c_int, [_P, C.POINTER(sc_template), C.c_int,
+                           C.POINTER(sc_plan)]),
+    "sc_match_async": (C.c_int, [_P, C.POINTER(sc_template), C.c_int,
+                                 C.POINTER(sc_plan)]),
+    "sc_sync": (C.c_int, [_P]),
+    "sc_match_template": (C.c_int, [_P, C.POINTER(sc_template),
+                                    C.POINTER(sc_plan), _fp, _fp]),
+    "sc_get_best": (C.c_int, [_P, _fp, _fp, _up]),
+    "sc_compare_begin": (C.c_int, [_P, C.c_int, C.c_int]),
+    "sc_compare_fold": (C.c_int, [_P, _dp, _dp, C.c_double, C.c_double]),
+    "sc_compare_end": (C.c_int, [_P, _dp, _dp, _dp, _dp]),
+    "sc_curvature": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, _fp]),
+    "sc_get_template_sums": (C.c_int, [_P, C.c_int, _dp, _dp]),
+    "sc_profile": (C.c_int, [_P, C.c_int]),
+    "sc_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_longlong), _dp]),
+    "sc_kernel_name": (C.c_char_p, [C.c_int]),
+    "sc_device_bytes": (C.c_size_t, [_P]),
+    "sc_comm_unique_id": (C.c_int, [_P]),
+    "sc_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "sc_halo_exchange": (C.c_int, [_P, _dp] + [C.c_int] * 6
+                         + [C.POINTER(sc_xfer), C.c_int, C.POINTER(_P)]),
+    "sc_comm_destroy": (C.c_int, [_P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and bind every exported function."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ScarpletHipError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as "
+            "g; g.build()'` or `make -C scarplet_amd/csrc` (needs hipcc); this "
+            "package has no CPU fallback" % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:
+        raise ScarpletHipError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError = ABI mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sc_abi_version() != ABI_VERSION:
+        raise ScarpletHipError("libscarplet_hip.so ABI %d != expected %d"
+                               % (lib.sc_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def _as(arr, ptr_type):
+    return arr.ctypes.data_as(ptr_type)
+
+
+class Context(object):
+    """One GPU's matcher state (an ``sc_ctx``)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        n = self.lib.sc_device_count()
+        if n <= 0:
+            raise ScarpletHipError(
+                "no HIP device visible: scarplet_amd needs an AMD GPU "
+                "(MI355X / gfx950); there is no CPU fallback")
+        self._h = _P()
+        rc = self.lib.sc_create(int(device), C.byref(self._h))
+        if rc != SC_OK:
+            raise ScarpletHipError("sc_create(device=%d) failed: %d"
+                                   % (device, rc))
+        self.device = int(device)
+        self.core = None
+
+    # -- plumbing ----------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != SC_OK:
+            msg = self.lib.sc_last_error(self._h)
+            raise ScarpletHipError("%s failed (%d): %s" % (
+                what, rc, msg.decode() if msg else ""))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.sc_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- DEM ----------------------------------------------------------------
+    def _dem_args(self, ly, lx, origin, shape, core, wrap):
+        ny, nx = shape
+        gy0, gx0 = origin
+        if core is None:
+            core = (0, ny, 0, nx)
+        self.core = tuple(int(v) for v in core)
+        self.shape = (int(ny), int(nx))
+        return [int(ly), int(lx), int(gy0), int(gx0), int(ny), int(nx)] \
+            + list(self.core)
+
+    def set_dem(self, z, dx, dy, xaxis, yaxis, origin=(0, 0), shape=None,
+                core=None, wrap=True):
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        ly, lx = z.shape
+        shape = z.shape if shape is None else shape
+        xa = np.ascontiguousarray(xaxis, dtype=np.float64)
+        ya = np.ascontiguousarray(yaxis, dtype=np.float64)
+        assert xa.size == shape[1] and ya.size == shape[0]
+        args = self._dem_args(ly, lx, origin, shape, core, wrap)
+        self._check(self.lib.sc_set_dem(
+            self._h, _as(z, _dp), *args, float(dx), float(dy), int(bool(wrap)),
+            _as(xa, _dp), _as(ya, _dp)), "sc_set_dem")
+
+    def set_dem_device(self, z_dev, ly, lx, dx, dy, xaxis, yaxis, origin,
+                       shape, core):
+        xa = np.ascontiguousarray(xaxis, dtype=np.float64)
+        ya = np.ascontiguousarray(yaxis, dtype=np.float64)
+        args = self._dem_args(ly, lx, origin, shape, core, False)
+        self._check(self.lib.sc_set_dem_device(
+            self._h, z_dev, *args, float(dx), float(dy), 0, _as(xa, _dp),
+            _as(ya, _dp)), "sc_set_dem_device")
+
+    def core_shape(self):
+        cy0, cy1, cx0, cx1 = self.core
+        return cy1 - cy0, cx1 - cx0
+
+    def curvature(self, cc, sc2, ss, block_shape):
+        out = np.empty(block_shape, dtype=np.float32)
+        self._check(self.lib.sc_curvature(self._h, cc, sc2, ss, _as(out, _fp)),
+                    "sc_curvature")
+        return out
+
+    # -- generic plugin windows --------------------------------------------
+    def upload_window(self, w):
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        slot = C.c_int(-1)
+        self._check(self.lib.sc_upload_window(
+            self._h, _as(w, _dp), w.shape[0], w.shape[1], C.byref(slot)),
+            "sc_upload_window")
+        return slot.value
+
+    def set_masks(self, slot, limits=None, err=None):
+        def conv(m):
+            if m is None:
+                return None, None
+            a = np.ascontiguousarray(m, dtype=np.uint8)
+            return a, _as(a, _bp)
+        la, lp = conv(limits)
+        ea, ep = conv(err)
+        self._check(self.lib.sc_set_masks(self._h, slot, lp, ep),
+                    "sc_set_masks")
+
+    def clear_windows(self):
+        self._check(self.lib.sc_clear_windows(self._h), "sc_clear_windows")
+
+    # -- hot path -----------------------------------------------------------
+    def reset_best(self):
+        self._check(self.lib.sc_reset_best(self._h), "sc_reset_best")
+
+    def match(self, templates, plan, sync=True):
+        fn = self.lib.sc_match if sync else self.lib.sc_match_async
+        self._check(fn(self._h, templates, len(templates), C.byref(plan)),
+                    "sc_match")
+
+    def sync(self):
+        self._check(self.lib.sc_sync(self._h), "sc_sync")
+
+    def match_template(self, template, plan):
+        h, w = self.core_shape()
+        amp = np.empty((h, w), dtype=np.float32)
+        snr = np.empty((h, w), dtype=np.float32)
+        self._check(self.lib.sc_match_template(
+            self._h, C.byref(template), C.byref(plan), _as(amp, _fp),
+            _as(snr, _fp)), "sc_match_template")
+        return amp, snr
+
+    def get_best(self):
+        h, w = self.core_shape()
+        amp = np.empty((h, w), dtype=np.float32)
+        snr = np.empty((h, w), dtype=np.float32)
+        idx = np.empty((h, w), dtype=np.uint32)
+        self._check(self.lib.sc_get_best(self._h, _as(amp, _fp), _as(snr, _fp),
+                                         _as(idx, _up)), "sc_get_best")
+        return amp, snr, idx
+
+    def template_sums(self, n):
+        a = np.empty(n)
+        b = np.empty(n)
+        self._check(self.lib.sc_get_template_sums(self._h, n, _as(a, _dp),
+                                                  _as(b, _dp)),
+                    "sc_get_template_sums")
+        return a, b
+
+    # -- measurement ----------------------------------------------------------
+    def profile(self, stride):
+        self._check(self.lib.sc_profile(self._h, int(stride)), "sc_profile")
+
+    def profile_get(self):
+        out = {}
+        for k, name in enumerate(K_NAMES):
+            n = C.c_longlong(0)
+            ms = C.c_double(0)
+            self._check(self.lib.sc_profile_get(self._h, k, C.byref(n),
+                                                C.byref(ms)), "sc_profile_get")
+            out[name] = (n.value, ms.value)
+        return out
+
+    def device_bytes(self):
+        return int(self.lib.sc_device_bytes(self._h))
+
+    # -- multi-GPU ------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        rc = self.lib.sc_comm_unique_id(buf)
+        if rc != SC_OK:
+            raise ScarpletHipError("sc_comm_unique_id failed: %d" % rc)
+        return buf.raw
+
+    def comm_init(self, uid, rank, nranks):
+        buf = C.create_string_buffer(bytes(uid), COMM_ID_BYTES)
+        self._check(self.lib.sc_comm_init(self._h, buf, rank, nranks),
+                    "sc_comm_init")
+
+    def halo_exchange(self, core, halo, xfers):
+        core = np.ascontiguousarray(core, dtype=np.float64)
+        arr = (sc_xfer * max(len(xfers), 1))()
+        for i, x in enumerate(xfers):
+            arr[i] = sc_xfer(*[int(v) for v in x])
+        z_dev = _P()
+        self._check(self.lib.sc_halo_exchange(
+            self._h, _as(core, _dp), core.shape[0], core.shape[1],
+            int(halo[0]), int(halo[1]), int(halo[2]), int(halo[3]), arr,
+            len(xfers), C.byref(z_dev)), "sc_halo_exchange")
+        return z_dev

@@ -1,0 +1,325 @@
+"""Template matching search drivers (host side) over the HIP engine.
+
+Drop-in for the reference's ``scarplet/core.py`` API on the hot path:
+
+    match(data, Template, **kwargs)                      core.py:266-294
+    calculate_best_fit_parameters(dem, Template, ...)    core.py:139-195
+    calculate_best_fit_parameters_serial(...)            core.py:65-136
+    match_template(data, Template, scale, age, angle)    core.py:297-377
+    compare(results, ny, nx)                             core.py:198-243
+    load(filename)                                       core.py:246-263
+
+Same names, arguments and return shapes.  What changed is where the work
+happens: the reference fans ``match_template`` out over a process pool, one
+full-size FFT convolution per (age, orientation), and folds the results on
+the host; here a search is ONE call into libscarplet_hip.so - every template
+becomes a small descriptor, the GPU synthesises the templates, correlates
+them against the curvature and keeps the per-cell best (amp, age, angle, snr)
+on the device.
+
+Differences a caller can observe (DESIGN.md "Parity"):
+  * amp / snr are computed in float32 on the device and returned as float64;
+  * templates are folded orientation-major (the reference's ``match`` folds
+    age-major); the two orders differ only where two templates tie exactly,
+    which in float arithmetic is rounding noise in the reference as well;
+  * a DEM with NaNs is rejected with ValueError (the reference returns
+    all-NaN maps): call ``data._fill_nodata()`` first, as ``load`` does.
+"""
+
+import numpy as np
+
+from scarplet_amd import _lib, _plan
+from scarplet_amd import WindowedTemplate as _WT
+from scarplet_amd.dem import DEMGrid
+
+__all__ = ["match", "match_template", "compare", "load",
+           "calculate_best_fit_parameters",
+           "calculate_best_fit_parameters_serial", "Matcher"]
+
+_CONTEXTS = {}
+
+
+def _context(device):
+    ctx = _CONTEXTS.get(device)
+    if ctx is None:
+        ctx = _lib.Context(device)
+        _CONTEXTS[device] = ctx
+    return ctx
+
+
+def _grid_of(data):
+    z = np.asarray(data._griddata)
+    if z.ndim != 2:
+        raise ValueError("data._griddata must be a 2-D array")
+    gi = data._georef_info
+    dx = float(gi.dx)
+    dy = float(gi.dy if gi.dy is not None else gi.dx)
+    return z, dx, dy
+
+
+class Matcher(object):
+    """A DEM resident on one GPU plus the running-best record of a search.
+
+    ``match`` & co. build one per call; benchmarks and multi-search workflows
+    keep one alive so the DEM stays in HBM."""
+
+    def __init__(self, data=None, device=0, ctx=None):
+        self.ctx = ctx if ctx is not None else _context(device)
+        self.templates = None
+        if data is not None:
+            self.set_data(data)
+
+    # -- DEM ------------------------------------------------------------------
+    def set_data(self, data):
+        z, dx, dy = _grid_of(data)
+        if np.isnan(z).any():
+            raise ValueError("DEM contains NaN cells; fill them first "
+                             "(DEMGrid._fill_nodata)")
+        self.ny, self.nx = z.shape
+        self.de = dx
+        self.dx, self.dy = dx, dy
+        self.core = (0, self.ny, 0, self.nx)
+        self.whole = True
+        self.ctx.set_dem(z, dx, dy, _WT.centred_axis(self.nx, dx),
+                         _WT.centred_axis(self.ny, dx))
+
+    def set_block(self, z_dev_or_host, origin, shape, core, dx, dy,
+                  block_shape=None):
+        """Multi-GPU: a halo-extended block of a larger DEM (dist.py)."""
+        self.ny, self.nx = shape
+        self.de = dx
+        self.dx, self.dy = dx, dy
+        self.core = tuple(core)
+        self.whole = False
+        xa = _WT.centred_axis(self.nx, dx)
+        ya = _WT.centred_axis(self.ny, dx)
+        if isinstance(z_dev_or_host, np.ndarray):
+            self.ctx.set_dem(z_dev_or_host, dx, dy, xa, ya, origin=origin,
+                             shape=shape, core=core, wrap=False)
+        else:
+            ly, lx = block_shape
+            self.ctx.set_dem_device(z_dev_or_host, ly, lx, dx, dy, xa, ya,
+                                    origin, shape, core)
+
+    # -- templates --------------------------------------------------------------
+    def describe(self, Template, scale, params, angles, **kwargs):
+        """Descriptors for the (param, angle) grid, orientation-major.
+        Returns (ctypes array, support bbox union, max taps)."""
+        n_par, n_ang = len(params), len(angles)
+        arr = (_lib.sc_template * (n_par * n_ang))()
+        boxes = []
+        k = 0
+        max_area = 0
+        for ib, ang in enumerate(angles):
+            cc, sc2, ss = _plan.curvature_coefficients(ang)
+            for ia, par in enumerate(params):
+                t = Template(scale, par, ang, self.nx, self.ny, self.de,
+                             **kwargs)
+                desc = t._device_descriptor() \
+                    if hasattr(t, "_device_descriptor") else None
+                if desc is None:
+                    desc = self._describe_generic(t)
+                s = arr[k]
+                s.kind, s.flags = desc["kind"], desc["flags"]
+                s.cos_a, s.sin_a = desc["cos_a"], desc["sin_a"]
+                s.c, s.d, s.p0, s.p1 = desc["c"], desc["d"], desc["p0"], desc["p1"]
+                s.cc, s.sc2, s.ss = cc, sc2, ss
+                s.ilo, s.ihi, s.jlo, s.jhi = desc["limits"]
+                s.pmin, s.pmax, s.qmin, s.qmax = desc["bbox"]
+                s.id = ia * n_ang + ib
+                s.window = desc.get("window", -1)
+                if s.pmax < s.pmin or s.qmax < s.qmin:
+                    # empty support: a 1-cell box of zeros keeps the kernels
+                    # uniform (W == 0 everywhere -> amp = nan/0 like numpy)
+                    s.pmin = s.pmax = s.qmin = s.qmax = 0
+                boxes.append((s.pmin, s.pmax, s.qmin, s.qmax))
+                max_area = max(max_area, (s.pmax - s.pmin + 1)
+                               * (s.qmax - s.qmin + 1))
+                k += 1
+        return arr, _plan.bbox_union(boxes), max_area
+
+    def _describe_generic(self, t):
+        """Any WindowedTemplate-like plugin: evaluate its numpy methods on the
+        host and upload the non-zero window and its masks
+        (plugin contract, core.py:345-346, 369-375)."""
+        W = np.asarray(t.template(), dtype=float)
+        if W.shape != (self.ny, self.nx):
+            raise ValueError("template() must return an (ny, nx) array")
+        nz = np.nonzero(W)
+        if nz[0].size == 0:
+            k0 = k1 = self.ny // 2
+            l0 = l1 = self.nx // 2
+        else:
+            k0, k1 = int(nz[0].min()), int(nz[0].max())
+            l0, l1 = int(nz[1].min()), int(nz[1].max())
+        win = W[k0:k1 + 1, l0:l1 + 1]
+        slot = self.ctx.upload_window(win)
+        lim = np.asarray(t.get_window_limits(), dtype=bool)
+        err = np.asarray(t.get_err_mask(), dtype=bool) \
+            if hasattr(t, "get_err_mask") else None
+        limits = (0, self.ny - 1, 0, self.nx - 1)
+        lim_mask = None
+        if lim.any():
+            keep_r = np.nonzero(~lim.all(axis=1))[0]
+            keep_c = np.nonzero(~lim.all(axis=0))[0]
+            rect = np.ones_like(lim)
+            if keep_r.size and keep_c.size:
+                rect[keep_r[0]:keep_r[-1] + 1, keep_c[0]:keep_c[-1] + 1] = False
+                limits = (int(keep_r[0]), int(keep_r[-1]),
+                          int(keep_c[0]), int(keep_c[-1]))
+            else:
+                limits = (0, -1, 0, -1)
+            if not np.array_equal(rect, lim):
+                lim_mask = lim
+        if lim_mask is not None or err is not None:
+            self.ctx.set_masks(slot, lim_mask, err)
+        alpha = getattr(t, "alpha", 0.0) or 0.0
+        return dict(kind=_WT.KIND_WINDOW, flags=0, cos_a=float(np.cos(alpha)),
+                    sin_a=float(np.sin(alpha)), c=0.0, d=0.0,
+                    p0=float(np.count_nonzero(win)),
+                    p1=float(np.sum(W ** 2)), limits=limits,
+                    bbox=(k0 - self.ny // 2, k1 - self.ny // 2,
+                          l0 - self.nx // 2, l1 - self.nx // 2), window=slot)
+
+    # -- planning -----------------------------------------------------------------
+    def plan_for(self, bbox, max_area, method="auto", group=1):
+        if method == "auto":
+            fft = _plan.Plan(self.ny, self.nx, self.core, bbox,
+                             whole=self.whole, method=_plan.METHOD_FFT)
+            n_cells = (self.core[1] - self.core[0]) * (self.core[3] - self.core[2])
+            method = "direct" if _plan.direct_cost(max_area) \
+                < _plan.fft_cost(fft, n_cells) else "fft"
+        m = _plan.METHOD_DIRECT if method == "direct" else _plan.METHOD_FFT
+        p = _plan.Plan(self.ny, self.nx, self.core, bbox, whole=self.whole,
+                       method=m, group=group)
+        sp = _lib.sc_plan(method=m, Ty=p.Ty, Tx=p.Tx, Vy=p.Vy, Vx=p.Vx,
+                          nty=p.nty, ntx=p.ntx, circ_y=int(p.circ_y),
+                          circ_x=int(p.circ_x), Py=p.Py, Qx=p.Qx, group=group)
+        return p, sp
+
+    # -- searches -------------------------------------------------------------------
+    def search(self, Template, scale, params, angles, method="auto", group=1,
+               reset=True, sync=True, **kwargs):
+        """Fold every (param, angle) template into the running best."""
+        params = np.atleast_1d(np.asarray(params, dtype=float))
+        angles = np.atleast_1d(np.asarray(angles, dtype=float))
+        arr, bbox, max_area = self.describe(Template, scale, params, angles,
+                                            **kwargs)
+        self.plan, sp = self.plan_for(bbox, max_area, method, group)
+        if reset:
+            self.ctx.reset_best()
+        self.ctx.match(arr, sp, sync=sync)
+        self.params, self.angles = params, angles
+        self.n_templates = len(arr)
+        return self
+
+    def result(self):
+        """(amp, age, angle, snr) float64 maps of the core region."""
+        amp, snr, idx = self.ctx.get_best()
+        n_ang = len(self.angles)
+        won = idx != _lib.ID_NONE
+        safe = np.where(won, idx, 0)
+        age = np.where(won, self.params[safe // n_ang], 0.0)
+        ang = np.where(won, self.angles[safe % n_ang], 0.0)
+        return (amp.astype(np.float64), age, ang, snr.astype(np.float64))
+
+    def match_template(self, Template, scale, age, angle, method="auto",
+                       **kwargs):
+        arr, bbox, max_area = self.describe(Template, scale, [age], [angle],
+                                            **kwargs)
+        self.plan, sp = self.plan_for(bbox, max_area, method)
+        amp, snr = self.ctx.match_template(arr[0], sp)
+        return amp.astype(np.float64), snr.astype(np.float64)
+
+
+# ------------------------------------------------------------------------------
+# reference API
+# ------------------------------------------------------------------------------
+def load(filename):
+    """Load a DEM and fill its nodata cells (core.py:246-263)."""
+    data = DEMGrid(filename)
+    data._fill_nodata()
+    return data
+
+
+def match_template(data, Template, scale, age, angle, **kwargs):
+    """Amplitude and SNR of one template at every cell (core.py:297-377).
+
+    Returns ``(amp, age, angle, snr)`` with ``age`` and ``angle`` the scalar
+    inputs, like the reference."""
+    opts = {k: kwargs.pop(k) for k in ("device", "method") if k in kwargs}
+    m = Matcher(data, device=opts.get("device", 0))
+    try:
+        amp, snr = m.match_template(Template, scale, age, angle,
+                                    method=opts.get("method", "auto"), **kwargs)
+    finally:
+        m.ctx.clear_windows()
+    return amp, age, angle, snr
+
+
+def calculate_best_fit_parameters(dem, Template, scale, age,
+                                  ang_max=np.pi / 2, ang_min=-np.pi / 2,
+                                  **kwargs):
+    """Best-fitting amplitude / orientation / SNR for one age over the
+    one-degree orientation grid (core.py:139-195).  Returns a (4, ny, nx)
+    array: amp, age, angle, snr.  Like the reference, extra keyword arguments
+    are accepted but not forwarded to the template (core.py:145, 182)."""
+    device = kwargs.pop("device", 0)
+    method = kwargs.pop("method", "auto")
+    m = Matcher(dem, device=device)
+    try:
+        m.search(Template, scale, [age], _plan.angle_grid(ang_min, ang_max),
+                 method=method)
+        return np.stack(m.result())
+    finally:
+        m.ctx.clear_windows()
+
+
+def calculate_best_fit_parameters_serial(dem, Template, scale,
+                                         ang_max=np.pi / 2,
+                                         ang_min=-np.pi / 2, **kwargs):
+    """Full (age, orientation) search, orientation-major, forwarding extra
+    keyword arguments to the template (core.py:65-136).  Returns the 4-tuple
+    (best_amp, best_age, best_angle, best_snr)."""
+    device = kwargs.pop("device", 0)
+    method = kwargs.pop("method", "auto")
+    m = Matcher(dem, device=device)
+    try:
+        m.search(Template, scale, _plan.age_grid(),
+                 _plan.angle_grid(ang_min, ang_max), method=method, **kwargs)
+        return m.result()
+    finally:
+        m.ctx.clear_windows()
+
+
+def match(data, Template, **kwargs):
+    """Match a template family to a DEM (core.py:266-294).
+
+    With ``age=``: one age, returns a (4, ny, nx) array.  Without: the 35-age
+    grid 10**arange(0, 3.5, 0.1), returns the 4-tuple (amp, age, angle, snr).
+    Keyword arguments: ``scale``, ``age``, ``ang_max``, ``ang_min`` as in the
+    reference, plus ``device=`` (GPU ordinal), ``method=`` ('auto', 'fft',
+    'direct') and ``ages=`` (override the age grid)."""
+    if 'age' in kwargs:
+        return calculate_best_fit_parameters(data, Template, **kwargs)
+    device = kwargs.pop("device", 0)
+    method = kwargs.pop("method", "auto")
+    ages = kwargs.pop("ages", None)
+    scale = kwargs.pop("scale")
+    ang_max = kwargs.pop("ang_max", np.pi / 2)
+    ang_min = kwargs.pop("ang_min", -np.pi / 2)
+    m = Matcher(data, device=device)
+    try:
+        m.search(Template, scale, _plan.age_grid() if ages is None else ages,
+                 _plan.angle_grid(ang_min, ang_max), method=method)
+        return m.result()
+    finally:
+        m.ctx.clear_windows()
+
+
+def compare(results, ny, nx):
+    """Fold an iterable of ``(amp, age, angle, snr)`` results into the
+    per-cell best by SNR (core.py:198-243): strict compares, a tie zeroes the
+    record, NaN is sticky.  Runs on the GPU (float64, like the reference)."""
+    from scarplet_amd import _fold
+    return _fold.compare(results, ny, nx)

@@ -1,0 +1,595 @@
+// C ABI of libscarplet_hip.so (include/scarplet_hip.h): context, DEM hand-over,
+// batching of templates into orientation runs, and measurement hooks.
+#include "sc_internal.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+int sc_fail(sc_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+int sc_ensure(sc_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return SC_OK;
+    if (b.p) {
+        SC_HIP(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    if (bytes == 0) bytes = 16;
+    SC_HIP(ctx, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return SC_OK;
+}
+
+static void buf_free(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+size_t sc_total_bytes(sc_ctx* c) {
+    DevBuf* arr[] = {&c->z, &c->xaxis, &c->yaxis, &c->A, &c->B, &c->C, &c->curv,
+                     &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
+                     &c->map_snr, &c->templ, &c->sums, &c->win_w, &c->win_m,
+                     &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh,
+                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage};
+    size_t s = 0;
+    for (DevBuf* b : arr) s += b->cap;
+    for (auto& w : c->windows) s += (size_t)w.h * w.wd * 5;
+    return s;
+}
+
+int sc_lds_attr(sc_ctx* ctx, const void* kernel, size_t bytes) {
+    auto it = ctx->lds_attr.find(kernel);
+    if (it != ctx->lds_attr.end() && it->second >= bytes) return SC_OK;
+    SC_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)bytes));
+    ctx->lds_attr[kernel] = bytes;
+    return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// profiling: HIP events on the context's stream around sampled launches
+// ---------------------------------------------------------------------------
+void sc_prof_begin(sc_ctx* ctx, int kernel) {
+    ctx->k_launches[kernel]++;
+    ctx->prof_cur = -1;
+    if (!ctx->prof) return;
+    if ((ctx->k_launches[kernel] - 1) % ctx->prof) return;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!ctx->ev_pool.empty()) {
+        ev = ctx->ev_pool.back();
+        ctx->ev_pool.pop_back();
+    } else {
+        if (hipEventCreate(&ev.first) != hipSuccess) return;
+        if (hipEventCreate(&ev.second) != hipSuccess) return;
+    }
+    (void)hipEventRecord(ev.first, ctx->stream);
+    ctx->prof_cur = kernel;
+    ctx->prof_ev0 = ev.first;
+    ctx->prof_ev1 = ev.second;
+}
+
+void sc_prof_end(sc_ctx* ctx) {
+    if (ctx->prof_cur < 0) return;
+    (void)hipEventRecord(ctx->prof_ev1, ctx->stream);
+    ctx->pending.push_back({ctx->prof_cur, {ctx->prof_ev0, ctx->prof_ev1}});
+    ctx->prof_cur = -1;
+}
+
+void sc_prof_collect(sc_ctx* ctx) {
+    for (auto& p : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
+            ctx->k_ms[p.first] += ms;
+            ctx->k_sampled[p.first]++;
+        }
+        ctx->ev_pool.push_back(p.second);
+    }
+    ctx->pending.clear();
+}
+
+// ---------------------------------------------------------------------------
+// lifetime
+// ---------------------------------------------------------------------------
+extern "C" int sc_abi_version(void) { return SC_ABI_VERSION; }
+
+extern "C" int sc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int sc_create(int device, sc_ctx** out) {
+    if (!out) return SC_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SC_ERR_HIP;
+    if (device < 0 || device >= n) return SC_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return SC_ERR_HIP;
+    sc_ctx* c = new sc_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return SC_ERR_HIP;
+    }
+    *out = c;
+    return SC_OK;
+}
+
+extern "C" int sc_clear_windows(sc_ctx* ctx) {
+    if (!ctx) return SC_ERR_INVALID;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& w : ctx->windows) {
+        if (w.w) (void)hipFree(w.w);
+        if (w.m) (void)hipFree(w.m);
+        if (w.mask_lim) (void)hipFree(w.mask_lim);
+        if (w.mask_err) (void)hipFree(w.mask_err);
+    }
+    ctx->windows.clear();
+    return SC_OK;
+}
+
+extern "C" void sc_destroy(sc_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    sc_comm_destroy(c);
+    sc_prof_collect(c);
+    for (auto& e : c->ev_pool) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    sc_clear_windows(c);
+    DevBuf* arr[] = {&c->z, &c->xaxis, &c->yaxis, &c->A, &c->B, &c->C, &c->curv,
+                     &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
+                     &c->map_snr, &c->templ, &c->sums, &c->win_w, &c->win_m,
+                     &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh,
+                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage};
+    for (DevBuf* b : arr) buf_free(*b);
+    for (int k = 0; k < 4; ++k) buf_free(c->cmp[k]);
+    for (int k = 0; k < 2; ++k) buf_free(c->cmp_in[k]);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* sc_last_error(sc_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : "null context";
+}
+
+extern "C" size_t sc_device_bytes(sc_ctx* ctx) { return ctx ? sc_total_bytes(ctx) : 0; }
+
+// ---------------------------------------------------------------------------
+// DEM hand-over
+// ---------------------------------------------------------------------------
+static int set_dem_common(sc_ctx* ctx, int ly, int lx, int gy0, int gx0, int ny,
+                          int nx, int cy0, int cy1, int cx0, int cx1, double dx,
+                          double dy, int wrap, const double* xaxis,
+                          const double* yaxis) {
+    if (ly < 3 || lx < 3 || ny < 3 || nx < 3 || !xaxis || !yaxis)
+        return sc_fail(ctx, SC_ERR_INVALID, "sc_set_dem: bad sizes or null axes");
+    if (cy0 < 0 || cy1 > ny || cx0 < 0 || cx1 > nx || cy0 >= cy1 || cx0 >= cx1)
+        return sc_fail(ctx, SC_ERR_INVALID, "sc_set_dem: bad core rectangle");
+    if (wrap && (ly != ny || lx != nx || gy0 != 0 || gx0 != 0))
+        return sc_fail(ctx, SC_ERR_INVALID, "sc_set_dem: wrap needs the whole DEM");
+    if (!wrap && (cy0 < gy0 || cy1 > gy0 + ly || cx0 < gx0 || cx1 > gx0 + lx))
+        return sc_fail(ctx, SC_ERR_INVALID, "sc_set_dem: core outside the block");
+    if (dx == 0.0 || dy == 0.0)
+        return sc_fail(ctx, SC_ERR_INVALID, "sc_set_dem: zero cell size");
+    Geom& g = ctx->g;
+    g.ly = ly; g.lx = lx; g.gy0 = gy0; g.gx0 = gx0; g.ny = ny; g.nx = nx;
+    g.cy0 = cy0; g.cy1 = cy1; g.cx0 = cx0; g.cx1 = cx1; g.wrap = wrap ? 1 : 0;
+    g.oy = ny % 2; g.ox = nx % 2;
+    ctx->dx = dx; ctx->dy = dy;
+    size_t nl = (size_t)ly * lx, nc = (size_t)(cy1 - cy0) * (cx1 - cx0);
+    int rc;
+    if ((rc = sc_ensure(ctx, ctx->xaxis, sizeof(double) * nx))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->yaxis, sizeof(double) * ny))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->A, sizeof(float) * nl))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->B, sizeof(float) * nl))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->C, sizeof(float) * nl))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->curv, sizeof(float) * nl))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->best_snr, sizeof(float) * nc))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->best_amp, sizeof(float) * nc))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->best_id, sizeof(uint32_t) * nc))) return rc;
+    SC_HIP(ctx, hipMemcpyAsync(ctx->xaxis.p, xaxis, sizeof(double) * nx,
+                               hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(ctx->yaxis.p, yaxis, sizeof(double) * ny,
+                               hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_curv_planes(ctx))) return rc;
+    ctx->have_dem = true;
+    if ((rc = sc_reset_best(ctx))) return rc;
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SC_OK;
+}
+
+extern "C" int sc_set_dem(sc_ctx* ctx, const double* z, int ly, int lx, int gy0,
+                          int gx0, int ny, int nx, int cy0, int cy1, int cx0,
+                          int cx1, double dx, double dy, int wrap,
+                          const double* xaxis, const double* yaxis) {
+    if (!ctx || !z) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    if (ly < 3 || lx < 3) return sc_fail(ctx, SC_ERR_INVALID, "sc_set_dem: block too small");
+    int rc = sc_ensure(ctx, ctx->z, sizeof(double) * (size_t)ly * lx);
+    if (rc) return rc;
+    SC_HIP(ctx, hipMemcpyAsync(ctx->z.p, z, sizeof(double) * (size_t)ly * lx,
+                               hipMemcpyHostToDevice, ctx->stream));
+    ctx->z_dev = (const double*)ctx->z.p;
+    return set_dem_common(ctx, ly, lx, gy0, gx0, ny, nx, cy0, cy1, cx0, cx1, dx,
+                          dy, wrap, xaxis, yaxis);
+}
+
+extern "C" int sc_set_dem_device(sc_ctx* ctx, const void* z_dev, int ly, int lx,
+                                 int gy0, int gx0, int ny, int nx, int cy0,
+                                 int cy1, int cx0, int cx1, double dx, double dy,
+                                 int wrap, const double* xaxis,
+                                 const double* yaxis) {
+    if (!ctx || !z_dev) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->z_dev = (const double*)z_dev;
+    return set_dem_common(ctx, ly, lx, gy0, gx0, ny, nx, cy0, cy1, cx0, cx1, dx,
+                          dy, wrap, xaxis, yaxis);
+}
+
+extern "C" int sc_curvature(sc_ctx* ctx, double cc, double sc2, double ss, float* out) {
+    if (!ctx || !out) return SC_ERR_INVALID;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = launch_curv_alpha(ctx, (float)cc, (float)sc2, (float)ss);
+    if (rc) return rc;
+    SC_HIP(ctx, hipMemcpyAsync(out, ctx->curv.p, sizeof(float) * (size_t)ctx->g.ly * ctx->g.lx,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// generic plugin windows
+// ---------------------------------------------------------------------------
+extern "C" int sc_upload_window(sc_ctx* ctx, const double* w, int h, int wd, int* slot) {
+    if (!ctx || !w || h <= 0 || wd <= 0 || !slot) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    size_t n = (size_t)h * wd;
+    std::vector<float> wf(n);
+    std::vector<uint8_t> wm(n);
+    for (size_t i = 0; i < n; ++i) {
+        wf[i] = (float)w[i];
+        wm[i] = (w[i] != 0.0) ? 1 : 0;
+    }
+    WindowSlot s;
+    s.h = h;
+    s.wd = wd;
+    SC_HIP(ctx, hipMalloc((void**)&s.w, n * sizeof(float)));
+    SC_HIP(ctx, hipMalloc((void**)&s.m, n));
+    SC_HIP(ctx, hipMemcpy(s.w, wf.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    SC_HIP(ctx, hipMemcpy(s.m, wm.data(), n, hipMemcpyHostToDevice));
+    ctx->windows.push_back(s);
+    *slot = (int)ctx->windows.size() - 1;
+    return SC_OK;
+}
+
+extern "C" int sc_set_masks(sc_ctx* ctx, int slot, const uint8_t* limits, const uint8_t* err) {
+    if (!ctx || slot < 0 || slot >= (int)ctx->windows.size()) return SC_ERR_INVALID;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WindowSlot& s = ctx->windows[slot];
+    size_t n = (size_t)ctx->g.ny * ctx->g.nx;
+    const uint8_t* src[2] = {limits, err};
+    uint8_t** dst[2] = {&s.mask_lim, &s.mask_err};
+    for (int k = 0; k < 2; ++k) {
+        if (*dst[k]) {
+            SC_HIP(ctx, hipFree(*dst[k]));
+            *dst[k] = nullptr;
+        }
+        if (src[k]) {
+            SC_HIP(ctx, hipMalloc((void**)dst[k], n));
+            SC_HIP(ctx, hipMemcpy(*dst[k], src[k], n, hipMemcpyHostToDevice));
+        }
+    }
+    return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// the hot path
+// ---------------------------------------------------------------------------
+extern "C" int sc_reset_best(sc_ctx* ctx) {
+    if (!ctx) return SC_ERR_INVALID;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
+    SC_HIP(ctx, hipMemsetAsync(ctx->best_snr.p, 0, sizeof(float) * nc, ctx->stream));
+    SC_HIP(ctx, hipMemsetAsync(ctx->best_amp.p, 0, sizeof(float) * nc, ctx->stream));
+    SC_HIP(ctx, hipMemsetAsync(ctx->best_id.p, 0xFF, sizeof(uint32_t) * nc, ctx->stream));
+    return SC_OK;
+}
+
+static int check_templates(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* plan) {
+    const Geom& g = ctx->g;
+    for (int i = 0; i < n; ++i) {
+        const sc_template& s = t[i];
+        if (s.kind < SC_KIND_SCARP || s.kind > SC_KIND_WINDOW)
+            return sc_fail(ctx, SC_ERR_INVALID, "template %d: unknown kind %d", i, s.kind);
+        if (s.pmax < s.pmin || s.qmax < s.qmin)
+            return sc_fail(ctx, SC_ERR_INVALID, "template %d: empty support box", i);
+        // support cells must exist on the ny x nx template grid
+        if (g.ny / 2 + s.pmin < 0 || g.ny / 2 + s.pmax >= g.ny ||
+            g.nx / 2 + s.qmin < 0 || g.nx / 2 + s.qmax >= g.nx)
+            return sc_fail(ctx, SC_ERR_INVALID, "template %d: support box leaves the grid", i);
+        if (s.kind == SC_KIND_WINDOW) {
+            if (s.window < 0 || s.window >= (int)ctx->windows.size())
+                return sc_fail(ctx, SC_ERR_INVALID, "template %d: bad window slot", i);
+            const WindowSlot& w = ctx->windows[s.window];
+            if (w.h != s.pmax - s.pmin + 1 || w.wd != s.qmax - s.qmin + 1)
+                return sc_fail(ctx, SC_ERR_INVALID, "template %d: window size mismatch", i);
+        }
+        if (plan->method == SC_METHOD_FFT) {
+            if (s.pmax > plan->Py || s.qmax > plan->Qx ||
+                plan->Py - s.pmin > plan->Ty - plan->Vy + (plan->circ_y ? plan->Ty : 0) ||
+                plan->Qx - s.qmin > plan->Tx - plan->Vx + (plan->circ_x ? plan->Tx : 0))
+                return sc_fail(ctx, SC_ERR_INVALID, "template %d: support exceeds the plan", i);
+            if (s.pmax - s.pmin >= plan->Ty || s.qmax - s.qmin >= plan->Tx)
+                return sc_fail(ctx, SC_ERR_INVALID, "template %d: support exceeds the tile", i);
+        }
+    }
+    return SC_OK;
+}
+
+static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* plan,
+                      bool to_maps) {
+    if (!ctx || !t || !plan || n <= 0) return SC_ERR_INVALID;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    if (plan->method != SC_METHOD_DIRECT && plan->method != SC_METHOD_FFT)
+        return sc_fail(ctx, SC_ERR_INVALID, "unknown method %d", plan->method);
+    int rc = check_templates(ctx, t, n, plan);
+    if (rc) return rc;
+    const Geom& g = ctx->g;
+    FftGeom fg{};
+    const int group = std::max(1, plan->group);
+    const int CHUNK = 64;
+    if (plan->method == SC_METHOD_FFT) {
+        fg.Ty = plan->Ty; fg.Tx = plan->Tx; fg.Vy = plan->Vy; fg.Vx = plan->Vx;
+        fg.nty = plan->nty; fg.ntx = plan->ntx; fg.circ_y = plan->circ_y;
+        fg.circ_x = plan->circ_x; fg.Py = plan->Py; fg.Qx = plan->Qx;
+        fg.ntiles = fg.nty * fg.ntx;
+        if (fg.nty < 1 || fg.ntx < 1 || fg.Vy < 1 || fg.Vx < 1)
+            return sc_fail(ctx, SC_ERR_INVALID, "bad tile plan");
+        if ((fg.circ_y && (fg.Ty != g.ny || !g.wrap || fg.nty != 1)) ||
+            (fg.circ_x && (fg.Tx != g.nx || !g.wrap || fg.ntx != 1)))
+            return sc_fail(ctx, SC_ERR_INVALID, "circular axis needs T == n and the whole DEM");
+        if ((long long)fg.nty * fg.Vy < g.cy1 - g.cy0 || (long long)fg.ntx * fg.Vx < g.cx1 - g.cx0)
+            return sc_fail(ctx, SC_ERR_INVALID, "tiles do not cover the core");
+        if ((rc = fft_prepare(ctx, fg, std::min(n, CHUNK), group))) return rc;
+    }
+    if (to_maps) {
+        size_t nc = (size_t)(g.cy1 - g.cy0) * (g.cx1 - g.cx0);
+        if ((rc = sc_ensure(ctx, ctx->map_amp, sizeof(float) * nc))) return rc;
+        if ((rc = sc_ensure(ctx, ctx->map_snr, sizeof(float) * nc))) return rc;
+    }
+
+    // device descriptors for the whole batch; windows are laid out per chunk
+    std::vector<TemplDev> h(n);
+    std::vector<double> sums(2 * (size_t)n, 0.0);
+    struct Chunk { int first, n, wh, ww; size_t cells; };
+    std::vector<Chunk> chunks;
+    size_t max_cells = 0;
+    for (int i = 0; i < n;) {
+        int j = i;
+        size_t off = 0;
+        int wh = 0, ww = 0;
+        while (j < n && j - i < CHUNK && t[j].cc == t[i].cc && t[j].sc2 == t[i].sc2 &&
+               t[j].ss == t[i].ss) {
+            const sc_template& s = t[j];
+            TemplDev& d = h[j];
+            d.kind = s.kind; d.flags = s.flags;
+            d.cos_a = s.cos_a; d.sin_a = s.sin_a; d.c = s.c; d.d = s.d;
+            d.p0 = s.p0; d.p1 = s.p1;
+            d.ilo = s.ilo; d.ihi = s.ihi; d.jlo = s.jlo; d.jhi = s.jhi;
+            if (s.flags & SC_FLAG_NO_LIMITS) { d.ilo = 0; d.ihi = g.ny - 1; d.jlo = 0; d.jhi = g.nx - 1; }
+            d.pmin = s.pmin; d.pmax = s.pmax; d.qmin = s.qmin; d.qmax = s.qmax;
+            d.id = s.id;
+            d.wh = s.pmax - s.pmin + 1;
+            d.ww = s.qmax - s.qmin + 1;
+            d.win_off = (long long)off;
+            d.mask_lim = nullptr; d.mask_err = nullptr;
+            if (s.kind == SC_KIND_WINDOW) {
+                d.mask_lim = ctx->windows[s.window].mask_lim;
+                d.mask_err = ctx->windows[s.window].mask_err;
+                sums[2 * (size_t)j] = s.p0;
+                sums[2 * (size_t)j + 1] = s.p1;
+            }
+            off += (size_t)d.wh * d.ww;
+            off = (off + 3) & ~(size_t)3;
+            wh = std::max(wh, d.wh);
+            ww = std::max(ww, d.ww);
+            ++j;
+        }
+        chunks.push_back({i, j - i, wh, ww, off});
+        max_cells = std::max(max_cells, off);
+        i = j;
+    }
+    if ((rc = sc_ensure(ctx, ctx->templ, sizeof(TemplDev) * n))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->sums, sizeof(double) * 2 * n))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->win_w, sizeof(float) * max_cells))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->win_m, max_cells))) return rc;
+    SC_HIP(ctx, hipMemcpyAsync(ctx->templ.p, h.data(), sizeof(TemplDev) * n,
+                               hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(ctx->sums.p, sums.data(), sizeof(double) * 2 * n,
+                               hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));   // h / sums leave scope below
+    ctx->last_batch = n;
+
+    double cur[3] = {0, 0, 0};
+    bool have_curv = false;
+    for (const Chunk& c : chunks) {
+        const sc_template& s0 = t[c.first];
+        if (!have_curv || s0.cc != cur[0] || s0.sc2 != cur[1] || s0.ss != cur[2]) {
+            if ((rc = launch_curv_alpha(ctx, (float)s0.cc, (float)s0.sc2, (float)s0.ss))) return rc;
+            if (plan->method == SC_METHOD_FFT && (rc = fft_forward_curv(ctx, fg))) return rc;
+            cur[0] = s0.cc; cur[1] = s0.sc2; cur[2] = s0.ss;
+            have_curv = true;
+        }
+        for (int j = c.first; j < c.first + c.n; ++j) {
+            if (t[j].kind != SC_KIND_WINDOW) continue;
+            const WindowSlot& w = ctx->windows[t[j].window];
+            size_t cells = (size_t)w.h * w.wd;
+            SC_HIP(ctx, hipMemcpyAsync((float*)ctx->win_w.p + h[j].win_off, w.w,
+                                       cells * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+            SC_HIP(ctx, hipMemcpyAsync((uint8_t*)ctx->win_m.p + h[j].win_off, w.m, cells,
+                                       hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        if ((rc = launch_windows(ctx, c.first, c.n, c.wh, c.ww))) return rc;
+        if (plan->method == SC_METHOD_DIRECT) {
+            if ((rc = launch_direct(ctx, c.first, c.n, to_maps))) return rc;
+        } else {
+            if ((rc = fft_forward_templates(ctx, fg, c.first, c.n))) return rc;
+            bool full = false;
+            for (int j = c.first; j < c.first + c.n; ++j)
+                full |= (h[j].flags & (SC_FLAG_ERR_XR_LE0 | SC_FLAG_ERR_XR_GE0)) != 0 ||
+                        h[j].mask_lim != nullptr || h[j].mask_err != nullptr;
+            if ((rc = fft_inverse_fold(ctx, fg, c.first, c.n, group, to_maps, full))) return rc;
+        }
+    }
+    return SC_OK;
+}
+
+extern "C" int sc_match_async(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* plan) {
+    return match_impl(ctx, t, n, plan, false);
+}
+
+extern "C" int sc_sync(sc_ctx* ctx) {
+    if (!ctx) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    sc_prof_collect(ctx);
+    return SC_OK;
+}
+
+extern "C" int sc_match(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* plan) {
+    int rc = match_impl(ctx, t, n, plan, false);
+    if (rc) return rc;
+    return sc_sync(ctx);
+}
+
+extern "C" int sc_match_template(sc_ctx* ctx, const sc_template* t, const sc_plan* plan,
+                                 float* amp, float* snr) {
+    if (!amp || !snr) return SC_ERR_INVALID;
+    int rc = match_impl(ctx, t, 1, plan, true);
+    if (rc) return rc;
+    size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
+    SC_HIP(ctx, hipMemcpyAsync(amp, ctx->map_amp.p, sizeof(float) * nc, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(snr, ctx->map_snr.p, sizeof(float) * nc, hipMemcpyDeviceToHost, ctx->stream));
+    return sc_sync(ctx);
+}
+
+extern "C" int sc_get_best(sc_ctx* ctx, float* amp, float* snr, uint32_t* id) {
+    if (!ctx || !amp || !snr || !id) return SC_ERR_INVALID;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
+    SC_HIP(ctx, hipMemcpyAsync(amp, ctx->best_amp.p, sizeof(float) * nc, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(snr, ctx->best_snr.p, sizeof(float) * nc, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(id, ctx->best_id.p, sizeof(uint32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
+    return sc_sync(ctx);
+}
+
+extern "C" int sc_get_template_sums(sc_ctx* ctx, int n, double* n_out, double* ts_out) {
+    if (!ctx || !n_out || !ts_out || n <= 0 || n > ctx->last_batch) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<double> h(2 * (size_t)n);
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SC_HIP(ctx, hipMemcpy(h.data(), ctx->sums.p, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        n_out[i] = h[2 * (size_t)i] + SC_EPS;
+        ts_out[i] = h[2 * (size_t)i + 1];
+    }
+    return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// compare() on host results
+// ---------------------------------------------------------------------------
+extern "C" int sc_compare_begin(sc_ctx* ctx, int ny, int nx) {
+    if (!ctx || ny <= 0 || nx <= 0) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    size_t n = (size_t)ny * nx;
+    int rc;
+    for (int k = 0; k < 4; ++k) {
+        if ((rc = sc_ensure(ctx, ctx->cmp[k], sizeof(double) * n))) return rc;
+        SC_HIP(ctx, hipMemsetAsync(ctx->cmp[k].p, 0, sizeof(double) * n, ctx->stream));
+    }
+    for (int k = 0; k < 2; ++k)
+        if ((rc = sc_ensure(ctx, ctx->cmp_in[k], sizeof(double) * n))) return rc;
+    ctx->cmp_n = n;
+    return SC_OK;
+}
+
+extern "C" int sc_compare_fold(sc_ctx* ctx, const double* amp, const double* snr,
+                               double age, double angle) {
+    if (!ctx || !amp || !snr || ctx->cmp_n == 0) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    size_t bytes = sizeof(double) * ctx->cmp_n;
+    SC_HIP(ctx, hipMemcpyAsync(ctx->cmp_in[0].p, amp, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(ctx->cmp_in[1].p, snr, bytes, hipMemcpyHostToDevice, ctx->stream));
+    int rc = launch_compare_fold(ctx, age, angle);
+    if (rc) return rc;
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SC_OK;
+}
+
+extern "C" int sc_compare_end(sc_ctx* ctx, double* amp, double* age, double* angle, double* snr) {
+    if (!ctx || !amp || !age || !angle || !snr || ctx->cmp_n == 0) return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    size_t bytes = sizeof(double) * ctx->cmp_n;
+    double* out[4] = {amp, age, angle, snr};
+    for (int k = 0; k < 4; ++k)
+        SC_HIP(ctx, hipMemcpyAsync(out[k], ctx->cmp[k].p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cmp_n = 0;
+    return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// measurement
+// ---------------------------------------------------------------------------
+extern "C" int sc_profile(sc_ctx* ctx, int enable) {
+    if (!ctx) return SC_ERR_INVALID;
+    sc_prof_collect(ctx);
+    ctx->prof = enable < 0 ? 0 : enable;
+    for (int k = 0; k < SC_K_COUNT; ++k) {
+        ctx->k_launches[k] = 0;
+        ctx->k_sampled[k] = 0;
+        ctx->k_ms[k] = 0.0;
+    }
+    return SC_OK;
+}
+
+extern "C" int sc_profile_get(sc_ctx* ctx, int kernel, long long* launches, double* total_ms) {
+    if (!ctx || kernel < 0 || kernel >= SC_K_COUNT) return SC_ERR_INVALID;
+    sc_prof_collect(ctx);
+    if (launches) *launches = ctx->k_launches[kernel];
+    if (total_ms) {
+        // sampled mean duration times the number of launches
+        double mean = ctx->k_sampled[kernel] ? ctx->k_ms[kernel] / (double)ctx->k_sampled[kernel] : 0.0;
+        *total_ms = mean * (double)ctx->k_launches[kernel];
+    }
+    return SC_OK;
+}
+
+extern "C" const char* sc_kernel_name(int kernel) {
+    static const char* names[SC_K_COUNT] = {"k_curv", "k_windows", "k_direct", "k_fwd_rows",
+                                            "k_fwd_cols", "k_inv_cols", "k_inv_rows"};
+    return (kernel >= 0 && kernel < SC_K_COUNT) ? names[kernel] : "?";
+}

@@ -1,0 +1,219 @@
+// Internal declarations shared by the translation units of libscarplet_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <limits.h>
+#include "../../include/scarplet_hip.h"
+
+#define SC_EPS 2.220446049250313e-16      // np.spacing(1), core.py:340
+#define SC_EXP_UNDERFLOW 745.1332191019412 // exp(-u) != 0  <=>  u < 1075 ln 2
+
+// Device-side view of one template of the current batch.
+struct TemplDev {
+    int32_t kind, flags;
+    double cos_a, sin_a, c, d, p0, p1;
+    int32_t ilo, ihi, jlo, jhi;
+    int32_t pmin, pmax, qmin, qmax;
+    uint32_t id;
+    int32_t wh, ww;            // window (bbox) height / width
+    long long win_off;         // element offset of the window in win_w / win_m
+    const uint8_t* mask_lim;   // optional explicit masks (generic plugins)
+    const uint8_t* mask_err;
+};
+
+// Geometry of the block held by a context, passed by value to kernels.
+struct Geom {
+    int ly, lx;        // local block
+    int gy0, gx0;      // global index of local (0,0)
+    int ny, nx;        // DEM size
+    int cy0, cy1, cx0, cx1;   // core
+    int wrap;
+    int oy, ox;        // ny % 2, nx % 2
+};
+
+struct FftGeom {
+    int Ty, Tx, Vy, Vx, nty, ntx, circ_y, circ_x, Py, Qx;
+    int ntiles;        // nty * ntx
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct WindowSlot {
+    float* w = nullptr;        // h x wd float32
+    uint8_t* m = nullptr;      // h x wd
+    int h = 0, wd = 0;
+    uint8_t* mask_lim = nullptr;
+    uint8_t* mask_err = nullptr;
+};
+
+struct sc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool have_dem = false;
+    Geom g{};
+    double dx = 1, dy = 1;
+    DevBuf z, xaxis, yaxis, A, B, C, curv;
+    bool z_borrowed = false;
+    const double* z_dev = nullptr;
+    DevBuf best_snr, best_amp, best_id;
+    DevBuf map_amp, map_snr;
+    DevBuf cmp[4], cmp_in[2];   // sc_compare_*: amp, age, angle, snr (float64)
+    size_t cmp_n = 0;
+    DevBuf templ, sums, win_w, win_m;
+    DevBuf tw_y, tw_x;
+    int tw_Ty = 0, tw_Tx = 0;
+    DevBuf blk, uc, uc2, vh, yw, ym, tiles;
+    std::vector<WindowSlot> windows;
+    int last_batch = 0;
+    // profiling
+    int prof = 0;              // 0 off, k: time every k-th launch of a kernel
+    int prof_cur = -1;         // kernel being bracketed (-1: not sampled)
+    hipEvent_t prof_ev0 = nullptr, prof_ev1 = nullptr;
+    long long k_launches[SC_K_COUNT] = {0};
+    long long k_sampled[SC_K_COUNT] = {0};
+    double k_ms[SC_K_COUNT] = {0};
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::map<const void*, size_t> lds_attr;
+    // comm
+    void* comm = nullptr;      // ncclComm_t
+    int rank = 0, nranks = 1;
+    DevBuf halo_z, halo_stage;
+};
+
+int sc_fail(sc_ctx* ctx, int code, const char* fmt, ...);
+int sc_ensure(sc_ctx* ctx, DevBuf& b, size_t bytes);
+size_t sc_total_bytes(sc_ctx* ctx);
+// raise a kernel's dynamic-LDS limit once (cached per kernel)
+int sc_lds_attr(sc_ctx* ctx, const void* kernel, size_t bytes);
+
+#define SC_HIP(ctx, call)                                                     \
+    do {                                                                      \
+        hipError_t e__ = (call);                                              \
+        if (e__ != hipSuccess)                                                \
+            return sc_fail(ctx, SC_ERR_HIP, "%s: %s (%s:%d)", #call,          \
+                           hipGetErrorString(e__), __FILE__, __LINE__);       \
+    } while (0)
+
+// profiling brackets around kernel launches
+void sc_prof_begin(sc_ctx* ctx, int kernel);
+void sc_prof_end(sc_ctx* ctx);
+void sc_prof_collect(sc_ctx* ctx);
+
+// ---- launchers implemented in sc_kernels.hip --------------------------------
+int launch_curv_planes(sc_ctx* ctx);
+int launch_curv_alpha(sc_ctx* ctx, float cc, float sc2, float ss);
+int launch_windows(sc_ctx* ctx, int first, int n, int wh_max, int ww_max);
+int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps);
+int launch_compare_fold(sc_ctx* ctx, double age, double angle);
+
+// ---- launchers implemented in sc_fft.hip ------------------------------------
+int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group);
+int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg);
+int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n);
+int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
+                     int group, bool to_maps, bool full_masks);
+bool fft_size_supported(int T);
+
+// ---- device helpers shared by both paths -------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ int wrap_index(int g, int n) {
+    g %= n;
+    return g < 0 ? g + n : g;
+}
+
+// curvature at GLOBAL cell (gi, gj) of the block held by the context: modulo
+// the DEM size when the block is the whole periodic DEM, otherwise relative to
+// the block origin (cells outside the block only feed discarded outputs).
+__device__ __forceinline__ float load_curv(const float* __restrict__ curv,
+                                           const Geom& g, int gi, int gj) {
+    int li, lj;
+    if (g.wrap) {
+        li = wrap_index(gi, g.ny);
+        lj = wrap_index(gj, g.nx);
+    } else {
+        li = gi - g.gy0;
+        lj = gj - g.gx0;
+        if (li < 0 || li >= g.ly || lj < 0 || lj >= g.lx) return 0.f;
+    }
+    return curv[(size_t)li * g.lx + lj];
+}
+
+// Per-template scalars of the epilogue, prepared once per template.
+struct EpiScal {
+    float inv_ts;      // 1 / sum(W**2)                       (core.py:356)
+    float inv_n;       // 1 / (count(W != 0) + eps)           (core.py:350)
+};
+__device__ __forceinline__ EpiScal sc_epi_scalars(const double* __restrict__ sums, int it) {
+    EpiScal s;
+    s.inv_n = (float)(1.0 / (sums[2 * it] + SC_EPS));
+    s.inv_ts = (float)(1.0 / sums[2 * it + 1]);
+    return s;
+}
+
+// FFT path: W and M = (W != 0) ride in ONE complex transform (W + iM) and are
+// separated afterwards as (v[f] +- conj v[-f])/2.  In float32 that difference
+// is only as accurate as the LARGER of the two spectra, and sum(M^2) = n is
+// 10^3..10^6 times sum(W^2); so W is scaled by alpha = sqrt(n / sum W^2) to
+// the same energy before the transform and divided out again after the inverse transform.
+__device__ __forceinline__ float sc_fft_alpha(const double* __restrict__ sums, int it) {
+    double n = sums[2 * it], ts = sums[2 * it + 1];
+    return (n > 0.0 && ts > 0.0) ? (float)sqrt(n / ts) : 1.0f;
+}
+// core.py:360-367 for one cell.  The reference forms
+//   amp = xcorr/ts, T1 = ts*amp**2, error = (T1 - 2*amp*xcorr + T3)/n + eps,
+//   snr = |T1/error|;  T1 - 2*amp*xcorr is -T1, so error = (T3 - T1)/n + eps.
+// float32 here: xcorr and T3 arrive as float32 sums, and the cancellation in
+// T3 - T1 amplifies THEIR rounding, not the epilogue's.
+__device__ __forceinline__ void sc_epilogue(float xc, float t3, const EpiScal& s,
+                                            float& amp_out, float& snr_out) {
+    float amp = xc * s.inv_ts;
+    float T1 = xc * amp;
+    float err = (t3 - T1) * s.inv_n + (float)SC_EPS;
+    amp_out = amp;
+    snr_out = fabsf(__fdividef(T1, err));
+}
+
+// masks of core.py:369-375 for global cell (gi, gj)
+__device__ __forceinline__ void sc_apply_masks(const TemplDev& t, const Geom& g,
+                                               const double* __restrict__ xaxis,
+                                               const double* __restrict__ yaxis,
+                                               int gi, int gj, float& amp,
+                                               float& snr) {
+    if (t.flags & (SC_FLAG_ERR_XR_LE0 | SC_FLAG_ERR_XR_GE0)) {
+        double xr = __dadd_rn(__dmul_rn(xaxis[gj], t.cos_a),
+                              __dmul_rn(yaxis[gi], t.sin_a));
+        bool m = (t.flags & SC_FLAG_ERR_XR_LE0) ? (xr <= 0.0) : (xr >= 0.0);
+        if (m) snr = 0.f;
+    }
+    if (t.mask_err && t.mask_err[(size_t)gi * g.nx + gj]) snr = 0.f;
+    bool keep = gi >= t.ilo && gi <= t.ihi && gj >= t.jlo && gj <= t.jhi;
+    if (t.mask_lim && t.mask_lim[(size_t)gi * g.nx + gj]) keep = false;
+    if (!keep) { amp = 0.f; snr = 0.f; }
+}
+
+// One step of compare() (core.py:230-240) on a (snr, amp, id) record.
+__device__ __forceinline__ bool sc_fold(float& b_snr, float& b_amp,
+                                        uint32_t& b_id, float t_snr,
+                                        float t_amp, uint32_t t_id) {
+    if (b_snr > t_snr) return false;              // keep
+    if (b_snr < t_snr) {                          // take
+        b_snr = t_snr; b_amp = t_amp; b_id = t_id;
+        return true;
+    }
+    // equal, or a NaN on either side: both compares false -> 0*x + 0*y
+    bool nan = (b_snr != b_snr) || (t_snr != t_snr);
+    bool changed = nan ? true : (b_snr != 0.f || b_amp != 0.f || b_id != SC_ID_NONE);
+    b_snr = nan ? __builtin_nanf("") : 0.f;
+    b_amp = 0.f;
+    b_id = SC_ID_NONE;
+    return changed;
+}
+#endif

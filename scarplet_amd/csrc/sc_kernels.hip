@@ -1,0 +1,368 @@
+// Curvature stencils, template-window synthesis and the real-space
+// (sliding window) matcher.  gfx950 only.
+#include "sc_internal.h"
+#include <algorithm>
+
+// ---------------------------------------------------------------------------
+// K1: the three alpha-independent curvature stencils (dem.py:88-101).
+// float64 in (the reference differences float64 elevations), float32 out.
+// Borders follow the GLOBAL cell index: d2z/dx2 is zero in the first and last
+// DEM column, d2z/dxdy in the first row/column, d2z/dy2 in the first and last
+// row.  One thread per cell, rows of the block are read as coalesced float64.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_curv_planes(const double* __restrict__ z, Geom g, double dx, double dy,
+              float* __restrict__ A, float* __restrict__ B,
+              float* __restrict__ C) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.y;
+    if (j >= g.lx) return;
+    int gi = wrap_index(g.gy0 + i, g.ny);
+    int gj = wrap_index(g.gx0 + j, g.nx);
+    // neighbours inside the local block (clamped: cells whose neighbour is
+    // missing lie in the outermost ring of a halo block and are never used)
+    int im = max(i - 1, 0), ip = min(i + 1, g.ly - 1);
+    int jm = max(j - 1, 0), jp = min(j + 1, g.lx - 1);
+    const double* r0 = z + (size_t)im * g.lx;
+    const double* r1 = z + (size_t)i * g.lx;
+    const double* r2 = z + (size_t)ip * g.lx;
+    double z11 = r1[j];
+    double a = 0.0, b = 0.0, c = 0.0;
+    if (gj >= 1 && gj <= g.nx - 2)          // np.diff(z, 2, 1) / dx**2
+        a = __ddiv_rn(__dsub_rn(__dsub_rn(r1[jp], z11), __dsub_rn(z11, r1[jm])),
+                      __dmul_rn(dx, dx));
+    if (gi >= 1 && gj >= 1) {               // np.diff(np.diff(z,1,1)/dx,1,0)/dx
+        double d1 = __ddiv_rn(__dsub_rn(z11, r1[jm]), dx);
+        double d0 = __ddiv_rn(__dsub_rn(r0[j], r0[jm]), dx);
+        b = __ddiv_rn(__dsub_rn(d1, d0), dx);
+    }
+    if (gi >= 1 && gi <= g.ny - 2)          // np.diff(z, 2, 0) / dy**2
+        c = __ddiv_rn(__dsub_rn(__dsub_rn(r2[j], z11), __dsub_rn(z11, r0[j])),
+                      __dmul_rn(dy, dy));
+    size_t o = (size_t)i * g.lx + j;
+    A[o] = (float)a;
+    B[o] = (float)b;
+    C[o] = (float)c;
+}
+
+// curv = cc*A - sc2*B + ss*C (dem.py:103-104), float4 per thread.
+__global__ void __launch_bounds__(256)
+k_curv_alpha(const float* __restrict__ A, const float* __restrict__ B,
+             const float* __restrict__ C, float cc, float sc2, float ss,
+             float* __restrict__ out, size_t n) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (; i < n; i += stride) {
+        if (i + 3 < n) {
+            float4 a = *reinterpret_cast<const float4*>(A + i);
+            float4 b = *reinterpret_cast<const float4*>(B + i);
+            float4 c = *reinterpret_cast<const float4*>(C + i);
+            float4 o;
+            o.x = cc * a.x - sc2 * b.x + ss * c.x;
+            o.y = cc * a.y - sc2 * b.y + ss * c.y;
+            o.z = cc * a.z - sc2 * b.z + ss * c.z;
+            o.w = cc * a.w - sc2 * b.w + ss * c.w;
+            *reinterpret_cast<float4*>(out + i) = o;
+        } else {
+            for (size_t k = i; k < n; ++k)
+                out[k] = cc * A[k] - sc2 * B[k] + ss * C[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2: template windows.  For every cell of a template's support bounding box
+// evaluate, in float64 and with the reference's operation order, the rotated
+// coordinates (WindowedTemplate.py:56-57), the window test (l.63) and the
+// profile (Scarp l.177-178, Ricker l.514-515), and write the dense window
+// W (float32) and M = (W != 0) (uint8).  count(M) and sum(W**2) are reduced
+// per wave and added with one float64 atomic per wave.
+// grid = (ceil(ww_max/64), wh_max, n_templates), block = 64 (one wave).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_windows(const TemplDev* __restrict__ templ, int first,
+          const double* __restrict__ xaxis, const double* __restrict__ yaxis,
+          int ny, int nx, float* __restrict__ win_w,
+          uint8_t* __restrict__ win_m, double* __restrict__ sums) {
+    const int it = first + blockIdx.z;
+    const TemplDev t = templ[it];
+    if (t.kind == SC_KIND_WINDOW) return;         // uploaded by the host
+    int a = blockIdx.y;
+    int b = blockIdx.x * 64 + threadIdx.x;
+    double cnt = 0.0, sq = 0.0;
+    if (a < t.wh && b < t.ww) {
+        int k = ny / 2 + t.pmin + a;
+        int l = nx / 2 + t.qmin + b;
+        double x = xaxis[l], y = yaxis[k];
+        double xr = __dadd_rn(__dmul_rn(x, t.cos_a), __dmul_rn(y, t.sin_a));
+        double yr = __dadd_rn(__dmul_rn(-x, t.sin_a), __dmul_rn(y, t.cos_a));
+        bool inside = (fabs(xr) < t.c) && (fabs(yr) < t.d);
+        double w = 0.0;
+        bool m = false;
+        if (inside) {
+            if (t.kind == SC_KIND_SCARP) {
+                w = __dmul_rn(__ddiv_rn(-xr, t.p0),
+                              exp(__ddiv_rn(-__dmul_rn(xr, xr), t.p1)));
+                m = (xr != 0.0);
+            } else {
+                double u = __dmul_rn(t.p0, xr);
+                double u2 = __dmul_rn(u, u);
+                double poly = __dsub_rn(1.0, __dmul_rn(2.0, u2));
+                m = (u2 < SC_EXP_UNDERFLOW) && (poly != 0.0);
+                w = m ? __dmul_rn(poly, exp(-u2)) : 0.0;
+            }
+            if (!m) w = 0.0;
+            if (t.flags & SC_FLAG_NEGATE) w = -w;
+        }
+        size_t o = (size_t)t.win_off + (size_t)a * t.ww + b;
+        win_w[o] = (float)w;
+        win_m[o] = m ? 1 : 0;
+        cnt = m ? 1.0 : 0.0;
+        sq = w * w;
+    }
+    for (int s = 32; s > 0; s >>= 1) {
+        cnt += __shfl_down(cnt, s, 64);
+        sq += __shfl_down(sq, s, 64);
+    }
+    if (threadIdx.x == 0 && (cnt != 0.0 || sq != 0.0)) {
+        atomicAdd(&sums[2 * it + 0], cnt);
+        atomicAdd(&sums[2 * it + 1], sq);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3 (real-space): sliding-window correlation of a batch of templates that
+// share one curvature plane, with the amp/SNR epilogue and the running-best
+// fold fused.  A workgroup owns a TY x TX patch of output cells and stages
+// the curvature it needs in LDS in slabs of template rows:
+//
+//   for each template t of the batch (all read the same curvature plane)
+//     for each slab of SR template rows
+//       LDS <- curvature rows/cols the patch needs for these template rows
+//       every thread accumulates its PX cells:  xc += W*c,  t3 += M*c*c
+//     epilogue (float64) + masks + fold into the thread's running best
+//   one read-modify-write of the best planes per cell
+//
+// Curvature rows are loaded as coalesced float runs; window taps are
+// wave-uniform (scalar loads); each thread keeps PX adjacent outputs so an
+// LDS value is reused PX times from registers.
+// ---------------------------------------------------------------------------
+#define DR_TX 64          // patch width  (cells)
+#define DR_TY 16          // patch height (cells)
+#define DR_PX 4           // outputs per thread along x
+#define DR_THREADS (DR_TX / DR_PX * DR_TY)     // 256
+#define DR_LDS_FLOATS (36 * 1024)              // 144 KiB
+
+__global__ void __launch_bounds__(DR_THREADS)
+k_direct(const float* __restrict__ curv, Geom g,
+         const TemplDev* __restrict__ templ, int first, int n_templ,
+         const float* __restrict__ win_w, const uint8_t* __restrict__ win_m,
+         const double* __restrict__ sums, const double* __restrict__ xaxis,
+         const double* __restrict__ yaxis, float* __restrict__ best_snr,
+         float* __restrict__ best_amp, uint32_t* __restrict__ best_id,
+         float* __restrict__ map_amp, float* __restrict__ map_snr) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tx = threadIdx.x % (DR_TX / DR_PX);
+    const int ty = threadIdx.x / (DR_TX / DR_PX);
+    const int i0 = g.cy0 + blockIdx.y * DR_TY;       // patch origin (global)
+    const int j0 = g.cx0 + blockIdx.x * DR_TX;
+    const int cw = g.cx1 - g.cx0;
+    const int gi = i0 + ty;
+    const int gjb = j0 + tx * DR_PX;
+
+    float b_snr[DR_PX], b_amp[DR_PX];
+    uint32_t b_id[DR_PX];
+    bool dirty[DR_PX];
+#pragma unroll
+    for (int u = 0; u < DR_PX; ++u) {
+        bool in = gi < g.cy1 && (gjb + u) < g.cx1;
+        size_t o = (size_t)(gi - g.cy0) * cw + (gjb + u - g.cx0);
+        b_snr[u] = (in && !map_amp) ? best_snr[o] : 0.f;
+        b_amp[u] = 0.f;
+        b_id[u] = SC_ID_NONE;
+        dirty[u] = false;
+    }
+
+    for (int it = 0; it < n_templ; ++it) {
+        const TemplDev t = templ[first + it];
+        const EpiScal es = sc_epi_scalars(sums, first + it);
+        float xc[DR_PX], t3[DR_PX];
+#pragma unroll
+        for (int u = 0; u < DR_PX; ++u) { xc[u] = 0.f; t3[u] = 0.f; }
+
+        // LDS slab: rows for template rows [a0, a0+sr): output row r, template
+        // row p reads curvature row r - p + oy.  Slab covers curvature rows
+        // i0 - (pmin+a0+sr-1) + oy ... i0 + DR_TY-1 - (pmin+a0) + oy
+        const int lw = DR_TX + t.ww - 1;              // slab width in cells
+        const int lwp = lw | 1;                       // odd pitch
+        int sr = DR_LDS_FLOATS / lwp - (DR_TY - 1);
+        if (sr > t.wh) sr = t.wh;
+        if (sr < 1) sr = 1;
+        // leftmost curvature column: j0 - qmax + ox
+        const int gj_left = j0 - t.qmax + g.ox;
+        for (int a0 = 0; a0 < t.wh; a0 += sr) {
+            const int na = min(sr, t.wh - a0);
+            const int rows = DR_TY + na - 1;
+            const int gi_top = i0 - (t.pmin + a0 + na - 1) + g.oy;
+            __syncthreads();
+            for (int e = threadIdx.x; e < rows * lw; e += DR_THREADS) {
+                int r = e / lw, c = e - r * lw;
+                lds[r * lwp + c] = load_curv(curv, g, gi_top + r, gj_left + c);
+            }
+            __syncthreads();
+            for (int a = 0; a < na; ++a) {
+                // template row p = pmin + a0 + a; curvature row for output
+                // row (i0+ty): i0 + ty - p + oy  -> slab row ty + (na-1-a)
+                const float* lrow = lds + (ty + (na - 1 - a)) * lwp;
+                const float* wrow = win_w + t.win_off + (size_t)(a0 + a) * t.ww;
+                const uint8_t* mrow = win_m + t.win_off + (size_t)(a0 + a) * t.ww;
+                // output col gjb+u, template col q = qmin + b reads curvature
+                // col gjb + u - q + ox -> slab col (tx*PX + u) + (ww-1-b)
+                const int cb = tx * DR_PX + (t.ww - 1);
+                // register window: entering iteration b, v[u] holds slab col
+                // cb + u - b + 1; the shift below turns that into cb + u - b.
+                float v[DR_PX];
+#pragma unroll
+                for (int u = 0; u < DR_PX - 1; ++u) v[u] = lrow[cb + u + 1];
+                v[DR_PX - 1] = 0.f;
+                for (int b = 0; b < t.ww; ++b) {
+#pragma unroll
+                    for (int u = DR_PX - 1; u > 0; --u) v[u] = v[u - 1];
+                    v[0] = lrow[cb - b];
+                    if (mrow[b]) {
+                        const float w = wrow[b];
+#pragma unroll
+                        for (int u = 0; u < DR_PX; ++u) {
+                            xc[u] = fmaf(w, v[u], xc[u]);
+                            t3[u] = fmaf(v[u], v[u], t3[u]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < DR_PX; ++u) {
+            int gj = gjb + u;
+            if (gi >= g.cy1 || gj >= g.cx1) continue;
+            float amp, snr;
+            sc_epilogue(xc[u], t3[u], es, amp, snr);
+            sc_apply_masks(t, g, xaxis, yaxis, gi, gj, amp, snr);
+            if (map_amp) {
+                size_t o = (size_t)(gi - g.cy0) * cw + (gj - g.cx0);
+                map_amp[o] = amp;
+                map_snr[o] = snr;
+            } else if (sc_fold(b_snr[u], b_amp[u], b_id[u], snr, amp, t.id)) {
+                dirty[u] = true;
+            }
+        }
+    }
+    if (!map_amp) {
+#pragma unroll
+        for (int u = 0; u < DR_PX; ++u) {
+            if (!dirty[u]) continue;
+            size_t o = (size_t)(gi - g.cy0) * cw + (gjb + u - g.cx0);
+            best_snr[o] = b_snr[u];
+            best_amp[o] = b_amp[u];
+            best_id[o] = b_id[u];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// compare() on host-provided float64 results (core.py:230-240), written the
+// way numexpr evaluates it: boolean * value + boolean * value, snr last.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_compare_fold(double* __restrict__ b_amp, double* __restrict__ b_age,
+               double* __restrict__ b_ang, double* __restrict__ b_snr,
+               const double* __restrict__ t_amp, const double* __restrict__ t_snr,
+               double age, double angle, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        double bs = b_snr[i], ts = t_snr[i];
+        double keep = (bs > ts) ? 1.0 : 0.0, take = (bs < ts) ? 1.0 : 0.0;
+        b_amp[i] = __dadd_rn(__dmul_rn(keep, b_amp[i]), __dmul_rn(take, t_amp[i]));
+        b_age[i] = __dadd_rn(__dmul_rn(keep, b_age[i]), __dmul_rn(take, age));
+        b_ang[i] = __dadd_rn(__dmul_rn(keep, b_ang[i]), __dmul_rn(take, angle));
+        b_snr[i] = __dadd_rn(__dmul_rn(keep, bs), __dmul_rn(take, ts));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+int launch_compare_fold(sc_ctx* ctx, double age, double angle) {
+    size_t n = ctx->cmp_n;
+    size_t blocks = std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_compare_fold, dim3((unsigned)std::max<size_t>(blocks, 1)), dim3(256), 0,
+                       ctx->stream, (double*)ctx->cmp[0].p, (double*)ctx->cmp[1].p,
+                       (double*)ctx->cmp[2].p, (double*)ctx->cmp[3].p,
+                       (const double*)ctx->cmp_in[0].p, (const double*)ctx->cmp_in[1].p,
+                       age, angle, n);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+int launch_curv_planes(sc_ctx* ctx) {
+    const Geom& g = ctx->g;
+    dim3 grid((g.lx + 255) / 256, g.ly);
+    sc_prof_begin(ctx, SC_K_CURV);
+    hipLaunchKernelGGL(k_curv_planes, grid, dim3(256), 0, ctx->stream,
+                       ctx->z_dev, g, ctx->dx, ctx->dy, (float*)ctx->A.p,
+                       (float*)ctx->B.p, (float*)ctx->C.p);
+    sc_prof_end(ctx);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+int launch_curv_alpha(sc_ctx* ctx, float cc, float sc2, float ss) {
+    size_t n = (size_t)ctx->g.ly * ctx->g.lx;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    sc_prof_begin(ctx, SC_K_CURV);
+    hipLaunchKernelGGL(k_curv_alpha, dim3((unsigned)blocks), dim3(256), 0,
+                       ctx->stream, (const float*)ctx->A.p,
+                       (const float*)ctx->B.p, (const float*)ctx->C.p, cc, sc2,
+                       ss, (float*)ctx->curv.p, n);
+    sc_prof_end(ctx);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+int launch_windows(sc_ctx* ctx, int first, int n, int wh_max, int ww_max) {
+    if (n <= 0 || wh_max <= 0 || ww_max <= 0) return SC_OK;
+    dim3 grid((ww_max + 63) / 64, wh_max, n);
+    sc_prof_begin(ctx, SC_K_WINDOWS);
+    hipLaunchKernelGGL(k_windows, grid, dim3(64), 0, ctx->stream,
+                       (const TemplDev*)ctx->templ.p, first,
+                       (const double*)ctx->xaxis.p, (const double*)ctx->yaxis.p,
+                       ctx->g.ny, ctx->g.nx, (float*)ctx->win_w.p,
+                       (uint8_t*)ctx->win_m.p, (double*)ctx->sums.p);
+    sc_prof_end(ctx);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps) {
+    const Geom& g = ctx->g;
+    int ch = g.cy1 - g.cy0, cw = g.cx1 - g.cx0;
+    dim3 grid((cw + DR_TX - 1) / DR_TX, (ch + DR_TY - 1) / DR_TY);
+    size_t lds = (size_t)DR_LDS_FLOATS * sizeof(float) + 4096;
+    int rc = sc_lds_attr(ctx, (const void*)k_direct, lds);
+    if (rc) return rc;
+    sc_prof_begin(ctx, SC_K_DIRECT);
+    hipLaunchKernelGGL(k_direct, grid, dim3(DR_THREADS), lds, ctx->stream,
+                       (const float*)ctx->curv.p, g,
+                       (const TemplDev*)ctx->templ.p, first, n,
+                       (const float*)ctx->win_w.p, (const uint8_t*)ctx->win_m.p,
+                       (const double*)ctx->sums.p, (const double*)ctx->xaxis.p,
+                       (const double*)ctx->yaxis.p, (float*)ctx->best_snr.p,
+                       (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p,
+                       to_maps ? (float*)ctx->map_amp.p : nullptr,
+                       to_maps ? (float*)ctx->map_snr.p : nullptr);
+    sc_prof_end(ctx);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}

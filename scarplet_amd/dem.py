@@ -1,0 +1,123 @@
+"""Elevation grids for the matcher (host side).
+
+Drop-in for the parts of the reference's ``scarplet/dem.py`` that the
+template-matching path touches: a ``DEMGrid`` carries ``_griddata`` (2-D
+float64 elevations) and ``_georef_info.dx/.dy`` (dem.py:203-218, 317,
+331-332).  Any object with those attributes - including the reference's own
+``DEMGrid`` - can be handed to ``scarplet_amd.match``.
+
+GDAL is not needed: grids are built from arrays, ``.npy`` files or GeoTIFFs
+read by the small reader in ``scarplet_amd/tiff.py``.
+"""
+
+import os
+
+import numpy as np
+
+FLOAT32_MIN = np.finfo(np.float32).min
+
+
+class GeorefInfo(object):
+    """Georeferencing record with the reference's field names
+    (dem.py:203-218)."""
+
+    def __init__(self):
+        self.geo_transform = None
+        self.projection = None
+        self.xllcenter = None
+        self.yllcenter = None
+        self.dx = None
+        self.dy = None
+        self.nx = None
+        self.ny = None
+        self.ulx = None
+        self.uly = None
+        self.lrx = None
+        self.lry = None
+
+
+class DEMGrid(object):
+    """Grid of elevation values.
+
+    ``DEMGrid(filename)`` loads ``.npy`` or GeoTIFF; ``DEMGrid.from_array``
+    wraps an array.  Nodata cells (``FLOAT32_MIN`` or the file's nodata tag)
+    become NaN like in the reference (dem.py:319-322, 361)."""
+
+    def __init__(self, filename=None):
+        self._georef_info = GeorefInfo()
+        self.filename = filename
+        self.label = ''
+        self.is_interpolated = False
+        self.nodata_value = np.nan
+        if filename is None:
+            self._griddata = np.empty((0, 0))
+            self.shape = (0, 0)
+        else:
+            self.load(filename)
+
+    @classmethod
+    def from_array(cls, z, dx=1.0, dy=None):
+        g = cls()
+        g._set(np.array(z, dtype=float), dx, dx if dy is None else dy)
+        return g
+
+    def _set(self, z, dx, dy, geo_transform=None):
+        self._griddata = z
+        self.shape = z.shape
+        gi = self._georef_info
+        gi.dx, gi.dy = dx, dy
+        gi.ny, gi.nx = z.shape
+        gi.geo_transform = geo_transform if geo_transform is not None \
+            else (0.0, dx, 0.0, 0.0, 0.0, dy)
+        gt = gi.geo_transform
+        gi.ulx, gi.uly = gt[0], gt[3]
+        gi.lrx = gt[0] + dx * gi.nx
+        gi.lry = gt[3] + dy * gi.ny
+        gi.xllcenter = gt[0] + dx
+        gi.yllcenter = gt[3] - (gi.ny + 1) * abs(dy)
+
+    def load(self, filename):
+        """Load a grid (dem.py:308-348 without GDAL)."""
+        self.label = os.path.basename(filename).split('.')[0]
+        ext = os.path.splitext(filename)[1].lower()
+        if ext == '.npy':
+            self._set(np.load(filename).astype(float), 1.0, 1.0)
+        elif ext in ('.tif', '.tiff'):
+            from scarplet_amd import tiff
+            z, gt, nodata = tiff.read_geotiff(filename)
+            z = z.astype(float)
+            if nodata is not None:
+                z[z == nodata] = np.nan
+            dx, dy = (gt[1], gt[5]) if gt is not None else (1.0, 1.0)
+            self._set(z, dx, dy, gt)
+        else:
+            raise ValueError("unsupported grid file: %s" % filename)
+        self._griddata[self._griddata == FLOAT32_MIN] = np.nan
+        self.filename = filename
+
+    def _fill_nodata(self):
+        """Fill NaN cells so the matcher's NaN-free precondition holds
+        (dem.py:388-414 wraps GDAL's FillNodata; here: iterative mean of the
+        valid 8-neighbours, which reproduces its behaviour for the isolated
+        gaps of the sample datasets but is NOT GDAL's inverse-distance
+        search)."""
+        z = self._griddata
+        mask = np.isnan(z)
+        self.nodata_mask = mask.copy()
+        while mask.any():
+            zp = np.pad(np.where(mask, 0.0, z), 1)
+            vp = np.pad((~mask).astype(float), 1)
+            acc = np.zeros_like(z)
+            cnt = np.zeros_like(z)
+            for di in (0, 1, 2):
+                for dj in (0, 1, 2):
+                    if di == 1 and dj == 1:
+                        continue
+                    acc += zp[di:di + z.shape[0], dj:dj + z.shape[1]]
+                    cnt += vp[di:di + z.shape[0], dj:dj + z.shape[1]]
+            fill = mask & (cnt > 0)
+            if not fill.any():
+                break
+            z[fill] = acc[fill] / cnt[fill]
+            mask = np.isnan(z)
+        self.is_interpolated = True
