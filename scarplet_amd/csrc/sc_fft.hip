@@ -343,8 +343,7 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
                     map_amp[o] = amp;
                     map_snr[o] = snr;
                 } else if (snr != 0.f) {
-                    // snr == 0 can change nothing: best > 0 keeps, best == 0
-                    // ties to the zero record it already is, NaN stays NaN
+                    // snr == 0 can change nothing (best >= 0, or sticky NaN)
                     float b_snr = best_snr[o], b_amp = 0.f;
                     uint32_t b_id = SC_ID_NONE;
                     if (sc_fold(b_snr, b_amp, b_id, snr, amp, tid_)) {

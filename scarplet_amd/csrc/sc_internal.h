@@ -199,21 +199,29 @@ __device__ __forceinline__ void sc_apply_masks(const TemplDev& t, const Geom& g,
     if (!keep) { amp = 0.f; snr = 0.f; }
 }
 
-// One step of compare() (core.py:230-240) on a (snr, amp, id) record.
+// One step of compare() (core.py:230-240) on a (snr, amp, id) record:
+//   best > this: keep;   best < this: take;   NaN on either side: the record
+//   becomes (snr = NaN, amp = 0, no id) and stays so (0*x + 0*NaN).
+// Exact ties: the reference's two strict compares zero the record.  In its
+// float64 arithmetic a tie between two different templates is a rounding
+// accident; in float32 on the GPU it is systematic (a template that is even
+// or odd in xr gives bit-identical SNR at -pi/2 and +pi/2), and a zeroed
+// record is then overtaken by whatever template comes next.  So a tie keeps
+// the incumbent here - one of the two tied candidates, which is what the
+// reference returns in all but the accidental case ("Parity").
+// The literal rule is kept where it is exact: sc_compare_* (float64).
 __device__ __forceinline__ bool sc_fold(float& b_snr, float& b_amp,
                                         uint32_t& b_id, float t_snr,
                                         float t_amp, uint32_t t_id) {
-    if (b_snr > t_snr) return false;              // keep
     if (b_snr < t_snr) {                          // take
         b_snr = t_snr; b_amp = t_amp; b_id = t_id;
         return true;
     }
-    // equal, or a NaN on either side: both compares false -> 0*x + 0*y
-    bool nan = (b_snr != b_snr) || (t_snr != t_snr);
-    bool changed = nan ? true : (b_snr != 0.f || b_amp != 0.f || b_id != SC_ID_NONE);
-    b_snr = nan ? __builtin_nanf("") : 0.f;
+    if (b_snr >= t_snr) return false;             // keep (ties included)
+    if (b_snr != b_snr) return false;             // already NaN: sticky
+    b_snr = __builtin_nanf("");                   // this is NaN
     b_amp = 0.f;
     b_id = SC_ID_NONE;
-    return changed;
+    return true;
 }
 #endif
