@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <algorithm>
 
 // ---------------------------------------------------------------------------
@@ -42,7 +43,7 @@ size_t sc_total_bytes(sc_ctx* c) {
     DevBuf* arr[] = {&c->z, &c->xaxis, &c->yaxis, &c->A, &c->B, &c->C, &c->curv,
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
                      &c->map_snr, &c->templ, &c->sums, &c->win_w, &c->win_m,
-                     &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh,
+                     &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
                      &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage};
     size_t s = 0;
     for (DevBuf* b : arr) s += b->cap;
@@ -120,6 +121,8 @@ extern "C" int sc_create(int device, sc_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return SC_ERR_HIP;
     sc_ctx* c = new sc_ctx();
     c->device = device;
+    if (const char* d = getenv("SC_DBG")) c->dbg = atoi(d);
+    if (const char* d = getenv("SC_VARIANT")) c->variant = atoi(d);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return SC_ERR_HIP;
@@ -155,7 +158,7 @@ extern "C" void sc_destroy(sc_ctx* c) {
     DevBuf* arr[] = {&c->z, &c->xaxis, &c->yaxis, &c->A, &c->B, &c->C, &c->curv,
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
                      &c->map_snr, &c->templ, &c->sums, &c->win_w, &c->win_m,
-                     &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh,
+                     &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
                      &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage};
     for (DevBuf* b : arr) buf_free(*b);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp[k]);

@@ -33,9 +33,45 @@ struct TileDev {
     int i0, j0, vy, vx, gi0, gj0;
 };
 
+// ---------------------------------------------------------------------------
+// In-LDS FFT of 4 lines of length T (complex float32).
+//
+// Stockham autosort, radices 16,16,..,r (r = T / 16^a in {1,2,4,8}); natural
+// order in and out.  Every thread owns one 16-point set per stage - elements
+// tt + j*T/16 - which is one radix-16 butterfly, or 16/r radix-r butterflies in
+// the last stage: the load pattern is the same in every stage and is contiguous
+// across lanes.  Outputs go to q + st*(R*p + m).  Lines are stored with one pad
+// element per 16 (index i lives at i + i/16): the first stage's stride-16
+// stores then fall on distinct banks (17*tt + m), later stages are contiguous.
+// Twiddles exist only in radix-16 stages: w^(e*m), e = p*st, from four table
+// loads (m = 1, 2, 4, 8) and eleven products.
+// ---------------------------------------------------------------------------
 __host__ __device__ constexpr int fft_threads(int T) {
-    return T >= 512 ? 512 : (T < 64 ? 64 : T);
+    return (T / 4) >= 512 ? 512 : ((T / 4) < 64 ? 64 : (T / 4));
 }
+// waves per SIMD the kernels are compiled for: two 512-thread workgroups per
+// CU (LDS allows it up to T = 2048), i.e. at most 128 VGPRs
+__host__ __device__ constexpr int fft_waves(int T) { return T >= 4096 ? 2 : 4; }
+__host__ __device__ constexpr int fft_line(int T) { return T + T / 16; }
+__host__ __device__ constexpr size_t fft_lds_bytes(int T) {
+    return (size_t)4 * fft_line(T) * sizeof(float2);
+}
+__device__ __forceinline__ int ph(int i) { return i + (i >> 4); }
+
+// Workgroup barrier for LDS hand-offs that leaves global loads in flight.
+// __syncthreads() also drains vmcnt (its fence covers global memory), which
+// would serialise the register prefetch of the next step behind every FFT
+// stage; here only this wave's LDS traffic is waited for (lgkmcnt) before the
+// barrier.  The "memory" clobbers keep the compiler from moving LDS accesses
+// across it; waits for prefetched registers are inserted by the compiler at
+// their first use.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+template <int T>
+__device__ __forceinline__ int lidx(int line, int i) { return line * fft_line(T) + ph(i); }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -46,76 +82,230 @@ __device__ __forceinline__ float2 cadd(float2 a, float2 b) {
 __device__ __forceinline__ float2 csub(float2 a, float2 b) {
     return make_float2(a.x - b.x, a.y - b.y);
 }
+// multiply by -j (forward) / +j (inverse)
+template <bool INV>
+__device__ __forceinline__ float2 mulj(float2 a) {
+    return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+template <bool INV>
+__device__ __forceinline__ float2 cw(float c, float s) {      // exp(-/+ i*angle)
+    return make_float2(c, INV ? s : -s);
+}
+template <bool INV>
+__device__ __forceinline__ void dft4(float2& a0, float2& a1, float2& a2, float2& a3) {
+    float2 apc = cadd(a0, a2), amc = csub(a0, a2);
+    float2 bpd = cadd(a1, a3), bmd = mulj<INV>(csub(a1, a3));
+    a0 = cadd(apc, bpd);
+    a1 = cadd(amc, bmd);
+    a2 = csub(apc, bpd);
+    a3 = csub(amc, bmd);
+}
 
-// Transform 4 independent lines of length T held in LDS (line l at s + l*T).
-// tw[k] = exp(-2 pi i k / T).  All NT threads of the workgroup take part.
-template <int T, bool INV>
-__device__ __forceinline__ void fft4_lines(float2* s, const float2* __restrict__ tw) {
+// radix-R butterfly on v[0..R-1] (natural order in); result X[m] is returned
+// through out(m).  All indices are compile-time after unrolling.
+template <int R, bool INV>
+struct Bfly;
+
+template <bool INV>
+struct Bfly<2, INV> {
+    static __device__ __forceinline__ void run(float2* v) {
+        float2 a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    }
+    static __device__ __forceinline__ constexpr int pos(int m) { return m; }
+};
+template <bool INV>
+struct Bfly<4, INV> {
+    static __device__ __forceinline__ void run(float2* v) { dft4<INV>(v[0], v[1], v[2], v[3]); }
+    static __device__ __forceinline__ constexpr int pos(int m) { return m; }
+};
+template <bool INV>
+struct Bfly<8, INV> {
+    // j = c + 2d, m = r + 4s: DFT4 over d, twiddle w8^(c r), DFT2 over c
+    static __device__ __forceinline__ void run(float2* v) {
+        dft4<INV>(v[0], v[2], v[4], v[6]);
+        dft4<INV>(v[1], v[3], v[5], v[7]);
+        const float h = 0.70710678118654752f;
+        v[3] = cmul(v[3], cw<INV>(h, h));
+        v[5] = mulj<INV>(v[5]);
+        v[7] = cmul(v[7], cw<INV>(-h, h));
+        Bfly<2, INV>::run(v + 0);
+        Bfly<2, INV>::run(v + 2);
+        Bfly<2, INV>::run(v + 4);
+        Bfly<2, INV>::run(v + 6);
+    }
+    // X[r + 4s] sits at v[2r + s]
+    static __device__ __forceinline__ constexpr int pos(int m) { return 2 * (m & 3) + (m >> 2); }
+};
+template <bool INV>
+struct Bfly<16, INV> {
+    // j = c + 4d, m = r + 4s: DFT4 over d, twiddle w16^(c r), DFT4 over c
+    static __device__ __forceinline__ void run(float2* v) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dft4<INV>(v[c], v[c + 4], v[c + 8], v[c + 12]);
+        const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f;
+        const float h = 0.70710678118654752f;
+        v[1 + 4] = cmul(v[1 + 4], cw<INV>(c1, s1));       // w^1
+        v[1 + 8] = cmul(v[1 + 8], cw<INV>(h, h));         // w^2
+        v[1 + 12] = cmul(v[1 + 12], cw<INV>(s1, c1));     // w^3
+        v[2 + 4] = cmul(v[2 + 4], cw<INV>(h, h));         // w^2
+        v[2 + 8] = mulj<INV>(v[2 + 8]);                   // w^4
+        v[2 + 12] = cmul(v[2 + 12], cw<INV>(-h, h));      // w^6
+        v[3 + 4] = cmul(v[3 + 4], cw<INV>(s1, c1));       // w^3
+        v[3 + 8] = cmul(v[3 + 8], cw<INV>(-h, h));        // w^6
+        v[3 + 12] = cmul(v[3 + 12], cw<INV>(-c1, -s1));   // w^9
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dft4<INV>(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]);
+    }
+    // X[r + 4s] sits at v[4r + s]
+    static __device__ __forceinline__ constexpr int pos(int m) { return 4 * (m & 3) + (m >> 2); }
+};
+
+// Twiddle bases of a thread, loaded ONCE per kernel: in the radix-16 stage at
+// stride 2^LST a thread needs w^(e), w^(2e), w^(4e), w^(8e) with e = p << LST,
+// which depends only on the thread (its set index tt), not on the data.  Kept
+// in registers so that no global load sits inside the transform: a load there
+// would drag every outstanding prefetch with it (vmcnt completes in order).
+template <int T>
+struct FftTw {
+    static constexpr int S = T / 16;
+    static constexpr int NT = fft_threads(T);
+    static constexpr int U = (4 * S + NT - 1) / NT;
+    static constexpr int LOGT = __builtin_ctz(T);
+    static constexpr int NST = (LOGT + 3) / 4;        // stages
+    static constexpr int NTW = NST - 1;               // all but the last carry twiddles
+    float2 w[NTW > 0 ? NTW : 1][U][4];
+    __device__ __forceinline__ void load(const float2* __restrict__ tw) {
+#pragma unroll
+        for (int k = 0; k < NTW; ++k) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int id = threadIdx.x + u * NT;
+                int tt = id % S;                       // bt == tt in radix-16 stages
+                int e = (tt >> (4 * k)) << (4 * k);
+                w[k][u][0] = tw[e];
+                w[k][u][1] = tw[2 * e];
+                w[k][u][2] = tw[4 * e];
+                w[k][u][3] = tw[8 * e];
+            }
+        }
+    }
+};
+
+// one Stockham stage of radix R at stride 2^LST over the 4 lines in LDS.
+// For T >= 256 every LDS address of the stage is (one per-thread base) +
+// (compile-time offset): S = T/16 and the strides are multiples of 16, so the
+// padding term (i >> 4) is affine in j and m, and the accesses compile to
+// ds_read/ds_write with immediate offsets instead of 32 address registers.
+template <int T, int R, int LST, bool INV>
+__device__ __forceinline__ void fft_stage(float2* s, const FftTw<T>& twr) {
+    constexpr int S = T / 16;                  // 16-point sets per line
     constexpr int NT = fft_threads(T);
-    constexpr int Q = T / 4;
-    constexpr int U = (T + NT - 1) / NT;       // butterflies per thread per stage
-    const int tid = threadIdx.x;
-    int lst = 0;
-#pragma unroll 1
-    for (int n = T; n >= 4; n >>= 2, lst += 2) {
-        float2 a[U][4];
+    constexpr int U = (4 * S + NT - 1) / NT;   // sets per thread
+    constexpr int NB = 16 / R;                 // butterflies per set
+    constexpr int LR = __builtin_ctz(R);
+    constexpr int ST = 1 << LST;
+    constexpr bool LAST = (R << LST) == T;     // n == R: all twiddles are 1
+    constexpr bool AFF = (S % 16) == 0;        // affine addressing available
+    constexpr int SP = S + S / 16;             // padded distance of S elements
+    static_assert(LAST || R == 16, "twiddled stages are radix 16");
+    float2 a[U][16];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int b = tid + u * NT;
-            if (b < T) {
-                int line = b / Q, t = b - line * Q;
-                const float2* base = s + line * T;
+    for (int u = 0; u < U; ++u) {
+        int id = threadIdx.x + u * NT;
+        if (id < 4 * S) {
+            int line = id / S, tt = id - line * S;
+            const float2* base = s + line * fft_line(T);
+            if (AFF) {
+                const float2* rb = base + ph(tt);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) a[u][k] = base[t + k * Q];
+                for (int j = 0; j < 16; ++j) a[u][j] = rb[j * SP];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) a[u][j] = base[ph(tt + j * S)];
             }
         }
-        __syncthreads();
+    }
+    lds_barrier();
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int b = tid + u * NT;
-            if (b < T) {
-                int line = b / Q, t = b - line * Q;
-                float2* base = s + line * T;
-                int p = t >> lst, q = t & ((1 << lst) - 1);
-                float2 w1 = tw[p << lst], w2 = tw[(2 * p) << lst], w3 = tw[(3 * p) << lst];
-                if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
-                float2 apc = cadd(a[u][0], a[u][2]), amc = csub(a[u][0], a[u][2]);
-                float2 bpd = cadd(a[u][1], a[u][3]), bmd = csub(a[u][1], a[u][3]);
-                float2 jbmd = make_float2(-bmd.y, bmd.x);      // j*(b-d)
-                float2 x1 = INV ? cadd(amc, jbmd) : csub(amc, jbmd);
-                float2 x3 = INV ? csub(amc, jbmd) : cadd(amc, jbmd);
-                int o = q + ((4 * p) << lst);
-                base[o] = cadd(apc, bpd);
-                base[o + (1 << lst)] = cmul(w1, x1);
-                base[o + (2 << lst)] = cmul(w2, csub(apc, bpd));
-                base[o + (3 << lst)] = cmul(w3, x3);
+    for (int u = 0; u < U; ++u) {
+        int id = threadIdx.x + u * NT;
+        if (id < 4 * S) {
+            int line = id / S, tt = id - line * S;
+            float2* base = s + line * fft_line(T);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float2 v[R];
+#pragma unroll
+                for (int k = 0; k < R; ++k) v[k] = a[u][b + NB * k];
+                Bfly<R, INV>::run(v);
+                const int bt = tt + b * S;             // butterfly index in [0, T/R)
+                const int p = bt >> LST, q = bt & (ST - 1);
+                const int o = q + (p << (LST + LR));
+                // output m goes to element o + m*ST
+                float2* wb;
+                int wstep;                             // padded distance of ST elements
+                if (LST >= 4) { wb = base + ph(o); wstep = ST + ST / 16; }
+                else if (LST == 0 && R == 16) { wb = base + 17 * bt; wstep = 1; }
+                else { wb = nullptr; wstep = 0; }
+                auto put = [&](int m, float2 val) {
+                    if (wb) wb[m * wstep] = val;
+                    else base[ph(o + (m << LST))] = val;
+                };
+                if (LAST) {
+#pragma unroll
+                    for (int m = 0; m < R; ++m) put(m, v[Bfly<R, INV>::pos(m)]);
+                } else {
+                    float2 w1 = twr.w[LST / 4][u][0], w2 = twr.w[LST / 4][u][1];
+                    float2 w4 = twr.w[LST / 4][u][2], w8 = twr.w[LST / 4][u][3];
+                    if (INV) { w1.y = -w1.y; w2.y = -w2.y; w4.y = -w4.y; w8.y = -w8.y; }
+                    // w^k for k = 1..7 one at a time; each also serves k + 8
+                    put(0, v[Bfly<R, INV>::pos(0)]);
+                    put(8, cmul(v[Bfly<R, INV>::pos(8)], w8));
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) {
+                        float2 wk = (k & 1) ? w1 : make_float2(1.f, 0.f);
+                        if (k == 2 || k == 6) wk = w2;
+                        if (k == 3 || k == 7) wk = cmul(w1, w2);
+                        if (k == 4) wk = w4;
+                        if (k >= 5) wk = cmul(wk, w4);
+                        put(k, cmul(v[Bfly<R, INV>::pos(k)], wk));
+                        put(k + 8, cmul(v[Bfly<R, INV>::pos(k + 8)], cmul(wk, w8)));
+                    }
+                }
             }
         }
-        __syncthreads();
     }
-    // odd power of two: one radix-2 stage, in place per thread
-    constexpr bool ODD = (__builtin_ctz(T) & 1) != 0;
-    if (ODD) {
-        constexpr int H = T / 2;
-        for (int b = tid; b < 4 * H; b += NT) {
-            int line = b / H, t = b - line * H;
-            float2* base = s + line * T;
-            float2 x = base[t], y = base[t + H];
-            base[t] = cadd(x, y);
-            base[t + H] = csub(x, y);
-        }
-        __syncthreads();
+    lds_barrier();
+}
+
+template <int T, int LST, bool INV>
+__device__ __forceinline__ void fft_stages(float2* s, const FftTw<T>& twr) {
+    if constexpr ((1 << LST) < T) {
+        constexpr int REM = T >> LST;
+        constexpr int R = REM >= 16 ? 16 : REM;
+        fft_stage<T, R, LST, INV>(s, twr);
+        fft_stages<T, LST + __builtin_ctz(R), INV>(s, twr);
     }
+}
+
+// Transform the 4 lines at s (padded layout, see lidx).  Ends with a barrier.
+template <int T, bool INV>
+__device__ __forceinline__ void fft4_lines(float2* s, const FftTw<T>& twr) {
+    fft_stages<T, 0, INV>(s, twr);
 }
 
 // ---- F1c: curvature of a tile pair -> row FFT -> blocked ---------------------
 // grid = (Ty/4, npairs); out plane index = pair*2 + {0: curv, 1: curv^2}
 template <int TX>
-__global__ void __launch_bounds__(fft_threads(TX))
+__global__ void __launch_bounds__(fft_threads(TX), fft_waves(TX))
 k_fwd_rows_curv(const float* __restrict__ curv, Geom g,
                 const TileDev* __restrict__ tiles, int Ty,
                 const float2* __restrict__ tw, float2* __restrict__ blk) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    FftTw<TX> twr;
+    twr.load(tw);
     constexpr int NT = fft_threads(TX);
     const int rb = blockIdx.x, pair = blockIdx.y;
     const TileDev ta = tiles[2 * pair], tb = tiles[2 * pair + 1];
@@ -134,30 +324,34 @@ k_fwd_rows_curv(const float* __restrict__ curv, Geom g,
 #pragma unroll
         for (int u = 0; u < E; ++u) {
             int e = threadIdx.x + u * NT;
-            sm[e] = pl ? make_float2(va[u] * va[u], vb[u] * vb[u])
-                       : make_float2(va[u], vb[u]);
+            sm[lidx<TX>(e / TX, e % TX)] = pl ? make_float2(va[u] * va[u], vb[u] * vb[u])
+                                              : make_float2(va[u], vb[u]);
         }
-        __syncthreads();
-        fft4_lines<TX, false>(sm, tw);
+        lds_barrier();
+        fft4_lines<TX, false>(sm, twr);
         float2* out = blk + (size_t)(pair * 2 + pl) * plane + (size_t)rb * 4 * TX;
-        for (int e = threadIdx.x; e < 4 * TX; e += NT) {
+#pragma unroll 4
+        for (int e = 2 * threadIdx.x; e < 4 * TX; e += 2 * NT) {
             int cb = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
-            out[e] = sm[rr * TX + 4 * cb + cc];
+            float2 x0 = sm[lidx<TX>(rr, 4 * cb + cc)], x1 = sm[lidx<TX>(rr, 4 * cb + cc + 1)];
+            *reinterpret_cast<float4*>(out + e) = make_float4(x0.x, x0.y, x1.x, x1.y);
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
 // ---- F1t: template tile v = W + iM -> row FFT -> blocked ---------------------
 // grid = (Ty/4, n_templates)
 template <int TX>
-__global__ void __launch_bounds__(fft_threads(TX))
+__global__ void __launch_bounds__(fft_threads(TX), fft_waves(TX))
 k_fwd_rows_templ(const TemplDev* __restrict__ templ, int first,
                  const float* __restrict__ win_w,
                  const uint8_t* __restrict__ win_m,
                  const double* __restrict__ sums, int Ty,
                  const float2* __restrict__ tw, float2* __restrict__ blk) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    FftTw<TX> twr;
+    twr.load(tw);
     constexpr int NT = fft_threads(TX);
     const int rb = blockIdx.x;
     const TemplDev t = templ[first + blockIdx.y];
@@ -175,7 +369,8 @@ k_fwd_rows_templ(const TemplDev* __restrict__ templ, int first,
         any |= prow[rr] != INT_MIN;
     }
     if (!any) {                       // block-uniform: rows outside the support
-        for (int e = threadIdx.x; e < 4 * TX; e += NT) out[e] = make_float2(0.f, 0.f);
+        for (int e = 2 * threadIdx.x; e < 4 * TX; e += 2 * NT)
+            *reinterpret_cast<float4*>(out + e) = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
     for (int e = threadIdx.x; e < 4 * TX; e += NT) {
@@ -186,13 +381,15 @@ k_fwd_rows_templ(const TemplDev* __restrict__ templ, int first,
             size_t o = (size_t)t.win_off + (size_t)(prow[rr] - t.pmin) * t.ww + (q - t.qmin);
             v = make_float2(alpha * win_w[o], win_m[o] ? 1.f : 0.f);
         }
-        sm[e] = v;
+        sm[lidx<TX>(rr, s)] = v;
     }
-    __syncthreads();
-    fft4_lines<TX, false>(sm, tw);
-    for (int e = threadIdx.x; e < 4 * TX; e += NT) {
+    lds_barrier();
+    fft4_lines<TX, false>(sm, twr);
+#pragma unroll 4
+    for (int e = 2 * threadIdx.x; e < 4 * TX; e += 2 * NT) {
         int cb = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
-        out[e] = sm[rr * TX + 4 * cb + cc];
+        float2 x0 = sm[lidx<TX>(rr, 4 * cb + cc)], x1 = sm[lidx<TX>(rr, 4 * cb + cc + 1)];
+        *reinterpret_cast<float4*>(out + e) = make_float4(x0.x, x0.y, x1.x, x1.y);
     }
 }
 
@@ -200,82 +397,159 @@ k_fwd_rows_templ(const TemplDev* __restrict__ templ, int first,
 // grid = (Tx/4, nplanes).  split2: input plane q goes to (q&1 ? out1 : out0)
 // at plane index q>>1 (curvature: curv / curv^2), else out0 plane q.
 template <int TY>
-__global__ void __launch_bounds__(fft_threads(TY))
+__global__ void __launch_bounds__(fft_threads(TY), fft_waves(TY))
 k_fwd_cols(const float2* __restrict__ blk, int Tx, const float2* __restrict__ tw,
            float2* __restrict__ out0, float2* __restrict__ out1, int split2) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    FftTw<TY> twr;
+    twr.load(tw);
     constexpr int NT = fft_threads(TY);
     const int cb = blockIdx.x, q = blockIdx.y;
     const size_t plane = (size_t)TY * Tx;
     const float2* in = blk + (size_t)q * plane;
     const int nbx = Tx >> 2;
-    for (int e = threadIdx.x; e < 4 * TY; e += NT) {
+#pragma unroll 4
+    for (int e = 2 * threadIdx.x; e < 4 * TY; e += 2 * NT) {      // 2 cells = 16 B per lane
         int rbk = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
-        sm[cc * TY + 4 * rbk + rr] = in[((size_t)rbk * nbx + cb) * 16 + (e & 15)];
+        float4 x = *reinterpret_cast<const float4*>(in + ((size_t)rbk * nbx + cb) * 16 + (e & 15));
+        sm[lidx<TY>(cc, 4 * rbk + rr)] = make_float2(x.x, x.y);
+        sm[lidx<TY>(cc + 1, 4 * rbk + rr)] = make_float2(x.z, x.w);
     }
-    __syncthreads();
-    fft4_lines<TY, false>(sm, tw);
+    lds_barrier();
+    fft4_lines<TY, false>(sm, twr);
     float2* out = split2 ? ((q & 1) ? out1 : out0) + (size_t)(q >> 1) * plane
                          : out0 + (size_t)q * plane;
     out += (size_t)cb * 4 * TY;                 // columns 4cb..4cb+3 are contiguous
-    for (int e = threadIdx.x; e < 4 * TY; e += NT) out[e] = sm[e];
+#pragma unroll 4
+    for (int e = 2 * threadIdx.x; e < 4 * TY; e += 2 * NT) {
+        int cc = e / TY, fy = e - cc * TY;
+        float2 x0 = sm[lidx<TY>(cc, fy)], x1 = sm[lidx<TY>(cc, fy + 1)];
+        *reinterpret_cast<float4*>(out + e) = make_float4(x0.x, x0.y, x1.x, x1.y);
+    }
+}
+
+// ---- split: vh = FFT(alpha*W + iM)  ->  wh = FFT(alpha*W), mh = FFT(M) -------
+// FFT(W)[f] = (v[f] + conj v[-f])/2, FFT(M)[f] = (v[f] - conj v[-f])/(2i).
+// Done once per template so that the inverse kernels (18 tile pairs per
+// template at C3) stream two aligned spectra instead of gathering v[-f].
+// grid = (Tx*Ty/2/256, n_templates), block = 256, 2 cells per thread.
+__global__ void __launch_bounds__(256)
+k_split_templ(const float2* __restrict__ vh, int Ty, int Tx,
+              float2* __restrict__ wh, float2* __restrict__ mh) {
+    const size_t plane = (size_t)Ty * Tx;
+    const float2* v = vh + (size_t)blockIdx.y * plane;
+    size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (e >= plane) return;
+    int fx = (int)(e / Ty), fy = (int)(e - (size_t)fx * Ty);         // fy even
+    const float2* vm = v + (size_t)((Tx - fx) & (Tx - 1)) * Ty;
+    float4 a = *reinterpret_cast<const float4*>(v + e);
+    float2 b0 = vm[(Ty - fy) & (Ty - 1)];
+    float2 b1 = vm[Ty - fy - 1];
+    float4 w = make_float4(0.5f * (a.x + b0.x), 0.5f * (a.y - b0.y),
+                           0.5f * (a.z + b1.x), 0.5f * (a.w - b1.y));
+    float4 m = make_float4(0.5f * (a.y + b0.y), -0.5f * (a.x - b0.x),
+                           0.5f * (a.w + b1.y), -0.5f * (a.z - b1.x));
+    *reinterpret_cast<float4*>(wh + (size_t)blockIdx.y * plane + e) = w;
+    *reinterpret_cast<float4*>(mh + (size_t)blockIdx.y * plane + e) = m;
 }
 
 // ---- I1: spectra product -> inverse column FFT -> blocked --------------------
-// grid = (Tx/4, G): template first+g against tile pair `pair`.
+// grid = (Tx/4): one workgroup per block of 4 columns.  For each plane (W: xcorr,
+// M: T3) the block's 4 columns of the curvature spectrum are parked in LDS once
+// and reused by all G templates of the launch; per template only FFT(W) or
+// FFT(M) is streamed from HBM.  The template loop is software pipelined: the
+// spectrum of template g+1 is fetched into registers while template g is
+// transformed in LDS (barriers that do not drain vmcnt: lds_barrier), so the HBM
+// stream and the LDS/VALU work overlap inside one 512-thread workgroup per CU.
+// Only the row blocks [rb_lo, rb_hi] that hold valid outputs are written.
 template <int TY>
-__global__ void __launch_bounds__(fft_threads(TY))
+__host__ __device__ constexpr bool inv_cols_park() { return TY <= 2048; }
+template <int TY>
+__host__ __device__ constexpr size_t inv_cols_lds() {
+    return fft_lds_bytes(TY) + (inv_cols_park<TY>() ? (size_t)4 * TY * sizeof(float2) : 0);
+}
+
+template <int TY>
+__global__ void __launch_bounds__(fft_threads(TY), 2)
 k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
-           const float2* __restrict__ vh, int Tx, int pair, int vfirst,
+           const float2* __restrict__ wh, const float2* __restrict__ mh, int Tx,
+           int pair, int vfirst, int G, int rb_lo, int rb_hi, int dbg,
            const float2* __restrict__ tw, float2* __restrict__ yw,
            float2* __restrict__ ym) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    FftTw<TY> twr;
+    twr.load(tw);
     constexpr int NT = fft_threads(TY);
-    constexpr int E = 4 * TY / NT;
-    const int cb = blockIdx.x, gidx = blockIdx.y;
+    constexpr int EP = 4 * TY / (2 * NT);     // float4 (2-cell) loads per thread per stream
+    constexpr bool PARK = inv_cols_park<TY>();
+    float4* xs = reinterpret_cast<float4*>(sm + 4 * fft_line(TY));   // parked spectrum, linear
+    const int cb = blockIdx.x;
     const size_t plane = (size_t)TY * Tx;
-    const float2* u1 = uc + (size_t)pair * plane + (size_t)cb * 4 * TY;
-    const float2* u2 = uc2 + (size_t)pair * plane + (size_t)cb * 4 * TY;
-    const float2* v = vh + (size_t)(vfirst + gidx) * plane;
+    const size_t col = (size_t)cb * 4 * TY;
     const int nbx = Tx >> 2;
+    float4 hreg[EP];
     for (int pl = 0; pl < 2; ++pl) {
-        const float2* uu = pl ? u2 : u1;
+        const float4* uu = reinterpret_cast<const float4*>((pl ? uc2 : uc) + (size_t)pair * plane + col);
+        const float4* hbase = reinterpret_cast<const float4*>((pl ? mh : wh) + (size_t)vfirst * plane + col);
+        const size_t hstep = plane / 2;
+        auto fetch = [&](int gi_) {
 #pragma unroll
-        for (int u = 0; u < E; ++u) {
-            int e = threadIdx.x + u * NT;
-            int cc = e / TY, fy = e - cc * TY;
-            int fx = 4 * cb + cc;
-            float2 a = v[(size_t)fx * TY + fy];
-            float2 b = v[(size_t)((Tx - fx) & (Tx - 1)) * TY + ((TY - fy) & (TY - 1))];
-            // FFT(W) = (a + conj b)/2 ; FFT(M) = (a - conj b)/(2i)
-            float2 h = pl ? make_float2(0.5f * (a.y + b.y), -0.5f * (a.x - b.x))
-                          : make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
-            sm[e] = cmul(h, uu[e]);
+            for (int u = 0; u < EP; ++u) hreg[u] = hbase[(size_t)gi_ * hstep + threadIdx.x + u * NT];
+        };
+        if (!(dbg & 16)) {
+            if (PARK) {
+#pragma unroll
+                for (int u = 0; u < EP; ++u) xs[threadIdx.x + u * NT] = uu[threadIdx.x + u * NT];
+            }
+            fetch(0);
         }
-        __syncthreads();
-        fft4_lines<TY, true>(sm, tw);
-        float2* o = (pl ? ym : yw) + (size_t)gidx * plane;
-        for (int e = threadIdx.x; e < 4 * TY; e += NT) {
-            int rbk = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
-            o[((size_t)rbk * nbx + cb) * 16 + (e & 15)] = sm[cc * TY + 4 * rbk + rr];
+        for (int gi_ = 0; gi_ < G; ++gi_) {
+#pragma unroll
+            for (int u = 0; u < EP; ++u) {
+                int e = 2 * (threadIdx.x + u * NT);
+                int cc = e / TY, fy = e - cc * TY;
+                float4 x = PARK ? xs[threadIdx.x + u * NT] : uu[threadIdx.x + u * NT];
+                sm[lidx<TY>(cc, fy)] = cmul(make_float2(hreg[u].x, hreg[u].y), make_float2(x.x, x.y));
+                sm[lidx<TY>(cc, fy + 1)] = cmul(make_float2(hreg[u].z, hreg[u].w), make_float2(x.z, x.w));
+            }
+            lds_barrier();
+            if (gi_ + 1 < G && !(dbg & 16)) fetch(gi_ + 1);
+            if (!(dbg & 32)) fft4_lines<TY, true>(sm, twr);
+            float2* o = (pl ? ym : yw) + (size_t)gi_ * plane;
+            const int e_lo = rb_lo * 16, e_hi = (rb_hi + 1) * 16;
+            if (!(dbg & 64))
+#pragma unroll 2
+            for (int e = e_lo + 2 * threadIdx.x; e < e_hi; e += 2 * NT) {
+                int rbk = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
+                float2 x0 = sm[lidx<TY>(cc, 4 * rbk + rr)], x1 = sm[lidx<TY>(cc + 1, 4 * rbk + rr)];
+                *reinterpret_cast<float4*>(o + ((size_t)rbk * nbx + cb) * 16 + (e & 15)) =
+                    make_float4(x0.x, x0.y, x1.x, x1.y);
+            }
+            lds_barrier();
         }
-        __syncthreads();
     }
 }
 
 // ---- I2: inverse row FFT -> epilogue -> fold ---------------------------------
-// grid = (Ty/4); loops over the G templates of the launch (fold order).
+// grid = (valid row blocks): one workgroup per block of 4 tile rows.  The rows
+// are done as two sub-batches of 2 rows x {W plane, M plane} = 4 LDS lines, so
+// xcorr and T3 of a cell come out of the same transform call.  Per sub-batch
+// the workgroup loops over the G templates of the launch, in fold order, with
+// the running best SNR of its cells in registers: the SNR plane is read once
+// per launch, and a template that wins a cell stores its (snr, amp, id) right
+// away (a few wins per cell per launch).  Software pipelined like I1.
 // FULL = false is the lean variant for templates whose only mask is the
 // window-limit rectangle (Scarp, Ricker); FULL = true adds the error masks and
 // the explicit per-cell masks of generic plugins.
 struct RowArgs {
     int Ty, Py, Qx, circ_y, circ_x;     // tile geometry
     int cy0, cx0, cw;                   // core origin and width
-    int pair, first, G;
+    int pair, first, G, rb_lo;
+    int dbg;                            // diagnostic ablation bits (SC_DBG), 0 in production
 };
 
 template <int TX, bool FULL>
-__global__ void __launch_bounds__(fft_threads(TX))
+__global__ void __launch_bounds__(fft_threads(TX), 2)
 k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
            RowArgs ra, Geom g, const TileDev* __restrict__ tiles,
            const TemplDev* __restrict__ templ, const double* __restrict__ sums,
@@ -284,75 +558,146 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
            float* __restrict__ best_amp, uint32_t* __restrict__ best_id,
            float* __restrict__ map_amp, float* __restrict__ map_snr) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    FftTw<TX> twr;
+    twr.load(tw);
     constexpr int NT = fft_threads(TX);
-    constexpr int E = 4 * TX / NT;
-    const int rb = blockIdx.x;
+    constexpr int E = 2 * TX / NT;          // cells per thread per sub-batch
+    constexpr int EP = 2 * TX / (2 * NT);   // float4 loads per thread per plane
+    const int rb = ra.rb_lo + blockIdx.x;
     const size_t plane = (size_t)ra.Ty * TX;
-    const TileDev* tl = tiles + 2 * ra.pair;
+    const TileDev tA = tiles[2 * ra.pair], tB = tiles[2 * ra.pair + 1];
     const float scale = 1.0f / ((float)ra.Ty * (float)TX);
-    for (int gi_ = 0; gi_ < ra.G; ++gi_) {
-        const TemplDev* tp = templ + ra.first + gi_;
-        const EpiScal es = sc_epi_scalars(sums, ra.first + gi_);
-        const float scale_w = scale / sc_fft_alpha(sums, ra.first + gi_);
-        const float2* in1 = yw + (size_t)gi_ * plane + (size_t)rb * 4 * TX;
-        const float2* in2 = ym + (size_t)gi_ * plane + (size_t)rb * 4 * TX;
-        __syncthreads();
-        for (int e = threadIdx.x; e < 4 * TX; e += NT) {
-            int cb = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
-            sm[rr * TX + 4 * cb + cc] = in1[e];
-        }
-        __syncthreads();
-        fft4_lines<TX, true>(sm, tw);
-        float2 xc[E];
+    const float2* base1 = yw + (size_t)rb * 4 * TX;
+    const float2* base2 = ym + (size_t)rb * 4 * TX;
+    float4 xreg[EP], yreg[EP];
+    for (int sb = 0; sb < 2; ++sb) {
+        auto fetch = [&](int gi_) {
+            // rows 2sb, 2sb+1 of every 4x4 block: 8 cells = 64 B contiguous
 #pragma unroll
-        for (int u = 0; u < E; ++u) xc[u] = sm[threadIdx.x + u * NT];
-        __syncthreads();
-        for (int e = threadIdx.x; e < 4 * TX; e += NT) {
-            int cb = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
-            sm[rr * TX + 4 * cb + cc] = in2[e];
-        }
-        __syncthreads();
-        fft4_lines<TX, true>(sm, tw);
-        const int ilo = tp->ilo, ihi = tp->ihi, jlo = tp->jlo, jhi = tp->jhi;
-        const uint32_t tid_ = tp->id;
-#pragma unroll
-        for (int u = 0; u < E; ++u) {
+            for (int u = 0; u < EP; ++u) {
+                int e = 2 * (threadIdx.x + u * NT);
+                int cb = e >> 3, r2 = (e >> 2) & 1, cc = e & 3;
+                size_t src = (size_t)gi_ * plane + (size_t)cb * 16 + (2 * sb + r2) * 4 + cc;
+                xreg[u] = *reinterpret_cast<const float4*>(base1 + src);
+                yreg[u] = *reinterpret_cast<const float4*>(base2 + src);
+            }
+        };
+        // cell u of this thread is tile-local (row0 + e/TX - Py, e%TX - Qx);
+        // slot 2u + part is that cell of tile A / B (re / im of the transforms)
+        const int row0 = 4 * rb + 2 * sb - ra.Py;
+        auto locate = [&](int u, int& ri, int& cj) {
             int e = threadIdx.x + u * NT;
-            int rr = e / TX, s = e - rr * TX;
-            float2 t3 = sm[e];
-            int ri = 4 * rb + rr - ra.Py;
-            int cj = s - ra.Qx;
+            int r2 = e / TX;
+            ri = row0 + r2;
+            cj = e - r2 * TX - ra.Qx;
             if (ra.circ_y) ri &= (ra.Ty - 1);
             if (ra.circ_x) cj &= (TX - 1);
+        };
+        float b_snr[2 * E];
+        unsigned valid = 0;
 #pragma unroll
-            for (int part = 0; part < 2; ++part) {
-                const TileDev* tile = tl + part;
-                if (ri < 0 || ri >= tile->vy || cj < 0 || cj >= tile->vx) continue;
-                int gi = tile->i0 + ri, gj = tile->j0 + cj;
-                float amp, snr;
-                sc_epilogue((part ? xc[u].y : xc[u].x) * scale_w,
-                            (part ? t3.y : t3.x) * scale, es, amp, snr);
-                if (FULL) {
-                    sc_apply_masks(*tp, g, xaxis, yaxis, gi, gj, amp, snr);
-                } else if (gi < ilo || gi > ihi || gj < jlo || gj > jhi) {
-                    amp = 0.f;
-                    snr = 0.f;
+        for (int u = 0; u < E; ++u) {
+            int ri, cj;
+            locate(u, ri, cj);
+            bool okA = ri >= 0 && ri < tA.vy && cj >= 0 && cj < tA.vx;
+            bool okB = ri >= 0 && ri < tB.vy && cj >= 0 && cj < tB.vx;
+            if (okA) valid |= 1u << (2 * u);
+            if (okB) valid |= 2u << (2 * u);
+            const bool rd = !map_amp && !(ra.dbg & 8);
+            b_snr[2 * u] = (okA && rd) ? best_snr[(size_t)(tA.i0 + ri - ra.cy0) * ra.cw + (tA.j0 + cj - ra.cx0)] : 0.f;
+            b_snr[2 * u + 1] = (okB && rd) ? best_snr[(size_t)(tB.i0 + ri - ra.cy0) * ra.cw + (tB.j0 + cj - ra.cx0)] : 0.f;
+        }
+        if (!(ra.dbg & 1)) fetch(0);
+        for (int gi_ = 0; gi_ < ra.G; ++gi_) {
+            const TemplDev* tp = templ + ra.first + gi_;
+            const EpiScal es = sc_epi_scalars(sums, ra.first + gi_);
+            const float scale_w = scale / sc_fft_alpha(sums, ra.first + gi_);
+            const uint32_t tid_ = tp->id;
+            // window-limit rectangle in tile-local coordinates (scalar)
+            const int rloA = tp->ilo - tA.i0, rhiA = tp->ihi - tA.i0, cloA = tp->jlo - tA.j0, chiA = tp->jhi - tA.j0;
+            const int rloB = tp->ilo - tB.i0, rhiB = tp->ihi - tB.i0, cloB = tp->jlo - tB.j0, chiB = tp->jhi - tB.j0;
+#pragma unroll
+            for (int u = 0; u < EP; ++u) {
+                int e = 2 * (threadIdx.x + u * NT);
+                int cb = e >> 3, r2 = (e >> 2) & 1, cc = e & 3;
+                sm[lidx<TX>(r2, 4 * cb + cc)] = make_float2(xreg[u].x, xreg[u].y);
+                sm[lidx<TX>(r2, 4 * cb + cc + 1)] = make_float2(xreg[u].z, xreg[u].w);
+                sm[lidx<TX>(2 + r2, 4 * cb + cc)] = make_float2(yreg[u].x, yreg[u].y);
+                sm[lidx<TX>(2 + r2, 4 * cb + cc + 1)] = make_float2(yreg[u].z, yreg[u].w);
+            }
+            lds_barrier();
+            if (gi_ + 1 < ra.G && !(ra.dbg & 1)) fetch(gi_ + 1);
+            if (!(ra.dbg & 2)) fft4_lines<TX, true>(sm, twr);
+            if (!(ra.dbg & 4)) {
+                // branch-free scoring of the 2E slots, then the (rare) stores
+                float t_amp[2 * E], t_snr[2 * E];
+#pragma unroll
+                for (int u = 0; u < E; ++u) {
+                    int e = threadIdx.x + u * NT;
+                    int r2 = e / TX, s = e - r2 * TX;
+                    float2 xc = sm[lidx<TX>(r2, s)];
+                    float2 t3 = sm[lidx<TX>(2 + r2, s)];
+                    int ri, cj;
+                    locate(u, ri, cj);
+#pragma unroll
+                    for (int part = 0; part < 2; ++part) {
+                        const int c = 2 * u + part;
+                        float amp, snr;
+                        sc_epilogue((part ? xc.y : xc.x) * scale_w,
+                                    (part ? t3.y : t3.x) * scale, es, amp, snr);
+                        bool keep = (valid >> c) & 1u;
+                        if (FULL) {
+                            if (keep)
+                                sc_apply_masks(*tp, g, xaxis, yaxis, (part ? tB.i0 : tA.i0) + ri,
+                                               (part ? tB.j0 : tA.j0) + cj, amp, snr);
+                        } else {
+                            keep = keep && (part ? (ri >= rloB && ri <= rhiB && cj >= cloB && cj <= chiB)
+                                                 : (ri >= rloA && ri <= rhiA && cj >= cloA && cj <= chiA));
+                        }
+                        t_amp[c] = keep ? amp : 0.f;
+                        t_snr[c] = keep ? snr : 0.f;
+                    }
                 }
-                size_t o = (size_t)(gi - ra.cy0) * ra.cw + (gj - ra.cx0);
+                unsigned won = 0;
                 if (map_amp) {
-                    map_amp[o] = amp;
-                    map_snr[o] = snr;
-                } else if (snr != 0.f) {
-                    // snr == 0 can change nothing (best >= 0, or sticky NaN)
-                    float b_snr = best_snr[o], b_amp = 0.f;
-                    uint32_t b_id = SC_ID_NONE;
-                    if (sc_fold(b_snr, b_amp, b_id, snr, amp, tid_)) {
-                        best_snr[o] = b_snr;
-                        best_amp[o] = b_amp;
-                        best_id[o] = b_id;
+                    won = valid;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 2 * E; ++c) {
+                        // sc_fold on the SNR alone: take if greater; a NaN score
+                        // poisons the cell once (core.py:230-240, see sc_fold)
+                        float bs = b_snr[c], ts = t_snr[c];
+                        bool take = bs < ts;
+                        bool poison = (ts != ts) && (bs == bs);
+                        b_snr[c] = (take || poison) ? ts : bs;
+                        if (take || poison) won |= 1u << c;
+                    }
+                }
+                if (won && !(ra.dbg & 8)) {
+#pragma unroll
+                    for (int u = 0; u < E; ++u) {
+                        int ri, cj;
+                        locate(u, ri, cj);
+#pragma unroll
+                        for (int part = 0; part < 2; ++part) {
+                            const int c = 2 * u + part;
+                            if (!((won >> c) & 1u)) continue;
+                            size_t o = (size_t)((part ? tB.i0 : tA.i0) + ri - ra.cy0) * ra.cw +
+                                       ((part ? tB.j0 : tA.j0) + cj - ra.cx0);
+                            if (map_amp) {
+                                map_amp[o] = t_amp[c];
+                                map_snr[o] = t_snr[c];
+                            } else {
+                                bool nan = t_snr[c] != t_snr[c];
+                                best_snr[o] = t_snr[c];
+                                best_amp[o] = nan ? 0.f : t_amp[c];
+                                best_id[o] = nan ? SC_ID_NONE : tid_;
+                            }
+                        }
                     }
                 }
             }
+            lds_barrier();
         }
     }
 }
@@ -412,6 +757,8 @@ int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group) {
     if ((rc = sc_ensure(ctx, ctx->uc, plane * np))) return rc;
     if ((rc = sc_ensure(ctx, ctx->uc2, plane * np))) return rc;
     if ((rc = sc_ensure(ctx, ctx->vh, plane * n_templ_chunk))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->wh, plane * n_templ_chunk))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->mh, plane * n_templ_chunk))) return rc;
     if ((rc = sc_ensure(ctx, ctx->yw, plane * group))) return rc;
     if ((rc = sc_ensure(ctx, ctx->ym, plane * group))) return rc;
     return SC_OK;
@@ -436,7 +783,7 @@ static int set_lds(sc_ctx* ctx, K kernel, size_t bytes) {
 
 static int launch_fwd_cols(sc_ctx* ctx, const FftGeom& fg, int nplanes,
                            float2* out0, float2* out1, int split2) {
-    size_t lds = (size_t)4 * fg.Ty * sizeof(float2);
+    size_t lds = fft_lds_bytes(fg.Ty);
     dim3 grid(fg.Tx / 4, nplanes);
     sc_prof_begin(ctx, SC_K_FWD_COLS);
 #define FN(T)                                                                  \
@@ -456,7 +803,7 @@ static int launch_fwd_cols(sc_ctx* ctx, const FftGeom& fg, int nplanes,
 
 int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg) {
     int np = npairs_of(fg);
-    size_t lds = (size_t)4 * fg.Tx * sizeof(float2);
+    size_t lds = fft_lds_bytes(fg.Tx);
     dim3 grid(fg.Ty / 4, np);
     sc_prof_begin(ctx, SC_K_FWD_ROWS);
 #define FN(T)                                                                  \
@@ -476,7 +823,7 @@ int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg) {
 }
 
 int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n) {
-    size_t lds = (size_t)4 * fg.Tx * sizeof(float2);
+    size_t lds = fft_lds_bytes(fg.Tx);
     dim3 grid(fg.Ty / 4, n);
     sc_prof_begin(ctx, SC_K_FWD_ROWS);
 #define FN(T)                                                                  \
@@ -494,7 +841,16 @@ int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n) {
 #undef FN
     sc_prof_end(ctx);
     SC_HIP(ctx, hipGetLastError());
-    return launch_fwd_cols(ctx, fg, n, (float2*)ctx->vh.p, nullptr, 0);
+    int rc = launch_fwd_cols(ctx, fg, n, (float2*)ctx->vh.p, nullptr, 0);
+    if (rc) return rc;
+    size_t cells = (size_t)fg.Ty * fg.Tx;
+    dim3 grid_s((unsigned)((cells / 2 + 255) / 256), n);
+    sc_prof_begin(ctx, SC_K_FWD_COLS);
+    hipLaunchKernelGGL(k_split_templ, grid_s, dim3(256), 0, ctx->stream, (const float2*)ctx->vh.p,
+                       fg.Ty, fg.Tx, (float2*)ctx->wh.p, (float2*)ctx->mh.p);
+    sc_prof_end(ctx);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
 }
 
 // Templates [first, first+n) of the current batch have their spectra in vh
@@ -503,29 +859,36 @@ int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n) {
 int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                      int group, bool to_maps, bool full_masks) {
     int np = npairs_of(fg);
-    size_t lds_c = (size_t)4 * fg.Ty * sizeof(float2);
-    size_t lds_r = (size_t)4 * fg.Tx * sizeof(float2);
+    size_t lds_r = fft_lds_bytes(fg.Tx);
+    // row blocks of a tile that hold valid outputs: r' in [Py, Py + Vy)
+    int rb_lo = 0, rb_hi = fg.Ty / 4 - 1;
+    if (!fg.circ_y) {
+        rb_lo = fg.Py / 4;
+        rb_hi = std::min(fg.Ty - 1, fg.Py + fg.Vy - 1) / 4;
+    }
     for (int pair = 0; pair < np; ++pair) {
         for (int g0 = 0; g0 < n; g0 += group) {
             int G = std::min(group, n - g0);
-            dim3 gridc(fg.Tx / 4, G);
+            dim3 gridc(fg.Tx / 4);
             sc_prof_begin(ctx, SC_K_INV_COLS);
 #define FN(T)                                                                  \
     {                                                                          \
-        int rc = set_lds(ctx, k_inv_cols<T>, lds_c);                           \
+        int rc = set_lds(ctx, k_inv_cols<T>, inv_cols_lds<T>());               \
         if (rc) return rc;                                                     \
-        hipLaunchKernelGGL(k_inv_cols<T>, gridc, dim3(fft_threads(T)), lds_c,  \
+        hipLaunchKernelGGL(k_inv_cols<T>, gridc, dim3(fft_threads(T)),         \
+                           inv_cols_lds<T>(),                                  \
                            ctx->stream, (const float2*)ctx->uc.p,              \
-                           (const float2*)ctx->uc2.p, (const float2*)ctx->vh.p,\
-                           fg.Tx, pair, g0, (const float2*)ctx->tw_y.p,        \
+                           (const float2*)ctx->uc2.p, (const float2*)ctx->wh.p,\
+                           (const float2*)ctx->mh.p, fg.Tx, pair, g0, G, rb_lo,\
+                           rb_hi, ctx->dbg, (const float2*)ctx->tw_y.p,        \
                            (float2*)ctx->yw.p, (float2*)ctx->ym.p);            \
     }
             DISPATCH_T(fg.Ty, FN)
 #undef FN
             sc_prof_end(ctx);
-            dim3 gridr(fg.Ty / 4);
+            dim3 gridr(rb_hi - rb_lo + 1);
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
-                       ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G};
+                       ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rb_lo, ctx->dbg};
             sc_prof_begin(ctx, SC_K_INV_ROWS);
 #define LAUNCH_ROWS(T, FULLV)                                                  \
     {                                                                          \

@@ -69,9 +69,11 @@ struct sc_ctx {
     DevBuf templ, sums, win_w, win_m;
     DevBuf tw_y, tw_x;
     int tw_Ty = 0, tw_Tx = 0;
-    DevBuf blk, uc, uc2, vh, yw, ym, tiles;
+    DevBuf blk, uc, uc2, vh, wh, mh, yw, ym, tiles;
     std::vector<WindowSlot> windows;
     int last_batch = 0;
+    int variant = 0;           // SC_VARIANT: kernel variant under evaluation
+    int dbg = 0;               // SC_DBG: timing-only ablation bits (wrong results)
     // profiling
     int prof = 0;              // 0 off, k: time every k-th launch of a kernel
     int prof_cur = -1;         // kernel being bracketed (-1: not sampled)

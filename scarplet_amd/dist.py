@@ -1,0 +1,249 @@
+"""Multi-GPU search: one process per GPU, the DEM cut into a grid of tiles.
+
+The reference has no distributed path (its only parallelism is a process pool
+over orientations, core.py:180-183); its authors tiled large DEMs by hand on
+a cluster (CHANGELOG.md:9).  Here a search over a DEM too large - or too slow -
+for one GPU is sharded spatially: every rank owns a rectangle of output cells,
+needs the elevations within one template half-extent (+1 cell for the
+curvature stencil) around it, and gets that halo from its neighbours.  The
+reference's convolution is circular, so the tile grid is a torus: the halo of
+an edge tile comes from the opposite side of the DEM.
+
+Nothing else is exchanged: results are disjoint tiles, so the "argmax
+all-reduce" of a replicated design degenerates to a gather of tiles.
+
+This module is pure host logic plus two executors for the same transfer list:
+  * ``exchange_gloo``  - torch.distributed point-to-point on host arrays
+    (CPU tests, and machines without xGMI);
+  * ``Context.halo_exchange`` (sc_halo_exchange) - grouped ncclSend/ncclRecv
+    on device buffers over RCCL.
+"""
+
+import numpy as np
+
+from scarplet_amd import _lib, _plan
+
+
+def grid_dims(nranks, ny, nx):
+    """py x px process grid with tiles as square as possible."""
+    best = None
+    for py in range(1, nranks + 1):
+        if nranks % py:
+            continue
+        px = nranks // py
+        aspect = abs(np.log((ny / py) / (nx / px)))
+        if best is None or aspect < best[0]:
+            best = (aspect, py, px)
+    return best[1], best[2]
+
+
+def cuts(n, parts):
+    """parts+1 cut positions splitting n cells as evenly as possible."""
+    return np.array([(n * k) // parts for k in range(parts + 1)], dtype=int)
+
+
+class Layout(object):
+    """Tile grid of a ny x nx DEM over py x px ranks (rank = ry*px + rx)."""
+
+    def __init__(self, ny, nx, py, px, halo):
+        self.ny, self.nx, self.py, self.px = ny, nx, py, px
+        self.cy, self.cx = cuts(ny, py), cuts(nx, px)
+        self.halo = tuple(int(h) for h in halo)       # (y_lo, y_hi, x_lo, x_hi)
+        if max(self.halo[:2]) >= ny or max(self.halo[2:]) >= nx:
+            raise ValueError("halo larger than the DEM")
+
+    @property
+    def nranks(self):
+        return self.py * self.px
+
+    def core(self, rank):
+        ry, rx = divmod(rank, self.px)
+        return (int(self.cy[ry]), int(self.cy[ry + 1]),
+                int(self.cx[rx]), int(self.cx[rx + 1]))
+
+    def block_origin(self, rank):
+        c = self.core(rank)
+        return c[0] - self.halo[0], c[2] - self.halo[2]
+
+    def block_shape(self, rank):
+        c = self.core(rank)
+        return (c[1] - c[0] + self.halo[0] + self.halo[1],
+                c[3] - c[2] + self.halo[2] + self.halo[3])
+
+    def transfers(self):
+        """Global, ordered list of rectangles that fill every rank's halo:
+        (src, dst, sy0, sx0, dy0, dx0, h, w) with (sy0, sx0) in the SOURCE
+        rank's block coordinates and (dy0, dx0) in the destination's.  Every
+        rank derives the same list, which is what keeps sends and receives
+        between a pair in matching order."""
+        out = []
+        for dst in range(self.nranks):
+            oy, ox = self.block_origin(dst)
+            bh, bw = self.block_shape(dst)
+            for ky in (-1, 0, 1):
+                for kx in (-1, 0, 1):
+                    for src in range(self.nranks):
+                        if src == dst and ky == 0 and kx == 0:
+                            continue
+                        sc = self.core(src)
+                        # source core as seen in the destination's unwrapped
+                        # coordinates (periodic image ky, kx)
+                        y0 = max(sc[0] + ky * self.ny, oy)
+                        y1 = min(sc[1] + ky * self.ny, oy + bh)
+                        x0 = max(sc[2] + kx * self.nx, ox)
+                        x1 = min(sc[3] + kx * self.nx, ox + bw)
+                        if y1 <= y0 or x1 <= x0:
+                            continue
+                        soy, sox = self.block_origin(src)
+                        out.append((src, dst,
+                                    y0 - ky * self.ny - soy, x0 - kx * self.nx - sox,
+                                    y0 - oy, x0 - ox, y1 - y0, x1 - x0))
+        return out
+
+    def rank_transfers(self, rank, with_tag=False):
+        """This rank's view: sc_xfer tuples (peer, kind, sy0, sx0, dy0, dx0,
+        h, w) in global order (``with_tag`` appends the global index, used as
+        the message tag by the host executor)."""
+        out = []
+        for tag, (src, dst, sy0, sx0, dy0, dx0, h, w) in enumerate(self.transfers()):
+            if src == rank and dst == rank:
+                x = (rank, _lib.XFER_LOCAL, sy0, sx0, dy0, dx0, h, w)
+            elif dst == rank:
+                x = (src, _lib.XFER_RECV, 0, 0, dy0, dx0, h, w)
+            elif src == rank:
+                x = (dst, _lib.XFER_SEND, sy0, sx0, 0, 0, h, w)
+            else:
+                continue
+            out.append(x + (tag,) if with_tag else x)
+        return out
+
+
+def halo_for_search(bbox, ny, nx):
+    """Halo a rank needs for a template batch with support box ``bbox``:
+    the template reach (_plan.halo_for) plus one cell for the curvature
+    stencil (dem.py:88-101)."""
+    return tuple(h + 1 for h in _plan.halo_for(bbox, ny, nx))
+
+
+def assemble_block_reference(z, layout, rank):
+    """What a rank's block must contain: the DEM indexed modulo its size.
+    (Used by the tests as the ground truth of an exchange.)"""
+    oy, ox = layout.block_origin(rank)
+    bh, bw = layout.block_shape(rank)
+    ii = (oy + np.arange(bh)) % layout.ny
+    jj = (ox + np.arange(bw)) % layout.nx
+    return np.asarray(z)[np.ix_(ii, jj)]
+
+
+def exchange_gloo(core, layout, rank, group=None):
+    """Host executor of the transfer list over torch.distributed (any
+    backend that supports CPU point-to-point; gloo in the tests)."""
+    import torch
+    import torch.distributed as dist
+    bh, bw = layout.block_shape(rank)
+    hy, _, hx, _ = layout.halo
+    blk = np.zeros((bh, bw), dtype=np.float64)
+    c = layout.core(rank)
+    blk[hy:hy + c[1] - c[0], hx:hx + c[3] - c[2]] = core
+    reqs, recvs = [], []
+    mine = layout.rank_transfers(rank, with_tag=True)
+    for (peer, kind, sy0, sx0, dy0, dx0, h, w, tag) in mine:
+        if kind == _lib.XFER_SEND:
+            t = torch.from_numpy(np.ascontiguousarray(blk[sy0:sy0 + h, sx0:sx0 + w]))
+            reqs.append(dist.isend(t, dst=peer, group=group, tag=tag))
+        elif kind == _lib.XFER_RECV:
+            t = torch.empty((h, w), dtype=torch.float64)
+            reqs.append(dist.irecv(t, src=peer, group=group, tag=tag))
+            recvs.append((t, dy0, dx0, h, w))
+    for r in reqs:
+        r.wait()
+    for (t, dy0, dx0, h, w) in recvs:
+        blk[dy0:dy0 + h, dx0:dx0 + w] = t.numpy()
+    for (peer, kind, sy0, sx0, dy0, dx0, h, w, tag) in mine:
+        if kind == _lib.XFER_LOCAL:
+            blk[dy0:dy0 + h, dx0:dx0 + w] = blk[sy0:sy0 + h, sx0:sx0 + w]
+    return blk
+
+
+class DistMatcher(object):
+    """Per-rank driver of a tiled search.
+
+    ``z_core`` is this rank's rectangle of the DEM (layout.core(rank)).
+    ``backend`` 'rccl' exchanges halos on the GPUs; 'gloo' on the host."""
+
+    def __init__(self, rank, nranks, shape, dx, dy, device=0, backend="rccl",
+                 broadcast_bytes=None):
+        from scarplet_amd.core import Matcher
+        self.rank, self.nranks = rank, nranks
+        self.ny, self.nx = shape
+        self.dx, self.dy = dx, dy
+        self.backend = backend
+        self.py, self.px = grid_dims(nranks, self.ny, self.nx)
+        self.m = Matcher(device=device)
+        # describe() only needs the grid geometry
+        self.m.ny, self.m.nx, self.m.de = self.ny, self.nx, dx
+        if backend == "rccl" and nranks > 1:
+            if broadcast_bytes is None:
+                broadcast_bytes = _torch_broadcast_bytes
+            uid = self.m.ctx.comm_unique_id() if rank == 0 else None
+            uid = broadcast_bytes(uid)
+            self.m.ctx.comm_init(uid, rank, nranks)
+
+    def core(self):
+        return Layout(self.ny, self.nx, self.py, self.px, (0, 0, 0, 0)).core(self.rank)
+
+    def load(self, z_core, bbox):
+        """Exchange halos sized for a template batch and hand the block to
+        the GPU."""
+        halo = halo_for_search(bbox, self.ny, self.nx)
+        self.layout = Layout(self.ny, self.nx, self.py, self.px, halo)
+        core = self.layout.core(self.rank)
+        origin = self.layout.block_origin(self.rank)
+        bshape = self.layout.block_shape(self.rank)
+        z_core = np.ascontiguousarray(z_core, dtype=np.float64)
+        assert z_core.shape == (core[1] - core[0], core[3] - core[2])
+        if self.backend == "rccl":
+            z_dev = self.m.ctx.halo_exchange(z_core, halo,
+                                             self.layout.rank_transfers(self.rank))
+            self.m.set_block(z_dev, origin, (self.ny, self.nx), core, self.dx,
+                             self.dy, block_shape=bshape)
+        else:
+            blk = exchange_gloo(z_core, self.layout, self.rank)
+            self.m.set_block(blk, origin, (self.ny, self.nx), core, self.dx, self.dy)
+        return self
+
+    def search(self, Template, scale, params, angles, z_core, method="fft",
+               group=1, **kwargs):
+        params = np.atleast_1d(np.asarray(params, dtype=float))
+        angles = np.atleast_1d(np.asarray(angles, dtype=float))
+        arr, bbox, max_area = self.m.describe(Template, scale, params, angles, **kwargs)
+        self.load(z_core, bbox)
+        self.m.plan, sp = self.m.plan_for(bbox, max_area, method, group)
+        self.m.ctx.reset_best()
+        self.m.ctx.match(arr, sp)
+        self.m.params, self.m.angles = params, angles
+        return self
+
+    def result(self):
+        """This rank's tile of (amp, age, angle, snr)."""
+        return self.m.result()
+
+    def gather(self, dst=0):
+        """Assemble the full maps on rank ``dst`` (None elsewhere)."""
+        import torch.distributed as dist
+        tiles = [None] * self.nranks if self.rank == dst else None
+        dist.gather_object((self.core(), self.result()), tiles, dst=dst)
+        if self.rank != dst:
+            return None
+        out = [np.zeros((self.ny, self.nx)) for _ in range(4)]
+        for core, res in tiles:
+            for k in range(4):
+                out[k][core[0]:core[1], core[2]:core[3]] = res[k]
+        return tuple(out)
+
+
+def _torch_broadcast_bytes(payload):
+    import torch.distributed as dist
+    box = [payload]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]

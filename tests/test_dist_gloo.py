@@ -1,0 +1,101 @@
+"""Multi-rank host logic on CPU: tile layout, torus halo transfer lists and
+their execution over torch.distributed/gloo with world_size 2 and 4."""
+import multiprocessing as mp
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from scarplet_amd import dist as sd
+
+
+def test_layout_tiles_the_dem():
+    for (n, ny, nx) in [(2, 100, 90), (4, 64, 200), (8, 10000, 10000), (6, 51, 47)]:
+        py, px = sd.grid_dims(n, ny, nx)
+        assert py * px == n
+        lay = sd.Layout(ny, nx, py, px, (3, 4, 5, 6))
+        cover = np.zeros((ny, nx), int)
+        for r in range(n):
+            c = lay.core(r)
+            cover[c[0]:c[1], c[2]:c[3]] += 1
+        assert (cover == 1).all()
+    assert sd.grid_dims(8, 10000, 10000) in ((2, 4), (4, 2))
+
+
+def test_transfer_list_fills_every_block():
+    """Executing the global list on host arrays reproduces DEM-modulo-size
+    blocks for every rank (includes periodic self-images when a rank owns a
+    whole axis)."""
+    rng = np.random.default_rng(5)
+    for (n, ny, nx, halo) in [(2, 40, 37, (7, 6, 9, 8)), (4, 30, 44, (5, 5, 12, 3)),
+                              (1, 20, 21, (4, 3, 2, 5)), (8, 64, 96, (10, 9, 11, 12))]:
+        z = rng.standard_normal((ny, nx))
+        py, px = sd.grid_dims(n, ny, nx)
+        lay = sd.Layout(ny, nx, py, px, halo)
+        blocks = []
+        for r in range(n):
+            b = np.full(lay.block_shape(r), np.nan)
+            c = lay.core(r)
+            b[halo[0]:halo[0] + c[1] - c[0], halo[2]:halo[2] + c[3] - c[2]] = z[c[0]:c[1], c[2]:c[3]]
+            blocks.append(b)
+        for (src, dst, sy0, sx0, dy0, dx0, h, w) in lay.transfers():
+            piece = blocks[src][sy0:sy0 + h, sx0:sx0 + w]
+            assert not np.isnan(piece).any(), "source rectangle outside the source core"
+            blocks[dst][dy0:dy0 + h, dx0:dx0 + w] = piece
+        for r in range(n):
+            assert np.array_equal(blocks[r], sd.assemble_block_reference(z, lay, r))
+        # per-rank views pair up: every send has its receive, in the same order
+        for a in range(n):
+            for b in range(n):
+                if a == b:
+                    continue
+                sends = [x[-1] for x in lay.rank_transfers(a, True) if x[1] == 1 and x[0] == b]
+                recvs = [x[-1] for x in lay.rank_transfers(b, True) if x[1] == 0 and x[0] == a]
+                assert sends == recvs
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ny, nx, halo, q):
+    try:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
+                                rank=rank, world_size=world)
+        z = np.random.default_rng(9).standard_normal((ny, nx))
+        py, px = sd.grid_dims(world, ny, nx)
+        lay = sd.Layout(ny, nx, py, px, halo)
+        c = lay.core(rank)
+        blk = sd.exchange_gloo(z[c[0]:c[1], c[2]:c[3]], lay, rank)
+        ok = np.array_equal(blk, sd.assemble_block_reference(z, lay, rank))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, bool(ok)))
+    except Exception as e:                       # pragma: no cover
+        q.put((rank, repr(e)))
+
+
+@pytest.mark.parametrize("world,ny,nx,halo", [(2, 48, 50, (9, 8, 7, 10)), (4, 40, 60, (6, 6, 13, 5))])
+def test_halo_exchange_over_gloo(world, ny, nx, halo):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ny, nx, halo, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)], res
+
+
+def test_halo_for_search_covers_the_reach():
+    # output cell i reads curvature rows i - pmax + oy .. i - pmin + oy, +1 for the stencil
+    assert sd.halo_for_search((-10, 9, -5, 6), 100, 101) == (10, 11, 6, 7)
+    assert sd.halo_for_search((-10, 9, -5, 6), 101, 100) == (9, 12, 7, 6)

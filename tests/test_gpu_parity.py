@@ -1,0 +1,316 @@
+"""Parity of the HIP paths with the oracle and the reference's golden vectors.
+
+Every test calls through the C ABI (scarplet_amd._lib -> libscarplet_hip.so).
+
+Stated tolerances (float32 device arithmetic vs the float64 reference):
+  amp : |d| <= AMP_RTOL * |amp| + AMP_ATOL * max|amp|
+  snr : |d| <= SNR_RTOL * snr  + SNR_ATOL * max(snr)
+  argmax (age, angle): exact, except where the oracle's best and the chosen
+  template's SNR differ by less than TIE_RTOL (near-tie policy, see
+  oracle.check_fold and DESIGN.md "Parity").
+"""
+import numpy as np
+import pytest
+
+import scarplet_oracle as orc
+import scarplet_amd as sl
+from scarplet_amd import _plan, synthetic
+from scarplet_amd import WindowedTemplate as WT
+from conftest import golden, load_cases
+
+pytestmark = pytest.mark.gpu
+
+AMP_RTOL, AMP_ATOL = 2e-4, 2e-6
+SNR_RTOL, SNR_ATOL = 2e-3, 2e-6
+TIE_RTOL = 4e-3
+
+CLS = {"scarp": WT.Scarp, "ricker": WT.Ricker,
+       "right_upper_break": WT.RightFacingUpperBreakScarp,
+       "left_upper_break": WT.LeftFacingUpperBreakScarp}
+
+
+def close_maps(amp, snr, o_amp, o_snr):
+    ea = np.abs(amp - o_amp) <= AMP_RTOL * np.abs(o_amp) + AMP_ATOL * np.max(np.abs(o_amp)) + 1e-30
+    es = np.abs(snr - o_snr) <= SNR_RTOL * np.abs(o_snr) + SNR_ATOL * np.max(np.abs(o_snr)) + 1e-30
+    return ea.all() and es.all(), (float(np.max(np.abs(amp - o_amp))), float(np.max(np.abs(snr - o_snr))))
+
+
+def grid(z, dx, dy=None):
+    return sl.DEMGrid.from_array(z, float(dx), None if dy is None else float(dy))
+
+
+# ------------------------------------------------------------------ K1
+def test_curvature_reference_goldens(gpu_ctx):
+    f = np.load(golden("ref_faultzone_curvature.npz"))
+    for name, sl_y, sl_x in (("tl", slice(None, -1), slice(None, -1)), ("br", slice(1, None), slice(1, None))):
+        z = f["z_" + name]
+        m = sl.Matcher(grid(z, 2.0, 2.0), ctx=gpu_ctx)
+        for deg, ang in zip((0, -90, -45, 45, 90), (0.0, -np.pi / 2, -np.pi / 4, np.pi / 4, np.pi / 2)):
+            c = m.ctx.curvature(*_plan.curvature_coefficients(ang), z.shape)
+            gold = f["gold_%s_%d" % (name, deg)]
+            assert np.allclose(c[sl_y, sl_x], gold[sl_y, sl_x], rtol=1e-5, atol=1e-6 * np.max(np.abs(gold)))
+
+
+# ------------------------------------------------------------------ K2..K4
+@pytest.mark.parametrize("method", ["direct", "fft"])
+def test_match_template_reference_outputs(gpu_ctx, method):
+    """amp / snr maps and the per-template scalars n, sum(W^2) against values
+    captured from the reference's match_template (core.py:297-377)."""
+    for c in load_cases("ref_match_template.npz"):
+        g = grid(c["z"], c["dx"], c["dy"])
+        m = sl.Matcher(g, ctx=gpu_ctx)
+        amp, snr = m.match_template(CLS[str(c["kind"])], float(c["scale"]), float(c["age"]),
+                                    float(c["ang"]), method=method)
+        n, ts = m.ctx.template_sums(1)
+        assert abs(n[0] - float(c["n"])) < 1e-6, "support size differs from the reference"
+        assert np.isclose(ts[0], float(c["ts"]), rtol=1e-12)
+        ok, err = close_maps(amp, snr, c["amp"], c["snr"])
+        assert ok, (str(c["kind"]), method, err)
+
+
+@pytest.mark.parametrize("method", ["direct", "fft"])
+@pytest.mark.parametrize("shape", [(64, 64), (61, 75), (96, 63), (65, 65), (200, 130)])
+def test_match_template_even_odd_sizes(gpu_ctx, method, shape):
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    z = (np.cumsum(rng.standard_normal(shape), 1) * 0.03 + rng.standard_normal(shape) * 0.04).astype(np.float32)
+    for de, scale, age, ang in [(1.0, 9, 4.0, 0.7), (2.0, 22, 20.0, -1.3), (1.0, 6, 1.0, 0.0)]:
+        m = sl.Matcher(grid(z, de), ctx=gpu_ctx)
+        amp, snr = m.match_template(WT.Scarp, scale, age, ang, method=method)
+        o_amp, _, _, o_snr = orc.match_template(z, de, de, orc.SCARP, scale, age, ang)
+        ok, err = close_maps(amp, snr, o_amp, o_snr)
+        assert ok, (shape, de, scale, age, ang, err)
+
+
+def test_fft_tiling_is_invisible(gpu_ctx):
+    """Overlap-save with different tile sizes, and the real-space path, give
+    the same maps (within float32 noise) on a DEM larger than one tile."""
+    g = synthetic.synthetic_scarp(700, seed=3)
+    z = g._griddata
+    m = sl.Matcher(g, ctx=gpu_ctx)
+    o_amp, _, _, o_snr = orc.match_template(z, 1.0, 1.0, orc.SCARP, 30, 50.0, 0.9)
+    outs = {}
+    for tmax in (256, 512, 1024):
+        arr, bbox, area = m.describe(WT.Scarp, 30, [50.0], [0.9])
+        p = _plan.Plan(m.ny, m.nx, m.core, bbox, whole=True, method=_plan.METHOD_FFT, t_max=tmax)
+        sp = sl._lib.sc_plan(method=1, Ty=p.Ty, Tx=p.Tx, Vy=p.Vy, Vx=p.Vx, nty=p.nty, ntx=p.ntx,
+                             circ_y=int(p.circ_y), circ_x=int(p.circ_x), Py=p.Py, Qx=p.Qx, group=1)
+        assert p.nty * p.ntx > 1
+        outs[tmax] = m.ctx.match_template(arr[0], sp)
+        ok, err = close_maps(outs[tmax][0], outs[tmax][1], o_amp, o_snr)
+        assert ok, (tmax, err)
+    amp_d, snr_d = m.match_template(WT.Scarp, 30, 50.0, 0.9, method="direct")
+    assert close_maps(amp_d, snr_d, o_amp, o_snr)[0]
+
+
+# ------------------------------------------------------------------ K5 + drivers
+def fold_check(res, z, dx, dy, kind, scale, params, angles):
+    a_st, s_st = orc.snr_stack(z, dx, dy, kind, scale, params, angles)
+    T = len(params) * len(angles)
+    ny, nx = z.shape
+    ages = np.repeat(np.asarray(params, float), len(angles))
+    angs = np.tile(np.asarray(angles, float), len(params))
+    return orc.check_fold(res, a_st.reshape(T, ny, nx), s_st.reshape(T, ny, nx), ages, angs,
+                          tie_rtol=TIE_RTOL, amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
+                          snr_tol=(SNR_RTOL, SNR_ATOL * np.max(s_st)))
+
+
+@pytest.mark.parametrize("method", ["direct", "fft"])
+def test_fold_against_oracle_stack(gpu_ctx, method):
+    rng = np.random.default_rng(21)
+    z = (np.cumsum(np.cumsum(rng.standard_normal((96, 90)), 0), 1) * 0.01
+         + rng.standard_normal((96, 90)) * 0.05).astype(np.float32)
+    params = [1.0, 3.16, 10.0, 31.6]
+    angles = _plan.angle_grid(-0.6, 0.6)
+    m = sl.Matcher(grid(z, 1.0), ctx=gpu_ctx)
+    res = m.search(WT.Scarp, 10, params, angles, method=method).result()
+    chk = fold_check(res, z, 1.0, 1.0, orc.SCARP, 10, params, angles)
+    assert chk["n_bad"] == 0, chk
+    assert chk["n_strict"] > 0.85 * chk["n"], chk
+
+
+@pytest.mark.parametrize("method", ["direct", "fft"])
+def test_fold_channel_even_template(gpu_ctx, method):
+    """Ricker is even in xr: -pi/2 and +pi/2 tie exactly; the near-tie policy
+    must classify those cells, everything else must match strictly."""
+    rng = np.random.default_rng(22)
+    z = (np.cumsum(rng.standard_normal((80, 96)), 0) * 0.04 + rng.standard_normal((80, 96)) * 0.03).astype(np.float32)
+    params = [0.1, 0.2]
+    angles = _plan.angle_grid()[::6]
+    m = sl.Matcher(grid(z, 1.0, -1.0), ctx=gpu_ctx)
+    res = m.search(WT.Channel, 6, params, angles, method=method).result()
+    chk = fold_check(res, z, 1.0, -1.0, orc.RICKER, 6, params, angles)
+    assert chk["n_bad"] == 0, chk
+
+
+def test_small_searches_reference(gpu_ctx):
+    """sl.match against outputs captured from the reference's sl.match."""
+    for c in load_cases("ref_match_small.npz"):
+        kw = dict(zip([str(k) for k in c["keys"]], [float(v) for v in c["vals"]]))
+        kind = str(c["kind"])
+        g = grid(c["z"], c["dx"], c["dy"])
+        res = sl.match(g, CLS[kind], **kw)
+        angles = _plan.angle_grid(kw["ang_min"], kw["ang_max"])
+        params = [kw["age"]] if "age" in kw else list(_plan.age_grid())
+        chk = fold_check(res, c["z"], float(c["dx"]), float(c["dy"]), kind, kw["scale"], params, angles)
+        assert chk["n_bad"] == 0, (kind, chk)
+        if kind != "ricker":
+            same = (np.asarray(res[1]) == c["res"][1]) & (np.asarray(res[2]) == c["res"][2])
+            assert same.mean() > 0.8, float(same.mean())
+
+
+def golden_check(res, gold):
+    """Against a reference golden without the per-template stack: cells whose
+    (age, angle) equal the golden's must match in amp/snr; any other cell must
+    be a near-tie, i.e. reach the golden's (maximal) SNR within TIE_RTOL."""
+    amp, age, ang, snr = [np.asarray(a) for a in res]
+    g_amp, g_age, g_ang, g_snr = gold
+    same = np.isclose(age, g_age, rtol=1e-9) & (ang == g_ang)
+    tol_a = AMP_RTOL * np.abs(g_amp) + AMP_ATOL * np.max(np.abs(g_amp)) + 1e-30
+    tol_s = SNR_RTOL * g_snr + SNR_ATOL * np.max(g_snr) + 1e-30
+    ok_same = same & (np.abs(amp - g_amp) <= tol_a) & (np.abs(snr - g_snr) <= tol_s)
+    near = ~same & (snr >= g_snr * (1 - TIE_RTOL)) & (snr <= g_snr * (1 + TIE_RTOL) + tol_s) & (g_snr > 0)
+    return ok_same, near
+
+
+def test_synthetic_single_age_golden(gpu_ctx):
+    """scarplet/tests/test_core.py:47-64 (synthetic_match2.npy)."""
+    z = np.load(golden("ref_synthetic_dem.npy"))
+    gold = np.load(golden("ref_synthetic_match2.npz"))["res"]
+    res = sl.match(grid(z, 1.0), sl.Scarp, scale=100, age=10, ang_max=np.pi / 2, ang_min=-np.pi / 2)
+    assert res.shape == (4, 200, 200) and res.dtype == np.float64
+    ok_same, near = golden_check(res, gold)
+    assert (ok_same | near).all()
+    assert ok_same.mean() > 0.99
+
+
+def test_synthetic_full_grid_golden(gpu_ctx):
+    """scarplet/tests/test_core.py:28-45 (synthetic_match1.npy): the only
+    end-to-end pin of the 35 x 181 search in the reference."""
+    z = np.load(golden("ref_synthetic_dem.npy"))
+    gold = np.load(golden("ref_synthetic_match1.npz"))["res"]
+    res = sl.match(grid(z, 1.0), sl.Scarp, scale=100, ang_max=np.pi / 2, ang_min=-np.pi / 2)
+    assert isinstance(res, tuple) and len(res) == 4
+    ok_same, near = golden_check(res, gold)
+    bad = ~(ok_same | near)
+    assert not bad.any(), (int(bad.sum()), np.argwhere(bad)[:5])
+    assert ok_same.mean() > 0.97, float(ok_same.mean())
+
+
+# ------------------------------------------------------------------ plugin API
+def test_generic_plugin_goes_through_the_window_path(gpu_ctx):
+    """A user subclass with its own template() (docs/source/new_template.rst
+    pattern) is evaluated on the host and uploaded."""
+    class Notch(WT.Scarp):
+        def _device_descriptor(self):
+            return None                     # force the generic path
+
+        def template(self):
+            W = super().template()
+            W[::3, :] = 0.0                 # not expressible analytically
+            return W
+
+    rng = np.random.default_rng(5)
+    z = rng.standard_normal((72, 80)).cumsum(1).astype(np.float32) * 0.05
+    g = grid(z, 1.0)
+    for method in ("direct", "fft"):
+        amp, _, _, snr = sl.match_template(g, Notch, 10, 8.0, 0.5, method=method)
+        t = Notch(10, 8.0, 0.5, 80, 72, 1.0)
+        curv = orc.directional_curvature(z, 1.0, 1.0, 0.5)
+        o_amp, o_snr = orc.match_arrays(curv, t.template(), t.get_window_limits())
+        assert close_maps(amp, snr, o_amp, o_snr)[0]
+
+
+def test_upper_break_err_masks(gpu_ctx):
+    rng = np.random.default_rng(6)
+    z = rng.standard_normal((70, 66)).cumsum(0).astype(np.float32) * 0.05
+    for cls, kind in ((WT.RightFacingUpperBreakScarp, orc.RIGHT_UPPER), (WT.LeftFacingUpperBreakScarp, orc.LEFT_UPPER)):
+        for method in ("direct", "fft"):
+            amp, _, _, snr = sl.match_template(grid(z, 1.0), cls, 10, 6.0, -0.4, method=method)
+            o_amp, _, _, o_snr = orc.match_template(z, 1.0, 1.0, kind, 10, 6.0, -0.4)
+            assert close_maps(amp, snr, o_amp, o_snr)[0]
+            assert (snr[o_snr == 0] == 0).all()
+
+
+def test_serial_driver_forwards_kwargs(gpu_ctx):
+    """calculate_best_fit_parameters_serial is the one route to the Shifted
+    templates (core.py:65-136 forwards **kwargs)."""
+    rng = np.random.default_rng(8)
+    z = rng.standard_normal((48, 52)).cumsum(1).astype(np.float32) * 0.05
+    res = sl.calculate_best_fit_parameters_serial(
+        grid(z, 1.0), WT.ShiftedLeftFacingUpperBreakScarp, 6, ang_max=0.05, ang_min=-0.05, dx=2, dy=1)
+    assert len(res) == 4 and res[0].shape == (48, 52)
+    angles = _plan.angle_grid(-0.05, 0.05)
+    best = None
+    for ang in angles:
+        for age in _plan.age_grid():
+            t = WT.ShiftedLeftFacingUpperBreakScarp(6, age, ang, 52, 48, 1.0, dx=2, dy=1)
+            curv = orc.directional_curvature(z, 1.0, 1.0, ang)
+            a, s = orc.match_arrays(curv, t.template(), t.get_window_limits(), t.get_err_mask())
+            best = s if best is None else np.maximum(best, s)
+    assert np.allclose(res[3], best, rtol=SNR_RTOL, atol=SNR_ATOL * best.max())
+
+
+def test_compare_is_the_reference_fold(gpu_ctx):
+    f = np.load(golden("ref_fold.npz"))
+    res = sl.compare(((f["amps"][i], f["ages"][i], f["angs"][i], f["snrs"][i])
+                      for i in range(len(f["ages"]))), 2, 2)
+    assert np.array_equal(np.stack(res), f["res"], equal_nan=True)
+    rng = np.random.default_rng(1)
+    rs = [(rng.standard_normal((33, 47)), float(k), 0.1 * k, np.abs(rng.standard_normal((33, 47)))) for k in range(7)]
+    rs[3][3][5, 5] = rs[2][3][5, 5]               # an exact tie zeroes the record
+    mine = sl.compare(iter(rs), 33, 47)
+    ref = orc.compare(iter(rs), 33, 47)
+    for a, b in zip(mine, ref):
+        assert np.array_equal(a, b)
+
+
+def test_nan_dem_is_rejected(gpu_ctx):
+    z = np.zeros((40, 40))
+    z[3, 4] = np.nan
+    with pytest.raises(ValueError):
+        sl.match(grid(z, 1.0), sl.Scarp, scale=5, age=10.)
+
+
+# ------------------------------------------------------------------ full size
+def test_full_size_properties(gpu_ctx):
+    """BASELINE-sized DEM (10000 x 10000), a slice of the 35 x 181 grid:
+    size-independent properties instead of the oracle -
+      * fold idempotence: searching twice without a reset changes nothing;
+      * linearity: doubling the relief doubles amp and leaves SNR / argmax;
+      * locality: a window of the result equals the oracle run on a crop
+        around it (interior cells only see the template's reach)."""
+    n = 10000
+    g = synthetic.synthetic_scarp(n)
+    ages = _plan.age_grid()[[4, 19, 34]]
+    angles = _plan.angle_grid()[[20, 95, 160]]
+    m = sl.Matcher(g, ctx=gpu_ctx)
+    m.search(sl.Scarp, 100, ages, angles, method="fft")
+    amp, age, ang, snr = m.result()
+    m.search(sl.Scarp, 100, ages, angles, method="fft", reset=False)
+    amp2, age2, ang2, snr2 = m.result()
+    assert np.array_equal(snr, snr2) and np.array_equal(amp, amp2) and np.array_equal(age, age2)
+
+    # locality: crop with margin >= template reach + stencil, compare interior
+    i0, j0, w, margin = 4200, 7300, 160, 330
+    sl_ = (slice(i0 - margin, i0 + w + margin), slice(j0 - margin, j0 + w + margin))
+    zc = g._griddata[sl_]
+    a_st, s_st = orc.snr_stack(zc, 1.0, 1.0, orc.SCARP, 100, ages, angles, workers=4)
+    # window limits of the crop differ from the full DEM's: compare un-masked stacks
+    inner = (slice(margin, margin + w), slice(margin, margin + w))
+    T = len(ages) * len(angles)
+    win = (slice(i0, i0 + w), slice(j0, j0 + w))
+    res_win = (amp[win], age[win], ang[win], snr[win])
+    chk = orc.check_fold(res_win, a_st.reshape(T, *zc.shape)[(slice(None),) + inner],
+                         s_st.reshape(T, *zc.shape)[(slice(None),) + inner],
+                         np.repeat(ages, len(angles)), np.tile(angles, len(ages)),
+                         tie_rtol=TIE_RTOL, amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
+                         snr_tol=(SNR_RTOL, SNR_ATOL * np.max(s_st)))
+    assert chk["n_bad"] == 0, chk
+
+    g2 = sl.DEMGrid.from_array(g._griddata * 2.0, 1.0)
+    m.set_data(g2)
+    m.search(sl.Scarp, 100, ages, angles, method="fft")
+    amp3, age3, ang3, snr3 = m.result()
+    assert np.allclose(amp3, 2 * amp, rtol=1e-4, atol=1e-6)
+    assert np.allclose(snr3, snr, rtol=2e-3, atol=1e-5)
+    assert (age3 == age).mean() > 0.999

@@ -1,0 +1,67 @@
+"""Host planning (tiles, halos, descriptors) checked end to end on the CPU:
+numpy model of the kernels (tests/pipeline_model.py) vs the oracle."""
+import numpy as np
+import pytest
+
+import scarplet_oracle as orc
+import pipeline_model as pm
+from scarplet_amd import _plan, WindowedTemplate as WT
+
+rng = np.random.default_rng(3)
+CASES = [
+    (WT.Scarp, orc.SCARP, 64, 64, 1., 10, [1., 31.6], [0., -1.2, np.pi / 2], 4096, True),
+    (WT.Scarp, orc.SCARP, 61, 75, 1., 8, [3.2], [0.4, -0.9], 4096, True),
+    (WT.Scarp, orc.SCARP, 65, 64, 2., 20, [10., 100.], [1.0], 4096, True),
+    (WT.Scarp, orc.SCARP, 150, 131, 1., 12, [1., 5.], [0.5], 64, True),
+    (WT.Scarp, orc.SCARP, 128, 128, 1., 12, [5.], [-0.2], 64, False),
+    (WT.Ricker, orc.RICKER, 64, 72, 1., 5, [0.1], [0.8], 4096, True),
+    (WT.Channel, orc.RICKER, 63, 60, 1., 8, [0.2], [np.pi / 2], 4096, True),
+    (WT.RightFacingUpperBreakScarp, orc.RIGHT_UPPER, 64, 66, 1., 10, [10.], [0.2], 4096, True),
+    (WT.LeftFacingUpperBreakScarp, orc.LEFT_UPPER, 61, 64, 1., 10, [5.], [-0.6], 4096, True),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%s-%dx%d" % (c[1], c[2], c[3]))
+def test_model_matches_oracle(case):
+    cls, kind, ny, nx, de, scale, params, angles, tmax, whole = case
+    z = (np.cumsum(rng.standard_normal((ny, nx)), 1) * 0.05
+         + rng.standard_normal((ny, nx)) * 0.02).astype(np.float32)
+    xa, ya = WT.centred_axis(nx, de), WT.centred_axis(ny, de)
+    A, B, C = pm.curvature_planes(z, de, de)
+    for ang in angles:
+        cc, sc2, ss = _plan.curvature_coefficients(ang)
+        curv = cc * A - sc2 * B + ss * C
+        assert np.allclose(curv, orc.directional_curvature(z, de, de, ang), rtol=1e-12, atol=1e-14)
+        descs = [cls(scale, p, ang, nx, ny, de)._device_descriptor() for p in params]
+        bbox = _plan.bbox_union([d["bbox"] for d in descs])
+        plan = _plan.Plan(ny, nx, (0, ny, 0, nx), bbox, whole=whole, t_max=tmax)
+        res = pm.match_batch_fft(curv, descs, plan, xa, ya)
+        for p, d, (amp, snr) in zip(params, descs, res):
+            o_amp, _, _, o_snr, det = orc.match_template(z, de, de, kind, scale, p, ang, details=True)
+            _, _, n, ts = pm.synth_window(d, xa, ya)
+            assert abs(n - det["n"]) < 0.5
+            assert abs(ts - det["template_sum"]) <= 1e-12 * abs(ts)
+            assert np.allclose(amp, o_amp, rtol=1e-8, atol=1e-10)
+            assert np.allclose(snr, o_snr, rtol=1e-6, atol=1e-8)
+            if ny * nx <= 70 * 70:
+                a2, s2 = pm.match_one_direct(curv, d, xa, ya)
+                assert np.allclose(a2, o_amp, rtol=1e-8, atol=1e-10)
+                assert np.allclose(s2, o_snr, rtol=1e-6, atol=1e-8)
+
+
+def test_tile_choice():
+    # 10000-cell axis, 35 x 181 Scarp grid at scale 100: span 306
+    T, V, nt, circ = _plan.choose_tile(10000, 306, 10000, True)
+    assert (T, circ) == (2048, False) and V == 2048 - 306 and nt * V >= 10000
+    # a power-of-two axis owned entirely uses its own periodicity
+    assert _plan.choose_tile(2048, 306, 2048, True) == (2048, 2048, 1, True)
+    # ... but not when the rank only owns part of it
+    assert _plan.choose_tile(1024, 306, 2048, False)[3] is False
+    with pytest.raises(ValueError):
+        _plan.choose_tile(10000, 5000, 10000, True)
+
+
+def test_search_grids_match_reference():
+    assert len(_plan.angle_grid()) == 181 and len(_plan.age_grid()) == 35
+    assert np.array_equal(_plan.angle_grid(-0.4, 0.4), orc.angle_grid(-0.4, 0.4))
+    assert np.array_equal(_plan.age_grid(), orc.age_grid())
