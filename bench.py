@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--ages", type=int, default=35)
     ap.add_argument("--angles", type=int, default=181)
     ap.add_argument("--method", default="fft")
-    ap.add_argument("--group", type=int, default=1)
+    ap.add_argument("--group", type=int, default=0, help="templates per inverse launch (0: auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-stride", type=int, default=16)
     return ap.parse_args()
@@ -91,7 +91,7 @@ def main():
     if world == 1:
         m = sl.Matcher(g, device=local)
         arr, bbox, area = m.describe(sl.Scarp, 100, ages, angles)
-        plan, sp = m.plan_for(bbox, area, a.method, a.group)
+        plan, sp = m.plan_for(bbox, area, a.method, a.group or None, n_params=len(ages))
 
         def step():
             m.ctx.reset_best()
@@ -103,7 +103,7 @@ def main():
         z_core = np.ascontiguousarray(g._griddata[c[0]:c[1], c[2]:c[3]])
         arr, bbox, area = dm.m.describe(sl.Scarp, 100, ages, angles)
         dm.load(z_core, bbox)                          # halo exchange over RCCL
-        plan, sp = dm.m.plan_for(bbox, area, a.method, a.group)
+        plan, sp = dm.m.plan_for(bbox, area, a.method, a.group or None, n_params=len(ages))
 
         def step():
             dm.load(z_core, bbox)                      # the exchange is part of a search

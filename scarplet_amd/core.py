@@ -182,7 +182,7 @@ class Matcher(object):
                           l0 - self.nx // 2, l1 - self.nx // 2), window=slot)
 
     # -- planning -----------------------------------------------------------------
-    def plan_for(self, bbox, max_area, method="auto", group=1):
+    def plan_for(self, bbox, max_area, method="auto", group=None, n_params=1):
         if method == "auto":
             fft = _plan.Plan(self.ny, self.nx, self.core, bbox,
                              whole=self.whole, method=_plan.METHOD_FFT)
@@ -191,21 +191,28 @@ class Matcher(object):
                 < _plan.fft_cost(fft, n_cells) else "fft"
         m = _plan.METHOD_DIRECT if method == "direct" else _plan.METHOD_FFT
         p = _plan.Plan(self.ny, self.nx, self.core, bbox, whole=self.whole,
-                       method=m, group=group)
+                       method=m)
+        if group is None:
+            # templates per inverse-transform launch: all parameters of one
+            # orientation, capped so the intermediate planes stay under ~4 GB
+            per_templ = 2 * 8 * max(p.Ty * p.Tx, 1)
+            group = int(max(1, min(n_params, 64, 4e9 // per_templ)))
+        p.group = group
         sp = _lib.sc_plan(method=m, Ty=p.Ty, Tx=p.Tx, Vy=p.Vy, Vx=p.Vx,
                           nty=p.nty, ntx=p.ntx, circ_y=int(p.circ_y),
                           circ_x=int(p.circ_x), Py=p.Py, Qx=p.Qx, group=group)
         return p, sp
 
     # -- searches -------------------------------------------------------------------
-    def search(self, Template, scale, params, angles, method="auto", group=1,
-               reset=True, sync=True, **kwargs):
+    def search(self, Template, scale, params, angles, method="auto",
+               group=None, reset=True, sync=True, **kwargs):
         """Fold every (param, angle) template into the running best."""
         params = np.atleast_1d(np.asarray(params, dtype=float))
         angles = np.atleast_1d(np.asarray(angles, dtype=float))
         arr, bbox, max_area = self.describe(Template, scale, params, angles,
                                             **kwargs)
-        self.plan, sp = self.plan_for(bbox, max_area, method, group)
+        self.plan, sp = self.plan_for(bbox, max_area, method, group,
+                                      n_params=len(params))
         if reset:
             self.ctx.reset_best()
         self.ctx.match(arr, sp, sync=sync)

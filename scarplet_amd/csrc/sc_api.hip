@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <math.h>
 #include <algorithm>
 
 // ---------------------------------------------------------------------------
@@ -42,7 +43,7 @@ static void buf_free(DevBuf& b) {
 size_t sc_total_bytes(sc_ctx* c) {
     DevBuf* arr[] = {&c->z, &c->xaxis, &c->yaxis, &c->A, &c->B, &c->C, &c->curv,
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
-                     &c->map_snr, &c->templ, &c->sums, &c->win_w, &c->win_m,
+                     &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
                      &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage};
     size_t s = 0;
@@ -123,6 +124,7 @@ extern "C" int sc_create(int device, sc_ctx** out) {
     c->device = device;
     if (const char* d = getenv("SC_DBG")) c->dbg = atoi(d);
     if (const char* d = getenv("SC_VARIANT")) c->variant = atoi(d);
+    if (const char* d = getenv("SC_KAPPA")) c->kappa = (float)atof(d);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return SC_ERR_HIP;
@@ -157,7 +159,7 @@ extern "C" void sc_destroy(sc_ctx* c) {
     sc_clear_windows(c);
     DevBuf* arr[] = {&c->z, &c->xaxis, &c->yaxis, &c->A, &c->B, &c->C, &c->curv,
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
-                     &c->map_snr, &c->templ, &c->sums, &c->win_w, &c->win_m,
+                     &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
                      &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage};
     for (DevBuf* b : arr) buf_free(*b);
@@ -266,11 +268,14 @@ extern "C" int sc_upload_window(sc_ctx* ctx, const double* w, int h, int wd, int
     size_t n = (size_t)h * wd;
     std::vector<float> wf(n);
     std::vector<uint8_t> wm(n);
+    double l1 = 0.0;
     for (size_t i = 0; i < n; ++i) {
         wf[i] = (float)w[i];
         wm[i] = (w[i] != 0.0) ? 1 : 0;
+        l1 += fabs(w[i]);
     }
     WindowSlot s;
+    s.l1 = l1;
     s.h = h;
     s.wd = wd;
     SC_HIP(ctx, hipMalloc((void**)&s.w, n * sizeof(float)));
@@ -384,7 +389,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
 
     // device descriptors for the whole batch; windows are laid out per chunk
     std::vector<TemplDev> h(n);
-    std::vector<double> sums(2 * (size_t)n, 0.0);
+    std::vector<double> sums(2 * (size_t)n, 0.0), wl1(n, 0.0);
     struct Chunk { int first, n, wh, ww; size_t cells; };
     std::vector<Chunk> chunks;
     size_t max_cells = 0;
@@ -412,6 +417,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
                 d.mask_err = ctx->windows[s.window].mask_err;
                 sums[2 * (size_t)j] = s.p0;
                 sums[2 * (size_t)j + 1] = s.p1;
+                wl1[j] = ctx->windows[s.window].l1;
             }
             off += (size_t)d.wh * d.ww;
             off = (off + 3) & ~(size_t)3;
@@ -425,11 +431,14 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
     }
     if ((rc = sc_ensure(ctx, ctx->templ, sizeof(TemplDev) * n))) return rc;
     if ((rc = sc_ensure(ctx, ctx->sums, sizeof(double) * 2 * n))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->wl1, sizeof(double) * n))) return rc;
     if ((rc = sc_ensure(ctx, ctx->win_w, sizeof(float) * max_cells))) return rc;
     if ((rc = sc_ensure(ctx, ctx->win_m, max_cells))) return rc;
     SC_HIP(ctx, hipMemcpyAsync(ctx->templ.p, h.data(), sizeof(TemplDev) * n,
                                hipMemcpyHostToDevice, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(ctx->sums.p, sums.data(), sizeof(double) * 2 * n,
+                               hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(ctx->wl1.p, wl1.data(), sizeof(double) * n,
                                hipMemcpyHostToDevice, ctx->stream));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));   // h / sums leave scope below
     ctx->last_batch = n;

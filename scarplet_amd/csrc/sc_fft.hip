@@ -302,7 +302,8 @@ template <int TX>
 __global__ void __launch_bounds__(fft_threads(TX), fft_waves(TX))
 k_fwd_rows_curv(const float* __restrict__ curv, Geom g,
                 const TileDev* __restrict__ tiles, int Ty,
-                const float2* __restrict__ tw, float2* __restrict__ blk) {
+                const float2* __restrict__ tw, float2* __restrict__ blk,
+                double* __restrict__ norms) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     FftTw<TX> twr;
     twr.load(tw);
@@ -319,6 +320,23 @@ k_fwd_rows_curv(const float* __restrict__ curv, Geom g,
         int rr = e / TX, s = e - rr * TX, r = 4 * rb + rr;
         va[u] = ta.vy > 0 ? load_curv(curv, g, ta.gi0 + r, ta.gj0 + s) : 0.f;
         vb[u] = tb.vy > 0 ? load_curv(curv, g, tb.gi0 + r, tb.gj0 + s) : 0.f;
+    }
+    {   // |curv|_2^2 and |curv^2|_2^2 of the tile pair (resolution floor, sc_epi_floor)
+        double s2 = 0.0, s4 = 0.0;
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            double a2 = (double)va[u] * va[u], b2 = (double)vb[u] * vb[u];
+            s2 += a2 + b2;
+            s4 += a2 * a2 + b2 * b2;
+        }
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            s2 += __shfl_down(s2, sft, 64);
+            s4 += __shfl_down(s4, sft, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&norms[2 * pair], s2);
+            atomicAdd(&norms[2 * pair + 1], s4);
+        }
     }
     for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
@@ -553,6 +571,7 @@ __global__ void __launch_bounds__(fft_threads(TX), 2)
 k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
            RowArgs ra, Geom g, const TileDev* __restrict__ tiles,
            const TemplDev* __restrict__ templ, const double* __restrict__ sums,
+           const double* __restrict__ wl1, const double* __restrict__ norms, float kappa,
            const double* __restrict__ xaxis, const double* __restrict__ yaxis,
            const float2* __restrict__ tw, float* __restrict__ best_snr,
            float* __restrict__ best_amp, uint32_t* __restrict__ best_id,
@@ -610,7 +629,10 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
         if (!(ra.dbg & 1)) fetch(0);
         for (int gi_ = 0; gi_ < ra.G; ++gi_) {
             const TemplDev* tp = templ + ra.first + gi_;
-            const EpiScal es = sc_epi_scalars(sums, ra.first + gi_);
+            EpiScal es = sc_epi_scalars(sums, ra.first + gi_);
+            sc_epi_floor(es, sums[2 * (ra.first + gi_)], sums[2 * (ra.first + gi_) + 1],
+                         wl1[ra.first + gi_], norms[2 * ra.pair], norms[2 * ra.pair + 1],
+                         (double)ra.Ty * TX, kappa);
             const float scale_w = scale / sc_fft_alpha(sums, ra.first + gi_);
             const uint32_t tid_ = tp->id;
             // window-limit rectangle in tile-local coordinates (scalar)
@@ -754,6 +776,7 @@ int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group) {
     size_t plane = (size_t)fg.Ty * fg.Tx * sizeof(float2);
     size_t nblk = std::max((size_t)2 * np, (size_t)n_templ_chunk);
     if ((rc = sc_ensure(ctx, ctx->blk, plane * nblk))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->norms, sizeof(double) * 2 * np))) return rc;
     if ((rc = sc_ensure(ctx, ctx->uc, plane * np))) return rc;
     if ((rc = sc_ensure(ctx, ctx->uc2, plane * np))) return rc;
     if ((rc = sc_ensure(ctx, ctx->vh, plane * n_templ_chunk))) return rc;
@@ -803,6 +826,7 @@ static int launch_fwd_cols(sc_ctx* ctx, const FftGeom& fg, int nplanes,
 
 int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg) {
     int np = npairs_of(fg);
+    SC_HIP(ctx, hipMemsetAsync(ctx->norms.p, 0, sizeof(double) * 2 * np, ctx->stream));
     size_t lds = fft_lds_bytes(fg.Tx);
     dim3 grid(fg.Ty / 4, np);
     sc_prof_begin(ctx, SC_K_FWD_ROWS);
@@ -813,7 +837,8 @@ int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg) {
         hipLaunchKernelGGL(k_fwd_rows_curv<T>, grid, dim3(fft_threads(T)),     \
                            lds, ctx->stream, (const float*)ctx->curv.p,        \
                            ctx->g, (const TileDev*)ctx->tiles.p, fg.Ty,        \
-                           (const float2*)ctx->tw_x.p, (float2*)ctx->blk.p);   \
+                           (const float2*)ctx->tw_x.p, (float2*)ctx->blk.p,    \
+                           (double*)ctx->norms.p);                             \
     }
     DISPATCH_T(fg.Tx, FN)
 #undef FN
@@ -900,6 +925,8 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                            (const TileDev*)ctx->tiles.p,                       \
                            (const TemplDev*)ctx->templ.p,                      \
                            (const double*)ctx->sums.p,                         \
+                           (const double*)ctx->wl1.p,                          \
+                           (const double*)ctx->norms.p, ctx->kappa,            \
                            (const double*)ctx->xaxis.p,                        \
                            (const double*)ctx->yaxis.p,                        \
                            (const float2*)ctx->tw_x.p,                         \

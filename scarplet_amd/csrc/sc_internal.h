@@ -45,6 +45,7 @@ struct DevBuf {
 };
 
 struct WindowSlot {
+    double l1 = 0.0;           // sum |W|
     float* w = nullptr;        // h x wd float32
     uint8_t* m = nullptr;      // h x wd
     int h = 0, wd = 0;
@@ -66,12 +67,13 @@ struct sc_ctx {
     DevBuf map_amp, map_snr;
     DevBuf cmp[4], cmp_in[2];   // sc_compare_*: amp, age, angle, snr (float64)
     size_t cmp_n = 0;
-    DevBuf templ, sums, win_w, win_m;
+    DevBuf templ, sums, wl1, norms, win_w, win_m;   // wl1: sum|W| per template; norms: per tile pair
     DevBuf tw_y, tw_x;
     int tw_Ty = 0, tw_Tx = 0;
     DevBuf blk, uc, uc2, vh, wh, mh, yw, ym, tiles;
     std::vector<WindowSlot> windows;
     int last_batch = 0;
+    float kappa = 4.f;         // float32 resolution floor of the FFT path, in units of eps
     int variant = 0;           // SC_VARIANT: kernel variant under evaluation
     int dbg = 0;               // SC_DBG: timing-only ablation bits (wrong results)
     // profiling
@@ -152,12 +154,39 @@ __device__ __forceinline__ float load_curv(const float* __restrict__ curv,
 struct EpiScal {
     float inv_ts;      // 1 / sum(W**2)                       (core.py:356)
     float inv_n;       // 1 / (count(W != 0) + eps)           (core.py:350)
+    float d3;          // float32 resolution of T3 (FFT path; 0 on the exact path)
+    float dx2;         // 2 * resolution of xcorr / sum(W**2)
+    float dxx;         // resolution of xcorr squared / sum(W**2)
 };
 __device__ __forceinline__ EpiScal sc_epi_scalars(const double* __restrict__ sums, int it) {
     EpiScal s;
     s.inv_n = (float)(1.0 / (sums[2 * it] + SC_EPS));
     s.inv_ts = (float)(1.0 / sums[2 * it + 1]);
+    s.d3 = s.dx2 = s.dxx = 0.f;
     return s;
+}
+
+// Resolution floor of the float32 transforms.  A length-N float32 FFT
+// convolution returns every output with an ABSOLUTE error of order
+// eps32 * |kernel|_1 * |data|_2 / sqrt(N): relative to the plane, not to the
+// cell.  Where a DEM has no noise floor of its own (synthetic test surfaces
+// with exactly flat regions) T3 and T1 of a far-away template both sink below
+// that error, their difference is rounding noise and T1/(T3 - T1) explodes -
+// the reference sees the same at 1e-16 and adds eps for it (core.py:365-366).
+// So T3 - T1 is not allowed below the resolution of its two terms:
+//   d3  for T3  = M * curv^2   (|M|_1 = n,       |curv^2|_2 over the tile pair)
+//   dx  for xcorr = W * curv   (|W|_1,           |curv|_2)
+// and T1 = xcorr^2 / ts carries 2|xcorr| dx / ts + dx^2 / ts.
+// kappa scales eps32 (calibrated against the reference golden).
+__device__ __forceinline__ void sc_epi_floor(EpiScal& s, double n, double ts, double l1,
+                                             double norm_c2, double norm_c4, double cells,
+                                             float kappa) {
+    const double e = (double)kappa * 5.9604644775390625e-08;
+    double d3 = e * n * sqrt(norm_c4 / cells);
+    double dx = e * l1 * sqrt(norm_c2 / cells);
+    s.d3 = (float)d3;
+    s.dx2 = (float)(2.0 * dx / ts);
+    s.dxx = (float)(dx * dx / ts);
 }
 
 // FFT path: W and M = (W != 0) ride in ONE complex transform (W + iM) and are
@@ -178,7 +207,8 @@ __device__ __forceinline__ void sc_epilogue(float xc, float t3, const EpiScal& s
                                             float& amp_out, float& snr_out) {
     float amp = xc * s.inv_ts;
     float T1 = xc * amp;
-    float err = (t3 - T1) * s.inv_n + (float)SC_EPS;
+    float d = fmaxf(t3 - T1, s.d3 + fabsf(xc) * s.dx2 + s.dxx);   // floor is 0 on the exact path
+    float err = d * s.inv_n + (float)SC_EPS;
     amp_out = amp;
     snr_out = fabsf(__fdividef(T1, err));
 }

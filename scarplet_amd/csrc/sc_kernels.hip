@@ -83,13 +83,14 @@ __global__ void __launch_bounds__(64)
 k_windows(const TemplDev* __restrict__ templ, int first,
           const double* __restrict__ xaxis, const double* __restrict__ yaxis,
           int ny, int nx, float* __restrict__ win_w,
-          uint8_t* __restrict__ win_m, double* __restrict__ sums) {
+          uint8_t* __restrict__ win_m, double* __restrict__ sums,
+          double* __restrict__ wl1) {
     const int it = first + blockIdx.z;
     const TemplDev t = templ[it];
     if (t.kind == SC_KIND_WINDOW) return;         // uploaded by the host
     int a = blockIdx.y;
     int b = blockIdx.x * 64 + threadIdx.x;
-    double cnt = 0.0, sq = 0.0;
+    double cnt = 0.0, sq = 0.0, ab = 0.0;
     if (a < t.wh && b < t.ww) {
         int k = ny / 2 + t.pmin + a;
         int l = nx / 2 + t.qmin + b;
@@ -119,14 +120,17 @@ k_windows(const TemplDev* __restrict__ templ, int first,
         win_m[o] = m ? 1 : 0;
         cnt = m ? 1.0 : 0.0;
         sq = w * w;
+        ab = fabs(w);
     }
     for (int s = 32; s > 0; s >>= 1) {
         cnt += __shfl_down(cnt, s, 64);
         sq += __shfl_down(sq, s, 64);
+        ab += __shfl_down(ab, s, 64);
     }
     if (threadIdx.x == 0 && (cnt != 0.0 || sq != 0.0)) {
         atomicAdd(&sums[2 * it + 0], cnt);
         atomicAdd(&sums[2 * it + 1], sq);
+        atomicAdd(&wl1[it], ab);
     }
 }
 
@@ -339,7 +343,8 @@ int launch_windows(sc_ctx* ctx, int first, int n, int wh_max, int ww_max) {
                        (const TemplDev*)ctx->templ.p, first,
                        (const double*)ctx->xaxis.p, (const double*)ctx->yaxis.p,
                        ctx->g.ny, ctx->g.nx, (float*)ctx->win_w.p,
-                       (uint8_t*)ctx->win_m.p, (double*)ctx->sums.p);
+                       (uint8_t*)ctx->win_m.p, (double*)ctx->sums.p,
+                       (double*)ctx->wl1.p);
     sc_prof_end(ctx);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;

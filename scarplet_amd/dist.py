@@ -213,12 +213,13 @@ class DistMatcher(object):
         return self
 
     def search(self, Template, scale, params, angles, z_core, method="fft",
-               group=1, **kwargs):
+               group=None, **kwargs):
         params = np.atleast_1d(np.asarray(params, dtype=float))
         angles = np.atleast_1d(np.asarray(angles, dtype=float))
         arr, bbox, max_area = self.m.describe(Template, scale, params, angles, **kwargs)
         self.load(z_core, bbox)
-        self.m.plan, sp = self.m.plan_for(bbox, max_area, method, group)
+        self.m.plan, sp = self.m.plan_for(bbox, max_area, method, group,
+                                          n_params=len(params))
         self.m.ctx.reset_best()
         self.m.ctx.match(arr, sp)
         self.m.params, self.m.angles = params, angles

@@ -154,8 +154,9 @@ def test_small_searches_reference(gpu_ctx):
         chk = fold_check(res, c["z"], float(c["dx"]), float(c["dy"]), kind, kw["scale"], params, angles)
         assert chk["n_bad"] == 0, (kind, chk)
         if kind != "ricker":
-            same = (np.asarray(res[1]) == c["res"][1]) & (np.asarray(res[2]) == c["res"][2])
-            assert same.mean() > 0.8, float(same.mean())
+            # (ages: numpy's 10**x differs by an ulp between the numpy that wrote the fixture and this one)
+            same = np.isclose(res[1], c["res"][1], rtol=1e-9) & (np.asarray(res[2]) == c["res"][2])
+            assert same.mean() > 0.9, float(same.mean())
 
 
 def golden_check(res, gold):
@@ -291,7 +292,8 @@ def test_full_size_properties(gpu_ctx):
     assert np.array_equal(snr, snr2) and np.array_equal(amp, amp2) and np.array_equal(age, age2)
 
     # locality: crop with margin >= template reach + stencil, compare interior
-    i0, j0, w, margin = 4200, 7300, 160, 330
+    # margin: the window-limit mask of the crop reaches up to 2c + d*sqrt(2) = 375 cells inwards
+    i0, j0, w, margin = 4200, 7300, 160, 400
     sl_ = (slice(i0 - margin, i0 + w + margin), slice(j0 - margin, j0 + w + margin))
     zc = g._griddata[sl_]
     a_st, s_st = orc.snr_stack(zc, 1.0, 1.0, orc.SCARP, 100, ages, angles, workers=4)
@@ -305,7 +307,17 @@ def test_full_size_properties(gpu_ctx):
                          np.repeat(ages, len(angles)), np.tile(angles, len(ages)),
                          tie_rtol=TIE_RTOL, amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
                          snr_tol=(SNR_RTOL, SNR_ATOL * np.max(s_st)))
-    assert chk["n_bad"] == 0, chk
+    if chk["n_bad"]:
+        S = s_st.reshape(T, *zc.shape)[(slice(None),) + inner]
+        A = a_st.reshape(T, *zc.shape)[(slice(None),) + inner]
+        msgs = []
+        for (i, j) in np.argwhere(~chk["ok"])[:6]:
+            top = np.argsort(S[:, i, j])[::-1][:3]
+            msgs.append("cell (%d,%d): got amp=%.6g age=%.6g ang=%.4f snr=%.6g; oracle top3 %s" % (
+                i, j, res_win[0][i, j], res_win[1][i, j], res_win[2][i, j], res_win[3][i, j],
+                [(float(np.repeat(ages, len(angles))[t]), float(np.tile(angles, len(ages))[t]),
+                  float(S[t, i, j]), float(A[t, i, j])) for t in top]))
+        raise AssertionError("\n".join(msgs))
 
     g2 = sl.DEMGrid.from_array(g._griddata * 2.0, 1.0)
     m.set_data(g2)

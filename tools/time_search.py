@@ -12,7 +12,7 @@ ap.add_argument("--n", type=int, default=4096)
 ap.add_argument("--ages", type=int, default=35)
 ap.add_argument("--angles", type=int, default=5)
 ap.add_argument("--method", default="fft")
-ap.add_argument("--group", type=int, default=1)
+ap.add_argument("--group", type=int, default=0)
 ap.add_argument("--scale", type=float, default=100.0)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--prof", type=int, default=8)
@@ -26,7 +26,7 @@ angs = _plan.angle_grid()[np.round(np.linspace(0, 180, a.angles)).astype(int)]
 for rep in range(a.reps):
     m.ctx.profile(a.prof)
     t0 = time.time()
-    m.search(sl.Scarp, a.scale, ages, angs, method=a.method, group=a.group)
+    m.search(sl.Scarp, a.scale, ages, angs, method=a.method, group=a.group or None)
     dt = time.time() - t0
     work = a.n * a.n * len(ages) * len(angs) / 1e6
     print("rep %d: %.3fs  %.0f Mpx.tmpl/s  plan %s  mem %.2f GB" % (rep, dt, work / dt, m.plan, m.ctx.device_bytes() / 1e9))
