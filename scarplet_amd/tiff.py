@@ -1,0 +1,123 @@
+"""Minimal GeoTIFF reader (no GDAL).
+
+Covers what single-band DEM rasters use in practice and what the reference's
+sample datasets need (scarplet/datasets/data/*.tif): classic (non-Big) TIFF,
+either byte order, strips or tiles, uncompressed or deflate, horizontal
+predictor, 8/16/32/64-bit integer or float samples, and the GeoTIFF tags
+that define the geotransform (ModelPixelScale + ModelTiepoint, or
+ModelTransformation) plus GDAL's nodata tag.  Replaces the read half of
+BaseSpatialGrid.load (dem.py:308-348); anything outside this subset raises.
+"""
+
+import struct
+import zlib
+
+import numpy as np
+
+_TYPES = {1: ("B", 1), 2: ("c", 1), 3: ("H", 2), 4: ("I", 4), 5: ("II", 8),
+          6: ("b", 1), 7: ("B", 1), 8: ("h", 2), 9: ("i", 4), 10: ("ii", 8),
+          11: ("f", 4), 12: ("d", 8), 16: ("Q", 8)}
+
+
+def _read_ifd(buf, off, bo):
+    (n,) = struct.unpack_from(bo + "H", buf, off)
+    tags = {}
+    for k in range(n):
+        tag, typ, cnt, val = struct.unpack_from(bo + "HHI4s", buf, off + 2 + 12 * k)
+        fmt, size = _TYPES.get(typ, (None, 0))
+        if fmt is None:
+            continue
+        total = size * cnt
+        if total <= 4:
+            data = val[:total]
+        else:
+            (ptr,) = struct.unpack(bo + "I", val)
+            data = buf[ptr:ptr + total]
+        if typ == 2:
+            tags[tag] = data.split(b"\0")[0].decode("ascii", "replace")
+        elif typ in (5, 10):
+            v = struct.unpack(bo + fmt[0] * (2 * cnt), data)
+            tags[tag] = tuple(v[2 * i] / v[2 * i + 1] if v[2 * i + 1] else 0.0 for i in range(cnt))
+        else:
+            tags[tag] = struct.unpack(bo + fmt * cnt, data)
+    return tags
+
+
+def read_geotiff(path):
+    """Returns (array, geo_transform or None, nodata or None).
+
+    geo_transform follows GDAL: (x0, dx, 0, y0, 0, dy) with dy negative for
+    north-up rasters (dem.py:324-332 reads dx = gt[1], dy = gt[5])."""
+    with open(path, "rb") as f:
+        buf = f.read()
+    if buf[:2] == b"II":
+        bo = "<"
+    elif buf[:2] == b"MM":
+        bo = ">"
+    else:
+        raise ValueError("%s: not a TIFF file" % path)
+    magic, ifd = struct.unpack_from(bo + "HI", buf, 2)
+    if magic != 42:
+        raise ValueError("%s: BigTIFF / unknown TIFF variant is not supported" % path)
+    t = _read_ifd(buf, ifd, bo)
+    width, height = t[256][0], t[257][0]
+    bits = t.get(258, (1,))[0]
+    comp = t.get(259, (1,))[0]
+    spp = t.get(277, (1,))[0]
+    fmt = t.get(339, (1,))[0]
+    pred = t.get(317, (1,))[0]
+    if spp != 1:
+        raise ValueError("%s: %d samples per pixel (single-band rasters only)" % (path, spp))
+    kind = {1: "u", 2: "i", 3: "f"}.get(fmt)
+    if kind is None or bits not in (8, 16, 32, 64):
+        raise ValueError("%s: unsupported sample format %d / %d bits" % (path, fmt, bits))
+    dtype = np.dtype(bo + kind + str(bits // 8))
+
+    def decode(raw, rows, cols):
+        if comp in (8, 32946):
+            raw = zlib.decompress(raw)
+        elif comp != 1:
+            raise ValueError("%s: compression %d is not supported" % (path, comp))
+        a = np.frombuffer(raw, dtype=dtype, count=rows * cols).reshape(rows, cols)
+        if pred == 2:
+            a = np.cumsum(a, axis=1, dtype=dtype)
+        elif pred != 1:
+            raise ValueError("%s: predictor %d is not supported" % (path, pred))
+        return a
+
+    out = np.empty((height, width), dtype=dtype.newbyteorder("="))
+    if 322 in t:                                    # tiled
+        tw, tl = t[322][0], t[323][0]
+        offs, cnts = t[324], t[325]
+        across = (width + tw - 1) // tw
+        for k, (o, c) in enumerate(zip(offs, cnts)):
+            ty, tx = divmod(k, across)
+            tile = decode(buf[o:o + c], tl, tw)
+            y0, x0 = ty * tl, tx * tw
+            h, w = min(tl, height - y0), min(tw, width - x0)
+            out[y0:y0 + h, x0:x0 + w] = tile[:h, :w]
+    else:                                           # strips
+        rps = t.get(278, (height,))[0]
+        offs, cnts = t[273], t[279]
+        for k, (o, c) in enumerate(zip(offs, cnts)):
+            y0 = k * rps
+            h = min(rps, height - y0)
+            out[y0:y0 + h] = decode(buf[o:o + c], h, width)
+
+    gt = None
+    if 33550 in t and 33922 in t:                   # ModelPixelScale + ModelTiepoint
+        sx, sy = t[33550][0], t[33550][1]
+        i, j, _, x, y, _ = t[33922][:6]
+        gt = (x - i * sx, sx, 0.0, y + j * sy, 0.0, -sy)
+    elif 34264 in t:                                # ModelTransformation (4x4, row major)
+        m = t[34264]
+        gt = (m[3], m[0], m[1], m[7], m[4], m[5])
+    nodata = None
+    if 42113 in t:
+        try:
+            nodata = float(t[42113])
+        except (TypeError, ValueError):
+            nodata = None
+        if nodata is not None and np.isnan(nodata):
+            nodata = None                           # NaN cells are already NaN
+    return out, gt, nodata
