@@ -1,0 +1,84 @@
+"""The multi-GPU decomposition on ONE GPU: every rank's halo-extended block is
+searched on its own (non-periodic block, window limits in global coordinates)
+and the stitched tiles must reproduce the whole-DEM search.  Also runs the RCCL
+entry points with a single-rank communicator (periodic self-images only)."""
+import numpy as np
+import pytest
+
+import scarplet_oracle as orc
+import scarplet_amd as sl
+from scarplet_amd import _plan, dist as sd, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def whole_and_tiled(g, Template, scale, params, angles, nranks, method, backend="host"):
+    z = g._griddata
+    ny, nx = z.shape
+    m = sl.Matcher(g)
+    whole = m.search(Template, scale, params, angles, method=method).result()
+    arr, bbox, area = m.describe(Template, scale, np.asarray(params, float), np.asarray(angles, float))
+    halo = sd.halo_for_search(bbox, ny, nx)
+    py, px = sd.grid_dims(nranks, ny, nx)
+    lay = sd.Layout(ny, nx, py, px, halo)
+    out = [np.zeros((ny, nx)) for _ in range(4)]
+    for r in range(nranks):
+        c = lay.core(r)
+        mt = sl.Matcher()
+        mt.ny, mt.nx, mt.de = ny, nx, g._georef_info.dx
+        blk = sd.assemble_block_reference(z, lay, r)
+        mt.set_block(np.ascontiguousarray(blk), lay.block_origin(r), (ny, nx), c,
+                     g._georef_info.dx, g._georef_info.dy)
+        mt.plan, sp = mt.plan_for(bbox, area, method, None, n_params=len(params))
+        mt.ctx.reset_best()
+        mt.ctx.match(arr, sp)
+        mt.params, mt.angles = np.asarray(params, float), np.asarray(angles, float)
+        res = mt.result()
+        for k in range(4):
+            out[k][c[0]:c[1], c[2]:c[3]] = res[k]
+    return whole, out
+
+
+@pytest.mark.parametrize("method", ["fft", "direct"])
+@pytest.mark.parametrize("nranks,shape", [(2, (150, 131)), (4, (200, 260)), (8, (256, 300))])
+def test_tiled_blocks_reproduce_whole_dem(method, nranks, shape):
+    g = synthetic.synthetic_scarp(shape[1], seed=nranks, ny=shape[0])
+    params = [2.0, 10.0, 50.0]
+    angles = _plan.angle_grid(-1.2, 1.2)[::12]
+    whole, tiled = whole_and_tiled(g, sl.Scarp, 12, params, angles, nranks, method)
+    same = (whole[1] == tiled[1]) & (whole[2] == tiled[2])
+    assert same.mean() > 0.995, float(same.mean())
+    assert np.allclose(whole[0][same], tiled[0][same], rtol=2e-4, atol=2e-6 * np.abs(whole[0]).max())
+    assert np.allclose(whole[3][same], tiled[3][same], rtol=2e-3, atol=2e-6 * whole[3].max())
+    # the few differing cells are near-ties: same SNR within tolerance
+    assert np.allclose(whole[3][~same], tiled[3][~same], rtol=4e-3)
+
+
+def test_tiled_blocks_against_oracle():
+    g = synthetic.synthetic_scarp(120, seed=5, ny=96)
+    z = g._griddata
+    params, angles = [3.0, 20.0], _plan.angle_grid(-0.5, 0.5)[::4]
+    _, tiled = whole_and_tiled(g, sl.Scarp, 10, params, angles, 4, "fft")
+    a_st, s_st = orc.snr_stack(z, 1.0, 1.0, orc.SCARP, 10, params, angles)
+    T = len(params) * len(angles)
+    chk = orc.check_fold(tiled, a_st.reshape(T, 96, 120), s_st.reshape(T, 96, 120),
+                         np.repeat(params, len(angles)), np.tile(angles, len(params)),
+                         tie_rtol=4e-3, amp_tol=(2e-4, 2e-6 * np.abs(a_st).max()),
+                         snr_tol=(2e-3, 2e-6 * s_st.max()))
+    assert chk["n_bad"] == 0, chk
+
+
+def test_rccl_single_rank_halo_exchange():
+    """sc_comm_init / sc_halo_exchange / sc_set_dem_device with one rank: the
+    halo consists of periodic images of the rank's own core."""
+    g = synthetic.synthetic_scarp(140, seed=9, ny=100)
+    z = g._griddata
+    params, angles = [5.0, 30.0], _plan.angle_grid(-0.3, 0.3)[::6]
+    m = sl.Matcher(g)
+    whole = m.search(sl.Scarp, 10, params, angles, method="fft").result()
+    dm = sd.DistMatcher(0, 1, z.shape, 1.0, 1.0, device=0, backend="rccl",
+                        broadcast_bytes=lambda b: b)
+    dm.m.ctx.comm_init(dm.m.ctx.comm_unique_id(), 0, 1)
+    res = dm.search(sl.Scarp, 10, params, angles, z, method="fft").result()
+    for k in range(4):
+        assert np.allclose(res[k], whole[k], rtol=2e-3, atol=1e-6 * np.abs(whole[k]).max() + 1e-12)
