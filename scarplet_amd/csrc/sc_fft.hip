@@ -23,9 +23,12 @@
 //               128-byte block per 4 rows).  Both sides move whole 128-byte
 //               lines, which is what fuses the transpose into the FFT kernels.
 //
-// The in-LDS FFT is a radix-4 Stockham autosort (natural order in and out):
-// every stage reads element t + k*T/4 (conflict-free) and writes
-// q + s*(4p + k); a final radix-2 stage handles odd log2(T).
+//   "rows2"     hand-off between I1 and I2: 128-byte blocks of 2 rows x 8
+//               columns, cell (r, c) at ((r/2)*(Tx/8) + c/8)*16 + (c%8)*2 + r%2.
+//               I1 (4 columns) writes 64-byte half blocks; I2 owns whole row
+//               pairs, i.e. one contiguous 2*Tx run per plane.
+//
+// The in-LDS FFT is a Stockham autosort with radices 16,16,..,r (see below).
 #include "sc_internal.h"
 #include <math.h>
 
@@ -52,7 +55,9 @@ __host__ __device__ constexpr int fft_threads(int T) {
 // waves per SIMD the kernels are compiled for: two 512-thread workgroups per
 // CU (LDS allows it up to T = 2048), i.e. at most 128 VGPRs
 __host__ __device__ constexpr int fft_waves(int T) { return T >= 4096 ? 2 : 4; }
-__host__ __device__ constexpr int fft_line(int T) { return T + T / 16; }
+// padded line: one pad per 16 elements, plus 8 so that consecutive lines start
+// 16 banks apart (lanes of one wave may alternate between two lines)
+__host__ __device__ constexpr int fft_line(int T) { return T + T / 16 + 8; }
 __host__ __device__ constexpr size_t fft_lds_bytes(int T) {
     return (size_t)4 * fft_line(T) * sizeof(float2);
 }
@@ -193,89 +198,105 @@ struct FftTw {
     }
 };
 
-// one Stockham stage of radix R at stride 2^LST over the 4 lines in LDS.
-// For T >= 256 every LDS address of the stage is (one per-thread base) +
+// ---- one Stockham stage, per 16-point set -------------------------------------
+// For T >= 256 every LDS address of a stage is (one per-thread base) +
 // (compile-time offset): S = T/16 and the strides are multiples of 16, so the
 // padding term (i >> 4) is affine in j and m, and the accesses compile to
 // ds_read/ds_write with immediate offsets instead of 32 address registers.
+
+// a[j] = line[tt + j*S]
+template <int T>
+__device__ __forceinline__ void set_load(const float2* line, int tt, float2 (&a)[16]) {
+    constexpr int S = T / 16;
+    if ((S % 16) == 0) {
+        const float2* rb = line + ph(tt);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = rb[j * (S + S / 16)];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = line[ph(tt + j * S)];
+    }
+}
+
+// twiddle applied to output m of a radix-16 butterfly, from the four bases
+// w^(e), w^(2e), w^(4e), w^(8e): w^k for k = 1..7 one at a time, each also
+// serving k + 8.  `put(m, value)` receives the finished outputs.
+template <bool INV, typename PUT>
+__device__ __forceinline__ void twiddle16(const float2 (&v)[16], const float2 (&w)[4], PUT put) {
+    float2 w1 = w[0], w2 = w[1], w4 = w[2], w8 = w[3];
+    if (INV) { w1.y = -w1.y; w2.y = -w2.y; w4.y = -w4.y; w8.y = -w8.y; }
+    put(0, v[Bfly<16, INV>::pos(0)]);
+    put(8, cmul(v[Bfly<16, INV>::pos(8)], w8));
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        float2 wk = (k & 1) ? w1 : make_float2(1.f, 0.f);
+        if (k == 2 || k == 6) wk = w2;
+        if (k == 3 || k == 7) wk = cmul(w1, w2);
+        if (k == 4) wk = w4;
+        if (k >= 5) wk = cmul(wk, w4);
+        put(k, cmul(v[Bfly<16, INV>::pos(k)], wk));
+        put(k + 8, cmul(v[Bfly<16, INV>::pos(k + 8)], cmul(wk, w8)));
+    }
+}
+
+// butterflies of the set (tt) in the stage (R, LST) and store to `line`
+template <int T, int R, int LST, bool INV>
+__device__ __forceinline__ void set_compute_store(float2* line, int tt, float2 (&a)[16],
+                                                  const float2 (&w)[4]) {
+    constexpr int S = T / 16;
+    constexpr int NB = 16 / R;
+    constexpr int LR = __builtin_ctz(R);
+    constexpr int ST = 1 << LST;
+    constexpr bool LAST = (R << LST) == T;     // n == R: all twiddles are 1
+    static_assert(LAST || R == 16, "twiddled stages are radix 16");
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float2 v[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = a[b + NB * k];
+        Bfly<R, INV>::run(v);
+        const int bt = tt + b * S;             // butterfly index in [0, T/R)
+        const int p = bt >> LST, q = bt & (ST - 1);
+        const int o = q + (p << (LST + LR));
+        // output m goes to element o + m*ST
+        float2* wb;
+        int wstep;                             // padded distance of ST elements
+        if (LST >= 4) { wb = line + ph(o); wstep = ST + ST / 16; }
+        else if (LST == 0 && R == 16) { wb = line + 17 * bt; wstep = 1; }
+        else { wb = nullptr; wstep = 0; }
+        auto put = [&](int m, float2 val) {
+            if (wb) wb[m * wstep] = val;
+            else line[ph(o + (m << LST))] = val;
+        };
+        if constexpr (LAST) {
+#pragma unroll
+            for (int m = 0; m < R; ++m) put(m, v[Bfly<R, INV>::pos(m)]);
+        } else {
+            twiddle16<INV>(v, w, put);
+        }
+    }
+}
+
+// one Stockham stage of radix R at stride 2^LST over the 4 lines in LDS,
+// standard mapping: set id -> line id / S, tt = id % S
 template <int T, int R, int LST, bool INV>
 __device__ __forceinline__ void fft_stage(float2* s, const FftTw<T>& twr) {
     constexpr int S = T / 16;                  // 16-point sets per line
     constexpr int NT = fft_threads(T);
     constexpr int U = (4 * S + NT - 1) / NT;   // sets per thread
-    constexpr int NB = 16 / R;                 // butterflies per set
-    constexpr int LR = __builtin_ctz(R);
-    constexpr int ST = 1 << LST;
-    constexpr bool LAST = (R << LST) == T;     // n == R: all twiddles are 1
-    constexpr bool AFF = (S % 16) == 0;        // affine addressing available
-    constexpr int SP = S + S / 16;             // padded distance of S elements
-    static_assert(LAST || R == 16, "twiddled stages are radix 16");
     float2 a[U][16];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         int id = threadIdx.x + u * NT;
-        if (id < 4 * S) {
-            int line = id / S, tt = id - line * S;
-            const float2* base = s + line * fft_line(T);
-            if (AFF) {
-                const float2* rb = base + ph(tt);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) a[u][j] = rb[j * SP];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) a[u][j] = base[ph(tt + j * S)];
-            }
-        }
+        if (id < 4 * S) set_load<T>(s + (id / S) * fft_line(T), id % S, a[u]);
     }
     lds_barrier();
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         int id = threadIdx.x + u * NT;
-        if (id < 4 * S) {
-            int line = id / S, tt = id - line * S;
-            float2* base = s + line * fft_line(T);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                float2 v[R];
-#pragma unroll
-                for (int k = 0; k < R; ++k) v[k] = a[u][b + NB * k];
-                Bfly<R, INV>::run(v);
-                const int bt = tt + b * S;             // butterfly index in [0, T/R)
-                const int p = bt >> LST, q = bt & (ST - 1);
-                const int o = q + (p << (LST + LR));
-                // output m goes to element o + m*ST
-                float2* wb;
-                int wstep;                             // padded distance of ST elements
-                if (LST >= 4) { wb = base + ph(o); wstep = ST + ST / 16; }
-                else if (LST == 0 && R == 16) { wb = base + 17 * bt; wstep = 1; }
-                else { wb = nullptr; wstep = 0; }
-                auto put = [&](int m, float2 val) {
-                    if (wb) wb[m * wstep] = val;
-                    else base[ph(o + (m << LST))] = val;
-                };
-                if (LAST) {
-#pragma unroll
-                    for (int m = 0; m < R; ++m) put(m, v[Bfly<R, INV>::pos(m)]);
-                } else {
-                    float2 w1 = twr.w[LST / 4][u][0], w2 = twr.w[LST / 4][u][1];
-                    float2 w4 = twr.w[LST / 4][u][2], w8 = twr.w[LST / 4][u][3];
-                    if (INV) { w1.y = -w1.y; w2.y = -w2.y; w4.y = -w4.y; w8.y = -w8.y; }
-                    // w^k for k = 1..7 one at a time; each also serves k + 8
-                    put(0, v[Bfly<R, INV>::pos(0)]);
-                    put(8, cmul(v[Bfly<R, INV>::pos(8)], w8));
-#pragma unroll
-                    for (int k = 1; k < 8; ++k) {
-                        float2 wk = (k & 1) ? w1 : make_float2(1.f, 0.f);
-                        if (k == 2 || k == 6) wk = w2;
-                        if (k == 3 || k == 7) wk = cmul(w1, w2);
-                        if (k == 4) wk = w4;
-                        if (k >= 5) wk = cmul(wk, w4);
-                        put(k, cmul(v[Bfly<R, INV>::pos(k)], wk));
-                        put(k + 8, cmul(v[Bfly<R, INV>::pos(k + 8)], cmul(wk, w8)));
-                    }
-                }
-            }
-        }
+        if (id < 4 * S)
+            set_compute_store<T, R, LST, INV>(s + (id / S) * fft_line(T), id % S, a[u],
+                                              twr.w[(LST / 4) < FftTw<T>::NTW ? LST / 4 : 0][u]);
     }
     lds_barrier();
 }
@@ -299,7 +320,7 @@ __device__ __forceinline__ void fft4_lines(float2* s, const FftTw<T>& twr) {
 // ---- F1c: curvature of a tile pair -> row FFT -> blocked ---------------------
 // grid = (Ty/4, npairs); out plane index = pair*2 + {0: curv, 1: curv^2}
 template <int TX>
-__global__ void __launch_bounds__(fft_threads(TX), fft_waves(TX))
+__global__ void __launch_bounds__(fft_threads(TX), 2)
 k_fwd_rows_curv(const float* __restrict__ curv, Geom g,
                 const TileDev* __restrict__ tiles, int Ty,
                 const float2* __restrict__ tw, float2* __restrict__ blk,
@@ -479,7 +500,7 @@ k_split_templ(const float2* __restrict__ vh, int Ty, int Tx,
 // spectrum of template g+1 is fetched into registers while template g is
 // transformed in LDS (barriers that do not drain vmcnt: lds_barrier), so the HBM
 // stream and the LDS/VALU work overlap inside one 512-thread workgroup per CU.
-// Only the row blocks [rb_lo, rb_hi] that hold valid outputs are written.
+// Only the row pairs [rp_lo, rp_hi] that hold valid outputs are written.
 template <int TY>
 __host__ __device__ constexpr bool inv_cols_park() { return TY <= 2048; }
 template <int TY>
@@ -491,7 +512,7 @@ template <int TY>
 __global__ void __launch_bounds__(fft_threads(TY), 2)
 k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
            const float2* __restrict__ wh, const float2* __restrict__ mh, int Tx,
-           int pair, int vfirst, int G, int rb_lo, int rb_hi, int dbg,
+           int pair, int vfirst, int G, int rp_lo, int rp_hi, int dbg,
            const float2* __restrict__ tw, float2* __restrict__ yw,
            float2* __restrict__ ym) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
@@ -501,10 +522,14 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
     constexpr int EP = 4 * TY / (2 * NT);     // float4 (2-cell) loads per thread per stream
     constexpr bool PARK = inv_cols_park<TY>();
     float4* xs = reinterpret_cast<float4*>(sm + 4 * fft_line(TY));   // parked spectrum, linear
-    const int cb = blockIdx.x;
+    // Column blocks 2m and 2m+1 write the two 64-byte halves of the same rows2
+    // lines.  Workgroups are dealt round-robin over the 8 XCDs, so the pair is
+    // given to workgroups b and b+8 (same XCD, dispatched together): their
+    // halves meet in that XCD's L2 and leave as whole lines.  Speed only.
+    const int b_ = blockIdx.x;
+    const int cb = 2 * ((b_ >> 4) * 8 + (b_ & 7)) + ((b_ >> 3) & 1);
     const size_t plane = (size_t)TY * Tx;
     const size_t col = (size_t)cb * 4 * TY;
-    const int nbx = Tx >> 2;
     float4 hreg[EP];
     for (int pl = 0; pl < 2; ++pl) {
         const float4* uu = reinterpret_cast<const float4*>((pl ? uc2 : uc) + (size_t)pair * plane + col);
@@ -533,14 +558,16 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
             lds_barrier();
             if (gi_ + 1 < G && !(dbg & 16)) fetch(gi_ + 1);
             if (!(dbg & 32)) fft4_lines<TY, true>(sm, twr);
-            float2* o = (pl ? ym : yw) + (size_t)gi_ * plane;
-            const int e_lo = rb_lo * 16, e_hi = (rb_hi + 1) * 16;
+            // rows2 layout: this block's 4 columns x 2 rows of a row pair are 64
+            // contiguous bytes; a thread stores (row 2rp, row 2rp+1) of one column
+            float2* o = (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)(cb >> 1) * 16 + (cb & 1) * 8;
+            const int e_lo = 4 * rp_lo, e_hi = 4 * (rp_hi + 1);
             if (!(dbg & 64))
 #pragma unroll 2
-            for (int e = e_lo + 2 * threadIdx.x; e < e_hi; e += 2 * NT) {
-                int rbk = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
-                float2 x0 = sm[lidx<TY>(cc, 4 * rbk + rr)], x1 = sm[lidx<TY>(cc + 1, 4 * rbk + rr)];
-                *reinterpret_cast<float4*>(o + ((size_t)rbk * nbx + cb) * 16 + (e & 15)) =
+            for (int e = e_lo + threadIdx.x; e < e_hi; e += NT) {
+                int rp = e >> 2, k = e & 3;
+                float2 x0 = sm[lidx<TY>(k, 2 * rp)], x1 = sm[lidx<TY>(k, 2 * rp + 1)];
+                *reinterpret_cast<float4*>(o + (size_t)rp * (Tx >> 3) * 16 + 2 * k) =
                     make_float4(x0.x, x0.y, x1.x, x1.y);
             }
             lds_barrier();
@@ -562,7 +589,8 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
 struct RowArgs {
     int Ty, Py, Qx, circ_y, circ_x;     // tile geometry
     int cy0, cx0, cw;                   // core origin and width
-    int pair, first, G, rb_lo;
+    int pair, first, G;
+    int rp_lo, rp_n;                    // valid row pairs of the tile: [rp_lo, rp_lo + rp_n)
     int dbg;                            // diagnostic ablation bits (SC_DBG), 0 in production
 };
 
@@ -582,28 +610,28 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
     constexpr int NT = fft_threads(TX);
     constexpr int E = 2 * TX / NT;          // cells per thread per sub-batch
     constexpr int EP = 2 * TX / (2 * NT);   // float4 loads per thread per plane
-    const int rb = ra.rb_lo + blockIdx.x;
     const size_t plane = (size_t)ra.Ty * TX;
     const TileDev tA = tiles[2 * ra.pair], tB = tiles[2 * ra.pair + 1];
     const float scale = 1.0f / ((float)ra.Ty * (float)TX);
-    const float2* base1 = yw + (size_t)rb * 4 * TX;
-    const float2* base2 = ym + (size_t)rb * 4 * TX;
     float4 xreg[EP], yreg[EP];
     for (int sb = 0; sb < 2; ++sb) {
+        // this workgroup takes row pairs 2*blockIdx.x and 2*blockIdx.x + 1 of the
+        // valid range, one per sub-batch (a row pair is a contiguous 2*TX run)
+        const int rp = ra.rp_lo + 2 * blockIdx.x + sb;
+        if (rp >= ra.rp_lo + ra.rp_n) break;              // block-uniform
+        const float2* base1 = yw + (size_t)rp * 2 * TX;
+        const float2* base2 = ym + (size_t)rp * 2 * TX;
         auto fetch = [&](int gi_) {
-            // rows 2sb, 2sb+1 of every 4x4 block: 8 cells = 64 B contiguous
 #pragma unroll
             for (int u = 0; u < EP; ++u) {
-                int e = 2 * (threadIdx.x + u * NT);
-                int cb = e >> 3, r2 = (e >> 2) & 1, cc = e & 3;
-                size_t src = (size_t)gi_ * plane + (size_t)cb * 16 + (2 * sb + r2) * 4 + cc;
+                size_t src = (size_t)gi_ * plane + 2 * (threadIdx.x + u * NT);
                 xreg[u] = *reinterpret_cast<const float4*>(base1 + src);
                 yreg[u] = *reinterpret_cast<const float4*>(base2 + src);
             }
         };
         // cell u of this thread is tile-local (row0 + e/TX - Py, e%TX - Qx);
         // slot 2u + part is that cell of tile A / B (re / im of the transforms)
-        const int row0 = 4 * rb + 2 * sb - ra.Py;
+        const int row0 = 2 * rp - ra.Py;
         auto locate = [&](int u, int& ri, int& cj) {
             int e = threadIdx.x + u * NT;
             int r2 = e / TX;
@@ -640,12 +668,11 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
             const int rloB = tp->ilo - tB.i0, rhiB = tp->ihi - tB.i0, cloB = tp->jlo - tB.j0, chiB = tp->jhi - tB.j0;
 #pragma unroll
             for (int u = 0; u < EP; ++u) {
-                int e = 2 * (threadIdx.x + u * NT);
-                int cb = e >> 3, r2 = (e >> 2) & 1, cc = e & 3;
-                sm[lidx<TX>(r2, 4 * cb + cc)] = make_float2(xreg[u].x, xreg[u].y);
-                sm[lidx<TX>(r2, 4 * cb + cc + 1)] = make_float2(xreg[u].z, xreg[u].w);
-                sm[lidx<TX>(2 + r2, 4 * cb + cc)] = make_float2(yreg[u].x, yreg[u].y);
-                sm[lidx<TX>(2 + r2, 4 * cb + cc + 1)] = make_float2(yreg[u].z, yreg[u].w);
+                int c = threadIdx.x + u * NT;       // column; the float4 holds rows 0 and 1
+                sm[lidx<TX>(0, c)] = make_float2(xreg[u].x, xreg[u].y);
+                sm[lidx<TX>(1, c)] = make_float2(xreg[u].z, xreg[u].w);
+                sm[lidx<TX>(2, c)] = make_float2(yreg[u].x, yreg[u].y);
+                sm[lidx<TX>(3, c)] = make_float2(yreg[u].z, yreg[u].w);
             }
             lds_barrier();
             if (gi_ + 1 < ra.G && !(ra.dbg & 1)) fetch(gi_ + 1);
@@ -721,6 +748,198 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
             }
             lds_barrier();
         }
+    }
+}
+
+// ---- I2 (fast): T in {512, 1024, 2048} ---------------------------------------
+// grid = (valid row pairs): one 512-thread workgroup per pair of tile rows, 4 LDS
+// lines = {W plane, M plane} x {row 0, row 1}.  Compared with the generic kernel
+// the transform is unrolled into its three stages so that
+//   * stage 1 takes its 16 points straight from global memory into registers
+//     (lanes alternate between the two rows: a wave reads whole 128-byte
+//     blocks of the rows2 layout) - no LDS fill pass;
+//   * stage 3 is fused with the epilogue: a thread computes the same butterflies
+//     of the W and the M line, so xcorr and T3 of its cells meet in registers -
+//     no LDS write of the result, no read back;
+//   * the next template's points are fetched right after stage 1 and stay in
+//     flight through stages 2-3 (nothing in between waits on vmcnt).
+// 2 LDS writes + 2 reads and 3 barriers per template instead of 4 + 4 and 8.
+template <int TX>
+__host__ __device__ constexpr bool inv_rows_fast_ok() { return TX == 512 || TX == 1024 || TX == 2048; }
+
+template <int TX, bool FULL>
+__global__ void __launch_bounds__(fft_threads(TX), 2)
+k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
+                RowArgs ra, Geom g, const TileDev* __restrict__ tiles,
+                const TemplDev* __restrict__ templ, const double* __restrict__ sums,
+                const double* __restrict__ wl1, const double* __restrict__ norms, float kappa,
+                const double* __restrict__ xaxis, const double* __restrict__ yaxis,
+                const float2* __restrict__ tw, float* __restrict__ best_snr,
+                float* __restrict__ best_amp, uint32_t* __restrict__ best_id,
+                float* __restrict__ map_amp, float* __restrict__ map_snr) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    constexpr int S = TX / 16;                 // 16-point sets per line; NT = 4S threads
+    constexpr int R3 = TX / 256;               // radix of the last stage (2, 4, 8)
+    constexpr int NB3 = 16 / R3;               // its butterflies per set
+    constexpr int NU = NB3 / 2;                // butterflies per plane per thread in stage 3
+    constexpr int NC = NU * R3;                // cells per thread (= 8)
+    constexpr int LINE = fft_line(TX);
+    static_assert(fft_threads(TX) == 4 * S && NC == 8, "fast I2 geometry");
+    const int id = threadIdx.x;
+    const int rp = ra.rp_lo + blockIdx.x;
+    const size_t plane = (size_t)ra.Ty * TX;
+    const TileDev tA = tiles[2 * ra.pair], tB = tiles[2 * ra.pair + 1];
+    const float scale = 1.0f / ((float)ra.Ty * (float)TX);
+
+    // stage-1 mapping: plane, row and set of this thread
+    const int pl1 = id / (2 * S), rr1 = id & 1, tt1 = (id % (2 * S)) >> 1;
+    float2* line1 = sm + (2 * pl1 + rr1) * LINE;
+    const float2* src1 = (pl1 ? ym : yw) + (size_t)rp * 2 * TX + (size_t)(tt1 >> 3) * 16 + (tt1 & 7) * 2 + rr1;
+    // stage-2 mapping (standard)
+    float2* line2 = sm + (id / S) * LINE;
+    const int tt2 = id % S;
+    // stage-3 mapping: row r3, butterflies rem3 + u*2S of both planes
+    const int r3 = id / (2 * S), rem3 = id % (2 * S);
+    const float2* lineW = sm + r3 * LINE;
+    const float2* lineM = sm + (2 + r3) * LINE;
+    // twiddle bases of stages 1 and 2
+    float2 w1[4], w2[4];
+    {
+        const int e1 = tt1, e2 = (tt2 >> 4) << 4;
+        w1[0] = tw[e1]; w1[1] = tw[2 * e1]; w1[2] = tw[4 * e1]; w1[3] = tw[8 * e1];
+        w2[0] = tw[e2]; w2[1] = tw[2 * e2]; w2[2] = tw[4 * e2]; w2[3] = tw[8 * e2];
+    }
+    // cells of this thread: row 2rp + r3, columns rem3 + u*2S + 256 m
+    int ri = 2 * rp + r3 - ra.Py;
+    if (ra.circ_y) ri &= (ra.Ty - 1);
+    const bool rowA = ri >= 0 && ri < tA.vy, rowB = ri >= 0 && ri < tB.vy;
+    auto col_of = [&](int c) {                  // c = u*R3 + m
+        int cj = rem3 + (c / R3) * 2 * S + 256 * (c % R3) - ra.Qx;
+        if (ra.circ_x) cj &= (TX - 1);
+        return cj;
+    };
+    float b_snr[2 * NC];
+    unsigned valid = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        int cj = col_of(c);
+        bool okA = rowA && cj >= 0 && cj < tA.vx;
+        bool okB = rowB && cj >= 0 && cj < tB.vx;
+        if (okA) valid |= 1u << (2 * c);
+        if (okB) valid |= 2u << (2 * c);
+        const bool rd = !map_amp && !(ra.dbg & 8);
+        b_snr[2 * c] = (okA && rd) ? best_snr[(size_t)(tA.i0 + ri - ra.cy0) * ra.cw + (tA.j0 + cj - ra.cx0)] : 0.f;
+        b_snr[2 * c + 1] = (okB && rd) ? best_snr[(size_t)(tB.i0 + ri - ra.cy0) * ra.cw + (tB.j0 + cj - ra.cx0)] : 0.f;
+    }
+
+    float2 a[16];
+    auto fetch = [&](int gi_) {
+        const float2* p = src1 + (size_t)gi_ * plane;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = p[2 * S * j];       // column tt1 + j*S
+    };
+    if (!(ra.dbg & 1)) fetch(0);
+    for (int gi_ = 0; gi_ < ra.G; ++gi_) {
+        const TemplDev* tp = templ + ra.first + gi_;
+        EpiScal es = sc_epi_scalars(sums, ra.first + gi_);
+        sc_epi_floor(es, sums[2 * (ra.first + gi_)], sums[2 * (ra.first + gi_) + 1],
+                     wl1[ra.first + gi_], norms[2 * ra.pair], norms[2 * ra.pair + 1],
+                     (double)ra.Ty * TX, kappa);
+        const float scale_w = scale / sc_fft_alpha(sums, ra.first + gi_);
+        const uint32_t tid_ = tp->id;
+        const int rloA = tp->ilo - tA.i0, rhiA = tp->ihi - tA.i0, cloA = tp->jlo - tA.j0, chiA = tp->jhi - tA.j0;
+        const int rloB = tp->ilo - tB.i0, rhiB = tp->ihi - tB.i0, cloB = tp->jlo - tB.j0, chiB = tp->jhi - tB.j0;
+        const bool rkA = ri >= rloA && ri <= rhiA, rkB = ri >= rloB && ri <= rhiB;
+
+        // ---- stage 1 (radix 16, stride 1) from registers
+        if (!(ra.dbg & 2)) set_compute_store<TX, 16, 0, true>(line1, tt1, a, w1);
+        lds_barrier();
+        if (gi_ + 1 < ra.G && !(ra.dbg & 1)) fetch(gi_ + 1);    // in flight through stages 2-3
+        // ---- stage 2 (radix 16, stride 16)
+        if (!(ra.dbg & 2)) {
+            float2 b[16];
+            set_load<TX>(line2, tt2, b);
+            lds_barrier();
+            set_compute_store<TX, 16, 4, true>(line2, tt2, b, w2);
+        } else {
+            lds_barrier();
+        }
+        lds_barrier();
+        // ---- stage 3 (radix R3, stride 256) fused with the epilogue
+        if (!(ra.dbg & 4)) {
+            float t_amp[2 * NC], t_snr[2 * NC];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int bt = rem3 + u * 2 * S;
+                float2 vw[R3], vm[R3];
+#pragma unroll
+                for (int k = 0; k < R3; ++k) {
+                    vw[k] = lineW[ph(bt) + k * 272];
+                    vm[k] = lineM[ph(bt) + k * 272];
+                }
+                Bfly<R3, true>::run(vw);
+                Bfly<R3, true>::run(vm);
+#pragma unroll
+                for (int m = 0; m < R3; ++m) {
+                    const int c = u * R3 + m;
+                    const float2 xc = vw[Bfly<R3, true>::pos(m)], t3 = vm[Bfly<R3, true>::pos(m)];
+                    const int cj = col_of(c);
+#pragma unroll
+                    for (int part = 0; part < 2; ++part) {
+                        float amp, snr;
+                        sc_epilogue((part ? xc.y : xc.x) * scale_w, (part ? t3.y : t3.x) * scale, es, amp, snr);
+                        bool keep = (valid >> (2 * c + part)) & 1u;
+                        if (FULL) {
+                            if (keep)
+                                sc_apply_masks(*tp, g, xaxis, yaxis, (part ? tB.i0 : tA.i0) + ri,
+                                               (part ? tB.j0 : tA.j0) + cj, amp, snr);
+                        } else {
+                            keep = keep && (part ? (rkB && cj >= cloB && cj <= chiB)
+                                                 : (rkA && cj >= cloA && cj <= chiA));
+                        }
+                        t_amp[2 * c + part] = keep ? amp : 0.f;
+                        t_snr[2 * c + part] = keep ? snr : 0.f;
+                    }
+                }
+            }
+            unsigned won = 0;
+            if (map_amp) {
+                won = valid;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 2 * NC; ++c) {
+                    // sc_fold on the SNR alone (see sc_fold for the tie / NaN rules)
+                    float bs = b_snr[c], ts = t_snr[c];
+                    bool take = bs < ts;
+                    bool poison = (ts != ts) && (bs == bs);
+                    b_snr[c] = (take || poison) ? ts : bs;
+                    if (take || poison) won |= 1u << c;
+                }
+            }
+            if (won && !(ra.dbg & 8)) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const int cj = col_of(c);
+#pragma unroll
+                    for (int part = 0; part < 2; ++part) {
+                        const int k = 2 * c + part;
+                        if (!((won >> k) & 1u)) continue;
+                        size_t o = (size_t)((part ? tB.i0 : tA.i0) + ri - ra.cy0) * ra.cw +
+                                   ((part ? tB.j0 : tA.j0) + cj - ra.cx0);
+                        if (map_amp) {
+                            map_amp[o] = t_amp[k];
+                            map_snr[o] = t_snr[k];
+                        } else {
+                            bool nan = t_snr[k] != t_snr[k];
+                            best_snr[o] = t_snr[k];
+                            best_amp[o] = nan ? 0.f : t_amp[k];
+                            best_id[o] = nan ? SC_ID_NONE : tid_;
+                        }
+                    }
+                }
+            }
+        }
+        lds_barrier();
     }
 }
 
@@ -885,12 +1104,13 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                      int group, bool to_maps, bool full_masks) {
     int np = npairs_of(fg);
     size_t lds_r = fft_lds_bytes(fg.Tx);
-    // row blocks of a tile that hold valid outputs: r' in [Py, Py + Vy)
-    int rb_lo = 0, rb_hi = fg.Ty / 4 - 1;
+    // row pairs of a tile that hold valid outputs: r' in [Py, Py + Vy)
+    int rp_lo = 0, rp_hi = fg.Ty / 2 - 1;
     if (!fg.circ_y) {
-        rb_lo = fg.Py / 4;
-        rb_hi = std::min(fg.Ty - 1, fg.Py + fg.Vy - 1) / 4;
+        rp_lo = fg.Py / 2;
+        rp_hi = std::min(fg.Ty - 1, fg.Py + fg.Vy - 1) / 2;
     }
+    const int rp_n = rp_hi - rp_lo + 1;
     for (int pair = 0; pair < np; ++pair) {
         for (int g0 = 0; g0 < n; g0 += group) {
             int G = std::min(group, n - g0);
@@ -904,41 +1124,51 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                            inv_cols_lds<T>(),                                  \
                            ctx->stream, (const float2*)ctx->uc.p,              \
                            (const float2*)ctx->uc2.p, (const float2*)ctx->wh.p,\
-                           (const float2*)ctx->mh.p, fg.Tx, pair, g0, G, rb_lo,\
-                           rb_hi, ctx->dbg, (const float2*)ctx->tw_y.p,        \
+                           (const float2*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo,\
+                           rp_hi, ctx->dbg, (const float2*)ctx->tw_y.p,        \
                            (float2*)ctx->yw.p, (float2*)ctx->ym.p);            \
     }
             DISPATCH_T(fg.Ty, FN)
 #undef FN
             sc_prof_end(ctx);
-            dim3 gridr(rb_hi - rb_lo + 1);
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
-                       ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rb_lo, ctx->dbg};
+                       ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg};
+            const bool fast = (fg.Tx == 512 || fg.Tx == 1024 || fg.Tx == 2048) && ctx->variant != 9;
+            dim3 gridr(fast ? rp_n : (rp_n + 1) / 2);
             sc_prof_begin(ctx, SC_K_INV_ROWS);
+#define ROW_ARGS                                                               \
+    lds_r, ctx->stream, (const float2*)ctx->yw.p, (const float2*)ctx->ym.p, ra, ctx->g,     \
+        (const TileDev*)ctx->tiles.p, (const TemplDev*)ctx->templ.p, (const double*)ctx->sums.p, \
+        (const double*)ctx->wl1.p, (const double*)ctx->norms.p, ctx->kappa,                 \
+        (const double*)ctx->xaxis.p, (const double*)ctx->yaxis.p, (const float2*)ctx->tw_x.p, \
+        (float*)ctx->best_snr.p, (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p,        \
+        to_maps ? (float*)ctx->map_amp.p : nullptr, to_maps ? (float*)ctx->map_snr.p : nullptr
 #define LAUNCH_ROWS(T, FULLV)                                                  \
     {                                                                          \
         int rc = set_lds(ctx, k_inv_rows<T, FULLV>, lds_r);                    \
         if (rc) return rc;                                                     \
-        hipLaunchKernelGGL((k_inv_rows<T, FULLV>), gridr, dim3(fft_threads(T)),\
-                           lds_r, ctx->stream, (const float2*)ctx->yw.p,       \
-                           (const float2*)ctx->ym.p, ra, ctx->g,               \
-                           (const TileDev*)ctx->tiles.p,                       \
-                           (const TemplDev*)ctx->templ.p,                      \
-                           (const double*)ctx->sums.p,                         \
-                           (const double*)ctx->wl1.p,                          \
-                           (const double*)ctx->norms.p, ctx->kappa,            \
-                           (const double*)ctx->xaxis.p,                        \
-                           (const double*)ctx->yaxis.p,                        \
-                           (const float2*)ctx->tw_x.p,                         \
-                           (float*)ctx->best_snr.p, (float*)ctx->best_amp.p,   \
-                           (uint32_t*)ctx->best_id.p,                          \
-                           to_maps ? (float*)ctx->map_amp.p : nullptr,         \
-                           to_maps ? (float*)ctx->map_snr.p : nullptr);        \
+        hipLaunchKernelGGL((k_inv_rows<T, FULLV>), gridr, dim3(fft_threads(T)), ROW_ARGS); \
     }
+#define LAUNCH_FAST(T, FULLV)                                                  \
+    {                                                                          \
+        int rc = set_lds(ctx, k_inv_rows_fast<T, FULLV>, lds_r);               \
+        if (rc) return rc;                                                     \
+        hipLaunchKernelGGL((k_inv_rows_fast<T, FULLV>), gridr, dim3(fft_threads(T)), ROW_ARGS); \
+    }
+            if (fast) {
+                switch (fg.Tx) {
+                    case 512: if (full_masks) LAUNCH_FAST(512, true) else LAUNCH_FAST(512, false) break;
+                    case 1024: if (full_masks) LAUNCH_FAST(1024, true) else LAUNCH_FAST(1024, false) break;
+                    default: if (full_masks) LAUNCH_FAST(2048, true) else LAUNCH_FAST(2048, false) break;
+                }
+            } else {
 #define FN(T) { if (full_masks) LAUNCH_ROWS(T, true) else LAUNCH_ROWS(T, false) }
-            DISPATCH_T(fg.Tx, FN)
+                DISPATCH_T(fg.Tx, FN)
 #undef FN
+            }
 #undef LAUNCH_ROWS
+#undef LAUNCH_FAST
+#undef ROW_ARGS
             sc_prof_end(ctx);
         }
     }
