@@ -73,6 +73,14 @@ def _is_pow2(n):
     return n > 0 and (n & (n - 1)) == 0
 
 
+# Relative cost per padded cell of the FFT kernels by tile size, measured on
+# MI355X (tools/crossover.py): the kernels are built around 512 ..
+# 2048 (one 16-point set per thread, 128..512 threads per workgroup); smaller
+# tiles leave most of a workgroup idle, 4096 runs the generic two-set path.
+TILE_PENALTY = {64: 20.0, 128: 8.0, 256: 5.0, 512: 1.0, 1024: 1.0, 2048: 1.0,
+                4096: 2.3}
+
+
 def choose_tile(n_core, span, n_global, whole_axis, t_max=T_MAX):
     """Pick the FFT length for one axis.
 
@@ -86,18 +94,21 @@ def choose_tile(n_core, span, n_global, whole_axis, t_max=T_MAX):
     power of two (and we own all of it) the DEM's own periodicity is used and
     nothing is wasted."""
     best = None
+
+    def cost(nt, t):
+        return nt * t * (math.log2(t) + 4.0) * TILE_PENALTY.get(t, 1.0)
+
     if whole_axis and _is_pow2(n_global) and T_MIN <= n_global <= t_max \
             and span < n_global:
-        best = (n_global * (math.log2(n_global) + 4.0), n_global, n_global, 1,
-                True)
+        best = (cost(1, n_global), n_global, n_global, 1, True)
     t = T_MIN
     while t <= t_max:
         if t > span:
             v = t - span
             nt = -(-n_core // v)
-            cost = nt * t * (math.log2(t) + 4.0)
-            if best is None or cost < best[0]:
-                best = (cost, t, v, nt, False)
+            c = cost(nt, t)
+            if best is None or c < best[0]:
+                best = (c, t, v, nt, False)
         t *= 2
     if best is None:
         raise ValueError("template support (%d cells) exceeds the largest "
@@ -162,4 +173,5 @@ def fft_cost(plan, n_cells):
     """Relative cost per output cell of the FFT path (same units as
     direct_cost; the constant is calibrated on MI355X)."""
     return 24.0 * (math.log2(plan.Ty) + math.log2(plan.Tx)) \
+        * math.sqrt(TILE_PENALTY.get(plan.Ty, 1.0) * TILE_PENALTY.get(plan.Tx, 1.0)) \
         * plan.padded_cells() / float(n_cells)

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Real-space vs FFT crossover: time both paths per template size (taps)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import scarplet_amd as sl
+from scarplet_amd import _plan, synthetic
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+g = synthetic.synthetic_scarp(n)
+m = sl.Matcher(g)
+angs = _plan.angle_grid()[[30, 90, 150]]
+print("DEM %dx%d; per row: scale, age, taps(n), direct ms/template, fft ms/template, plan" % (n, n))
+for scale in (5, 10, 20, 50, 100):
+    for age in (1.0, 10.0, 100.0, 1000.0):
+        row = []
+        for meth in ("direct", "fft"):
+            arr, bbox, area = m.describe(sl.Scarp, scale, np.array([age]), angs)
+            if meth == "direct" and area > 20000:
+                row.append(float("nan")); continue
+            m.search(sl.Scarp, scale, [age], angs, method=meth)      # warm
+            t0 = time.perf_counter()
+            for _ in range(3):
+                m.search(sl.Scarp, scale, [age], angs, method=meth)
+            row.append((time.perf_counter() - t0) / 3 / len(angs) * 1e3)
+        nn, _ = m.ctx.template_sums(1)
+        print("scale %4d age %7.1f taps %7d  direct %8.3f  fft %8.3f  %s" % (scale, age, nn[0], row[0], row[1], m.plan))
