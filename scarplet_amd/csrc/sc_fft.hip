@@ -470,15 +470,20 @@ k_fwd_cols(const float2* __restrict__ blk, int Tx, const float2* __restrict__ tw
 // ---- split: vh = FFT(alpha*W + iM)  ->  wh = FFT(alpha*W), mh = FFT(M) -------
 // FFT(W)[f] = (v[f] + conj v[-f])/2, FFT(M)[f] = (v[f] - conj v[-f])/(2i).
 // Done once per template so that the inverse kernels (18 tile pairs per
-// template at C3) stream two aligned spectra instead of gathering v[-f].
-// grid = (Tx*Ty/2/256, n_templates), block = 256, 2 cells per thread.
+// template at C3) stream aligned spectra instead of gathering v[-f].  W and M
+// are real, so their spectra are Hermitian: only columns fx = 0 .. Tx/2+3 are
+// stored (the 4-column blocks up to the one holding Tx/2); I1 rebuilds the rest
+// as conj(H[-fy, Tx-fx]) - half the bytes of the dominant HBM stream.
+// grid = ((Tx/2+4)*Ty/2/256, n_templates), block = 256, 2 cells per thread.
+__host__ __device__ constexpr size_t half_plane(int Ty, int Tx) { return (size_t)(Tx / 2 + 4) * Ty; }
+
 __global__ void __launch_bounds__(256)
 k_split_templ(const float2* __restrict__ vh, int Ty, int Tx,
               float2* __restrict__ wh, float2* __restrict__ mh) {
-    const size_t plane = (size_t)Ty * Tx;
+    const size_t plane = (size_t)Ty * Tx, hplane = half_plane(Ty, Tx);
     const float2* v = vh + (size_t)blockIdx.y * plane;
     size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
-    if (e >= plane) return;
+    if (e >= hplane) return;
     int fx = (int)(e / Ty), fy = (int)(e - (size_t)fx * Ty);         // fy even
     const float2* vm = v + (size_t)((Tx - fx) & (Tx - 1)) * Ty;
     float4 a = *reinterpret_cast<const float4*>(v + e);
@@ -488,8 +493,8 @@ k_split_templ(const float2* __restrict__ vh, int Ty, int Tx,
                            0.5f * (a.z + b1.x), 0.5f * (a.w - b1.y));
     float4 m = make_float4(0.5f * (a.y + b0.y), -0.5f * (a.x - b0.x),
                            0.5f * (a.w + b1.y), -0.5f * (a.z - b1.x));
-    *reinterpret_cast<float4*>(wh + (size_t)blockIdx.y * plane + e) = w;
-    *reinterpret_cast<float4*>(mh + (size_t)blockIdx.y * plane + e) = m;
+    *reinterpret_cast<float4*>(wh + (size_t)blockIdx.y * hplane + e) = w;
+    *reinterpret_cast<float4*>(mh + (size_t)blockIdx.y * hplane + e) = m;
 }
 
 // ---- I1: spectra product -> inverse column FFT -> blocked --------------------
@@ -508,11 +513,11 @@ __host__ __device__ constexpr size_t inv_cols_lds() {
     return fft_lds_bytes(TY) + (inv_cols_park<TY>() ? (size_t)4 * TY * sizeof(float2) : 0);
 }
 
-template <int TY>
+template <int TY, bool MIRROR>
 __global__ void __launch_bounds__(fft_threads(TY), 2)
 k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
            const float2* __restrict__ wh, const float2* __restrict__ mh, int Tx,
-           int pair, int vfirst, int G, int rp_lo, int rp_hi, int dbg,
+           int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, int dbg,
            const float2* __restrict__ tw, float2* __restrict__ yw,
            float2* __restrict__ ym) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
@@ -522,22 +527,30 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
     constexpr int EP = 4 * TY / (2 * NT);     // float4 (2-cell) loads per thread per stream
     constexpr bool PARK = inv_cols_park<TY>();
     float4* xs = reinterpret_cast<float4*>(sm + 4 * fft_line(TY));   // parked spectrum, linear
-    // Column blocks 2m and 2m+1 write the two 64-byte halves of the same rows2
-    // lines.  Workgroups are dealt round-robin over the 8 XCDs, so the pair is
-    // given to workgroups b and b+8 (same XCD, dispatched together): their
-    // halves meet in that XCD's L2 and leave as whole lines.  Speed only.
-    const int b_ = blockIdx.x;
-    const int cb = 2 * ((b_ >> 4) * 8 + (b_ & 7)) + ((b_ >> 3) & 1);
+    // MIRROR = false: blocks 0 .. Tx/8-1 (fx < Tx/2, spectrum stored);
+    // MIRROR = true : blocks Tx/8 .. Tx/4-1 (fx >= Tx/2, rebuilt from the stored
+    //                 columns Tx-fx <= Tx/2; Tx/2 mirrors onto itself).
+    // Two launches instead of one branchy kernel: the branch cost registers.
+    const int cb = cb0 + blockIdx.x;
+    constexpr bool mirrored = MIRROR;
     const size_t plane = (size_t)TY * Tx;
     const size_t col = (size_t)cb * 4 * TY;
     float4 hreg[EP];
     for (int pl = 0; pl < 2; ++pl) {
         const float4* uu = reinterpret_cast<const float4*>((pl ? uc2 : uc) + (size_t)pair * plane + col);
-        const float4* hbase = reinterpret_cast<const float4*>((pl ? mh : wh) + (size_t)vfirst * plane + col);
-        const size_t hstep = plane / 2;
+        // template spectrum: stored for fx <= Tx/2+3; blocks beyond take the
+        // mirrored columns Tx-fx (a contiguous 4-column run, not block aligned),
+        // reversed in fy and conjugated
+        const size_t hplane = half_plane(TY, Tx);
+        const float2* hsrc = (pl ? mh : wh) + (size_t)vfirst * hplane +
+                             (mirrored ? (size_t)(Tx - 4 * cb - 3) * TY : col);
+        // the fetch is the same aligned linear stream for both kinds of block;
+        // a mirrored block applies the reversal when it fills the LDS lines
         auto fetch = [&](int gi_) {
+            const float2* p = hsrc + (size_t)gi_ * hplane;
 #pragma unroll
-            for (int u = 0; u < EP; ++u) hreg[u] = hbase[(size_t)gi_ * hstep + threadIdx.x + u * NT];
+            for (int u = 0; u < EP; ++u)
+                hreg[u] = *reinterpret_cast<const float4*>(p + 2 * (threadIdx.x + u * NT));
         };
         if (!(dbg & 16)) {
             if (PARK) {
@@ -546,14 +559,32 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
             }
             fetch(0);
         }
+        if (PARK && mirrored) lds_barrier();      // mirrored fills read other threads' cells of xs
         for (int gi_ = 0; gi_ < G; ++gi_) {
+            if (!mirrored) {
 #pragma unroll
-            for (int u = 0; u < EP; ++u) {
-                int e = 2 * (threadIdx.x + u * NT);
-                int cc = e / TY, fy = e - cc * TY;
-                float4 x = PARK ? xs[threadIdx.x + u * NT] : uu[threadIdx.x + u * NT];
-                sm[lidx<TY>(cc, fy)] = cmul(make_float2(hreg[u].x, hreg[u].y), make_float2(x.x, x.y));
-                sm[lidx<TY>(cc, fy + 1)] = cmul(make_float2(hreg[u].z, hreg[u].w), make_float2(x.z, x.w));
+                for (int u = 0; u < EP; ++u) {
+                    int e = 2 * (threadIdx.x + u * NT);
+                    int cc = e / TY, fy = e - cc * TY;
+                    float4 x = PARK ? xs[threadIdx.x + u * NT] : uu[threadIdx.x + u * NT];
+                    sm[lidx<TY>(cc, fy)] = cmul(make_float2(hreg[u].x, hreg[u].y), make_float2(x.x, x.y));
+                    sm[lidx<TY>(cc, fy + 1)] = cmul(make_float2(hreg[u].z, hreg[u].w), make_float2(x.z, x.w));
+                }
+            } else {
+                // source cell (column 3-cc of the run, row m) is the conjugate of
+                // target cell (column cc, row (TY - m) % TY)
+                const float2* x2 = PARK ? reinterpret_cast<const float2*>(xs)
+                                        : reinterpret_cast<const float2*>(uu);
+#pragma unroll
+                for (int u = 0; u < EP; ++u) {
+                    int e = 2 * (threadIdx.x + u * NT);
+                    int sc = e / TY, m = e - sc * TY;
+                    int cc = 3 - sc;
+                    int f0 = (TY - m) & (TY - 1), f1 = (TY - m - 1) & (TY - 1);
+                    float2 x0 = x2[cc * TY + f0], x1 = x2[cc * TY + f1];
+                    sm[lidx<TY>(cc, f0)] = cmul(make_float2(hreg[u].x, -hreg[u].y), x0);
+                    sm[lidx<TY>(cc, f1)] = cmul(make_float2(hreg[u].z, -hreg[u].w), x1);
+                }
             }
             lds_barrier();
             if (gi_ + 1 < G && !(dbg & 16)) fetch(gi_ + 1);
@@ -865,9 +896,13 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             lds_barrier();
         }
         lds_barrier();
-        // ---- stage 3 (radix R3, stride 256) fused with the epilogue
+        // ---- stage 3 (radix R3, stride 256) fused with the epilogue: every
+        // output is scored as soon as its two butterflies have produced it
         if (!(ra.dbg & 4)) {
-            float t_amp[2 * NC], t_snr[2 * NC];
+            // fold the transform scale into the per-template scalars:
+            // xcorr = xr*scale_w, T3 = tr*scale  =>  amp = xr*ka, T1 = xr^2*kt
+            const float ka = scale_w * es.inv_ts, kt = scale_w * ka;
+            const float kx2 = scale_w * es.dx2;
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int bt = rem3 + u * 2 * S;
@@ -886,9 +921,13 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                     const int cj = col_of(c);
 #pragma unroll
                     for (int part = 0; part < 2; ++part) {
-                        float amp, snr;
-                        sc_epilogue((part ? xc.y : xc.x) * scale_w, (part ? t3.y : t3.x) * scale, es, amp, snr);
-                        bool keep = (valid >> (2 * c + part)) & 1u;
+                        const int k = 2 * c + part;
+                        const float xr = part ? xc.y : xc.x, tr = part ? t3.y : t3.x;
+                        const float T1 = xr * xr * kt;
+                        const float d = fmaxf(tr * scale - T1, es.d3 + fabsf(xr) * kx2 + es.dxx);
+                        float snr = fabsf(__fdividef(T1, d * es.inv_n + (float)SC_EPS));
+                        float amp = xr * ka;
+                        bool keep = (valid >> k) & 1u;
                         if (FULL) {
                             if (keep)
                                 sc_apply_masks(*tp, g, xaxis, yaxis, (part ? tB.i0 : tA.i0) + ri,
@@ -897,43 +936,23 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                             keep = keep && (part ? (rkB && cj >= cloB && cj <= chiB)
                                                  : (rkA && cj >= cloA && cj <= chiA));
                         }
-                        t_amp[2 * c + part] = keep ? amp : 0.f;
-                        t_snr[2 * c + part] = keep ? snr : 0.f;
-                    }
-                }
-            }
-            unsigned won = 0;
-            if (map_amp) {
-                won = valid;
-            } else {
-#pragma unroll
-                for (int c = 0; c < 2 * NC; ++c) {
-                    // sc_fold on the SNR alone (see sc_fold for the tie / NaN rules)
-                    float bs = b_snr[c], ts = t_snr[c];
-                    bool take = bs < ts;
-                    bool poison = (ts != ts) && (bs == bs);
-                    b_snr[c] = (take || poison) ? ts : bs;
-                    if (take || poison) won |= 1u << c;
-                }
-            }
-            if (won && !(ra.dbg & 8)) {
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const int cj = col_of(c);
-#pragma unroll
-                    for (int part = 0; part < 2; ++part) {
-                        const int k = 2 * c + part;
-                        if (!((won >> k) & 1u)) continue;
-                        size_t o = (size_t)((part ? tB.i0 : tA.i0) + ri - ra.cy0) * ra.cw +
-                                   ((part ? tB.j0 : tA.j0) + cj - ra.cx0);
-                        if (map_amp) {
-                            map_amp[o] = t_amp[k];
-                            map_snr[o] = t_snr[k];
-                        } else {
-                            bool nan = t_snr[k] != t_snr[k];
-                            best_snr[o] = t_snr[k];
-                            best_amp[o] = nan ? 0.f : t_amp[k];
-                            best_id[o] = nan ? SC_ID_NONE : tid_;
+                        snr = keep ? snr : 0.f;
+                        // sc_fold on the SNR alone (see sc_fold for the tie / NaN rules)
+                        const float bs = b_snr[k];
+                        const bool nan = snr != snr;
+                        const bool won = map_amp ? ((valid >> k) & 1u) : ((bs < snr) || (nan && bs == bs));
+                        if (!map_amp && won) b_snr[k] = snr;
+                        if (won && !(ra.dbg & 8)) {
+                            size_t o = (size_t)((part ? tB.i0 : tA.i0) + ri - ra.cy0) * ra.cw +
+                                       ((part ? tB.j0 : tA.j0) + cj - ra.cx0);
+                            if (map_amp) {
+                                map_amp[o] = keep ? amp : 0.f;
+                                map_snr[o] = snr;
+                            } else {
+                                best_snr[o] = snr;
+                                best_amp[o] = nan ? 0.f : amp;
+                                best_id[o] = nan ? SC_ID_NONE : tid_;
+                            }
                         }
                     }
                 }
@@ -999,8 +1018,9 @@ int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group) {
     if ((rc = sc_ensure(ctx, ctx->uc, plane * np))) return rc;
     if ((rc = sc_ensure(ctx, ctx->uc2, plane * np))) return rc;
     if ((rc = sc_ensure(ctx, ctx->vh, plane * n_templ_chunk))) return rc;
-    if ((rc = sc_ensure(ctx, ctx->wh, plane * n_templ_chunk))) return rc;
-    if ((rc = sc_ensure(ctx, ctx->mh, plane * n_templ_chunk))) return rc;
+    size_t hplane = half_plane(fg.Ty, fg.Tx) * sizeof(float2);
+    if ((rc = sc_ensure(ctx, ctx->wh, hplane * n_templ_chunk))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->mh, hplane * n_templ_chunk))) return rc;
     if ((rc = sc_ensure(ctx, ctx->yw, plane * group))) return rc;
     if ((rc = sc_ensure(ctx, ctx->ym, plane * group))) return rc;
     return SC_OK;
@@ -1087,7 +1107,7 @@ int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n) {
     SC_HIP(ctx, hipGetLastError());
     int rc = launch_fwd_cols(ctx, fg, n, (float2*)ctx->vh.p, nullptr, 0);
     if (rc) return rc;
-    size_t cells = (size_t)fg.Ty * fg.Tx;
+    size_t cells = half_plane(fg.Ty, fg.Tx);
     dim3 grid_s((unsigned)((cells / 2 + 255) / 256), n);
     sc_prof_begin(ctx, SC_K_FWD_COLS);
     hipLaunchKernelGGL(k_split_templ, grid_s, dim3(256), 0, ctx->stream, (const float2*)ctx->vh.p,
@@ -1114,22 +1134,27 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     for (int pair = 0; pair < np; ++pair) {
         for (int g0 = 0; g0 < n; g0 += group) {
             int G = std::min(group, n - g0);
-            dim3 gridc(fg.Tx / 4);
             sc_prof_begin(ctx, SC_K_INV_COLS);
+#define COL_ARGS(CB0)                                                          \
+    ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float2*)ctx->wh.p, \
+        (const float2*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, ctx->dbg,        \
+        (const float2*)ctx->tw_y.p, (float2*)ctx->yw.p, (float2*)ctx->ym.p
 #define FN(T)                                                                  \
     {                                                                          \
-        int rc = set_lds(ctx, k_inv_cols<T>, inv_cols_lds<T>());               \
+        int rc = set_lds(ctx, k_inv_cols<T, false>, inv_cols_lds<T>());        \
         if (rc) return rc;                                                     \
-        hipLaunchKernelGGL(k_inv_cols<T>, gridc, dim3(fft_threads(T)),         \
-                           inv_cols_lds<T>(),                                  \
-                           ctx->stream, (const float2*)ctx->uc.p,              \
-                           (const float2*)ctx->uc2.p, (const float2*)ctx->wh.p,\
-                           (const float2*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo,\
-                           rp_hi, ctx->dbg, (const float2*)ctx->tw_y.p,        \
-                           (float2*)ctx->yw.p, (float2*)ctx->ym.p);            \
+        rc = set_lds(ctx, k_inv_cols<T, true>, inv_cols_lds<T>());             \
+        if (rc) return rc;                                                     \
+        const int nlo = fg.Tx / 8, nhi = fg.Tx / 4 - nlo;                      \
+        hipLaunchKernelGGL((k_inv_cols<T, false>), dim3(nlo), dim3(fft_threads(T)), \
+                           inv_cols_lds<T>(), COL_ARGS(0));                    \
+        if (nhi > 0)                                                           \
+            hipLaunchKernelGGL((k_inv_cols<T, true>), dim3(nhi), dim3(fft_threads(T)), \
+                               inv_cols_lds<T>(), COL_ARGS(nlo));              \
     }
             DISPATCH_T(fg.Ty, FN)
 #undef FN
+#undef COL_ARGS
             sc_prof_end(ctx);
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
                        ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg};
