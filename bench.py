@@ -32,13 +32,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=10000, help="DEM size (default: C3)")
+    ap.add_argument("--size", dest="n", type=int, default=10000, help="DEM size (default: C3)")
     ap.add_argument("--ages", type=int, default=35)
     ap.add_argument("--angles", type=int, default=181)
     ap.add_argument("--method", default="fft")
     ap.add_argument("--group", type=int, default=0, help="templates per inverse launch (0: auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-stride", type=int, default=16)
+    ap.add_argument("--halo", default="rccl", choices=["rccl", "gloo"],
+                    help="halo exchange executor for --gpus > 1 (gloo: host arrays, for bring-up)")
     return ap.parse_args()
 
 
@@ -87,8 +89,10 @@ def main():
         dist.init_process_group("gloo")
 
     import scarplet_amd as sl
-    from scarplet_amd import _plan, synthetic
+    from scarplet_amd import _plan, synthetic, _lib
     from scarplet_amd import dist as sd
+    ndev = max(1, _lib.load().sc_device_count())
+    device = local % ndev                      # one rank per GPU; wraps only in bring-up runs
 
     ages = _plan.age_grid()[np.round(np.linspace(0, 34, a.ages)).astype(int)]
     angles = _plan.angle_grid()[np.round(np.linspace(0, 180, a.angles)).astype(int)]
@@ -97,7 +101,7 @@ def main():
     units = float(a.n) * a.n * n_templates             # px.template per step
 
     if world == 1:
-        m = sl.Matcher(g, device=local)
+        m = sl.Matcher(g, device=device)
         arr, bbox, area = m.describe(sl.Scarp, 100, ages, angles)
         plan, sp = m.plan_for(bbox, area, a.method, a.group or None, n_params=len(ages))
 
@@ -106,7 +110,7 @@ def main():
             m.ctx.match(arr, sp, sync=True)
         ctx = m.ctx
     else:
-        dm = sd.DistMatcher(rank, world, (a.n, a.n), 1.0, 1.0, device=local, backend="rccl")
+        dm = sd.DistMatcher(rank, world, (a.n, a.n), 1.0, 1.0, device=device, backend=a.halo)
         c = dm.core()
         z_core = np.ascontiguousarray(g._griddata[c[0]:c[1], c[2]:c[3]])
         arr, bbox, area = dm.m.describe(sl.Scarp, 100, ages, angles)
@@ -154,7 +158,9 @@ def main():
         achieved = ALGO_BYTES_PER_UNIT * per_launch_units / avg_s / 1e9 if avg_s > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
+        default_workload = (world == 1 and a.n == 10000 and len(ages) == 35 and len(angles) == 181
+                            and a.method == "fft")
+        if os.path.exists(tf) and default_workload:      # measured on exactly this workload
             try:
                 traffic = json.load(open(tf)).get(dom)
             except Exception:

@@ -902,7 +902,10 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             // fold the transform scale into the per-template scalars:
             // xcorr = xr*scale_w, T3 = tr*scale  =>  amp = xr*ka, T1 = xr^2*kt
             const float ka = scale_w * es.inv_ts, kt = scale_w * ka;
-            const float kx2 = scale_w * es.dx2;
+            const float kx2 = scale_w * es.dx2, fl0 = es.d3 + es.dxx;
+            // window-limit columns as one unsigned range test per part
+            const unsigned spanA = (unsigned)(chiA - cloA), spanB = (unsigned)(chiB - cloB);
+            const bool colsA = chiA >= cloA && rkA, colsB = chiB >= cloB && rkB;
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int bt = rem3 + u * 2 * S;
@@ -923,30 +926,33 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                     for (int part = 0; part < 2; ++part) {
                         const int k = 2 * c + part;
                         const float xr = part ? xc.y : xc.x, tr = part ? t3.y : t3.x;
+                        // core.py:360-367 with the float32 resolution floor (sc_epilogue)
                         const float T1 = xr * xr * kt;
-                        const float d = fmaxf(tr * scale - T1, es.d3 + fabsf(xr) * kx2 + es.dxx);
-                        float snr = fabsf(__fdividef(T1, d * es.inv_n + (float)SC_EPS));
-                        float amp = xr * ka;
+                        const float d = fmaxf(fmaf(tr, scale, -T1), fmaf(fabsf(xr), kx2, fl0));
+                        float snr = fabsf(T1 * __builtin_amdgcn_rcpf(fmaf(d, es.inv_n, (float)SC_EPS)));
                         bool keep = (valid >> k) & 1u;
                         if (FULL) {
+                            float amp = xr * ka;
                             if (keep)
                                 sc_apply_masks(*tp, g, xaxis, yaxis, (part ? tB.i0 : tA.i0) + ri,
                                                (part ? tB.j0 : tA.j0) + cj, amp, snr);
                         } else {
-                            keep = keep && (part ? (rkB && cj >= cloB && cj <= chiB)
-                                                 : (rkA && cj >= cloA && cj <= chiA));
+                            keep = keep && (part ? (colsB && (unsigned)(cj - cloB) <= spanB)
+                                                 : (colsA && (unsigned)(cj - cloA) <= spanA));
                         }
                         snr = keep ? snr : 0.f;
-                        // sc_fold on the SNR alone (see sc_fold for the tie / NaN rules)
+                        // sc_fold on the SNR alone: take if greater; a NaN score poisons
+                        // the cell once and stays (see sc_fold)
                         const float bs = b_snr[k];
-                        const bool nan = snr != snr;
-                        const bool won = map_amp ? ((valid >> k) & 1u) : ((bs < snr) || (nan && bs == bs));
-                        if (!map_amp && won) b_snr[k] = snr;
+                        const bool won = map_amp ? ((valid >> k) & 1u) : (!(snr <= bs) && bs == bs);
+                        if (!map_amp) b_snr[k] = won ? snr : bs;
                         if (won && !(ra.dbg & 8)) {
+                            const bool nan = snr != snr;
+                            const float amp = keep ? xr * ka : 0.f;
                             size_t o = (size_t)((part ? tB.i0 : tA.i0) + ri - ra.cy0) * ra.cw +
                                        ((part ? tB.j0 : tA.j0) + cj - ra.cx0);
                             if (map_amp) {
-                                map_amp[o] = keep ? amp : 0.f;
+                                map_amp[o] = amp;
                                 map_snr[o] = snr;
                             } else {
                                 best_snr[o] = snr;

@@ -210,7 +210,7 @@ __device__ __forceinline__ void sc_epilogue(float xc, float t3, const EpiScal& s
     float d = fmaxf(t3 - T1, s.d3 + fabsf(xc) * s.dx2 + s.dxx);   // floor is 0 on the exact path
     float err = d * s.inv_n + (float)SC_EPS;
     amp_out = amp;
-    snr_out = fabsf(__fdividef(T1, err));
+    snr_out = fabsf(T1 * __builtin_amdgcn_rcpf(err));      // v_rcp_f32, 1 ulp
 }
 
 // masks of core.py:369-375 for global cell (gi, gj)
