@@ -931,8 +931,8 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                         const float d = fmaxf(fmaf(tr, scale, -T1), fmaf(fabsf(xr), kx2, fl0));
                         float snr = fabsf(T1 * __builtin_amdgcn_rcpf(fmaf(d, es.inv_n, (float)SC_EPS)));
                         bool keep = (valid >> k) & 1u;
+                        float amp = xr * ka;
                         if (FULL) {
-                            float amp = xr * ka;
                             if (keep)
                                 sc_apply_masks(*tp, g, xaxis, yaxis, (part ? tB.i0 : tA.i0) + ri,
                                                (part ? tB.j0 : tA.j0) + cj, amp, snr);
@@ -941,6 +941,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                                                  : (colsA && (unsigned)(cj - cloA) <= spanA));
                         }
                         snr = keep ? snr : 0.f;
+                        amp = keep ? amp : 0.f;
                         // sc_fold on the SNR alone: take if greater; a NaN score poisons
                         // the cell once and stays (see sc_fold)
                         const float bs = b_snr[k];
@@ -948,7 +949,6 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                         if (!map_amp) b_snr[k] = won ? snr : bs;
                         if (won && !(ra.dbg & 8)) {
                             const bool nan = snr != snr;
-                            const float amp = keep ? xr * ka : 0.f;
                             size_t o = (size_t)((part ? tB.i0 : tA.i0) + ri - ra.cy0) * ra.cw +
                                        ((part ? tB.j0 : tA.j0) + cj - ra.cx0);
                             if (map_amp) {
