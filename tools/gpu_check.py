@@ -100,6 +100,8 @@ if __name__ == "__main__":
     check_single(WT.RightFacingUpperBreakScarp, 64, 66, 1.0, 10, 10.0, 0.2)
     check_single(WT.LeftFacingUpperBreakScarp, 61, 64, 1.0, 10, 5.0, -0.6)
     check_single(WT.Scarp, 1100, 1000, 1.0, 100, 1000.0, 0.6, methods=("fft",))
+    check_single(WT.Scarp, 1000, 1500, 1.0, 100, 300.0, -0.8, methods=("fft",))
+    check_single(WT.Scarp, 2500, 2300, 1.0, 100, 100.0, 0.4, methods=("fft",))
     for meth in ("direct", "fft"):
         check_fold(WT.Scarp, 96, 90, 1.0, 10, [1.0, 3.16, 10.0, 31.6], _plan.angle_grid(-0.5, 0.5), meth)
         check_fold(WT.Channel, 80, 96, 1.0, 6, [0.1, 0.2], _plan.angle_grid(-np.pi / 2, np.pi / 2)[::6], meth)
