@@ -84,7 +84,8 @@ class DEMGrid(object):
             self._set(np.load(filename).astype(float), 1.0, 1.0)
         elif ext in ('.tif', '.tiff'):
             from scarplet_amd import tiff
-            z, gt, nodata = tiff.read_geotiff(filename)
+            z, gt, nodata, geokeys = tiff.read_geotiff_full(filename)
+            self._georef_info.projection = geokeys
             z = z.astype(float)
             if nodata is not None:
                 z[z == nodata] = np.nan
@@ -94,6 +95,18 @@ class DEMGrid(object):
             raise ValueError("unsupported grid file: %s" % filename)
         self._griddata[self._griddata == FLOAT32_MIN] = np.nan
         self.filename = filename
+
+    def save(self, filename):
+        """Save the grid as a georeferenced TIFF (dem.py:291-306 without
+        GDAL): float32 samples like the reference's GDT_Float32 grids, NaN
+        cells written as the float32 nodata value the loader maps back."""
+        from scarplet_amd import tiff
+        z = np.where(np.isnan(self._griddata), FLOAT32_MIN,
+                     self._griddata).astype(np.float32)
+        gi = self._georef_info
+        proj = gi.projection if isinstance(gi.projection, dict) else None
+        tiff.write_geotiff(filename, z, gi.geo_transform,
+                           nodata=float(FLOAT32_MIN), geokeys=proj)
 
     def _fill_nodata(self):
         """Fill NaN cells so the matcher's NaN-free precondition holds

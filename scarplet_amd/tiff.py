@@ -1,4 +1,4 @@
-"""Minimal GeoTIFF reader (no GDAL).
+"""Minimal GeoTIFF reader and writer (no GDAL).
 
 Covers what single-band DEM rasters use in practice and what the reference's
 sample datasets need (scarplet/datasets/data/*.tif): classic (non-Big) TIFF,
@@ -7,6 +7,9 @@ predictor, 8/16/32/64-bit integer or float samples, and the GeoTIFF tags
 that define the geotransform (ModelPixelScale + ModelTiepoint, or
 ModelTransformation) plus GDAL's nodata tag.  Replaces the read half of
 BaseSpatialGrid.load (dem.py:308-348); anything outside this subset raises.
+``write_geotiff`` is the counterpart of BaseSpatialGrid.save (dem.py:291-306):
+one uncompressed strip image with the geotransform tags, the nodata tag and
+the source file's GeoKey directory (the projection) passed through verbatim.
 """
 
 import struct
@@ -43,11 +46,20 @@ def _read_ifd(buf, off, bo):
     return tags
 
 
+GEOKEY_TAGS = (34735, 34736, 34737)      # GeoKeyDirectory, DoubleParams, AsciiParams
+
+
 def read_geotiff(path):
     """Returns (array, geo_transform or None, nodata or None).
 
     geo_transform follows GDAL: (x0, dx, 0, y0, 0, dy) with dy negative for
     north-up rasters (dem.py:324-332 reads dx = gt[1], dy = gt[5])."""
+    return read_geotiff_full(path)[:3]
+
+
+def read_geotiff_full(path):
+    """read_geotiff plus the projection: a dict {tag: value} of the GeoKey
+    tags present in the file (opaque; write_geotiff stores it back)."""
     with open(path, "rb") as f:
         buf = f.read()
     if buf[:2] == b"II":
@@ -120,4 +132,89 @@ def read_geotiff(path):
             nodata = None
         if nodata is not None and np.isnan(nodata):
             nodata = None                           # NaN cells are already NaN
-    return out, gt, nodata
+    geokeys = dict((k, t[k]) for k in GEOKEY_TAGS if k in t)
+    return out, gt, nodata, geokeys
+
+
+def write_geotiff(path, array, geo_transform=None, nodata=None, geokeys=None):
+    """Write a single-band little-endian classic TIFF (one uncompressed strip).
+
+    array: 2-D, any of the dtypes read_geotiff accepts (float64 grids are
+    stored as given; pass ``array.astype('f4')`` for compact output).
+    geo_transform: GDAL 6-tuple; axis-aligned transforms become
+    ModelPixelScale + ModelTiepoint, rotated ones ModelTransformation."""
+    a = np.ascontiguousarray(array)
+    if a.ndim != 2:
+        raise ValueError("write_geotiff: single-band 2-D arrays only")
+    kind = {"u": 1, "i": 2, "f": 3}.get(a.dtype.kind)
+    if kind is None or a.dtype.itemsize not in (1, 2, 4, 8) or \
+            (kind == 3 and a.dtype.itemsize < 4):
+        raise ValueError("write_geotiff: unsupported dtype %s" % a.dtype)
+    a = a.astype(a.dtype.newbyteorder("<"), copy=False)
+    h, w = a.shape
+    entries = []                                    # (tag, type, count, bytes)
+
+    def add(tag, typ, values):
+        fmt = {2: None, 3: "H", 4: "I", 12: "d"}[typ]
+        if typ == 2:
+            data = values.encode("ascii") + b"\0"
+            cnt = len(data)
+        else:
+            cnt = len(values)
+            data = struct.pack("<%d%s" % (cnt, fmt), *values)
+        entries.append((tag, typ, cnt, data))
+
+    add(256, 4, [w])
+    add(257, 4, [h])
+    add(258, 3, [a.dtype.itemsize * 8])
+    add(259, 3, [1])
+    add(262, 3, [1])                                # BlackIsZero
+    add(273, 4, [0])                                # strip offset, patched below
+    add(277, 3, [1])
+    add(278, 4, [h])
+    add(279, 4, [a.nbytes])
+    add(284, 3, [1])
+    add(339, 3, [kind])
+    if geo_transform is not None:
+        x0, dx, rx, y0, ry, dy = [float(v) for v in geo_transform]
+        if rx == 0.0 and ry == 0.0 and dx > 0 and dy < 0:
+            add(33550, 12, [dx, -dy, 0.0])
+            add(33922, 12, [0.0, 0.0, 0.0, x0, y0, 0.0])
+        else:
+            add(34264, 12, [dx, rx, 0.0, x0, ry, dy, 0.0, y0,
+                            0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0])
+    for tag in GEOKEY_TAGS:
+        if geokeys and tag in geokeys:
+            v = geokeys[tag]
+            if tag == 34737:
+                add(tag, 2, v if isinstance(v, str) else "".join(v))
+            else:
+                add(tag, 3 if tag == 34735 else 12, list(v))
+    if nodata is not None:
+        add(42113, 2, repr(float(nodata)))
+    entries.sort(key=lambda e: e[0])
+
+    if a.nbytes + 4096 + sum(len(e[3]) for e in entries) >= 2 ** 32:
+        raise ValueError("write_geotiff: raster too large for classic TIFF")
+    data_off = 8
+    ifd_off = data_off + a.nbytes + (a.nbytes & 1)
+    extra_off = ifd_off + 2 + 12 * len(entries) + 4
+    ifd = struct.pack("<H", len(entries))
+    extra = b""
+    for tag, typ, cnt, data in entries:
+        if tag == 273:
+            data = struct.pack("<I", data_off)
+        if len(data) <= 4:
+            field = data.ljust(4, b"\0")
+        else:
+            field = struct.pack("<I", extra_off + len(extra))
+            extra += data + (b"\0" if len(data) & 1 else b"")
+        ifd += struct.pack("<HHI", tag, typ, cnt) + field
+    ifd += struct.pack("<I", 0)
+    with open(path, "wb") as f:
+        f.write(b"II" + struct.pack("<HI", 42, ifd_off))
+        f.write(a.tobytes())
+        if a.nbytes & 1:
+            f.write(b"\0")
+        f.write(ifd)
+        f.write(extra)

@@ -1,0 +1,120 @@
+"""BASELINE.json's configurations other than the bench workload, as parity
+cases on the device (C1 Carrizo lidar, C2 2048^2 synthetic, C5 Grand Canyon
+channels), plus the batch chunking of one orientation run.
+
+DEM fixtures: tests/golden/dem_carrizo.npz and dem_grandcanyon.npz hold the
+rasters of the reference's sample datasets (scarplet/datasets/data/*.tif)
+converted to arrays; tolerances and the near-tie policy are those of
+test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+import scarplet_oracle as orc
+import scarplet_amd as sl
+from scarplet_amd import _plan, synthetic
+from scarplet_amd import WindowedTemplate as WT
+from conftest import golden
+from test_gpu_parity import (AMP_RTOL, AMP_ATOL, SNR_RTOL, SNR_ATOL, TIE_RTOL,
+                             fold_check, grid)
+
+pytestmark = pytest.mark.gpu
+
+
+def dem_fixture(name):
+    f = np.load(golden(name))
+    return f["z"].astype(float), float(f["dx"]), float(f["dy"])
+
+
+def test_c1_carrizo_single_age_35_orientations(gpu_ctx):
+    """configs[0]: load_carrizo(), Scarp, scale=100, age=10, 35 orientations
+    (one-degree steps over +-17 degrees), 900 x 505 lidar DEM at 2 m."""
+    z, dx, dy = dem_fixture("dem_carrizo.npz")
+    assert z.shape == (900, 505) and (dx, dy) == (2.0, 2.0)
+    lim = 17 * np.pi / 180
+    angles = _plan.angle_grid(-lim, lim)
+    assert len(angles) == 35
+    res = sl.match(grid(z, dx, dy), sl.Scarp, scale=100, age=10, ang_min=-lim, ang_max=lim)
+    assert res.shape == (4,) + z.shape
+    chk = fold_check(res, z, dx, dy, orc.SCARP, 100, [10.0], angles)
+    assert chk["n_bad"] == 0, chk
+    assert chk["n_strict"] > 0.9 * chk["n"], chk
+    assert set(np.unique(res[1])) <= {0.0, 10.0}
+
+
+def test_c5_grandcanyon_channel_readme_example(gpu_ctx):
+    """configs[4], single width: the README / channels.ipynb call
+    sl.match(load_grandcanyon(), Channel, scale=10, age=0.1, +-pi/2) with
+    dx = 1, dy = -1 as the notebook sets them."""
+    z, dx, dy = dem_fixture("dem_grandcanyon.npz")
+    assert z.shape == (512, 512)
+    res = sl.match(grid(z, dx, dy), sl.Channel, scale=10., age=0.1,
+                   ang_min=-np.pi / 2, ang_max=np.pi / 2)
+    chk = fold_check(res, z, dx, dy, orc.RICKER, 10., [0.1], _plan.angle_grid())
+    assert chk["n_bad"] == 0, chk
+
+
+def test_c5_grandcanyon_channel_five_widths(gpu_ctx):
+    """configs[4]: Channel (Ricker) plugin, 5 wavelet widths x orientations in
+    ONE device fold (every third degree here so the oracle stack stays small;
+    the 181-orientation grid of a single width is the test above)."""
+    z, dx, dy = dem_fixture("dem_grandcanyon.npz")
+    widths = [0.05, 0.1, 0.2, 0.4, 0.8]
+    angles = _plan.angle_grid()[::3]
+    a_st, s_st = orc.snr_stack(z, dx, dy, orc.RICKER, 10., widths, angles, workers=4)
+    T = len(widths) * len(angles)
+    for method in ("fft", "direct"):
+        m = sl.Matcher(grid(z, dx, dy), ctx=gpu_ctx)
+        res = m.search(WT.Channel, 10., widths, angles, method=method).result()
+        chk = orc.check_fold(res, a_st.reshape(T, *z.shape), s_st.reshape(T, *z.shape),
+                             np.repeat(widths, len(angles)), np.tile(angles, len(widths)),
+                             tie_rtol=TIE_RTOL, amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
+                             snr_tol=(SNR_RTOL, SNR_ATOL * np.max(s_st)))
+        assert chk["n_bad"] == 0, (method, chk["n_bad"])
+        assert len(np.unique(res[1][res[3] > 0])) > 1     # more than one width wins somewhere
+
+
+def test_c2_synthetic_2048_ten_ages_91_orientations(gpu_ctx):
+    """configs[1]: 2048 x 2048 synthetic DEM (circular FFT mode, T = 2048),
+    Scarp, 10 ages x 91 orientations.  The oracle cannot build the 910-map
+    stack at this size, so a sample of templates is checked instead:
+      * max property: the folded SNR is >= every sampled template's SNR;
+      * where a sampled template won, amp / SNR equal the oracle's map;
+      * every winner lies on the searched grid."""
+    n = 2048
+    g = synthetic.synthetic_scarp(n)
+    z = g._griddata
+    ages = _plan.age_grid()[0:30:3]
+    angles = _plan.angle_grid(-np.pi / 4, np.pi / 4)
+    assert len(ages) == 10 and len(angles) == 91
+    m = sl.Matcher(g, ctx=gpu_ctx)
+    p = m.search(sl.Scarp, 100, ages, angles, method="fft")
+    amp, age, ang, snr = m.result()
+    assert np.isin(age[snr > 0], ages).all() and np.isin(ang[snr > 0], angles).all()
+
+    won = 0
+    for ia, ib in [(0, 0), (3, 45), (5, 45), (9, 90), (7, 20), (2, 70)]:
+        o_amp, _, _, o_snr = orc.match_template(z, 1.0, 1.0, orc.SCARP, 100, ages[ia], angles[ib], workers=4)
+        tol_s = SNR_RTOL * o_snr + SNR_ATOL * np.max(o_snr)
+        assert (snr >= o_snr * (1 - TIE_RTOL) - tol_s).all(), (ia, ib)
+        mine = np.isclose(age, ages[ia], rtol=1e-9) & (ang == angles[ib])
+        won += int(mine.sum())
+        assert (np.abs(snr - o_snr)[mine] <= tol_s[mine]).all(), (ia, ib)
+        tol_a = AMP_RTOL * np.abs(o_amp) + AMP_ATOL * np.max(np.abs(o_amp))
+        assert (np.abs(amp - o_amp)[mine] <= tol_a[mine]).all(), (ia, ib)
+    assert won > 0
+
+
+def test_more_parameters_than_one_batch(gpu_ctx):
+    """An orientation run longer than the device batch (64 templates) is
+    split into chunks that fold into the same running best."""
+    rng = np.random.default_rng(64)
+    z = (np.cumsum(np.cumsum(rng.standard_normal((90, 100)), 0), 1) * 0.01
+         + rng.standard_normal((90, 100)) * 0.05).astype(np.float32)
+    ages = list(10 ** np.linspace(0, 2, 70))
+    angles = np.array([-0.4, 0.0, 0.9])
+    for method in ("fft", "direct"):
+        m = sl.Matcher(grid(z, 1.0), ctx=gpu_ctx)
+        res = m.search(WT.Scarp, 8, ages, angles, method=method).result()
+        chk = fold_check(res, z, 1.0, 1.0, orc.SCARP, 8, ages, angles)
+        assert chk["n_bad"] == 0, (method, chk)

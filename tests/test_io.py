@@ -39,3 +39,32 @@ def test_fill_nodata_leaves_no_nan():
     g._fill_nodata()
     assert not np.isnan(g._griddata).any() and g.is_interpolated
     assert abs(g._griddata[5, 11] - 16.0) < 1.0          # planar surface: the fill stays on it
+
+
+def test_save_round_trip_keeps_grid_georeferencing_and_nodata(tmp_path):
+    """DEMGrid.save (dem.py:291-306): float32 GeoTIFF that loads back to the
+    same grid, geotransform and projection keys; NaN cells survive as nodata."""
+    g = sl.DEMGrid(golden("grandcanyon_crop.tif"))
+    g._griddata[3, 5] = np.nan
+    out = str(tmp_path / "out.tif")
+    g.save(out)
+    h = sl.DEMGrid(out)
+    assert h._griddata.shape == g._griddata.shape
+    assert np.isnan(h._griddata[3, 5]) and np.isnan(h._griddata).sum() == 1
+    ok = ~np.isnan(g._griddata)
+    assert (h._griddata[ok] == g._griddata[ok].astype(np.float32)).all()
+    assert np.allclose(h._georef_info.geo_transform, g._georef_info.geo_transform)
+    assert h._georef_info.projection == g._georef_info.projection
+    assert (h._georef_info.dx, h._georef_info.dy) == (g._georef_info.dx, g._georef_info.dy)
+
+
+def test_write_geotiff_dtypes_and_rotated_transform(tmp_path):
+    rng = np.random.default_rng(3)
+    for dt in ("u1", "i2", "u4", "f4", "f8"):
+        a = (rng.random((7, 11)) * 100).astype(dt)
+        out = str(tmp_path / ("a_%s.tif" % dt))
+        gt = (10.0, 2.0, 0.5, 20.0, -0.5, 3.0)
+        tiff.write_geotiff(out, a, gt, nodata=-1.0)
+        b, gt2, nd = tiff.read_geotiff(out)
+        assert b.dtype == a.dtype and (a == b).all()
+        assert np.allclose(gt, gt2) and nd == -1.0
