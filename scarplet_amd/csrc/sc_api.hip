@@ -366,7 +366,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
     const Geom& g = ctx->g;
     FftGeom fg{};
     const int group = std::max(1, plan->group);
-    const int CHUNK = 64;
+    const int CHUNK = SC_MAX_GROUP;
     if (plan->method == SC_METHOD_FFT) {
         fg.Ty = plan->Ty; fg.Tx = plan->Tx; fg.Vy = plan->Vy; fg.Vx = plan->Vx;
         fg.nty = plan->nty; fg.ntx = plan->ntx; fg.circ_y = plan->circ_y;

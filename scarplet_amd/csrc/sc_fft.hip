@@ -783,23 +783,133 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
 }
 
 // ---- I2 (fast): T in {512, 1024, 2048} ---------------------------------------
-// grid = (valid row pairs): one 512-thread workgroup per pair of tile rows, 4 LDS
-// lines = {W plane, M plane} x {row 0, row 1}.  Compared with the generic kernel
-// the transform is unrolled into its three stages so that
-//   * stage 1 takes its 16 points straight from global memory into registers
-//     (lanes alternate between the two rows: a wave reads whole 128-byte
-//     blocks of the rows2 layout) - no LDS fill pass;
+// One workgroup (T/8 threads) per tile ROW, 2 LDS lines = {W plane, M plane}.
+// Compared with the generic kernel the transform is unrolled into its three
+// stages so that
+//   * stage 1 takes its 16 points straight from global memory into registers -
+//     no LDS fill pass;
 //   * stage 3 is fused with the epilogue: a thread computes the same butterflies
 //     of the W and the M line, so xcorr and T3 of its cells meet in registers -
 //     no LDS write of the result, no read back;
-//   * the next template's points are fetched right after stage 1 and stay in
-//     flight through stages 2-3 (nothing in between waits on vmcnt).
-// 2 LDS writes + 2 reads and 3 barriers per template instead of 4 + 4 and 8.
+//   * the running best record of a thread's 16 cells stays in registers across
+//     the G templates of the launch and is written back once.
+// Small workgroups on purpose: three of them share a CU (3 waves per SIMD, 168
+// VGPRs each), so one computes while another sits in a barrier or waits for LDS
+// or HBM; a 512-thread workgroup per row pair left the SIMDs idle two thirds of
+// the time.  Complex values are native 2-vectors (v_pk_add/mul/fma_f32: one
+// instruction per complex add, two per complex product) and twiddles come from
+// small LDS tables.  The two rows of a rows2 pair share their 128-byte lines:
+// their workgroups are given block ids 8 apart, i.e. the same XCD at the same
+// time, so the second reader hits in that XCD's L2.
+#ifndef SC_I2_FETCH_AT
+#define SC_I2_FETCH_AT 0
+#endif
+namespace pk {
+typedef float v2 __attribute__((ext_vector_type(2)));
+
+// a * w (complex): two packed instructions, the half-swaps and the sign ride on
+// the op_sel / neg modifiers
+__device__ __forceinline__ v2 cmul(v2 a, v2 w) {
+    v2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// a * w with w a compile-time constant held in a scalar register pair
+__device__ __forceinline__ v2 cmul_k(v2 a, v2 w) {
+    v2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    return r;
+}
+// inverse transforms only: multiply by +j, constants are exp(+i angle)
+__device__ __forceinline__ v2 mulj(v2 a) { return v2{-a.y, a.x}; }
+__device__ __forceinline__ void dft4(v2& a0, v2& a1, v2& a2, v2& a3) {
+    v2 apc = a0 + a2, amc = a0 - a2, bpd = a1 + a3, bmd = mulj(a1 - a3);
+    a0 = apc + bpd;
+    a1 = amc + bmd;
+    a2 = apc - bpd;
+    a3 = amc - bmd;
+}
+template <int R>
+struct B;
+template <>
+struct B<2> {
+    static __device__ __forceinline__ void run(v2* v) {
+        v2 a = v[0], b = v[1];
+        v[0] = a + b;
+        v[1] = a - b;
+    }
+    static __device__ __forceinline__ constexpr int pos(int m) { return m; }
+};
+template <>
+struct B<4> {
+    static __device__ __forceinline__ void run(v2* v) { dft4(v[0], v[1], v[2], v[3]); }
+    static __device__ __forceinline__ constexpr int pos(int m) { return m; }
+};
+template <>
+struct B<8> {
+    static __device__ __forceinline__ void run(v2* v) {
+        dft4(v[0], v[2], v[4], v[6]);
+        dft4(v[1], v[3], v[5], v[7]);
+        const float h = 0.70710678118654752f;
+        v[3] = cmul_k(v[3], v2{h, h});
+        v[5] = mulj(v[5]);
+        v[7] = cmul_k(v[7], v2{-h, h});
+        B<2>::run(v + 0);
+        B<2>::run(v + 2);
+        B<2>::run(v + 4);
+        B<2>::run(v + 6);
+    }
+    static __device__ __forceinline__ constexpr int pos(int m) { return 2 * (m & 3) + (m >> 2); }
+};
+template <>
+struct B<16> {
+    static __device__ __forceinline__ void run(v2* v) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dft4(v[c], v[c + 4], v[c + 8], v[c + 12]);
+        const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f;
+        const float h = 0.70710678118654752f;
+        v[5] = cmul_k(v[5], v2{c1, s1});
+        v[9] = cmul_k(v[9], v2{h, h});
+        v[13] = cmul_k(v[13], v2{s1, c1});
+        v[6] = cmul_k(v[6], v2{h, h});
+        v[10] = mulj(v[10]);
+        v[14] = cmul_k(v[14], v2{-h, h});
+        v[7] = cmul_k(v[7], v2{s1, c1});
+        v[11] = cmul_k(v[11], v2{-h, h});
+        v[15] = cmul_k(v[15], v2{-c1, -s1});
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dft4(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]);
+    }
+    static __device__ __forceinline__ constexpr int pos(int m) { return 4 * (m & 3) + (m >> 2); }
+};
+}  // namespace pk
+
 template <int TX>
 __host__ __device__ constexpr bool inv_rows_fast_ok() { return TX == 512 || TX == 1024 || TX == 2048; }
 
-template <int TX, bool FULL>
-__global__ void __launch_bounds__(fft_threads(TX), 2)
+// Byte-offset access to the best-record planes: one 32-bit offset per cell on
+// top of the (uniform) plane pointer.
+template <typename V>
+__device__ __forceinline__ V& at_bytes(V* base, uint32_t off) {
+    return *reinterpret_cast<V*>(reinterpret_cast<char*>(base) + off);
+}
+constexpr int EPI_FLOATS = 8;                  // per-template scalars staged in LDS
+// LDS: 4 lines | per-template scalars | stage-1 twiddle bases (4 per set index)
+//      | stage-2 twiddles (16 per p = 0 .. S/16-1)
+template <int TX>
+__host__ __device__ constexpr int inv_rows_fast_threads() { return TX / 8; }
+template <int TX>
+__host__ __device__ constexpr size_t inv_rows_fast_lds() {
+    return fft_lds_bytes(TX) / 2 + (size_t)SC_MAX_GROUP * EPI_FLOATS * sizeof(float) +
+           (size_t)(TX / 16) * 4 * sizeof(float2) + (size_t)(TX / 256) * 16 * sizeof(float2);
+}
+
+template <int TX, bool FULL, bool MAPS>
+__global__ void __launch_bounds__(inv_rows_fast_threads<TX>(), 3)
 k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 RowArgs ra, Geom g, const TileDev* __restrict__ tiles,
                 const TemplDev* __restrict__ templ, const double* __restrict__ sums,
@@ -808,163 +918,251 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 const float2* __restrict__ tw, float* __restrict__ best_snr,
                 float* __restrict__ best_amp, uint32_t* __restrict__ best_id,
                 float* __restrict__ map_amp, float* __restrict__ map_snr) {
-    extern __shared__ __attribute__((aligned(16))) float2 sm[];
-    constexpr int S = TX / 16;                 // 16-point sets per line; NT = 4S threads
+    using pk::v2;
+    extern __shared__ __attribute__((aligned(16))) float2 sm_[];
+    v2* sm = reinterpret_cast<v2*>(sm_);
+    constexpr int S = TX / 16;                 // 16-point sets per line; NT = 2S threads
+    constexpr int NT = 2 * S;
     constexpr int R3 = TX / 256;               // radix of the last stage (2, 4, 8)
     constexpr int NB3 = 16 / R3;               // its butterflies per set
     constexpr int NU = NB3 / 2;                // butterflies per plane per thread in stage 3
     constexpr int NC = NU * R3;                // cells per thread (= 8)
     constexpr int LINE = fft_line(TX);
-    static_assert(fft_threads(TX) == 4 * S && NC == 8, "fast I2 geometry");
+    constexpr int FETCH_AT = SC_I2_FETCH_AT;   // next template's points: 0 after stage 1, 1 after stage 2
+    static_assert(inv_rows_fast_threads<TX>() == NT && NC == 8, "fast I2 geometry");
     const int id = threadIdx.x;
-    const int rp = ra.rp_lo + blockIdx.x;
+    // blocks b and b + 8 take the two rows of one pair (same XCD, same time)
+    const int pi = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7), rh = (blockIdx.x >> 3) & 1;
+    if (pi >= ra.rp_n) return;
+    const int rp = ra.rp_lo + pi;
     const size_t plane = (size_t)ra.Ty * TX;
     const TileDev tA = tiles[2 * ra.pair], tB = tiles[2 * ra.pair + 1];
     const float scale = 1.0f / ((float)ra.Ty * (float)TX);
 
-    // stage-1 mapping: plane, row and set of this thread
-    const int pl1 = id / (2 * S), rr1 = id & 1, tt1 = (id % (2 * S)) >> 1;
-    float2* line1 = sm + (2 * pl1 + rr1) * LINE;
-    const float2* src1 = (pl1 ? ym : yw) + (size_t)rp * 2 * TX + (size_t)(tt1 >> 3) * 16 + (tt1 & 7) * 2 + rr1;
-    // stage-2 mapping (standard)
-    float2* line2 = sm + (id / S) * LINE;
-    const int tt2 = id % S;
-    // stage-3 mapping: row r3, butterflies rem3 + u*2S of both planes
-    const int r3 = id / (2 * S), rem3 = id % (2 * S);
-    const float2* lineW = sm + r3 * LINE;
-    const float2* lineM = sm + (2 + r3) * LINE;
-    // twiddle bases of stages 1 and 2
-    float2 w1[4], w2[4];
-    {
-        const int e1 = tt1, e2 = (tt2 >> 4) << 4;
-        w1[0] = tw[e1]; w1[1] = tw[2 * e1]; w1[2] = tw[4 * e1]; w1[3] = tw[8 * e1];
-        w2[0] = tw[e2]; w2[1] = tw[2 * e2]; w2[2] = tw[4 * e2]; w2[3] = tw[8 * e2];
+    float* epi = reinterpret_cast<float*>(sm + 2 * LINE);
+    v2* tw1 = reinterpret_cast<v2*>(epi + SC_MAX_GROUP * EPI_FLOATS);
+    v2* tw2 = tw1 + 4 * S;
+    // per-template scalars of the epilogue (float64 arithmetic on the template
+    // sums) are the same for every cell: thread t prepares template t once and
+    // parks the five floats in LDS.  xcorr = xr*scale_w, T3 = tr*scale
+    //   =>  amp = xr*ka, T1 = xr^2*kt, floor = |xr|*kx2 + fl0
+    if (id < ra.G) {
+        const int it = ra.first + id;
+        EpiScal es = sc_epi_scalars(sums, it);
+        sc_epi_floor(es, sums[2 * it], sums[2 * it + 1], wl1[it], norms[2 * ra.pair],
+                     norms[2 * ra.pair + 1], (double)ra.Ty * TX, kappa);
+        const float scale_w = scale / sc_fft_alpha(sums, it);
+        const float ka = scale_w * es.inv_ts;
+        float* e = epi + EPI_FLOATS * id;
+        e[0] = ka;
+        e[1] = scale_w * ka;
+        e[2] = scale_w * es.dx2;
+        e[3] = es.d3 + es.dxx;
+        e[4] = es.inv_n;
     }
-    // cells of this thread: row 2rp + r3, columns rem3 + u*2S + 256 m
-    int ri = 2 * rp + r3 - ra.Py;
+    // twiddle tables (inverse transform: conjugates of the forward table):
+    //   stage 1 (stride 1):  set tt multiplies output m by w^(tt*m); bases m = 1,2,4,8
+    //   stage 2 (stride 16): set tt multiplies output m by w^(16*(tt>>4)*m)
+    for (int i = id; i < 4 * S; i += NT) {
+        float2 w = tw[(i >> 2) << (i & 3)];
+        tw1[i] = v2{w.x, -w.y};
+    }
+    for (int i = id; i < S; i += NT) {
+        float2 w = tw[((i >> 4) << 4) * (i & 15)];
+        tw2[i] = v2{w.x, -w.y};
+    }
+
+    // stage-1 mapping: plane and set of this thread (the plane is the same for a
+    // whole wave when S is a multiple of 64: keep its base pointer scalar then)
+    const int pl1 = (S % 64 == 0) ? __builtin_amdgcn_readfirstlane(id / S) : id / S;
+    const int tt1 = id % S;
+    v2* line1 = sm + pl1 * LINE + 17 * tt1;
+    const char* src1 = reinterpret_cast<const char*>((pl1 ? ym : yw) + (size_t)rp * 2 * TX);
+    const uint32_t voff1 = (uint32_t)(((tt1 >> 3) * 16 + (tt1 & 7) * 2 + rh) * sizeof(float2));
+    // stage-2 mapping (standard): line id / S, set tt2
+    const int tt2 = id % S;
+    v2* line2 = sm + (id / S) * LINE;
+    const v2* rd2 = line2 + ph(tt2);
+    v2* wr2 = line2 + ph((tt2 & 15) + ((tt2 >> 4) << 8));
+    const v2* twp2 = tw2 + ((tt2 >> 4) << 4);
+    // stage-3 mapping: butterflies id + u*2S of both planes
+    const int rem3 = id;
+    const v2* lineW = sm + ph(rem3);
+    const v2* lineM = lineW + LINE;
+    // cells of this thread: row 2rp + rh (tile row ri), columns
+    // cj0 + u*2S + 256 m, c = u*R3 + m; part 0 belongs to tile A (real part of
+    // the packed transform), part 1 to tile B
+    int ri = 2 * rp + rh - ra.Py;
     if (ra.circ_y) ri &= (ra.Ty - 1);
     const bool rowA = ri >= 0 && ri < tA.vy, rowB = ri >= 0 && ri < tB.vy;
-    auto col_of = [&](int c) {                  // c = u*R3 + m
-        int cj = rem3 + (c / R3) * 2 * S + 256 * (c % R3) - ra.Qx;
-        if (ra.circ_x) cj &= (TX - 1);
-        return cj;
-    };
-    float b_snr[2 * NC];
-    unsigned valid = 0;
+    if (!rowA && !rowB) return;                                  // whole workgroup
+    int cj0 = rem3 - ra.Qx;
+    const int cmask = ra.circ_x ? TX - 1 : -1;
+    auto col_of = [&](int c) { return (cj0 + (c / R3) * 2 * S + 256 * (c % R3)) & cmask; };
+    // byte offset of tile column 0 of this thread's row in the best-record planes
+    const uint32_t offA = (uint32_t)(((size_t)(tA.i0 + ri - ra.cy0) * ra.cw + (tA.j0 - ra.cx0)) * 4);
+    const uint32_t offB = (uint32_t)(((size_t)(tB.i0 + ri - ra.cy0) * ra.cw + (tB.j0 - ra.cx0)) * 4);
+    // running best record of the 16 cells, in registers across the G templates
+    // of the launch; written back once at the end, and only where a template
+    // of this launch won (b_id leaves its sentinel).  A stored NaN SNR stays:
+    // nothing compares greater than it (sc_fold's sticky NaN); a NaN score never
+    // wins here - it cannot arise from the finite DEMs the host lets through.
+    // The winner is remembered as its index in the launch, one byte per cell
+    // (0xFF: unchanged), four cells to a register.
+    float b_snr[2 * NC], b_amp[2 * NC];
+    uint32_t b_ix[NC / 2];
+#pragma unroll
+    for (int c = 0; c < NC / 2; ++c) b_ix[c] = 0xFFFFFFFFu;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        int cj = col_of(c);
-        bool okA = rowA && cj >= 0 && cj < tA.vx;
-        bool okB = rowB && cj >= 0 && cj < tB.vx;
-        if (okA) valid |= 1u << (2 * c);
-        if (okB) valid |= 2u << (2 * c);
-        const bool rd = !map_amp && !(ra.dbg & 8);
-        b_snr[2 * c] = (okA && rd) ? best_snr[(size_t)(tA.i0 + ri - ra.cy0) * ra.cw + (tA.j0 + cj - ra.cx0)] : 0.f;
-        b_snr[2 * c + 1] = (okB && rd) ? best_snr[(size_t)(tB.i0 + ri - ra.cy0) * ra.cw + (tB.j0 + cj - ra.cx0)] : 0.f;
+        const int cj = col_of(c);
+        const bool okA = !MAPS && rowA && cj >= 0 && cj < tA.vx;
+        const bool okB = !MAPS && rowB && cj >= 0 && cj < tB.vx;
+        b_snr[2 * c] = okA ? at_bytes(best_snr, offA + 4u * (uint32_t)cj) : 0.f;
+        b_snr[2 * c + 1] = okB ? at_bytes(best_snr, offB + 4u * (uint32_t)cj) : 0.f;
+        b_amp[2 * c] = b_amp[2 * c + 1] = 0.f;
     }
 
-    float2 a[16];
+    v2 a[16];
     auto fetch = [&](int gi_) {
-        const float2* p = src1 + (size_t)gi_ * plane;
+        const char* p = src1 + (size_t)gi_ * plane * sizeof(float2);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = p[2 * S * j];       // column tt1 + j*S
+        for (int j = 0; j < 16; ++j)                             // column tt1 + j*S
+            a[j] = *reinterpret_cast<const v2*>(p + (size_t)j * 2 * S * sizeof(float2) + voff1);
     };
-    if (!(ra.dbg & 1)) fetch(0);
+    fetch(0);
+    lds_barrier();                                               // tables and scalars are in place
     for (int gi_ = 0; gi_ < ra.G; ++gi_) {
         const TemplDev* tp = templ + ra.first + gi_;
-        EpiScal es = sc_epi_scalars(sums, ra.first + gi_);
-        sc_epi_floor(es, sums[2 * (ra.first + gi_)], sums[2 * (ra.first + gi_) + 1],
-                     wl1[ra.first + gi_], norms[2 * ra.pair], norms[2 * ra.pair + 1],
-                     (double)ra.Ty * TX, kappa);
-        const float scale_w = scale / sc_fft_alpha(sums, ra.first + gi_);
-        const uint32_t tid_ = tp->id;
-        const int rloA = tp->ilo - tA.i0, rhiA = tp->ihi - tA.i0, cloA = tp->jlo - tA.j0, chiA = tp->jhi - tA.j0;
-        const int rloB = tp->ilo - tB.i0, rhiB = tp->ihi - tB.i0, cloB = tp->jlo - tB.j0, chiB = tp->jhi - tB.j0;
-        const bool rkA = ri >= rloA && ri <= rhiA, rkB = ri >= rloB && ri <= rhiB;
+        const uint32_t gi4 = (uint32_t)gi_ * 0x01010101u;
+        // the columns are two instructions away from cj0: keep them out of the
+        // loop-invariant registers (eight of them would not fit)
+        asm volatile("" : "+v"(cj0));
 
-        // ---- stage 1 (radix 16, stride 1) from registers
-        if (!(ra.dbg & 2)) set_compute_store<TX, 16, 0, true>(line1, tt1, a, w1);
-        lds_barrier();
-        if (gi_ + 1 < ra.G && !(ra.dbg & 1)) fetch(gi_ + 1);    // in flight through stages 2-3
-        // ---- stage 2 (radix 16, stride 16)
-        if (!(ra.dbg & 2)) {
-            float2 b[16];
-            set_load<TX>(line2, tt2, b);
-            lds_barrier();
-            set_compute_store<TX, 16, 4, true>(line2, tt2, b, w2);
-        } else {
-            lds_barrier();
+        // ---- stage 1 (radix 16, stride 1) from registers: outputs 16 tt1 + m
+        {
+            pk::B<16>::run(a);
+            const v2 w1 = tw1[4 * tt1], w2 = tw1[4 * tt1 + 1], w4 = tw1[4 * tt1 + 2], w8 = tw1[4 * tt1 + 3];
+            line1[0] = a[pk::B<16>::pos(0)];
+            line1[8] = pk::cmul(a[pk::B<16>::pos(8)], w8);
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                v2 wk = (k & 1) ? w1 : v2{1.f, 0.f};
+                if (k == 2 || k == 6) wk = w2;
+                if (k == 3 || k == 7) wk = pk::cmul(w1, w2);
+                if (k == 4) wk = w4;
+                if (k >= 5) wk = pk::cmul(wk, w4);
+                line1[k] = pk::cmul(a[pk::B<16>::pos(k)], wk);
+                line1[k + 8] = pk::cmul(a[pk::B<16>::pos(k + 8)], pk::cmul(wk, w8));
+            }
         }
+        lds_barrier();
+        if (FETCH_AT == 0 && gi_ + 1 < ra.G) fetch(gi_ + 1);     // in flight through stages 2-3
+        // ---- stage 2 (radix 16, stride 16): elements tt2 + j*S -> o + 16 m
+        {
+            v2 b[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) b[j] = rd2[j * (S + S / 16)];
+            lds_barrier();
+            pk::B<16>::run(b);
+            wr2[0] = b[pk::B<16>::pos(0)];
+#pragma unroll
+            for (int m = 1; m < 16; ++m) wr2[17 * m] = pk::cmul(b[pk::B<16>::pos(m)], twp2[m]);
+        }
+        if (FETCH_AT == 1 && gi_ + 1 < ra.G) fetch(gi_ + 1);     // in flight through stage 3
         lds_barrier();
         // ---- stage 3 (radix R3, stride 256) fused with the epilogue: every
         // output is scored as soon as its two butterflies have produced it
-        if (!(ra.dbg & 4)) {
-            // fold the transform scale into the per-template scalars:
-            // xcorr = xr*scale_w, T3 = tr*scale  =>  amp = xr*ka, T1 = xr^2*kt
-            const float ka = scale_w * es.inv_ts, kt = scale_w * ka;
-            const float kx2 = scale_w * es.dx2, fl0 = es.d3 + es.dxx;
-            // window-limit columns as one unsigned range test per part
-            const unsigned spanA = (unsigned)(chiA - cloA), spanB = (unsigned)(chiB - cloB);
-            const bool colsA = chiA >= cloA && rkA, colsB = chiB >= cloB && rkB;
+        const float* e = epi + EPI_FLOATS * gi_;
+        const float ka = e[0], kt = e[1], kx2 = e[2], fl0 = e[3], inv_n = e[4];
+        // cells that may score, per part: inside the tile's valid extent AND
+        // (lean variant) inside the template's window-limit rectangle - one
+        // unsigned range test on the column; a row outside makes the range empty
+        int loA = 0, hiA = tA.vx - 1, loB = 0, hiB = tB.vx - 1;
+        bool rA = rowA, rB = rowB;
+        if (!FULL && !MAPS) {
+            loA = max(loA, tp->jlo - tA.j0); hiA = min(hiA, tp->jhi - tA.j0);
+            loB = max(loB, tp->jlo - tB.j0); hiB = min(hiB, tp->jhi - tB.j0);
+            rA = rA && ri >= tp->ilo - tA.i0 && ri <= tp->ihi - tA.i0;
+            rB = rB && ri >= tp->ilo - tB.i0 && ri <= tp->ihi - tB.i0;
+        }
+        const unsigned spanA = (rA && hiA >= loA) ? (unsigned)(hiA - loA) : 0u;
+        const unsigned spanB = (rB && hiB >= loB) ? (unsigned)(hiB - loB) : 0u;
+        const int baseA = (rA && hiA >= loA) ? loA : 0x40000000;      // no column reaches it
+        const int baseB = (rB && hiB >= loB) ? loB : 0x40000000;
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int bt = rem3 + u * 2 * S;
-                float2 vw[R3], vm[R3];
+        for (int u = 0; u < NU; ++u) {
+            v2 vw[R3], vm[R3];
 #pragma unroll
-                for (int k = 0; k < R3; ++k) {
-                    vw[k] = lineW[ph(bt) + k * 272];
-                    vm[k] = lineM[ph(bt) + k * 272];
-                }
-                Bfly<R3, true>::run(vw);
-                Bfly<R3, true>::run(vm);
+            for (int k = 0; k < R3; ++k) {
+                vw[k] = lineW[u * (2 * S + 2 * S / 16) + k * 272];
+                vm[k] = lineM[u * (2 * S + 2 * S / 16) + k * 272];
+            }
+            pk::B<R3>::run(vw);
+            pk::B<R3>::run(vm);
 #pragma unroll
-                for (int m = 0; m < R3; ++m) {
-                    const int c = u * R3 + m;
-                    const float2 xc = vw[Bfly<R3, true>::pos(m)], t3 = vm[Bfly<R3, true>::pos(m)];
-                    const int cj = col_of(c);
+            for (int m = 0; m < R3; ++m) {
+                const int c = u * R3 + m;
+                const v2 xc = vw[pk::B<R3>::pos(m)], t3 = vm[pk::B<R3>::pos(m)];
+                const int cj = col_of(c);
 #pragma unroll
-                    for (int part = 0; part < 2; ++part) {
-                        const int k = 2 * c + part;
-                        const float xr = part ? xc.y : xc.x, tr = part ? t3.y : t3.x;
-                        // core.py:360-367 with the float32 resolution floor (sc_epilogue)
-                        const float T1 = xr * xr * kt;
-                        const float d = fmaxf(fmaf(tr, scale, -T1), fmaf(fabsf(xr), kx2, fl0));
-                        float snr = fabsf(T1 * __builtin_amdgcn_rcpf(fmaf(d, es.inv_n, (float)SC_EPS)));
-                        bool keep = (valid >> k) & 1u;
-                        float amp = xr * ka;
-                        if (FULL) {
-                            if (keep)
+                for (int part = 0; part < 2; ++part) {
+                    const int k = 2 * c + part;
+                    const float xr = part ? xc.y : xc.x, tr = part ? t3.y : t3.x;
+                    // core.py:360-367 with the float32 resolution floor (sc_epilogue)
+                    const float T1 = xr * xr * kt;
+                    const float d = fmaxf(fmaf(tr, scale, -T1), fmaf(fabsf(xr), kx2, fl0));
+                    float snr = fabsf(T1 * __builtin_amdgcn_rcpf(fmaf(d, inv_n, (float)SC_EPS)));
+                    const bool in = (unsigned)(cj - (part ? baseB : baseA)) <= (part ? spanB : spanA);
+                    float amp = xr * ka;
+                    if (MAPS || FULL) {
+                        // `in` is the tile's valid extent here; masks per cell
+                        if (in) {
+                            if (FULL)
                                 sc_apply_masks(*tp, g, xaxis, yaxis, (part ? tB.i0 : tA.i0) + ri,
                                                (part ? tB.j0 : tA.j0) + cj, amp, snr);
-                        } else {
-                            keep = keep && (part ? (colsB && (unsigned)(cj - cloB) <= spanB)
-                                                 : (colsA && (unsigned)(cj - cloA) <= spanA));
-                        }
-                        snr = keep ? snr : 0.f;
-                        amp = keep ? amp : 0.f;
-                        // sc_fold on the SNR alone: take if greater; a NaN score poisons
-                        // the cell once and stays (see sc_fold)
-                        const float bs = b_snr[k];
-                        const bool won = map_amp ? ((valid >> k) & 1u) : (!(snr <= bs) && bs == bs);
-                        if (!map_amp) b_snr[k] = won ? snr : bs;
-                        if (won && !(ra.dbg & 8)) {
-                            const bool nan = snr != snr;
-                            size_t o = (size_t)((part ? tB.i0 : tA.i0) + ri - ra.cy0) * ra.cw +
-                                       ((part ? tB.j0 : tA.j0) + cj - ra.cx0);
-                            if (map_amp) {
-                                map_amp[o] = amp;
-                                map_snr[o] = snr;
-                            } else {
-                                best_snr[o] = snr;
-                                best_amp[o] = nan ? 0.f : amp;
-                                best_id[o] = nan ? SC_ID_NONE : tid_;
+                            else if (!(ri >= tp->ilo - (part ? tB.i0 : tA.i0) &&
+                                       ri <= tp->ihi - (part ? tB.i0 : tA.i0) &&
+                                       cj >= tp->jlo - (part ? tB.j0 : tA.j0) &&
+                                       cj <= tp->jhi - (part ? tB.j0 : tA.j0))) {
+                                amp = 0.f;
+                                snr = 0.f;
                             }
+                            if (MAPS) {
+                                const uint32_t o = (part ? offB : offA) + 4u * (uint32_t)cj;
+                                at_bytes(map_amp, o) = amp;
+                                at_bytes(map_snr, o) = snr;
+                            }
+                        } else {
+                            snr = 0.f;
                         }
+                    } else {
+                        snr = in ? snr : 0.f;
+                    }
+                    if (!MAPS) {
+                        // sc_fold: take if greater, ties keep the incumbent
+                        const bool won = snr > b_snr[k];
+                        b_snr[k] = won ? snr : b_snr[k];
+                        b_amp[k] = won ? amp : b_amp[k];
+                        const uint32_t bm = 0xFFu << (8 * (k & 3));
+                        b_ix[k >> 2] = won ? ((b_ix[k >> 2] & ~bm) | (gi4 & bm)) : b_ix[k >> 2];
                     }
                 }
             }
         }
         lds_barrier();
+    }
+    if (!MAPS) {
+#pragma unroll
+        for (int k = 0; k < 2 * NC; ++k) {
+            const uint32_t ix = (b_ix[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            if (ix != 0xFFu) {
+                const uint32_t o = ((k & 1) ? offB : offA) + 4u * (uint32_t)col_of(k >> 1);
+                at_bytes(best_snr, o) = b_snr[k];
+                at_bytes(best_amp, o) = b_amp[k];
+                at_bytes(best_id, o) = templ[ra.first + ix].id;
+            }
+        }
     }
 }
 
@@ -1137,6 +1335,11 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         rp_hi = std::min(fg.Ty - 1, fg.Py + fg.Vy - 1) / 2;
     }
     const int rp_n = rp_hi - rp_lo + 1;
+    // the row kernels address the best-record planes with 32-bit byte offsets
+    if ((size_t)(ctx->g.cy1 - ctx->g.cy0) * (size_t)(ctx->g.cx1 - ctx->g.cx0) >= ((size_t)1 << 30))
+        return sc_fail(ctx, SC_ERR_UNSUPPORTED, "core block of 2^30 cells or more");
+    if (group > SC_MAX_GROUP)
+        return sc_fail(ctx, SC_ERR_INVALID, "group %d exceeds %d", group, SC_MAX_GROUP);
     for (int pair = 0; pair < np; ++pair) {
         for (int g0 = 0; g0 < n; g0 += group) {
             int G = std::min(group, n - g0);
@@ -1165,10 +1368,11 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
                        ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg};
             const bool fast = (fg.Tx == 512 || fg.Tx == 1024 || fg.Tx == 2048) && ctx->variant != 9;
-            dim3 gridr(fast ? rp_n : (rp_n + 1) / 2);
+            dim3 gridr(fast ? ((rp_n + 7) / 8) * 16 : (rp_n + 1) / 2);
             sc_prof_begin(ctx, SC_K_INV_ROWS);
-#define ROW_ARGS                                                               \
-    lds_r, ctx->stream, (const float2*)ctx->yw.p, (const float2*)ctx->ym.p, ra, ctx->g,     \
+#define ROW_ARGS lds_r, FAST_ARGS
+#define FAST_ARGS                                                              \
+    ctx->stream, (const float2*)ctx->yw.p, (const float2*)ctx->ym.p, ra, ctx->g,     \
         (const TileDev*)ctx->tiles.p, (const TemplDev*)ctx->templ.p, (const double*)ctx->sums.p, \
         (const double*)ctx->wl1.p, (const double*)ctx->norms.p, ctx->kappa,                 \
         (const double*)ctx->xaxis.p, (const double*)ctx->yaxis.p, (const float2*)ctx->tw_x.p, \
@@ -1180,12 +1384,15 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         if (rc) return rc;                                                     \
         hipLaunchKernelGGL((k_inv_rows<T, FULLV>), gridr, dim3(fft_threads(T)), ROW_ARGS); \
     }
-#define LAUNCH_FAST(T, FULLV)                                                  \
+#define LAUNCH_FAST2(T, FULLV, MAPSV)                                          \
     {                                                                          \
-        int rc = set_lds(ctx, k_inv_rows_fast<T, FULLV>, lds_r);               \
+        int rc = set_lds(ctx, k_inv_rows_fast<T, FULLV, MAPSV>, inv_rows_fast_lds<T>()); \
         if (rc) return rc;                                                     \
-        hipLaunchKernelGGL((k_inv_rows_fast<T, FULLV>), gridr, dim3(fft_threads(T)), ROW_ARGS); \
+        hipLaunchKernelGGL((k_inv_rows_fast<T, FULLV, MAPSV>), gridr,          \
+                           dim3(inv_rows_fast_threads<T>()), inv_rows_fast_lds<T>(), FAST_ARGS); \
     }
+#define LAUNCH_FAST(T, FULLV)                                                  \
+    { if (to_maps) LAUNCH_FAST2(T, FULLV, true) else LAUNCH_FAST2(T, FULLV, false) }
             if (fast) {
                 switch (fg.Tx) {
                     case 512: if (full_masks) LAUNCH_FAST(512, true) else LAUNCH_FAST(512, false) break;
@@ -1199,7 +1406,9 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             }
 #undef LAUNCH_ROWS
 #undef LAUNCH_FAST
+#undef LAUNCH_FAST2
 #undef ROW_ARGS
+#undef FAST_ARGS
             sc_prof_end(ctx);
         }
     }

@@ -53,6 +53,9 @@ struct WindowSlot {
     uint8_t* mask_err = nullptr;
 };
 
+// templates per inverse launch (sc_match batches an orientation run in chunks)
+#define SC_MAX_GROUP 64
+
 struct sc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
