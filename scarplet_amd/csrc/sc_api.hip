@@ -466,12 +466,22 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
         if (plan->method == SC_METHOD_DIRECT) {
             if ((rc = launch_direct(ctx, c.first, c.n, to_maps))) return rc;
         } else {
-            if ((rc = fft_forward_templates(ctx, fg, c.first, c.n))) return rc;
+            // flip symmetry of the built-in templates (k_split_templ_sym): the same
+            // parity for the whole chunk, and support boxes that map onto themselves
+            int parity = -1;
+            for (int j = c.first; j < c.first + c.n; ++j) {
+                int pj = t[j].kind == SC_KIND_SCARP ? 1 : (t[j].kind == SC_KIND_RICKER ? 2 : 0);
+                if (t[j].pmin + t[j].pmax != -(1 - ctx->g.oy) || t[j].qmin + t[j].qmax != -(1 - ctx->g.ox))
+                    pj = 0;
+                parity = (parity == -1 || parity == pj) ? pj : 0;
+            }
+            if (parity < 0) parity = 0;
+            if ((rc = fft_forward_templates(ctx, fg, c.first, c.n, parity))) return rc;
             bool full = false;
             for (int j = c.first; j < c.first + c.n; ++j)
                 full |= (h[j].flags & (SC_FLAG_ERR_XR_LE0 | SC_FLAG_ERR_XR_GE0)) != 0 ||
                         h[j].mask_lim != nullptr || h[j].mask_err != nullptr;
-            if ((rc = fft_inverse_fold(ctx, fg, c.first, c.n, group, to_maps, full))) return rc;
+            if ((rc = fft_inverse_fold(ctx, fg, c.first, c.n, group, to_maps, full, parity))) return rc;
         }
     }
     return SC_OK;

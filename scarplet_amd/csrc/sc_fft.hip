@@ -497,6 +497,54 @@ k_split_templ(const float2* __restrict__ vh, int Ty, int Tx,
     *reinterpret_cast<float4*>(mh + (size_t)blockIdx.y * hplane + e) = m;
 }
 
+// ---- split, symmetric templates ------------------------------------------------
+// Scarp (and its UpperBreak variants) is odd, Ricker is even under the flip of
+// the DEM grid about its centre ((n-1)/2 per axis; exact in float64, the grid
+// axes are antisymmetric), and M = (W != 0) is even either way.  In the tile the
+// template sits wrapped around index 0, so the flip is p -> -p - k per axis with
+// k = 1 - n % 2, and
+//   FFT(W)[f] = i * a[f] * P[f]   (odd)   or   a[f] * P[f]   (even),
+//   FFT(M)[f] =     b[f] * P[f],          P[f] = exp(i pi (ky fy/Ty + kx fx/Tx))
+// with a, b REAL.  Only a and b are stored (half plane, 4 bytes per cell): the
+// stream I1 reads per template is a quarter of the full complex spectra; the
+// phase P is folded into the parked curvature spectrum there.  Taking the real /
+// imaginary part also drops the rounding noise of the transform that breaks the
+// symmetry.  parity: 1 odd, 2 even.
+__device__ __forceinline__ float2 phase_pi(float ang) {       // exp(i pi ang)
+    float s, c;
+    sincospif(ang, &s, &c);
+    return make_float2(c, s);
+}
+__global__ void __launch_bounds__(256)
+k_split_templ_sym(const float2* __restrict__ vh, int Ty, int Tx, int ky, int kx, int parity,
+                  float* __restrict__ wa, float* __restrict__ mb) {
+    const size_t plane = (size_t)Ty * Tx, hplane = half_plane(Ty, Tx);
+    const float2* v = vh + (size_t)blockIdx.y * plane;
+    size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (e >= hplane) return;
+    int fx = (int)(e / Ty), fy = (int)(e - (size_t)fx * Ty);         // fy even
+    const float2* vm = v + (size_t)((Tx - fx) & (Tx - 1)) * Ty;
+    float4 a = *reinterpret_cast<const float4*>(v + e);
+    float2 b0 = vm[(Ty - fy) & (Ty - 1)];
+    float2 b1 = vm[Ty - fy - 1];
+    float2 w[2] = {make_float2(0.5f * (a.x + b0.x), 0.5f * (a.y - b0.y)),
+                   make_float2(0.5f * (a.z + b1.x), 0.5f * (a.w - b1.y))};
+    float2 m[2] = {make_float2(0.5f * (a.y + b0.y), -0.5f * (a.x - b0.x)),
+                   make_float2(0.5f * (a.w + b1.y), -0.5f * (a.z - b1.x))};
+    float ra[2], rb[2];
+    const float ax = (float)(kx * fx) / (float)Tx;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float2 ph_ = phase_pi((float)(ky * (fy + k)) / (float)Ty + ax);
+        // x * conj(P)
+        float wr = w[k].x * ph_.x + w[k].y * ph_.y, wi = w[k].y * ph_.x - w[k].x * ph_.y;
+        ra[k] = parity == 1 ? wi : wr;
+        rb[k] = m[k].x * ph_.x + m[k].y * ph_.y;
+    }
+    *reinterpret_cast<float2*>(wa + (size_t)blockIdx.y * hplane + e) = make_float2(ra[0], ra[1]);
+    *reinterpret_cast<float2*>(mb + (size_t)blockIdx.y * hplane + e) = make_float2(rb[0], rb[1]);
+}
+
 // ---- I1: spectra product -> inverse column FFT -> blocked --------------------
 // grid = (Tx/4): one workgroup per block of 4 columns.  For each plane (W: xcorr,
 // M: T3) the block's 4 columns of the curvature spectrum are parked in LDS once
@@ -594,6 +642,109 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
             float2* o = (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)(cb >> 1) * 16 + (cb & 1) * 8;
             const int e_lo = 4 * rp_lo, e_hi = 4 * (rp_hi + 1);
             if (!(dbg & 64))
+#pragma unroll 2
+            for (int e = e_lo + threadIdx.x; e < e_hi; e += NT) {
+                int rp = e >> 2, k = e & 3;
+                float2 x0 = sm[lidx<TY>(k, 2 * rp)], x1 = sm[lidx<TY>(k, 2 * rp + 1)];
+                *reinterpret_cast<float4*>(o + (size_t)rp * (Tx >> 3) * 16 + 2 * k) =
+                    make_float4(x0.x, x0.y, x1.x, x1.y);
+            }
+            lds_barrier();
+        }
+    }
+}
+
+// ---- I1 for symmetric templates -----------------------------------------------
+// Same structure as k_inv_cols; the template stream is the real coefficient a
+// (W plane) or b (M plane) of k_split_templ_sym, and the phase - with the factor
+// i of an odd W - is multiplied into the curvature spectrum when it is parked:
+//   direct   blocks: Y[f]  = a[f]  * (X[f]  * P[f]  * {i})
+//   mirrored blocks: Y[ft] = a[fs] * (X[ft] * conj(P[fs]) * {-i}),  fs = -ft mod T
+// (FFT(W)[ft] = conj(FFT(W)[fs]); conj(P[fs]) is not P[ft]: the half-cell phase
+// has period 2T.)
+template <int TY, bool MIRROR>
+__global__ void __launch_bounds__(fft_threads(TY), 2)
+k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
+               const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
+               int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, int ky, int kx,
+               int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
+               float2* __restrict__ ym) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    static_assert(inv_cols_park<TY>(), "symmetric I1 parks the spectrum");
+    FftTw<TY> twr;
+    twr.load(tw);
+    constexpr int NT = fft_threads(TY);
+    constexpr int EP = 4 * TY / (2 * NT);     // 2-cell loads per thread per stream
+    float4* xs = reinterpret_cast<float4*>(sm + 4 * fft_line(TY));   // parked spectrum, linear
+    const int cb = cb0 + blockIdx.x;
+    constexpr bool mirrored = MIRROR;
+    const size_t plane = (size_t)TY * Tx;
+    const size_t col = (size_t)cb * 4 * TY;
+    const size_t hplane = half_plane(TY, Tx);
+    float2 hreg[EP];
+    for (int pl = 0; pl < 2; ++pl) {
+        const float4* uu = reinterpret_cast<const float4*>((pl ? uc2 : uc) + (size_t)pair * plane + col);
+        const float* hsrc = (pl ? mb : wa) + (size_t)vfirst * hplane +
+                            (mirrored ? (size_t)(Tx - 4 * cb - 3) * TY : col);
+        auto fetch = [&](int gi_) {
+            const float* p = hsrc + (size_t)gi_ * hplane;
+#pragma unroll
+            for (int u = 0; u < EP; ++u)
+                hreg[u] = *reinterpret_cast<const float2*>(p + 2 * (threadIdx.x + u * NT));
+        };
+        const bool rot = pl == 0 && parity == 1;          // odd W: factor i (direct) / -i (mirrored)
+#pragma unroll
+        for (int u = 0; u < EP; ++u) {
+            const int e = 2 * (threadIdx.x + u * NT);
+            const int cc = e / TY, fy = e - cc * TY, fx = 4 * cb + cc;
+            float4 x = uu[threadIdx.x + u * NT];
+            float2 xv[2] = {make_float2(x.x, x.y), make_float2(x.z, x.w)};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float ang;
+                if (!mirrored)
+                    ang = (float)(ky * (fy + k)) / (float)TY + (float)(kx * fx) / (float)Tx;
+                else
+                    ang = -((float)(ky * ((TY - fy - k) & (TY - 1))) / (float)TY +
+                            (float)(kx * ((Tx - fx) & (Tx - 1))) / (float)Tx);
+                float2 v = cmul(xv[k], phase_pi(ang));
+                if (rot) v = mirrored ? make_float2(v.y, -v.x) : make_float2(-v.y, v.x);
+                xv[k] = v;
+            }
+            xs[threadIdx.x + u * NT] = make_float4(xv[0].x, xv[0].y, xv[1].x, xv[1].y);
+        }
+        fetch(0);
+        if (mirrored) lds_barrier();      // mirrored fills read other threads' cells of xs
+        for (int gi_ = 0; gi_ < G; ++gi_) {
+            if (!mirrored) {
+#pragma unroll
+                for (int u = 0; u < EP; ++u) {
+                    int e = 2 * (threadIdx.x + u * NT);
+                    int cc = e / TY, fy = e - cc * TY;
+                    float4 x = xs[threadIdx.x + u * NT];
+                    sm[lidx<TY>(cc, fy)] = make_float2(hreg[u].x * x.x, hreg[u].x * x.y);
+                    sm[lidx<TY>(cc, fy + 1)] = make_float2(hreg[u].y * x.z, hreg[u].y * x.w);
+                }
+            } else {
+                // source cell (column 3-cc of the run, row m) pairs with target cell
+                // (column cc, row (TY - m) % TY)
+                const float2* x2 = reinterpret_cast<const float2*>(xs);
+#pragma unroll
+                for (int u = 0; u < EP; ++u) {
+                    int e = 2 * (threadIdx.x + u * NT);
+                    int sc = e / TY, m = e - sc * TY;
+                    int cc = 3 - sc;
+                    int f0 = (TY - m) & (TY - 1), f1 = (TY - m - 1) & (TY - 1);
+                    float2 x0 = x2[cc * TY + f0], x1 = x2[cc * TY + f1];
+                    sm[lidx<TY>(cc, f0)] = make_float2(hreg[u].x * x0.x, hreg[u].x * x0.y);
+                    sm[lidx<TY>(cc, f1)] = make_float2(hreg[u].y * x1.x, hreg[u].y * x1.y);
+                }
+            }
+            lds_barrier();
+            if (gi_ + 1 < G) fetch(gi_ + 1);
+            fft4_lines<TY, true>(sm, twr);
+            float2* o = (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)(cb >> 1) * 16 + (cb & 1) * 8;
+            const int e_lo = 4 * rp_lo, e_hi = 4 * (rp_hi + 1);
 #pragma unroll 2
             for (int e = e_lo + threadIdx.x; e < e_hi; e += NT) {
                 int rp = e >> 2, k = e & 3;
@@ -1290,7 +1441,13 @@ int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg) {
     return launch_fwd_cols(ctx, fg, 2 * np, (float2*)ctx->uc.p, (float2*)ctx->uc2.p, 1);
 }
 
-int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n) {
+// Symmetric fast path (k_split_templ_sym / k_inv_cols_sym): all templates of the
+// chunk share one parity and the tile is small enough for the parked spectrum.
+static bool fft_use_sym(const sc_ctx* ctx, const FftGeom& fg, int parity) {
+    return parity != 0 && fg.Ty <= 2048 && ctx->variant != 8;
+}
+
+int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n, int parity) {
     size_t lds = fft_lds_bytes(fg.Tx);
     dim3 grid(fg.Ty / 4, n);
     sc_prof_begin(ctx, SC_K_FWD_ROWS);
@@ -1314,8 +1471,13 @@ int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n) {
     size_t cells = half_plane(fg.Ty, fg.Tx);
     dim3 grid_s((unsigned)((cells / 2 + 255) / 256), n);
     sc_prof_begin(ctx, SC_K_FWD_COLS);
-    hipLaunchKernelGGL(k_split_templ, grid_s, dim3(256), 0, ctx->stream, (const float2*)ctx->vh.p,
-                       fg.Ty, fg.Tx, (float2*)ctx->wh.p, (float2*)ctx->mh.p);
+    if (fft_use_sym(ctx, fg, parity))
+        hipLaunchKernelGGL(k_split_templ_sym, grid_s, dim3(256), 0, ctx->stream,
+                           (const float2*)ctx->vh.p, fg.Ty, fg.Tx, 1 - ctx->g.oy, 1 - ctx->g.ox,
+                           parity, (float*)ctx->wh.p, (float*)ctx->mh.p);
+    else
+        hipLaunchKernelGGL(k_split_templ, grid_s, dim3(256), 0, ctx->stream, (const float2*)ctx->vh.p,
+                           fg.Ty, fg.Tx, (float2*)ctx->wh.p, (float2*)ctx->mh.p);
     sc_prof_end(ctx);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
@@ -1325,7 +1487,8 @@ int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n) {
 // planes [0, n).  For every tile pair: inverse transforms in groups of `group`
 // templates, folded in template order.
 int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
-                     int group, bool to_maps, bool full_masks) {
+                     int group, bool to_maps, bool full_masks, int parity) {
+    const bool sym = fft_use_sym(ctx, fg, parity);
     int np = npairs_of(fg);
     size_t lds_r = fft_lds_bytes(fg.Tx);
     // row pairs of a tile that hold valid outputs: r' in [Py, Py + Vy)
@@ -1348,6 +1511,23 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float2*)ctx->wh.p, \
         (const float2*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, ctx->dbg,        \
         (const float2*)ctx->tw_y.p, (float2*)ctx->yw.p, (float2*)ctx->ym.p
+#define SYM_ARGS(CB0)                                                          \
+    ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float*)ctx->wh.p, \
+        (const float*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, 1 - ctx->g.oy,     \
+        1 - ctx->g.ox, parity, (const float2*)ctx->tw_y.p, (float2*)ctx->yw.p, (float2*)ctx->ym.p
+#define FN_SYM(T)                                                              \
+    {                                                                          \
+        int rc = set_lds(ctx, k_inv_cols_sym<T, false>, inv_cols_lds<T>());    \
+        if (rc) return rc;                                                     \
+        rc = set_lds(ctx, k_inv_cols_sym<T, true>, inv_cols_lds<T>());         \
+        if (rc) return rc;                                                     \
+        const int nlo = fg.Tx / 8, nhi = fg.Tx / 4 - nlo;                      \
+        hipLaunchKernelGGL((k_inv_cols_sym<T, false>), dim3(nlo), dim3(fft_threads(T)), \
+                           inv_cols_lds<T>(), SYM_ARGS(0));                    \
+        if (nhi > 0)                                                           \
+            hipLaunchKernelGGL((k_inv_cols_sym<T, true>), dim3(nhi), dim3(fft_threads(T)), \
+                               inv_cols_lds<T>(), SYM_ARGS(nlo));              \
+    }
 #define FN(T)                                                                  \
     {                                                                          \
         int rc = set_lds(ctx, k_inv_cols<T, false>, inv_cols_lds<T>());        \
@@ -1361,8 +1541,21 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             hipLaunchKernelGGL((k_inv_cols<T, true>), dim3(nhi), dim3(fft_threads(T)), \
                                inv_cols_lds<T>(), COL_ARGS(nlo));              \
     }
-            DISPATCH_T(fg.Ty, FN)
+            if (sym) {
+                switch (fg.Ty) {
+                    case 64: FN_SYM(64); break;
+                    case 128: FN_SYM(128); break;
+                    case 256: FN_SYM(256); break;
+                    case 512: FN_SYM(512); break;
+                    case 1024: FN_SYM(1024); break;
+                    default: FN_SYM(2048); break;
+                }
+            } else {
+                DISPATCH_T(fg.Ty, FN)
+            }
 #undef FN
+#undef FN_SYM
+#undef SYM_ARGS
 #undef COL_ARGS
             sc_prof_end(ctx);
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,

@@ -124,9 +124,9 @@ int launch_compare_fold(sc_ctx* ctx, double age, double angle);
 // ---- launchers implemented in sc_fft.hip ------------------------------------
 int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group);
 int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg);
-int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n);
+int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n, int parity);
 int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
-                     int group, bool to_maps, bool full_masks);
+                     int group, bool to_maps, bool full_masks, int parity);
 bool fft_size_supported(int T);
 
 // ---- device helpers shared by both paths -------------------------------------
