@@ -167,6 +167,113 @@ struct Bfly<16, INV> {
     static __device__ __forceinline__ constexpr int pos(int m) { return 4 * (m & 3) + (m >> 2); }
 };
 
+// ---------------------------------------------------------------------------
+// Packed complex arithmetic: a complex value is a native 2-vector, so a complex
+// add is one v_pk_add_f32 and a complex product two instructions (v_pk_mul_f32 +
+// v_pk_fma_f32), the half-swaps and signs riding on the op_sel / neg modifiers.
+// Left to itself the compiler pairs unrelated scalars into packed operations and
+// pays for it in register moves.
+// ---------------------------------------------------------------------------
+namespace pk {
+typedef float v2 __attribute__((ext_vector_type(2)));
+
+// a * w
+__device__ __forceinline__ v2 cmul(v2 a, v2 w) {
+    v2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// a * conj(w)
+__device__ __forceinline__ v2 cmulc(v2 a, v2 w) {
+    v2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// a * w with w a compile-time constant held in a scalar register pair
+__device__ __forceinline__ v2 cmul_k(v2 a, v2 w) {
+    v2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    return r;
+}
+// multiply by -j (forward) / +j (inverse); exp(-/+ i angle) from (cos, sin)
+template <bool INV>
+__device__ __forceinline__ v2 mulj(v2 a) { return INV ? v2{-a.y, a.x} : v2{a.y, -a.x}; }
+template <bool INV>
+__device__ __forceinline__ v2 cw(float c, float s) { return v2{c, INV ? s : -s}; }
+template <bool INV>
+__device__ __forceinline__ void dft4(v2& a0, v2& a1, v2& a2, v2& a3) {
+    v2 apc = a0 + a2, amc = a0 - a2, bpd = a1 + a3, bmd = mulj<INV>(a1 - a3);
+    a0 = apc + bpd;
+    a1 = amc + bmd;
+    a2 = apc - bpd;
+    a3 = amc - bmd;
+}
+// radix-R butterfly on v[0..R-1] (natural order in); X[m] ends up in v[pos(m)]
+template <int R, bool INV>
+struct B;
+template <bool INV>
+struct B<2, INV> {
+    static __device__ __forceinline__ void run(v2* v) {
+        v2 a = v[0], b = v[1];
+        v[0] = a + b;
+        v[1] = a - b;
+    }
+    static __device__ __forceinline__ constexpr int pos(int m) { return m; }
+};
+template <bool INV>
+struct B<4, INV> {
+    static __device__ __forceinline__ void run(v2* v) { dft4<INV>(v[0], v[1], v[2], v[3]); }
+    static __device__ __forceinline__ constexpr int pos(int m) { return m; }
+};
+template <bool INV>
+struct B<8, INV> {
+    // j = c + 2d, m = r + 4s: DFT4 over d, twiddle w8^(c r), DFT2 over c
+    static __device__ __forceinline__ void run(v2* v) {
+        dft4<INV>(v[0], v[2], v[4], v[6]);
+        dft4<INV>(v[1], v[3], v[5], v[7]);
+        const float h = 0.70710678118654752f;
+        v[3] = cmul_k(v[3], cw<INV>(h, h));
+        v[5] = mulj<INV>(v[5]);
+        v[7] = cmul_k(v[7], cw<INV>(-h, h));
+        B<2, INV>::run(v + 0);
+        B<2, INV>::run(v + 2);
+        B<2, INV>::run(v + 4);
+        B<2, INV>::run(v + 6);
+    }
+    // X[r + 4s] sits at v[2r + s]
+    static __device__ __forceinline__ constexpr int pos(int m) { return 2 * (m & 3) + (m >> 2); }
+};
+template <bool INV>
+struct B<16, INV> {
+    // j = c + 4d, m = r + 4s: DFT4 over d, twiddle w16^(c r), DFT4 over c
+    static __device__ __forceinline__ void run(v2* v) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dft4<INV>(v[c], v[c + 4], v[c + 8], v[c + 12]);
+        const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f;
+        const float h = 0.70710678118654752f;
+        v[5] = cmul_k(v[5], cw<INV>(c1, s1));        // w^1
+        v[9] = cmul_k(v[9], cw<INV>(h, h));          // w^2
+        v[13] = cmul_k(v[13], cw<INV>(s1, c1));      // w^3
+        v[6] = cmul_k(v[6], cw<INV>(h, h));          // w^2
+        v[10] = mulj<INV>(v[10]);                    // w^4
+        v[14] = cmul_k(v[14], cw<INV>(-h, h));       // w^6
+        v[7] = cmul_k(v[7], cw<INV>(s1, c1));        // w^3
+        v[11] = cmul_k(v[11], cw<INV>(-h, h));       // w^6
+        v[15] = cmul_k(v[15], cw<INV>(-c1, -s1));    // w^9
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dft4<INV>(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]);
+    }
+    // X[r + 4s] sits at v[4r + s]
+    static __device__ __forceinline__ constexpr int pos(int m) { return 4 * (m & 3) + (m >> 2); }
+};
+}  // namespace pk
+
 // Twiddle bases of a thread, loaded ONCE per kernel: in the radix-16 stage at
 // stride 2^LST a thread needs w^(e), w^(2e), w^(4e), w^(8e) with e = p << LST,
 // which depends only on the thread (its set index tt), not on the data.  Kept
@@ -219,58 +326,63 @@ __device__ __forceinline__ void set_load(const float2* line, int tt, float2 (&a)
 }
 
 // twiddle applied to output m of a radix-16 butterfly, from the four bases
-// w^(e), w^(2e), w^(4e), w^(8e): w^k for k = 1..7 one at a time, each also
-// serving k + 8.  `put(m, value)` receives the finished outputs.
+// w^(e), w^(2e), w^(4e), w^(8e) of the forward table: w^k for k = 1..7 one at a
+// time, each also serving k + 8; the inverse transform multiplies by the
+// conjugate.  `put(m, value)` receives the finished outputs.
 template <bool INV, typename PUT>
-__device__ __forceinline__ void twiddle16(const float2 (&v)[16], const float2 (&w)[4], PUT put) {
-    float2 w1 = w[0], w2 = w[1], w4 = w[2], w8 = w[3];
-    if (INV) { w1.y = -w1.y; w2.y = -w2.y; w4.y = -w4.y; w8.y = -w8.y; }
-    put(0, v[Bfly<16, INV>::pos(0)]);
-    put(8, cmul(v[Bfly<16, INV>::pos(8)], w8));
+__device__ __forceinline__ void twiddle16(const pk::v2 (&v)[16], const float2 (&w)[4], PUT put) {
+    using pk::v2;
+    const v2 w1 = v2{w[0].x, w[0].y}, w2 = v2{w[1].x, w[1].y}, w4 = v2{w[2].x, w[2].y},
+             w8 = v2{w[3].x, w[3].y};
+    auto tw = [](v2 a, v2 wk) { return INV ? pk::cmulc(a, wk) : pk::cmul(a, wk); };
+    put(0, v[pk::B<16, INV>::pos(0)]);
+    put(8, tw(v[pk::B<16, INV>::pos(8)], w8));
 #pragma unroll
     for (int k = 1; k < 8; ++k) {
-        float2 wk = (k & 1) ? w1 : make_float2(1.f, 0.f);
+        v2 wk = (k & 1) ? w1 : v2{1.f, 0.f};
         if (k == 2 || k == 6) wk = w2;
-        if (k == 3 || k == 7) wk = cmul(w1, w2);
+        if (k == 3 || k == 7) wk = pk::cmul(w1, w2);
         if (k == 4) wk = w4;
-        if (k >= 5) wk = cmul(wk, w4);
-        put(k, cmul(v[Bfly<16, INV>::pos(k)], wk));
-        put(k + 8, cmul(v[Bfly<16, INV>::pos(k + 8)], cmul(wk, w8)));
+        if (k >= 5) wk = pk::cmul(wk, w4);
+        put(k, tw(v[pk::B<16, INV>::pos(k)], wk));
+        put(k + 8, tw(v[pk::B<16, INV>::pos(k + 8)], pk::cmul(wk, w8)));
     }
 }
 
 // butterflies of the set (tt) in the stage (R, LST) and store to `line`
 template <int T, int R, int LST, bool INV>
-__device__ __forceinline__ void set_compute_store(float2* line, int tt, float2 (&a)[16],
+__device__ __forceinline__ void set_compute_store(float2* line_, int tt, float2 (&a)[16],
                                                   const float2 (&w)[4]) {
+    using pk::v2;
     constexpr int S = T / 16;
     constexpr int NB = 16 / R;
     constexpr int LR = __builtin_ctz(R);
     constexpr int ST = 1 << LST;
     constexpr bool LAST = (R << LST) == T;     // n == R: all twiddles are 1
     static_assert(LAST || R == 16, "twiddled stages are radix 16");
+    v2* line = reinterpret_cast<v2*>(line_);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        float2 v[R];
+        v2 v[R];
 #pragma unroll
-        for (int k = 0; k < R; ++k) v[k] = a[b + NB * k];
-        Bfly<R, INV>::run(v);
+        for (int k = 0; k < R; ++k) v[k] = v2{a[b + NB * k].x, a[b + NB * k].y};
+        pk::B<R, INV>::run(v);
         const int bt = tt + b * S;             // butterfly index in [0, T/R)
         const int p = bt >> LST, q = bt & (ST - 1);
         const int o = q + (p << (LST + LR));
         // output m goes to element o + m*ST
-        float2* wb;
+        v2* wb;
         int wstep;                             // padded distance of ST elements
         if (LST >= 4) { wb = line + ph(o); wstep = ST + ST / 16; }
         else if (LST == 0 && R == 16) { wb = line + 17 * bt; wstep = 1; }
         else { wb = nullptr; wstep = 0; }
-        auto put = [&](int m, float2 val) {
+        auto put = [&](int m, v2 val) {
             if (wb) wb[m * wstep] = val;
             else line[ph(o + (m << LST))] = val;
         };
         if constexpr (LAST) {
 #pragma unroll
-            for (int m = 0; m < R; ++m) put(m, v[Bfly<R, INV>::pos(m)]);
+            for (int m = 0; m < R; ++m) put(m, v[pk::B<R, INV>::pos(m)]);
         } else {
             twiddle16<INV>(v, w, put);
         }
@@ -955,89 +1067,6 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
 #ifndef SC_I2_FETCH_AT
 #define SC_I2_FETCH_AT 0
 #endif
-namespace pk {
-typedef float v2 __attribute__((ext_vector_type(2)));
-
-// a * w (complex): two packed instructions, the half-swaps and the sign ride on
-// the op_sel / neg modifiers
-__device__ __forceinline__ v2 cmul(v2 a, v2 w) {
-    v2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
-        : "=v"(r) : "v"(a), "v"(w), "v"(t));
-    return r;
-}
-// a * w with w a compile-time constant held in a scalar register pair
-__device__ __forceinline__ v2 cmul_k(v2 a, v2 w) {
-    v2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
-        : "=v"(r) : "v"(a), "s"(w), "v"(t));
-    return r;
-}
-// inverse transforms only: multiply by +j, constants are exp(+i angle)
-__device__ __forceinline__ v2 mulj(v2 a) { return v2{-a.y, a.x}; }
-__device__ __forceinline__ void dft4(v2& a0, v2& a1, v2& a2, v2& a3) {
-    v2 apc = a0 + a2, amc = a0 - a2, bpd = a1 + a3, bmd = mulj(a1 - a3);
-    a0 = apc + bpd;
-    a1 = amc + bmd;
-    a2 = apc - bpd;
-    a3 = amc - bmd;
-}
-template <int R>
-struct B;
-template <>
-struct B<2> {
-    static __device__ __forceinline__ void run(v2* v) {
-        v2 a = v[0], b = v[1];
-        v[0] = a + b;
-        v[1] = a - b;
-    }
-    static __device__ __forceinline__ constexpr int pos(int m) { return m; }
-};
-template <>
-struct B<4> {
-    static __device__ __forceinline__ void run(v2* v) { dft4(v[0], v[1], v[2], v[3]); }
-    static __device__ __forceinline__ constexpr int pos(int m) { return m; }
-};
-template <>
-struct B<8> {
-    static __device__ __forceinline__ void run(v2* v) {
-        dft4(v[0], v[2], v[4], v[6]);
-        dft4(v[1], v[3], v[5], v[7]);
-        const float h = 0.70710678118654752f;
-        v[3] = cmul_k(v[3], v2{h, h});
-        v[5] = mulj(v[5]);
-        v[7] = cmul_k(v[7], v2{-h, h});
-        B<2>::run(v + 0);
-        B<2>::run(v + 2);
-        B<2>::run(v + 4);
-        B<2>::run(v + 6);
-    }
-    static __device__ __forceinline__ constexpr int pos(int m) { return 2 * (m & 3) + (m >> 2); }
-};
-template <>
-struct B<16> {
-    static __device__ __forceinline__ void run(v2* v) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) dft4(v[c], v[c + 4], v[c + 8], v[c + 12]);
-        const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f;
-        const float h = 0.70710678118654752f;
-        v[5] = cmul_k(v[5], v2{c1, s1});
-        v[9] = cmul_k(v[9], v2{h, h});
-        v[13] = cmul_k(v[13], v2{s1, c1});
-        v[6] = cmul_k(v[6], v2{h, h});
-        v[10] = mulj(v[10]);
-        v[14] = cmul_k(v[14], v2{-h, h});
-        v[7] = cmul_k(v[7], v2{s1, c1});
-        v[11] = cmul_k(v[11], v2{-h, h});
-        v[15] = cmul_k(v[15], v2{-c1, -s1});
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dft4(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]);
-    }
-    static __device__ __forceinline__ constexpr int pos(int m) { return 4 * (m & 3) + (m >> 2); }
-};
-}  // namespace pk
 
 template <int TX>
 __host__ __device__ constexpr bool inv_rows_fast_ok() { return TX == 512 || TX == 1024 || TX == 2048; }
@@ -1192,10 +1221,10 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
 
         // ---- stage 1 (radix 16, stride 1) from registers: outputs 16 tt1 + m
         {
-            pk::B<16>::run(a);
+            pk::B<16, true>::run(a);
             const v2 w1 = tw1[4 * tt1], w2 = tw1[4 * tt1 + 1], w4 = tw1[4 * tt1 + 2], w8 = tw1[4 * tt1 + 3];
-            line1[0] = a[pk::B<16>::pos(0)];
-            line1[8] = pk::cmul(a[pk::B<16>::pos(8)], w8);
+            line1[0] = a[pk::B<16, true>::pos(0)];
+            line1[8] = pk::cmul(a[pk::B<16, true>::pos(8)], w8);
 #pragma unroll
             for (int k = 1; k < 8; ++k) {
                 v2 wk = (k & 1) ? w1 : v2{1.f, 0.f};
@@ -1203,8 +1232,8 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 if (k == 3 || k == 7) wk = pk::cmul(w1, w2);
                 if (k == 4) wk = w4;
                 if (k >= 5) wk = pk::cmul(wk, w4);
-                line1[k] = pk::cmul(a[pk::B<16>::pos(k)], wk);
-                line1[k + 8] = pk::cmul(a[pk::B<16>::pos(k + 8)], pk::cmul(wk, w8));
+                line1[k] = pk::cmul(a[pk::B<16, true>::pos(k)], wk);
+                line1[k + 8] = pk::cmul(a[pk::B<16, true>::pos(k + 8)], pk::cmul(wk, w8));
             }
         }
         lds_barrier();
@@ -1215,10 +1244,10 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
 #pragma unroll
             for (int j = 0; j < 16; ++j) b[j] = rd2[j * (S + S / 16)];
             lds_barrier();
-            pk::B<16>::run(b);
-            wr2[0] = b[pk::B<16>::pos(0)];
+            pk::B<16, true>::run(b);
+            wr2[0] = b[pk::B<16, true>::pos(0)];
 #pragma unroll
-            for (int m = 1; m < 16; ++m) wr2[17 * m] = pk::cmul(b[pk::B<16>::pos(m)], twp2[m]);
+            for (int m = 1; m < 16; ++m) wr2[17 * m] = pk::cmul(b[pk::B<16, true>::pos(m)], twp2[m]);
         }
         if (FETCH_AT == 1 && gi_ + 1 < ra.G) fetch(gi_ + 1);     // in flight through stage 3
         lds_barrier();
@@ -1249,12 +1278,12 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 vw[k] = lineW[u * (2 * S + 2 * S / 16) + k * 272];
                 vm[k] = lineM[u * (2 * S + 2 * S / 16) + k * 272];
             }
-            pk::B<R3>::run(vw);
-            pk::B<R3>::run(vm);
+            pk::B<R3, true>::run(vw);
+            pk::B<R3, true>::run(vm);
 #pragma unroll
             for (int m = 0; m < R3; ++m) {
                 const int c = u * R3 + m;
-                const v2 xc = vw[pk::B<R3>::pos(m)], t3 = vm[pk::B<R3>::pos(m)];
+                const v2 xc = vw[pk::B<R3, true>::pos(m)], t3 = vm[pk::B<R3, true>::pos(m)];
                 const int cj = col_of(c);
 #pragma unroll
                 for (int part = 0; part < 2; ++part) {
