@@ -886,7 +886,12 @@ struct RowArgs {
     int pair, first, G;
     int rp_lo, rp_n;                    // valid row pairs of the tile: [rp_lo, rp_lo + rp_n)
     int dbg;                            // diagnostic ablation bits (SC_DBG), 0 in production
+    int ystride;                        // planes between the Y blocks of consecutive tile pairs
 };
+// One launch may serve several tile pairs (grid.y): pair = ra.pair + blockIdx.y,
+// its Y planes ystride planes further on.  More workgroups per launch fill the
+// last round of the chip better (a row's workgroup lives for the whole template
+// loop, and 1816 rows on 768 slots would leave a third of the last round idle).
 
 template <int TX, bool FULL>
 __global__ void __launch_bounds__(fft_threads(TX), 2)
@@ -905,6 +910,9 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
     constexpr int E = 2 * TX / NT;          // cells per thread per sub-batch
     constexpr int EP = 2 * TX / (2 * NT);   // float4 loads per thread per plane
     const size_t plane = (size_t)ra.Ty * TX;
+    ra.pair += blockIdx.y;
+    yw += (size_t)blockIdx.y * ra.ystride * plane;
+    ym += (size_t)blockIdx.y * ra.ystride * plane;
     const TileDev tA = tiles[2 * ra.pair], tB = tiles[2 * ra.pair + 1];
     const float scale = 1.0f / ((float)ra.Ty * (float)TX);
     float4 xreg[EP], yreg[EP];
@@ -1116,6 +1124,9 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     if (pi >= ra.rp_n) return;
     const int rp = ra.rp_lo + pi;
     const size_t plane = (size_t)ra.Ty * TX;
+    ra.pair += blockIdx.y;
+    yw += (size_t)blockIdx.y * ra.ystride * plane;
+    ym += (size_t)blockIdx.y * ra.ystride * plane;
     const TileDev tA = tiles[2 * ra.pair], tB = tiles[2 * ra.pair + 1];
     const float scale = 1.0f / ((float)ra.Ty * (float)TX);
 
@@ -1405,8 +1416,21 @@ int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group) {
     size_t hplane = half_plane(fg.Ty, fg.Tx) * sizeof(float2);
     if ((rc = sc_ensure(ctx, ctx->wh, hplane * n_templ_chunk))) return rc;
     if ((rc = sc_ensure(ctx, ctx->mh, hplane * n_templ_chunk))) return rc;
-    if ((rc = sc_ensure(ctx, ctx->yw, plane * group))) return rc;
-    if ((rc = sc_ensure(ctx, ctx->ym, plane * group))) return rc;
+    // Y blocks of several tile pairs per inverse launch (see RowArgs): as many as
+    // a quarter of the free device memory (at most 32 GB, SC_Y_GB overrides) holds
+    int pb = 1;
+    {
+        size_t free_b = 0, total_b = 0;
+        double budget = 0.0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            budget = std::min(32e9, 0.25 * (double)(free_b + ctx->yw.cap + ctx->ym.cap));
+        if (const char* e = getenv("SC_Y_GB")) budget = atof(e) * 1e9;
+        double per_pair = 2.0 * (double)plane * group;
+        pb = (int)std::max(1.0, std::min((double)np, floor(budget / per_pair)));
+    }
+    ctx->fft_pb = pb;
+    if ((rc = sc_ensure(ctx, ctx->yw, plane * group * pb))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->ym, plane * group * pb))) return rc;
     return SC_OK;
 }
 
@@ -1532,18 +1556,25 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         return sc_fail(ctx, SC_ERR_UNSUPPORTED, "core block of 2^30 cells or more");
     if (group > SC_MAX_GROUP)
         return sc_fail(ctx, SC_ERR_INVALID, "group %d exceeds %d", group, SC_MAX_GROUP);
-    for (int pair = 0; pair < np; ++pair) {
+    const int pb = std::max(1, ctx->fft_pb);
+    const size_t yblock = (size_t)fg.Ty * fg.Tx * group;          // cells per pair in yw / ym
+    for (int pair0 = 0; pair0 < np; pair0 += pb) {
+        const int pc = std::min(pb, np - pair0);
         for (int g0 = 0; g0 < n; g0 += group) {
             int G = std::min(group, n - g0);
             sc_prof_begin(ctx, SC_K_INV_COLS);
+            for (int pl_ = 0; pl_ < pc; ++pl_) {
+            const int pair = pair0 + pl_;
+            float2* ywp = (float2*)ctx->yw.p + (size_t)pl_ * yblock;
+            float2* ymp = (float2*)ctx->ym.p + (size_t)pl_ * yblock;
 #define COL_ARGS(CB0)                                                          \
     ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float2*)ctx->wh.p, \
         (const float2*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, ctx->dbg,        \
-        (const float2*)ctx->tw_y.p, (float2*)ctx->yw.p, (float2*)ctx->ym.p
+        (const float2*)ctx->tw_y.p, ywp, ymp
 #define SYM_ARGS(CB0)                                                          \
     ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float*)ctx->wh.p, \
         (const float*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, 1 - ctx->g.oy,     \
-        1 - ctx->g.ox, parity, (const float2*)ctx->tw_y.p, (float2*)ctx->yw.p, (float2*)ctx->ym.p
+        1 - ctx->g.ox, parity, (const float2*)ctx->tw_y.p, ywp, ymp
 #define FN_SYM(T)                                                              \
     {                                                                          \
         int rc = set_lds(ctx, k_inv_cols_sym<T, false>, inv_cols_lds<T>());    \
@@ -1586,11 +1617,13 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
 #undef FN_SYM
 #undef SYM_ARGS
 #undef COL_ARGS
+            }
             sc_prof_end(ctx);
+            const int pair = pair0;
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
-                       ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg};
+                       ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg, group};
             const bool fast = (fg.Tx == 512 || fg.Tx == 1024 || fg.Tx == 2048) && ctx->variant != 9;
-            dim3 gridr(fast ? ((rp_n + 7) / 8) * 16 : (rp_n + 1) / 2);
+            dim3 gridr(fast ? ((rp_n + 7) / 8) * 16 : (rp_n + 1) / 2, pc);
             sc_prof_begin(ctx, SC_K_INV_ROWS);
 #define ROW_ARGS lds_r, FAST_ARGS
 #define FAST_ARGS                                                              \

@@ -73,6 +73,7 @@ struct sc_ctx {
     DevBuf templ, sums, wl1, norms, win_w, win_m;   // wl1: sum|W| per template; norms: per tile pair
     DevBuf tw_y, tw_x;
     int tw_Ty = 0, tw_Tx = 0;
+    int fft_pb = 1;            // tile pairs per inverse launch (fft_prepare)
     DevBuf blk, uc, uc2, vh, wh, mh, yw, ym, tiles;
     std::vector<WindowSlot> windows;
     int last_batch = 0;
