@@ -947,12 +947,11 @@ k_inv_cols_sym2(const float2* __restrict__ uc, const float2* __restrict__ uc2,
     // coefficient stream: direct cells (fx, fy); mirrored cells (Tx - fx, -fy mod TY)
     const float* hsrc = (pl ? mb : wa) + (size_t)vfirst * hplane +
                         (MIRROR ? (size_t)(Tx - fx) * TY : (size_t)fx * TY);
-    int hoff[2];                               // j = 0 and the step for j >= 1
-    hoff[0] = MIRROR ? ((TY - tt) & (TY - 1)) : tt;
+    const int h0 = MIRROR ? ((TY - tt) & (TY - 1)) : tt;      // j = 0: -0 is 0
     float h[16];
     auto fetch = [&](int gi_) {
         const float* p = hsrc + (size_t)gi_ * hplane;
-        h[0] = p[hoff[0]];
+        h[0] = p[h0];
 #pragma unroll
         for (int j = 1; j < 16; ++j) h[j] = MIRROR ? p[TY - tt - j * S] : p[tt + j * S];
     };
@@ -1021,9 +1020,8 @@ k_inv_cols_sym2(const float2* __restrict__ uc, const float2* __restrict__ uc2,
             for (int e = e_lo + id; e < e_hi; e += NT) {
                 int rp = e >> 2, k = e & 3;
                 v2 x0 = sm[k * LINE + ph(2 * rp)], x1 = sm[k * LINE + ph(2 * rp + 1)];
-                float2* dst = (dbg & 128) ? (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)cb * (TY / 2) * 8 + (size_t)e * 2
-                                          : o + (size_t)rp * (Tx >> 3) * 16 + 2 * k;
-                *reinterpret_cast<float4*>(dst) = make_float4(x0.x, x0.y, x1.x, x1.y);
+                *reinterpret_cast<float4*>(o + (size_t)rp * (Tx >> 3) * 16 + 2 * k) =
+                    make_float4(x0.x, x0.y, x1.x, x1.y);
             }
         }
         lds_barrier();
@@ -1378,15 +1376,6 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     v2 a[16];
     auto fetch = [&](int gi_) {
         const char* p = src1 + (size_t)gi_ * plane * sizeof(float2);
-        if (ra.dbg & 16) {                                       // timing experiment: column-block-major Y
-            const char* q = reinterpret_cast<const char*>(pl1 ? ym : yw) + (size_t)gi_ * plane * sizeof(float2);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int c = tt1 + j * S;
-                a[j] = *reinterpret_cast<const v2*>(q + ((size_t)(c >> 2) * (ra.Ty / 2) + rp) * 64 + (c & 3) * 16 + rh * 8);
-            }
-            return;
-        }
 #pragma unroll
         for (int j = 0; j < 16; ++j)                             // column tt1 + j*S
             a[j] = *reinterpret_cast<const v2*>(p + (size_t)j * 2 * S * sizeof(float2) + voff1);
