@@ -25,6 +25,9 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_UNIT = 28.0        # bytes per px.template
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
+# profiling slot of the library -> kernel symbols as rocprofv3 lists them (Scarp / Ricker
+# searches at T = 512..2048; each tile pair takes one launch of either instantiation)
+KERNEL_SYMBOLS = {"k_inv_cols": "k_inv_cols_sym<T,false|true>", "k_inv_rows": "k_inv_rows_fast<T,false,false>"}
 
 
 def parse():
@@ -175,7 +178,8 @@ def main():
                        "scale=100, %d ages x %d orientations" % (a.n, a.n, len(ages), len(angles)),
                        "method": a.method, "tiles": "%dx%d of %dx%d" % (plan.nty, plan.ntx, plan.Ty, plan.Tx),
                        "ranks": "%d (%s tile grid)" % (world, "x".join(map(str, sd.grid_dims(world, a.n, a.n))))},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOLS.get(dom, dom) if a.method == "fft" else dom,
+                         "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "launches": int(launches),
                          "avg_launch_us": round(1e6 * avg_s, 2),

@@ -64,11 +64,15 @@ int sc_lds_attr(sc_ctx* ctx, const void* kernel, size_t bytes) {
 // ---------------------------------------------------------------------------
 // profiling: HIP events on the context's stream around sampled launches
 // ---------------------------------------------------------------------------
+// A bracket may hold several launches of the same kernel (sc_prof_end's n):
+// launches are counted one by one, and a sampled bracket contributes its
+// elapsed time divided over its n launches.
 void sc_prof_begin(sc_ctx* ctx, int kernel) {
-    ctx->k_launches[kernel]++;
     ctx->prof_cur = -1;
+    ctx->prof_kernel = kernel;
+    const long long b = ctx->k_brackets[kernel]++;
     if (!ctx->prof) return;
-    if ((ctx->k_launches[kernel] - 1) % ctx->prof) return;
+    if (b % ctx->prof) return;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (!ctx->ev_pool.empty()) {
         ev = ctx->ev_pool.back();
@@ -83,23 +87,27 @@ void sc_prof_begin(sc_ctx* ctx, int kernel) {
     ctx->prof_ev1 = ev.second;
 }
 
-void sc_prof_end(sc_ctx* ctx) {
+void sc_prof_end(sc_ctx* ctx, int n) {
+    ctx->k_launches[ctx->prof_kernel] += n;
     if (ctx->prof_cur < 0) return;
     (void)hipEventRecord(ctx->prof_ev1, ctx->stream);
     ctx->pending.push_back({ctx->prof_cur, {ctx->prof_ev0, ctx->prof_ev1}});
+    ctx->pending_n.push_back(n);
     ctx->prof_cur = -1;
 }
 
 void sc_prof_collect(sc_ctx* ctx) {
-    for (auto& p : ctx->pending) {
+    for (size_t i = 0; i < ctx->pending.size(); ++i) {
+        auto& p = ctx->pending[i];
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
             ctx->k_ms[p.first] += ms;
-            ctx->k_sampled[p.first]++;
+            ctx->k_sampled[p.first] += ctx->pending_n[i];
         }
         ctx->ev_pool.push_back(p.second);
     }
     ctx->pending.clear();
+    ctx->pending_n.clear();
 }
 
 // ---------------------------------------------------------------------------
@@ -592,6 +600,7 @@ extern "C" int sc_profile(sc_ctx* ctx, int enable) {
     ctx->prof = enable < 0 ? 0 : enable;
     for (int k = 0; k < SC_K_COUNT; ++k) {
         ctx->k_launches[k] = 0;
+        ctx->k_brackets[k] = 0;
         ctx->k_sampled[k] = 0;
         ctx->k_ms[k] = 0.0;
     }

@@ -783,7 +783,6 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                float2* __restrict__ ym) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     static_assert(inv_cols_park<TY>(), "symmetric I1 parks the spectrum");
-    parity &= 255;                             // (upper bits: SC_DBG, used by k_inv_cols_sym2)
     FftTw<TY> twr;
     twr.load(tw);
     constexpr int NT = fft_threads(TY);
@@ -867,164 +866,6 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
             }
             lds_barrier();
         }
-    }
-}
-
-// ---- I1 for symmetric templates, T in {512, 1024, 2048} ------------------------
-// grid = (Tx/8 column blocks, 2 planes) per launch (direct / mirrored half), one
-// workgroup of TY/4 threads per 4 columns of ONE plane.  Built like the fast I2
-// kernel so that two workgroups share a CU (<= 128 VGPRs, ~75 KB of LDS):
-//   * a thread owns the 16 points tt + j*S of one column in stage 1; its 16
-//     cells of the phase-carrying curvature spectrum stay in registers for the
-//     whole template loop (nothing parked in LDS);
-//   * per template it fetches the 16 real coefficients of those cells (a wave
-//     reads 256 contiguous bytes per instruction; descending addresses in the
-//     mirrored half), multiplies and runs stage 1 straight from registers;
-//   * stage 3 works in place (its outputs are its inputs' addresses), twiddles
-//     come from LDS tables, complex arithmetic is packed.
-template <int TY>
-__host__ __device__ constexpr bool inv_cols_sym2_ok() { return TY == 512 || TY == 1024 || TY == 2048; }
-template <int TY>
-__host__ __device__ constexpr size_t inv_cols_sym2_lds() {
-    return fft_lds_bytes(TY) + (size_t)(TY / 16) * 4 * sizeof(float2) + (size_t)(TY / 16) * sizeof(float2);
-}
-
-template <int TY, bool MIRROR>
-__global__ void __launch_bounds__(TY / 4, 4)
-k_inv_cols_sym2(const float2* __restrict__ uc, const float2* __restrict__ uc2,
-                const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
-                int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, int ky, int kx,
-                int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
-                float2* __restrict__ ym) {
-    using pk::v2;
-    const int dbg = parity >> 8;               // SC_DBG ablation bits (timing experiments only)
-    parity &= 255;
-    extern __shared__ __attribute__((aligned(16))) float2 sm_[];
-    v2* sm = reinterpret_cast<v2*>(sm_);
-    constexpr int S = TY / 16;                 // 16-point sets per line
-    constexpr int NT = 4 * S;
-    constexpr int R3 = TY / 256;               // radix of the last stage (2, 4, 8)
-    constexpr int NB3 = 16 / R3;               // its butterflies per set
-    constexpr int LINE = fft_line(TY);
-    const int id = threadIdx.x;
-    const int cb = cb0 + blockIdx.x, pl = blockIdx.y;
-    const size_t plane = (size_t)TY * Tx, hplane = half_plane(TY, Tx);
-    v2* tw1 = sm + 4 * LINE;
-    v2* tw2 = tw1 + 4 * S;
-    for (int i = id; i < 4 * S; i += NT) {
-        float2 w = tw[(i >> 2) << (i & 3)];
-        tw1[i] = v2{w.x, -w.y};
-    }
-    for (int i = id; i < S; i += NT) {
-        float2 w = tw[((i >> 4) << 4) * (i & 15)];
-        tw2[i] = v2{w.x, -w.y};
-    }
-    // column cc of the block, set tt: points fy = tt + j*S
-    const int cc = id / S, tt = id % S;
-    const int fx = 4 * cb + cc;
-    v2* line = sm + cc * LINE;
-    // curvature spectrum of this thread's cells, phase (and the factor +-i of an
-    // odd W) folded in - see k_inv_cols_sym
-    v2 xr[16];
-    {
-        const float2* X = (pl ? uc2 : uc) + (size_t)pair * plane + (size_t)fx * TY + tt;
-        const bool rot = pl == 0 && parity == 1;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int fy = tt + j * S;
-            float2 x = X[j * S];
-            float ang;
-            if (!MIRROR)
-                ang = (float)(ky * fy) / (float)TY + (float)(kx * fx) / (float)Tx;
-            else
-                ang = -((float)(ky * ((TY - fy) & (TY - 1))) / (float)TY +
-                        (float)(kx * ((Tx - fx) & (Tx - 1))) / (float)Tx);
-            float2 v = cmul(x, phase_pi(ang));
-            if (rot) v = MIRROR ? make_float2(v.y, -v.x) : make_float2(-v.y, v.x);
-            xr[j] = v2{v.x, v.y};
-        }
-    }
-    // coefficient stream: direct cells (fx, fy); mirrored cells (Tx - fx, -fy mod TY)
-    const float* hsrc = (pl ? mb : wa) + (size_t)vfirst * hplane +
-                        (MIRROR ? (size_t)(Tx - fx) * TY : (size_t)fx * TY);
-    const int h0 = MIRROR ? ((TY - tt) & (TY - 1)) : tt;      // j = 0: -0 is 0
-    float h[16];
-    auto fetch = [&](int gi_) {
-        const float* p = hsrc + (size_t)gi_ * hplane;
-        h[0] = p[h0];
-#pragma unroll
-        for (int j = 1; j < 16; ++j) h[j] = MIRROR ? p[TY - tt - j * S] : p[tt + j * S];
-    };
-    if (!(dbg & 16)) fetch(0);
-    // stage-2 / stage-3 addresses (same line, same set index as stage 1)
-    const v2* rd2 = line + ph(tt);
-    v2* wr2 = line + ph((tt & 15) + ((tt >> 4) << 8));
-    const v2* twp2 = tw2 + ((tt >> 4) << 4);
-    float2* yo = (pl ? ym : yw) + (size_t)(cb >> 1) * 16 + (cb & 1) * 8;
-    lds_barrier();                                               // twiddle tables are in place
-    for (int gi_ = 0; gi_ < G; ++gi_) {
-        // ---- product and stage 1 (radix 16, stride 1) from registers
-        {
-            v2 a[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) a[j] = xr[j] * v2{h[j], h[j]};
-            if (gi_ + 1 < G && !(dbg & 16)) fetch(gi_ + 1);      // in flight through the transform
-            if (!(dbg & 32)) pk::B<16, true>::run(a);
-            const v2 w1 = tw1[4 * tt], w2 = tw1[4 * tt + 1], w4 = tw1[4 * tt + 2], w8 = tw1[4 * tt + 3];
-            v2* o = line + 17 * tt;
-            o[0] = a[pk::B<16, true>::pos(0)];
-            o[8] = pk::cmul(a[pk::B<16, true>::pos(8)], w8);
-#pragma unroll
-            for (int k = 1; k < 8; ++k) {
-                v2 wk = (k & 1) ? w1 : v2{1.f, 0.f};
-                if (k == 2 || k == 6) wk = w2;
-                if (k == 3 || k == 7) wk = pk::cmul(w1, w2);
-                if (k == 4) wk = w4;
-                if (k >= 5) wk = pk::cmul(wk, w4);
-                o[k] = pk::cmul(a[pk::B<16, true>::pos(k)], wk);
-                o[k + 8] = pk::cmul(a[pk::B<16, true>::pos(k + 8)], pk::cmul(wk, w8));
-            }
-        }
-        lds_barrier();
-        // ---- stage 2 (radix 16, stride 16)
-        {
-            v2 b[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) b[j] = rd2[j * (S + S / 16)];
-            lds_barrier();
-            if (!(dbg & 32)) pk::B<16, true>::run(b);
-            wr2[0] = b[pk::B<16, true>::pos(0)];
-#pragma unroll
-            for (int m = 1; m < 16; ++m) wr2[17 * m] = pk::cmul(b[pk::B<16, true>::pos(m)], twp2[m]);
-        }
-        lds_barrier();
-        // ---- stage 3 (radix R3, stride 256), in place
-#pragma unroll
-        for (int b = 0; b < NB3; ++b) {
-            v2* q = line + ph(tt + b * S);
-            v2 v[R3];
-#pragma unroll
-            for (int k = 0; k < R3; ++k) v[k] = q[k * 272];
-            if (!(dbg & 32)) pk::B<R3, true>::run(v);
-#pragma unroll
-            for (int m = 0; m < R3; ++m) q[m * 272] = v[pk::B<R3, true>::pos(m)];
-        }
-        lds_barrier();
-        // ---- valid row pairs -> rows2 layout: this block's 4 columns x 2 rows of
-        // a row pair are 64 contiguous bytes
-        {
-            float2* o = yo + (size_t)gi_ * plane;
-            const int e_lo = 4 * rp_lo, e_hi = 4 * (rp_hi + 1);
-            if (!(dbg & 64))
-#pragma unroll 2
-            for (int e = e_lo + id; e < e_hi; e += NT) {
-                int rp = e >> 2, k = e & 3;
-                v2 x0 = sm[k * LINE + ph(2 * rp)], x1 = sm[k * LINE + ph(2 * rp + 1)];
-                *reinterpret_cast<float4*>(o + (size_t)rp * (Tx >> 3) * 16 + 2 * k) =
-                    make_float4(x0.x, x0.y, x1.x, x1.y);
-            }
-        }
-        lds_barrier();
     }
 }
 
@@ -1733,7 +1574,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
 #define SYM_ARGS(CB0)                                                          \
     ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float*)ctx->wh.p, \
         (const float*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, 1 - ctx->g.oy,     \
-        1 - ctx->g.ox, parity | (ctx->dbg << 8), (const float2*)ctx->tw_y.p, ywp, ymp
+        1 - ctx->g.ox, parity, (const float2*)ctx->tw_y.p, ywp, ymp
 #define FN_SYM(T)                                                              \
     {                                                                          \
         int rc = set_lds(ctx, k_inv_cols_sym<T, false>, inv_cols_lds<T>());    \
@@ -1760,27 +1601,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             hipLaunchKernelGGL((k_inv_cols<T, true>), dim3(nhi), dim3(fft_threads(T)), \
                                inv_cols_lds<T>(), COL_ARGS(nlo));              \
     }
-            if (sym && (fg.Ty == 512 || fg.Ty == 1024 || fg.Ty == 2048) && ctx->variant != 6) {
-#define FN_SYM2(T)                                                             \
-    {                                                                          \
-        int rc = set_lds(ctx, k_inv_cols_sym2<T, false>, inv_cols_sym2_lds<T>()); \
-        if (rc) return rc;                                                     \
-        rc = set_lds(ctx, k_inv_cols_sym2<T, true>, inv_cols_sym2_lds<T>());   \
-        if (rc) return rc;                                                     \
-        const int nlo = fg.Tx / 8, nhi = fg.Tx / 4 - nlo;                      \
-        hipLaunchKernelGGL((k_inv_cols_sym2<T, false>), dim3(nlo, 2), dim3(T / 4), \
-                           inv_cols_sym2_lds<T>(), SYM_ARGS(0));               \
-        if (nhi > 0)                                                           \
-            hipLaunchKernelGGL((k_inv_cols_sym2<T, true>), dim3(nhi, 2), dim3(T / 4), \
-                               inv_cols_sym2_lds<T>(), SYM_ARGS(nlo));         \
-    }
-                switch (fg.Ty) {
-                    case 512: FN_SYM2(512); break;
-                    case 1024: FN_SYM2(1024); break;
-                    default: FN_SYM2(2048); break;
-                }
-#undef FN_SYM2
-            } else if (sym) {
+            if (sym) {
                 switch (fg.Ty) {
                     case 64: FN_SYM(64); break;
                     case 128: FN_SYM(128); break;
@@ -1797,7 +1618,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
 #undef SYM_ARGS
 #undef COL_ARGS
             }
-            sc_prof_end(ctx);
+            sc_prof_end(ctx, 2 * pc);                 // direct + mirrored launch per tile pair
             const int pair = pair0;
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
                        ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg, group};

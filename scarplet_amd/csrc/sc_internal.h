@@ -85,6 +85,9 @@ struct sc_ctx {
     int prof_cur = -1;         // kernel being bracketed (-1: not sampled)
     hipEvent_t prof_ev0 = nullptr, prof_ev1 = nullptr;
     long long k_launches[SC_K_COUNT] = {0};
+    long long k_brackets[SC_K_COUNT] = {0};
+    int prof_kernel = 0;
+    std::vector<int> pending_n;
     long long k_sampled[SC_K_COUNT] = {0};
     double k_ms[SC_K_COUNT] = {0};
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
@@ -112,7 +115,7 @@ int sc_lds_attr(sc_ctx* ctx, const void* kernel, size_t bytes);
 
 // profiling brackets around kernel launches
 void sc_prof_begin(sc_ctx* ctx, int kernel);
-void sc_prof_end(sc_ctx* ctx);
+void sc_prof_end(sc_ctx* ctx, int n = 1);
 void sc_prof_collect(sc_ctx* ctx);
 
 // ---- launchers implemented in sc_kernels.hip --------------------------------
