@@ -679,7 +679,7 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
            const float2* __restrict__ wh, const float2* __restrict__ mh, int Tx,
            int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, int dbg,
            const float2* __restrict__ tw, float2* __restrict__ yw,
-           float2* __restrict__ ym) {
+           float2* __restrict__ ym, int ystride) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     FftTw<TY> twr;
     twr.load(tw);
@@ -692,6 +692,10 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
     //                 columns Tx-fx <= Tx/2; Tx/2 mirrors onto itself).
     // Two launches instead of one branchy kernel: the branch cost registers.
     const int cb = cb0 + blockIdx.x;
+    // several tile pairs per launch (grid.y): pair + blockIdx.y, its Y block ystride planes on
+    pair += blockIdx.y;
+    yw += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
+    ym += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
     constexpr bool mirrored = MIRROR;
     const size_t plane = (size_t)TY * Tx;
     const size_t col = (size_t)cb * 4 * TY;
@@ -780,7 +784,7 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
                int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, int ky, int kx,
                int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
-               float2* __restrict__ ym) {
+               float2* __restrict__ ym, int ystride) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     static_assert(inv_cols_park<TY>(), "symmetric I1 parks the spectrum");
     FftTw<TY> twr;
@@ -789,6 +793,10 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
     constexpr int EP = 4 * TY / (2 * NT);     // 2-cell loads per thread per stream
     float4* xs = reinterpret_cast<float4*>(sm + 4 * fft_line(TY));   // parked spectrum, linear
     const int cb = cb0 + blockIdx.x;
+    // several tile pairs per launch (grid.y): pair + blockIdx.y, its Y block ystride planes on
+    pair += blockIdx.y;
+    yw += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
+    ym += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
     constexpr bool mirrored = MIRROR;
     const size_t plane = (size_t)TY * Tx;
     const size_t col = (size_t)cb * 4 * TY;
@@ -1562,19 +1570,28 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         const int pc = std::min(pb, np - pair0);
         for (int g0 = 0; g0 < n; g0 += group) {
             int G = std::min(group, n - g0);
+            // I1: as many tile pairs per launch as it takes to fill the chip once
+            // (one 2048-tile pair does; longer launches lost 6 % on the sustained C3 run)
+            const size_t lds_c = (size_t)4 * fft_line(fg.Ty) * sizeof(float2) +
+                                 (fg.Ty <= 2048 ? (size_t)4 * fg.Ty * sizeof(float2) : 0);
+            const int slots = 256 * (int)std::max<size_t>(1, (size_t)(160 * 1024) / lds_c);
+            const int pi1 = std::max(1, std::min(pc, (slots + fg.Tx / 8 - 1) / (fg.Tx / 8)));
             sc_prof_begin(ctx, SC_K_INV_COLS);
-            for (int pl_ = 0; pl_ < pc; ++pl_) {
-            const int pair = pair0 + pl_;
-            float2* ywp = (float2*)ctx->yw.p + (size_t)pl_ * yblock;
-            float2* ymp = (float2*)ctx->ym.p + (size_t)pl_ * yblock;
+            int n_i1 = 0;
+            for (int pl0 = 0; pl0 < pc; pl0 += pi1) {
+            const int pcc = std::min(pi1, pc - pl0);
+            const int pair = pair0 + pl0;
+            float2* ywp = (float2*)ctx->yw.p + (size_t)pl0 * yblock;
+            float2* ymp = (float2*)ctx->ym.p + (size_t)pl0 * yblock;
+            n_i1 += 2;
 #define COL_ARGS(CB0)                                                          \
     ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float2*)ctx->wh.p, \
         (const float2*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, ctx->dbg,        \
-        (const float2*)ctx->tw_y.p, ywp, ymp
+        (const float2*)ctx->tw_y.p, ywp, ymp, group
 #define SYM_ARGS(CB0)                                                          \
     ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float*)ctx->wh.p, \
         (const float*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, 1 - ctx->g.oy,     \
-        1 - ctx->g.ox, parity, (const float2*)ctx->tw_y.p, ywp, ymp
+        1 - ctx->g.ox, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group
 #define FN_SYM(T)                                                              \
     {                                                                          \
         int rc = set_lds(ctx, k_inv_cols_sym<T, false>, inv_cols_lds<T>());    \
@@ -1582,10 +1599,10 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         rc = set_lds(ctx, k_inv_cols_sym<T, true>, inv_cols_lds<T>());         \
         if (rc) return rc;                                                     \
         const int nlo = fg.Tx / 8, nhi = fg.Tx / 4 - nlo;                      \
-        hipLaunchKernelGGL((k_inv_cols_sym<T, false>), dim3(nlo), dim3(fft_threads(T)), \
+        hipLaunchKernelGGL((k_inv_cols_sym<T, false>), dim3(nlo, pcc), dim3(fft_threads(T)), \
                            inv_cols_lds<T>(), SYM_ARGS(0));                    \
         if (nhi > 0)                                                           \
-            hipLaunchKernelGGL((k_inv_cols_sym<T, true>), dim3(nhi), dim3(fft_threads(T)), \
+            hipLaunchKernelGGL((k_inv_cols_sym<T, true>), dim3(nhi, pcc), dim3(fft_threads(T)), \
                                inv_cols_lds<T>(), SYM_ARGS(nlo));              \
     }
 #define FN(T)                                                                  \
@@ -1595,10 +1612,10 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         rc = set_lds(ctx, k_inv_cols<T, true>, inv_cols_lds<T>());             \
         if (rc) return rc;                                                     \
         const int nlo = fg.Tx / 8, nhi = fg.Tx / 4 - nlo;                      \
-        hipLaunchKernelGGL((k_inv_cols<T, false>), dim3(nlo), dim3(fft_threads(T)), \
+        hipLaunchKernelGGL((k_inv_cols<T, false>), dim3(nlo, pcc), dim3(fft_threads(T)), \
                            inv_cols_lds<T>(), COL_ARGS(0));                    \
         if (nhi > 0)                                                           \
-            hipLaunchKernelGGL((k_inv_cols<T, true>), dim3(nhi), dim3(fft_threads(T)), \
+            hipLaunchKernelGGL((k_inv_cols<T, true>), dim3(nhi, pcc), dim3(fft_threads(T)), \
                                inv_cols_lds<T>(), COL_ARGS(nlo));              \
     }
             if (sym) {
@@ -1618,7 +1635,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
 #undef SYM_ARGS
 #undef COL_ARGS
             }
-            sc_prof_end(ctx, 2 * pc);                 // direct + mirrored launch per tile pair
+            sc_prof_end(ctx, n_i1);                   // direct + mirrored launches
             const int pair = pair0;
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
                        ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg, group};
