@@ -432,11 +432,11 @@ __device__ __forceinline__ void fft4_lines(float2* s, const FftTw<T>& twr) {
 // ---- F1c: curvature of a tile pair -> row FFT -> blocked ---------------------
 // grid = (Ty/4, npairs); out plane index = pair*2 + {0: curv, 1: curv^2}
 template <int TX>
-__global__ void __launch_bounds__(fft_threads(TX), 2)
+__global__ void __launch_bounds__(fft_threads(TX), 4)
 k_fwd_rows_curv(const float* __restrict__ curv, Geom g,
                 const TileDev* __restrict__ tiles, int Ty,
                 const float2* __restrict__ tw, float2* __restrict__ blk,
-                double* __restrict__ norms) {
+                double* __restrict__ norms, int dbg) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     FftTw<TX> twr;
     twr.load(tw);
@@ -444,34 +444,84 @@ k_fwd_rows_curv(const float* __restrict__ curv, Geom g,
     const int rb = blockIdx.x, pair = blockIdx.y;
     const TileDev ta = tiles[2 * pair], tb = tiles[2 * pair + 1];
     const size_t plane = (size_t)Ty * TX;
-    // curvature values of this thread's cells stay in registers for plane 1
     constexpr int E = 4 * TX / NT;
-    float va[E], vb[E];
+    static_assert(TX % NT == 0, "a thread's cell u lies in row (u*NT)/TX, column (u*NT)%TX + tid");
+    // Local row of each of the 4 tile rows (the same for the whole workgroup) and
+    // the local column of this thread's cells, without a division per cell: on
+    // the periodic DEM the tile origin is reduced once and a cell wraps at most
+    // once when the DEM is at least as wide as the tile.
+    auto load_tile = [&](const TileDev& t, float (&v)[E]) {
+        if (t.vy <= 0) {
 #pragma unroll
-    for (int u = 0; u < E; ++u) {
-        int e = threadIdx.x + u * NT;
-        int rr = e / TX, s = e - rr * TX, r = 4 * rb + rr;
-        va[u] = ta.vy > 0 ? load_curv(curv, g, ta.gi0 + r, ta.gj0 + s) : 0.f;
-        vb[u] = tb.vy > 0 ? load_curv(curv, g, tb.gi0 + r, tb.gj0 + s) : 0.f;
-    }
-    {   // |curv|_2^2 and |curv^2|_2^2 of the tile pair (resolution floor, sc_epi_floor)
-        double s2 = 0.0, s4 = 0.0;
+            for (int u = 0; u < E; ++u) v[u] = 0.f;
+            return;
+        }
+        const int j0 = g.wrap ? wrap_index(t.gj0, g.nx) : t.gj0 - g.gx0;
+        const bool once = g.nx >= TX;
 #pragma unroll
-        for (int u = 0; u < E; ++u) {
-            double a2 = (double)va[u] * va[u], b2 = (double)vb[u] * vb[u];
-            s2 += a2 + b2;
-            s4 += a2 * a2 + b2 * b2;
+        for (int rr = 0; rr < 4; ++rr) {
+            const int gi = t.gi0 + 4 * rb + rr;
+            const int li = g.wrap ? wrap_index(gi, g.ny) : gi - g.gy0;
+            const bool row_ok = g.wrap || (li >= 0 && li < g.ly);
+            const float* row = curv + (size_t)(row_ok ? li : 0) * g.lx;
+#pragma unroll
+            for (int u = 0; u < E; ++u) {
+                if ((u * NT) / TX != rr) continue;
+                int lj = j0 + (u * NT) % TX + (int)threadIdx.x;
+                bool ok = row_ok;
+                if (g.wrap) {
+                    if (once) lj = lj >= g.nx ? lj - g.nx : lj;
+                    else lj %= g.nx;
+                } else {
+                    ok = ok && lj >= 0 && lj < g.lx;
+                }
+                v[u] = ok ? row[ok ? lj : 0] : 0.f;
+            }
         }
-        for (int sft = 32; sft > 0; sft >>= 1) {
-            s2 += __shfl_down(s2, sft, 64);
-            s4 += __shfl_down(s4, sft, 64);
-        }
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&norms[2 * pair], s2);
-            atomicAdd(&norms[2 * pair + 1], s4);
-        }
-    }
+    };
+    // The two planes (curv, curv^2) are transformed one after the other; the
+    // values are fetched again for the second (they come from L2) rather than
+    // held in 32 registers across the first transform, which keeps the kernel at
+    // two workgroups per CU.
     for (int pl = 0; pl < 2; ++pl) {
+        float va[E], vb[E];
+        if (!(dbg & 8)) { load_tile(ta, va); load_tile(tb, vb); }
+        else {
+#pragma unroll
+            for (int u = 0; u < E; ++u) va[u] = vb[u] = 1.f + u;
+        }
+        if (pl == 0 && !(dbg & 1)) {  // |curv|_2^2 and |curv^2|_2^2 of the tile pair (resolution floor, sc_epi_floor)
+            double s2 = 0.0, s4 = 0.0;
+#pragma unroll
+            for (int u = 0; u < E; ++u) {
+                double a2 = (double)va[u] * va[u], b2 = (double)vb[u] * vb[u];
+                s2 += a2 + b2;
+                s4 += a2 * a2 + b2 * b2;
+            }
+            for (int sft = 32; sft > 0; sft >>= 1) {
+                s2 += __shfl_down(s2, sft, 64);
+                s4 += __shfl_down(s4, sft, 64);
+            }
+            // one atomic pair per workgroup: 512 workgroups add into the same two
+            // doubles, and same-address float64 atomics serialise (one per wave cost
+            // 670 us of this kernel's 1 200 at C3)
+            __shared__ double red[2 * (NT / 64)];
+            if ((threadIdx.x & 63) == 0) {
+                red[2 * (threadIdx.x >> 6)] = s2;
+                red[2 * (threadIdx.x >> 6) + 1] = s4;
+            }
+            lds_barrier();
+            if (threadIdx.x == 0) {
+                double t2 = 0.0, t4 = 0.0;
+#pragma unroll
+                for (int w = 0; w < NT / 64; ++w) {
+                    t2 += red[2 * w];
+                    t4 += red[2 * w + 1];
+                }
+                atomicAdd(&norms[2 * pair], t2);
+                atomicAdd(&norms[2 * pair + 1], t4);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < E; ++u) {
             int e = threadIdx.x + u * NT;
@@ -479,8 +529,9 @@ k_fwd_rows_curv(const float* __restrict__ curv, Geom g,
                                               : make_float2(va[u], vb[u]);
         }
         lds_barrier();
-        fft4_lines<TX, false>(sm, twr);
+        if (!(dbg & 2)) fft4_lines<TX, false>(sm, twr);
         float2* out = blk + (size_t)(pair * 2 + pl) * plane + (size_t)rb * 4 * TX;
+        if (!(dbg & 4))
 #pragma unroll 4
         for (int e = 2 * threadIdx.x; e < 4 * TX; e += 2 * NT) {
             int cb = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
@@ -1493,7 +1544,7 @@ int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg) {
                            lds, ctx->stream, (const float*)ctx->curv.p,        \
                            ctx->g, (const TileDev*)ctx->tiles.p, fg.Ty,        \
                            (const float2*)ctx->tw_x.p, (float2*)ctx->blk.p,    \
-                           (double*)ctx->norms.p);                             \
+                           (double*)ctx->norms.p, ctx->dbg);                   \
     }
     DISPATCH_T(fg.Tx, FN)
 #undef FN
