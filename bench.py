@@ -174,8 +174,10 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C3: %dx%d synthetic erf-scarp DEM (BASELINE.md s3), Scarp, "
-                       "scale=100, %d ages x %d orientations" % (a.n, a.n, len(ages), len(angles)),
+            "config": {"workload": "%s: %dx%d synthetic erf-scarp DEM (BASELINE.md s3), Scarp, "
+                       "scale=100, %d ages x %d orientations" % (
+                           "C3" if (a.n == 10000 and len(ages) == 35 and len(angles) == 181) else "reduced",
+                           a.n, a.n, len(ages), len(angles)),
                        "method": a.method, "tiles": "%dx%d of %dx%d" % (plan.nty, plan.ntx, plan.Ty, plan.Tx),
                        "ranks": "%d (%s tile grid)" % (world, "x".join(map(str, sd.grid_dims(world, a.n, a.n))))},
             "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOLS.get(dom, dom) if a.method == "fft" else dom,
