@@ -31,6 +31,7 @@
 // The in-LDS FFT is a Stockham autosort with radices 16,16,..,r (see below).
 #include "sc_internal.h"
 #include <math.h>
+#include <type_traits>
 
 struct TileDev {
     int i0, j0, vy, vx, gi0, gj0;
@@ -829,7 +830,12 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
 //   mirrored blocks: Y[ft] = a[fs] * (X[ft] * conj(P[fs]) * {-i}),  fs = -ft mod T
 // (FFT(W)[ft] = conj(FFT(W)[fs]); conj(P[fs]) is not P[ft]: the half-cell phase
 // has period 2T.)
-template <int TY, bool MIRROR>
+// PT ("paired templates"): the launch serves a tile pair whose second tile is empty
+// (odd tile count, single-tile DEMs).  Instead of leaving the imaginary half of
+// the transform idle, two TEMPLATES ride in it: Y = IFFT(X (a_g + i a_g+1) P), whose
+// real part is template g's result and whose imaginary part is template g+1's
+// (X is the spectrum of ONE real tile).  Plane k of Y holds templates 2k, 2k+1.
+template <int TY, bool MIRROR, bool PT>
 __global__ void __launch_bounds__(fft_threads(TY), 2)
 k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
@@ -852,16 +858,28 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
     const size_t plane = (size_t)TY * Tx;
     const size_t col = (size_t)cb * 4 * TY;
     const size_t hplane = half_plane(TY, Tx);
-    float2 hreg[EP];
+    float2 hreg[EP], hreg2[PT ? EP : 1];
+    const int NG = PT ? (G + 1) / 2 : G;       // inverse transforms of the launch
     for (int pl = 0; pl < 2; ++pl) {
         const float4* uu = reinterpret_cast<const float4*>((pl ? uc2 : uc) + (size_t)pair * plane + col);
         const float* hsrc = (pl ? mb : wa) + (size_t)vfirst * hplane +
                             (mirrored ? (size_t)(Tx - 4 * cb - 3) * TY : col);
         auto fetch = [&](int gi_) {
-            const float* p = hsrc + (size_t)gi_ * hplane;
+            const float* p = hsrc + (size_t)(PT ? 2 * gi_ : gi_) * hplane;
 #pragma unroll
             for (int u = 0; u < EP; ++u)
                 hreg[u] = *reinterpret_cast<const float2*>(p + 2 * (threadIdx.x + u * NT));
+            if constexpr (PT) {
+                const bool has2 = 2 * gi_ + 1 < G;
+#pragma unroll
+                for (int u = 0; u < EP; ++u)
+                    hreg2[u] = has2 ? *reinterpret_cast<const float2*>(p + hplane + 2 * (threadIdx.x + u * NT))
+                                    : make_float2(0.f, 0.f);
+            }
+        };
+        // cell value: x * a (one template) or x * (a + i a2) (two templates)
+        auto prod = [&](float2 x, float a, float a2) {
+            return PT ? make_float2(x.x * a - x.y * a2, x.x * a2 + x.y * a) : make_float2(a * x.x, a * x.y);
         };
         const bool rot = pl == 0 && parity == 1;          // odd W: factor i (direct) / -i (mirrored)
 #pragma unroll
@@ -886,15 +904,15 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
         }
         fetch(0);
         if (mirrored) lds_barrier();      // mirrored fills read other threads' cells of xs
-        for (int gi_ = 0; gi_ < G; ++gi_) {
+        for (int gi_ = 0; gi_ < NG; ++gi_) {
             if (!mirrored) {
 #pragma unroll
                 for (int u = 0; u < EP; ++u) {
                     int e = 2 * (threadIdx.x + u * NT);
                     int cc = e / TY, fy = e - cc * TY;
                     float4 x = xs[threadIdx.x + u * NT];
-                    sm[lidx<TY>(cc, fy)] = make_float2(hreg[u].x * x.x, hreg[u].x * x.y);
-                    sm[lidx<TY>(cc, fy + 1)] = make_float2(hreg[u].y * x.z, hreg[u].y * x.w);
+                    sm[lidx<TY>(cc, fy)] = prod(make_float2(x.x, x.y), hreg[u].x, hreg2[PT ? u : 0].x);
+                    sm[lidx<TY>(cc, fy + 1)] = prod(make_float2(x.z, x.w), hreg[u].y, hreg2[PT ? u : 0].y);
                 }
             } else {
                 // source cell (column 3-cc of the run, row m) pairs with target cell
@@ -907,12 +925,12 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                     int cc = 3 - sc;
                     int f0 = (TY - m) & (TY - 1), f1 = (TY - m - 1) & (TY - 1);
                     float2 x0 = x2[cc * TY + f0], x1 = x2[cc * TY + f1];
-                    sm[lidx<TY>(cc, f0)] = make_float2(hreg[u].x * x0.x, hreg[u].x * x0.y);
-                    sm[lidx<TY>(cc, f1)] = make_float2(hreg[u].y * x1.x, hreg[u].y * x1.y);
+                    sm[lidx<TY>(cc, f0)] = prod(x0, hreg[u].x, hreg2[PT ? u : 0].x);
+                    sm[lidx<TY>(cc, f1)] = prod(x1, hreg[u].y, hreg2[PT ? u : 0].y);
                 }
             }
             lds_barrier();
-            if (gi_ + 1 < G) fetch(gi_ + 1);
+            if (gi_ + 1 < NG) fetch(gi_ + 1);
             fft4_lines<TY, true>(sm, twr);
             float2* o = (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)(cb >> 1) * 16 + (cb & 1) * 8;
             const int e_lo = 4 * rp_lo, e_hi = 4 * (rp_hi + 1);
@@ -1155,7 +1173,7 @@ __host__ __device__ constexpr size_t inv_rows_fast_lds() {
            (size_t)(TX / 16) * 4 * sizeof(float2) + (size_t)(TX / 256) * 16 * sizeof(float2);
 }
 
-template <int TX, bool FULL, bool MAPS>
+template <int TX, bool FULL, bool MAPS, bool PT>
 __global__ void __launch_bounds__(inv_rows_fast_threads<TX>(), 3)
 k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 RowArgs ra, Geom g, const TileDev* __restrict__ tiles,
@@ -1252,27 +1270,37 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     // byte offset of tile column 0 of this thread's row in the best-record planes
     const uint32_t offA = (uint32_t)(((size_t)(tA.i0 + ri - ra.cy0) * ra.cw + (tA.j0 - ra.cx0)) * 4);
     const uint32_t offB = (uint32_t)(((size_t)(tB.i0 + ri - ra.cy0) * ra.cw + (tB.j0 - ra.cx0)) * 4);
-    // running best record of the 16 cells, in registers across the G templates
-    // of the launch; written back once at the end, and only where a template
-    // of this launch won (b_id leaves its sentinel).  A stored NaN SNR stays:
-    // nothing compares greater than it (sc_fold's sticky NaN); a NaN score never
-    // wins here - it cannot arise from the finite DEMs the host lets through.
+    // The two halves ("parts") of a packed output: tiles A and B under one
+    // template, or - PT, the pair's second tile is empty - templates 2k and 2k+1
+    // on tile A (see k_inv_cols_sym).  Everything below is written per part.
+    auto tile_of = [&](int part) -> const TileDev& { return (PT || part == 0) ? tA : tB; };
+    auto off_of = [&](int part) { return (PT || part == 0) ? offA : offB; };
+    auto row_of = [&](int part) { return (PT || part == 0) ? rowA : rowB; };
+    // running best record of the thread's cells (16: 8 columns x 2 tiles; PT: 8),
+    // in registers across the templates of the launch; written back once at the
+    // end, and only where a template of this launch won.  A stored NaN SNR
+    // stays: nothing compares greater than it (sc_fold's sticky NaN); a NaN score
+    // never wins here - it cannot arise from the finite DEMs the host lets through.
     // The winner is remembered as its index in the launch, one byte per cell
     // (0xFF: unchanged), four cells to a register.
-    float b_snr[2 * NC], b_amp[2 * NC];
-    uint32_t b_ix[NC / 2];
+    constexpr int NBEST = PT ? NC : 2 * NC;
+    auto best_of = [](int c, int part) { return PT ? c : 2 * c + part; };
+    float b_snr[NBEST], b_amp[NBEST];
+    uint32_t b_ix[NBEST / 4];
 #pragma unroll
-    for (int c = 0; c < NC / 2; ++c) b_ix[c] = 0xFFFFFFFFu;
+    for (int c = 0; c < NBEST / 4; ++c) b_ix[c] = 0xFFFFFFFFu;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int cj = col_of(c);
-        const bool okA = !MAPS && rowA && cj >= 0 && cj < tA.vx;
-        const bool okB = !MAPS && rowB && cj >= 0 && cj < tB.vx;
-        b_snr[2 * c] = okA ? at_bytes(best_snr, offA + 4u * (uint32_t)cj) : 0.f;
-        b_snr[2 * c + 1] = okB ? at_bytes(best_snr, offB + 4u * (uint32_t)cj) : 0.f;
-        b_amp[2 * c] = b_amp[2 * c + 1] = 0.f;
+#pragma unroll
+        for (int part = 0; part < (PT ? 1 : 2); ++part) {
+            const bool ok = !MAPS && row_of(part) && cj >= 0 && cj < tile_of(part).vx;
+            b_snr[best_of(c, part)] = ok ? at_bytes(best_snr, off_of(part) + 4u * (uint32_t)cj) : 0.f;
+            b_amp[best_of(c, part)] = 0.f;
+        }
     }
 
+    const int NG = PT ? (ra.G + 1) / 2 : ra.G;                   // transforms of the launch
     v2 a[16];
     auto fetch = [&](int gi_) {
         const char* p = src1 + (size_t)gi_ * plane * sizeof(float2);
@@ -1282,9 +1310,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     };
     fetch(0);
     lds_barrier();                                               // tables and scalars are in place
-    for (int gi_ = 0; gi_ < ra.G; ++gi_) {
-        const TemplDev* tp = templ + ra.first + gi_;
-        const uint32_t gi4 = (uint32_t)gi_ * 0x01010101u;
+    for (int gi_ = 0; gi_ < NG; ++gi_) {
         // the columns are two instructions away from cj0: keep them out of the
         // loop-invariant registers (eight of them would not fit)
         asm volatile("" : "+v"(cj0));
@@ -1307,7 +1333,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             }
         }
         lds_barrier();
-        if (FETCH_AT == 0 && gi_ + 1 < ra.G) fetch(gi_ + 1);     // in flight through stages 2-3
+        if (FETCH_AT == 0 && gi_ + 1 < NG) fetch(gi_ + 1);       // in flight through stages 2-3
         // ---- stage 2 (radix 16, stride 16): elements tt2 + j*S -> o + 16 m
         {
             v2 b[16];
@@ -1319,27 +1345,40 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
 #pragma unroll
             for (int m = 1; m < 16; ++m) wr2[17 * m] = pk::cmul(b[pk::B<16, true>::pos(m)], twp2[m]);
         }
-        if (FETCH_AT == 1 && gi_ + 1 < ra.G) fetch(gi_ + 1);     // in flight through stage 3
+        if (FETCH_AT == 1 && gi_ + 1 < NG) fetch(gi_ + 1);       // in flight through stage 3
         lds_barrier();
         // ---- stage 3 (radix R3, stride 256) fused with the epilogue: every
-        // output is scored as soon as its two butterflies have produced it
-        const float* e = epi + EPI_FLOATS * gi_;
-        const float ka = e[0], kt = e[1], kx2 = e[2], fl0 = e[3], inv_n = e[4];
-        // cells that may score, per part: inside the tile's valid extent AND
-        // (lean variant) inside the template's window-limit rectangle - one
-        // unsigned range test on the column; a row outside makes the range empty
-        int loA = 0, hiA = tA.vx - 1, loB = 0, hiB = tB.vx - 1;
-        bool rA = rowA, rB = rowB;
-        if (!FULL && !MAPS) {
-            loA = max(loA, tp->jlo - tA.j0); hiA = min(hiA, tp->jhi - tA.j0);
-            loB = max(loB, tp->jlo - tB.j0); hiB = min(hiB, tp->jhi - tB.j0);
-            rA = rA && ri >= tp->ilo - tA.i0 && ri <= tp->ihi - tA.i0;
-            rB = rB && ri >= tp->ilo - tB.i0 && ri <= tp->ihi - tB.i0;
+        // output is scored as soon as its two butterflies have produced it.
+        // Per part: the template, its scalars, and the cells that may score -
+        // inside the tile's valid extent AND (lean variant) inside the template's
+        // window-limit rectangle, as one unsigned range test on the column; a row
+        // outside (or a missing second template) makes the range empty.
+        const TemplDev* tpp[2];
+        float ka[2], kt[2], kx2[2], fl0[2], inv_n[2];
+        unsigned span[2];
+        int base[2];
+        uint32_t ix4[2];
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const int tg = PT ? 2 * gi_ + part : gi_;
+            const bool have = !PT || tg < ra.G;
+            const int tgc = have ? tg : 2 * gi_;
+            const TemplDev* tp = templ + ra.first + tgc;
+            const TileDev& t = tile_of(part);
+            const float* e = epi + EPI_FLOATS * tgc;
+            tpp[part] = tp;
+            ka[part] = e[0]; kt[part] = e[1]; kx2[part] = e[2]; fl0[part] = e[3]; inv_n[part] = e[4];
+            ix4[part] = (uint32_t)tgc * 0x01010101u;
+            int lo = 0, hi = t.vx - 1;
+            bool r = row_of(part) && have;
+            if (!FULL && !MAPS) {
+                lo = max(lo, tp->jlo - t.j0);
+                hi = min(hi, tp->jhi - t.j0);
+                r = r && ri >= tp->ilo - t.i0 && ri <= tp->ihi - t.i0;
+            }
+            span[part] = (r && hi >= lo) ? (unsigned)(hi - lo) : 0u;
+            base[part] = (r && hi >= lo) ? lo : 0x40000000;      // no column reaches it
         }
-        const unsigned spanA = (rA && hiA >= loA) ? (unsigned)(hiA - loA) : 0u;
-        const unsigned spanB = (rB && hiB >= loB) ? (unsigned)(hiB - loB) : 0u;
-        const int baseA = (rA && hiA >= loA) ? loA : 0x40000000;      // no column reaches it
-        const int baseB = (rB && hiB >= loB) ? loB : 0x40000000;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             v2 vw[R3], vm[R3];
@@ -1357,29 +1396,28 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 const int cj = col_of(c);
 #pragma unroll
                 for (int part = 0; part < 2; ++part) {
-                    const int k = 2 * c + part;
+                    const int k = best_of(c, part);
+                    const TileDev& t = tile_of(part);
+                    const TemplDev* tp = tpp[part];
                     const float xr = part ? xc.y : xc.x, tr = part ? t3.y : t3.x;
                     // core.py:360-367 with the float32 resolution floor (sc_epilogue)
-                    const float T1 = xr * xr * kt;
-                    const float d = fmaxf(fmaf(tr, scale, -T1), fmaf(fabsf(xr), kx2, fl0));
-                    float snr = fabsf(T1 * __builtin_amdgcn_rcpf(fmaf(d, inv_n, (float)SC_EPS)));
-                    const bool in = (unsigned)(cj - (part ? baseB : baseA)) <= (part ? spanB : spanA);
-                    float amp = xr * ka;
+                    const float T1 = xr * xr * kt[part];
+                    const float d = fmaxf(fmaf(tr, scale, -T1), fmaf(fabsf(xr), kx2[part], fl0[part]));
+                    float snr = fabsf(T1 * __builtin_amdgcn_rcpf(fmaf(d, inv_n[part], (float)SC_EPS)));
+                    const bool in = (unsigned)(cj - base[part]) <= span[part];
+                    float amp = xr * ka[part];
                     if (MAPS || FULL) {
                         // `in` is the tile's valid extent here; masks per cell
                         if (in) {
                             if (FULL)
-                                sc_apply_masks(*tp, g, xaxis, yaxis, (part ? tB.i0 : tA.i0) + ri,
-                                               (part ? tB.j0 : tA.j0) + cj, amp, snr);
-                            else if (!(ri >= tp->ilo - (part ? tB.i0 : tA.i0) &&
-                                       ri <= tp->ihi - (part ? tB.i0 : tA.i0) &&
-                                       cj >= tp->jlo - (part ? tB.j0 : tA.j0) &&
-                                       cj <= tp->jhi - (part ? tB.j0 : tA.j0))) {
+                                sc_apply_masks(*tp, g, xaxis, yaxis, t.i0 + ri, t.j0 + cj, amp, snr);
+                            else if (!(ri >= tp->ilo - t.i0 && ri <= tp->ihi - t.i0 &&
+                                       cj >= tp->jlo - t.j0 && cj <= tp->jhi - t.j0)) {
                                 amp = 0.f;
                                 snr = 0.f;
                             }
                             if (MAPS) {
-                                const uint32_t o = (part ? offB : offA) + 4u * (uint32_t)cj;
+                                const uint32_t o = off_of(part) + 4u * (uint32_t)cj;
                                 at_bytes(map_amp, o) = amp;
                                 at_bytes(map_snr, o) = snr;
                             }
@@ -1395,7 +1433,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                         b_snr[k] = won ? snr : b_snr[k];
                         b_amp[k] = won ? amp : b_amp[k];
                         const uint32_t bm = 0xFFu << (8 * (k & 3));
-                        b_ix[k >> 2] = won ? ((b_ix[k >> 2] & ~bm) | (gi4 & bm)) : b_ix[k >> 2];
+                        b_ix[k >> 2] = won ? ((b_ix[k >> 2] & ~bm) | (ix4[part] & bm)) : b_ix[k >> 2];
                     }
                 }
             }
@@ -1404,10 +1442,11 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     }
     if (!MAPS) {
 #pragma unroll
-        for (int k = 0; k < 2 * NC; ++k) {
+        for (int k = 0; k < NBEST; ++k) {
             const uint32_t ix = (b_ix[k >> 2] >> (8 * (k & 3))) & 0xFFu;
             if (ix != 0xFFu) {
-                const uint32_t o = ((k & 1) ? offB : offA) + 4u * (uint32_t)col_of(k >> 1);
+                const int c = PT ? k : k >> 1, part = PT ? 0 : (k & 1);
+                const uint32_t o = off_of(part) + 4u * (uint32_t)col_of(c);
                 at_bytes(best_snr, o) = b_snr[k];
                 at_bytes(best_amp, o) = b_amp[k];
                 at_bytes(best_id, o) = templ[ra.first + ix].id;
@@ -1617,8 +1656,12 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         return sc_fail(ctx, SC_ERR_INVALID, "group %d exceeds %d", group, SC_MAX_GROUP);
     const int pb = std::max(1, ctx->fft_pb);
     const size_t yblock = (size_t)fg.Ty * fg.Tx * group;          // cells per pair in yw / ym
-    for (int pair0 = 0; pair0 < np; pair0 += pb) {
-        const int pc = std::min(pb, np - pair0);
+    const bool fast = (fg.Tx == 512 || fg.Tx == 1024 || fg.Tx == 2048) && ctx->variant != 9;
+    // One chunk = pc tile pairs through I1 and I2, group by group.  PTV: the chunk is a
+    // single pair whose second tile is empty; templates ride in pairs instead (see
+    // k_inv_cols_sym) - the symmetric I1 and the fast I2 know that mode.
+    auto chunk = [&](int pair0, int pc, auto ptc) -> int {
+        constexpr bool PTV = decltype(ptc)::value;
         for (int g0 = 0; g0 < n; g0 += group) {
             int G = std::min(group, n - g0);
             // I1: as many tile pairs per launch as it takes to fill the chip once
@@ -1645,15 +1688,15 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         1 - ctx->g.ox, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group
 #define FN_SYM(T)                                                              \
     {                                                                          \
-        int rc = set_lds(ctx, k_inv_cols_sym<T, false>, inv_cols_lds<T>());    \
+        int rc = set_lds(ctx, k_inv_cols_sym<T, false, PTV>, inv_cols_lds<T>());    \
         if (rc) return rc;                                                     \
-        rc = set_lds(ctx, k_inv_cols_sym<T, true>, inv_cols_lds<T>());         \
+        rc = set_lds(ctx, k_inv_cols_sym<T, true, PTV>, inv_cols_lds<T>());         \
         if (rc) return rc;                                                     \
         const int nlo = fg.Tx / 8, nhi = fg.Tx / 4 - nlo;                      \
-        hipLaunchKernelGGL((k_inv_cols_sym<T, false>), dim3(nlo, pcc), dim3(fft_threads(T)), \
+        hipLaunchKernelGGL((k_inv_cols_sym<T, false, PTV>), dim3(nlo, pcc), dim3(fft_threads(T)), \
                            inv_cols_lds<T>(), SYM_ARGS(0));                    \
         if (nhi > 0)                                                           \
-            hipLaunchKernelGGL((k_inv_cols_sym<T, true>), dim3(nhi, pcc), dim3(fft_threads(T)), \
+            hipLaunchKernelGGL((k_inv_cols_sym<T, true, PTV>), dim3(nhi, pcc), dim3(fft_threads(T)), \
                                inv_cols_lds<T>(), SYM_ARGS(nlo));              \
     }
 #define FN(T)                                                                  \
@@ -1690,8 +1733,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             const int pair = pair0;
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
                        ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg, group};
-            const bool fast = (fg.Tx == 512 || fg.Tx == 1024 || fg.Tx == 2048) && ctx->variant != 9;
-            dim3 gridr(fast ? ((rp_n + 7) / 8) * 16 : (rp_n + 1) / 2, pc);
+                        dim3 gridr(fast ? ((rp_n + 7) / 8) * 16 : (rp_n + 1) / 2, pc);
             sc_prof_begin(ctx, SC_K_INV_ROWS);
 #define ROW_ARGS lds_r, FAST_ARGS
 #define FAST_ARGS                                                              \
@@ -1709,9 +1751,9 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     }
 #define LAUNCH_FAST2(T, FULLV, MAPSV)                                          \
     {                                                                          \
-        int rc = set_lds(ctx, k_inv_rows_fast<T, FULLV, MAPSV>, inv_rows_fast_lds<T>()); \
+        int rc = set_lds(ctx, k_inv_rows_fast<T, FULLV, MAPSV, PTV>, inv_rows_fast_lds<T>()); \
         if (rc) return rc;                                                     \
-        hipLaunchKernelGGL((k_inv_rows_fast<T, FULLV, MAPSV>), gridr,          \
+        hipLaunchKernelGGL((k_inv_rows_fast<T, FULLV, MAPSV, PTV>), gridr,          \
                            dim3(inv_rows_fast_threads<T>()), inv_rows_fast_lds<T>(), FAST_ARGS); \
     }
 #define LAUNCH_FAST(T, FULLV)                                                  \
@@ -1734,6 +1776,17 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
 #undef FAST_ARGS
             sc_prof_end(ctx);
         }
+        return SC_OK;
+    };
+    const bool pt = sym && fast && (fg.ntiles & 1) && ctx->variant != 5;
+    const int np_main = pt ? np - 1 : np;
+    for (int pair0 = 0; pair0 < np_main; pair0 += pb) {
+        int rc = chunk(pair0, std::min(pb, np_main - pair0), std::false_type{});
+        if (rc) return rc;
+    }
+    if (pt) {
+        int rc = chunk(np - 1, 1, std::true_type{});
+        if (rc) return rc;
     }
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;

@@ -118,3 +118,28 @@ def test_more_parameters_than_one_batch(gpu_ctx):
         res = m.search(WT.Scarp, 8, ages, angles, method=method).result()
         chk = fold_check(res, z, 1.0, 1.0, orc.SCARP, 8, ages, angles)
         assert chk["n_bad"] == 0, (method, chk)
+
+
+def test_odd_tile_count_and_odd_template_count(gpu_ctx):
+    """A tile pair whose second tile is empty carries two TEMPLATES per transform
+    instead (k_inv_cols_sym / k_inv_rows_fast, "paired templates"): exercised with an
+    odd number of tiles and an odd number of templates per orientation."""
+    ages, angles = [2.0, 20.0, 200.0], np.array([-0.8, 0.3])
+    for n in range(600, 1000, 20):
+        g = synthetic.synthetic_scarp(n, ny=n - 30, seed=n)
+        m = sl.Matcher(g, ctx=gpu_ctx)
+        arr, bbox, area = m.describe(WT.Scarp, 30, ages, angles)
+        p = _plan.Plan(m.ny, m.nx, m.core, bbox, whole=True, method=_plan.METHOD_FFT, t_max=512)
+        if (p.nty * p.ntx) % 2 == 1 and p.nty * p.ntx > 1:
+            break
+    else:
+        pytest.fail("no DEM size with an odd tile count found")
+    sp = sl._lib.sc_plan(method=1, Ty=p.Ty, Tx=p.Tx, Vy=p.Vy, Vx=p.Vx, nty=p.nty, ntx=p.ntx,
+                         circ_y=int(p.circ_y), circ_x=int(p.circ_x), Py=p.Py, Qx=p.Qx, group=len(ages))
+    m.ctx.reset_best()
+    m.ctx.match(arr, sp, sync=True)
+    m.params, m.angles, m.n_templates = np.asarray(ages), angles, len(arr)
+    res = m.result()
+    chk = fold_check(res, g._griddata, 1.0, 1.0, orc.SCARP, 30, ages, angles)
+    assert chk["n_bad"] == 0, (p, chk)
+    assert chk["n_strict"] > 0.9 * chk["n"], chk

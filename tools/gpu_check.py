@@ -69,7 +69,8 @@ def check_fold(cls, ny, nx, de, scale, params, angs, method):
     ages = np.repeat(np.asarray(params, float), len(angs))
     angles = np.tile(np.asarray(angs, float), len(params))
     chk = orc.check_fold(res, a_st.reshape(T, ny, nx), s_st.reshape(T, ny, nx), ages, angles,
-                         tie_rtol=1e-4, amp_tol=(2e-4, 1e-6), snr_tol=(2e-3, 1e-6))
+                         tie_rtol=1e-4, amp_tol=(2e-4, 2e-6 * float(np.max(np.abs(a_st)))),
+                         snr_tol=(2e-3, 2e-6 * float(np.max(s_st))))
     print("fold %-8s %-6s %dx%d %d templates: bad=%d strict=%d tie=%d of %d  (%.2fs)" % (
         cls.__name__[:8], method, ny, nx, T, chk["n_bad"], chk["n_strict"], chk["n_tie"], chk["n"], dt))
     bad = np.argwhere(~chk["ok"])[:6]
@@ -102,6 +103,12 @@ if __name__ == "__main__":
     check_single(WT.Scarp, 1100, 1000, 1.0, 100, 1000.0, 0.6, methods=("fft",))
     check_single(WT.Scarp, 1000, 1500, 1.0, 100, 300.0, -0.8, methods=("fft",))
     check_single(WT.Scarp, 2500, 2300, 1.0, 100, 100.0, 0.4, methods=("fft",))
+    check_single(WT.Scarp, 2200, 2100, 1.0, 100, 30.0, -0.2, methods=("fft",))      # 3x3 tiles: odd count
     for meth in ("direct", "fft"):
         check_fold(WT.Scarp, 96, 90, 1.0, 10, [1.0, 3.16, 10.0, 31.6], _plan.angle_grid(-0.5, 0.5), meth)
         check_fold(WT.Channel, 80, 96, 1.0, 6, [0.1, 0.2], _plan.angle_grid(-np.pi / 2, np.pi / 2)[::6], meth)
+    # odd number of templates per orientation (paired-template mode leaves one single)
+    check_fold(WT.Scarp, 96, 90, 1.0, 10, [1.0, 3.16, 10.0, 31.6, 50.0], _plan.angle_grid(-0.5, 0.5)[::4], "fft")
+    check_fold(WT.Scarp, 130, 140, 1.0, 12, [2.0], _plan.angle_grid(-0.5, 0.5)[::4], "fft")
+    # odd tile count (the last tile alone in its pair) and several templates
+    check_fold(WT.Scarp, 2200, 2100, 1.0, 100, [3.0, 30.0, 300.0], np.array([-0.7, 1.2]), "fft")
