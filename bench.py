@@ -27,7 +27,7 @@ ALGO_BYTES_PER_UNIT = 28.0        # bytes per px.templat
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
 # profiling slot of the library -> kernel symbols as rocprofv3 lists them (Scarp / Ricker
 # searches at T = 512..2048; each tile pair takes one launch of either instantiation)
-KERNEL_SYMBOLS = {"k_inv_cols": "k_inv_cols_sym<T,false|true>", "k_inv_rows": "k_inv_rows_fast<T,false,false>"}
+KERNEL_SYMBOLS = {"k_inv_cols": "k_inv_cols_sym<T,false|true,false>", "k_inv_rows": "k_inv_rows_fast<T,false,false,false>"}
 
 
 def parse():
