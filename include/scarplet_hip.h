@@ -159,6 +159,13 @@ int sc_match_template(sc_ctx* ctx, const sc_template* t, const sc_plan* plan,
 /* Copy the running best of the core region to the host. */
 int sc_get_best(sc_ctx* ctx, float* amp, float* snr, uint32_t* id);
 
+/* The running best as the reference returns it (core.py:243, 194): four float64
+ * planes [amp, age, angle, snr] of the core region, out = 4 x (cy1-cy0) x
+ * (cx1-cx0) doubles.  param_of_id / angle_of_id map a template id (< n_ids) to
+ * its (age, orientation); cells no template has won are all zero. */
+int sc_get_result(sc_ctx* ctx, const double* param_of_id, const double* angle_of_id,
+                  int n_ids, double* out);
+
 /*
  * compare() for results that already sit on the host (core.py:198-243), e.g.
  * user code that calls match_template() per orientation and folds itself.

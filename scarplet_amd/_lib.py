@@ -86,6 +86,7 @@ SIGNATURES = {
     "sc_match_template": (C.c_int, [_P, C.POINTER(sc_template),
                                     C.POINTER(sc_plan), _fp, _fp]),
     "sc_get_best": (C.c_int, [_P, _fp, _fp, _up]),
+    "sc_get_result": (C.c_int, [_P, _dp, _dp, C.c_int, _dp]),
     "sc_compare_begin": (C.c_int, [_P, C.c_int, C.c_int]),
     "sc_compare_fold": (C.c_int, [_P, _dp, _dp, C.c_double, C.c_double]),
     "sc_compare_end": (C.c_int, [_P, _dp, _dp, _dp, _dp]),
@@ -265,6 +266,16 @@ class Context(object):
         self._check(self.lib.sc_get_best(self._h, _as(amp, _fp), _as(snr, _fp),
                                          _as(idx, _up)), "sc_get_best")
         return amp, snr, idx
+
+    def get_result(self, param_of_id, angle_of_id):
+        """(4, h, w) float64: amp, age, angle, snr of the running best."""
+        h, w = self.core_shape()
+        par = np.ascontiguousarray(param_of_id, dtype=np.float64)
+        ang = np.ascontiguousarray(angle_of_id, dtype=np.float64)
+        out = np.empty((4, h, w), dtype=np.float64)
+        self._check(self.lib.sc_get_result(self._h, _as(par, _dp), _as(ang, _dp),
+                                           len(par), _as(out, _dp)), "sc_get_result")
+        return out
 
     def template_sums(self, n):
         a = np.empty(n)

@@ -222,13 +222,16 @@ class Matcher(object):
 
     def result(self):
         """(amp, age, angle, snr) float64 maps of the core region."""
-        amp, snr, idx = self.ctx.get_best()
-        n_ang = len(self.angles)
-        won = idx != _lib.ID_NONE
-        safe = np.where(won, idx, 0)
-        age = np.where(won, self.params[safe // n_ang], 0.0)
-        ang = np.where(won, self.angles[safe % n_ang], 0.0)
-        return (amp.astype(np.float64), age, ang, snr.astype(np.float64))
+        # template id = i_param * n_angles + i_angle (describe()); the conversion
+        # of the float32 record into the reference's float64 planes runs on the
+        # device, the host receives the finished (4, h, w) array
+        out = self.result_array()
+        return (out[0], out[1], out[2], out[3])
+
+    def result_array(self):
+        """The same as one (4, h, w) float64 array."""
+        return self.ctx.get_result(np.repeat(self.params, len(self.angles)),
+                                   np.tile(self.angles, len(self.params)))
 
     def match_template(self, Template, scale, age, angle, method="auto",
                        **kwargs):
@@ -277,7 +280,7 @@ def calculate_best_fit_parameters(dem, Template, scale, age,
     try:
         m.search(Template, scale, [age], _plan.angle_grid(ang_min, ang_max),
                  method=method)
-        return np.stack(m.result())
+        return m.result_array()
     finally:
         m.ctx.clear_windows()
 

@@ -45,7 +45,7 @@ size_t sc_total_bytes(sc_ctx* c) {
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
-                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage};
+                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res};
     size_t s = 0;
     for (DevBuf* b : arr) s += b->cap;
     for (auto& w : c->windows) s += (size_t)w.h * w.wd * 5;
@@ -169,7 +169,7 @@ extern "C" void sc_destroy(sc_ctx* c) {
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
-                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage};
+                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res};
     for (DevBuf* b : arr) buf_free(*b);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp[k]);
     for (int k = 0; k < 2; ++k) buf_free(c->cmp_in[k]);
@@ -532,6 +532,42 @@ extern "C" int sc_get_best(sc_ctx* ctx, float* amp, float* snr, uint32_t* id) {
     SC_HIP(ctx, hipMemcpyAsync(amp, ctx->best_amp.p, sizeof(float) * nc, hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(snr, ctx->best_snr.p, sizeof(float) * nc, hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(id, ctx->best_id.p, sizeof(uint32_t) * nc, hipMemcpyDeviceToHost, ctx->stream));
+    return sc_sync(ctx);
+}
+
+// (amp, snr, id) float32 record -> the reference's four float64 planes
+__global__ void __launch_bounds__(256)
+k_result(const float* __restrict__ amp, const float* __restrict__ snr,
+         const uint32_t* __restrict__ id, const double* __restrict__ par,
+         const double* __restrict__ ang, uint32_t n_ids, size_t nc, double* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nc; i += (size_t)gridDim.x * 256) {
+        const uint32_t t = id[i];
+        const bool won = t < n_ids;                 // SC_ID_NONE is larger than any id
+        out[i] = (double)amp[i];
+        out[nc + i] = won ? par[t] : 0.0;
+        out[2 * nc + i] = won ? ang[t] : 0.0;
+        out[3 * nc + i] = (double)snr[i];
+    }
+}
+
+extern "C" int sc_get_result(sc_ctx* ctx, const double* param_of_id, const double* angle_of_id,
+                             int n_ids, double* out) {
+    if (!ctx || !param_of_id || !angle_of_id || n_ids <= 0 || !out) return SC_ERR_INVALID;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
+    int rc = sc_ensure(ctx, ctx->res, sizeof(double) * (4 * nc + 2 * (size_t)n_ids));
+    if (rc) return rc;
+    double* planes = (double*)ctx->res.p;
+    double* tab = planes + 4 * nc;
+    SC_HIP(ctx, hipMemcpyAsync(tab, param_of_id, sizeof(double) * n_ids, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(tab + n_ids, angle_of_id, sizeof(double) * n_ids, hipMemcpyHostToDevice, ctx->stream));
+    const unsigned blocks = (unsigned)std::min<size_t>((nc + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(k_result, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)ctx->best_amp.p,
+                       (const float*)ctx->best_snr.p, (const uint32_t*)ctx->best_id.p,
+                       (const double*)tab, (const double*)(tab + n_ids), (uint32_t)n_ids, nc, planes);
+    SC_HIP(ctx, hipGetLastError());
+    SC_HIP(ctx, hipMemcpyAsync(out, planes, sizeof(double) * 4 * nc, hipMemcpyDeviceToHost, ctx->stream));
     return sc_sync(ctx);
 }
 

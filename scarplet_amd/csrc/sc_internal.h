@@ -97,6 +97,7 @@ struct sc_ctx {
     void* comm = nullptr;      // ncclComm_t
     int rank = 0, nranks = 1;
     DevBuf halo_z, halo_stage;
+    DevBuf res;                // sc_get_result: four float64 planes + the id tables
 };
 
 int sc_fail(sc_ctx* ctx, int code, const char* fmt, ...);
