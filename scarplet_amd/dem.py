@@ -108,6 +108,18 @@ class DEMGrid(object):
         tiff.write_geotiff(filename, z, gi.geo_transform,
                            nodata=float(FLOAT32_MIN), geokeys=proj)
 
+    def save_results(self, filename, results):
+        """Write a search result as the 4-band float32 raster the reference's
+        pipeline publishes (CHANGELOG.md:20-24: 1 = amplitude, 2 = relative age,
+        3 = orientation, 4 = SNR) with this grid's georeferencing."""
+        from scarplet_amd import tiff
+        res = np.asarray(results, dtype=np.float32)
+        if res.shape != (4,) + tuple(self._griddata.shape):
+            raise ValueError("results must be (4, ny, nx) for this grid")
+        gi = self._georef_info
+        proj = gi.projection if isinstance(gi.projection, dict) else None
+        tiff.write_geotiff(filename, res, gi.geo_transform, geokeys=proj)
+
     def _fill_nodata(self):
         """Fill NaN cells so the matcher's NaN-free precondition holds
         (dem.py:388-414 wraps GDAL's FillNodata; here: iterative mean of the

@@ -78,8 +78,10 @@ def read_geotiff_full(path):
     spp = t.get(277, (1,))[0]
     fmt = t.get(339, (1,))[0]
     pred = t.get(317, (1,))[0]
-    if spp != 1:
-        raise ValueError("%s: %d samples per pixel (single-band rasters only)" % (path, spp))
+    planar = t.get(284, (1,))[0]
+    if spp != 1 and planar != 2:
+        raise ValueError("%s: %d interleaved samples per pixel (single-band or band-separate "
+                         "rasters only)" % (path, spp))
     kind = {1: "u", 2: "i", 3: "f"}.get(fmt)
     if kind is None or bits not in (8, 16, 32, 64):
         raise ValueError("%s: unsupported sample format %d / %d bits" % (path, fmt, bits))
@@ -97,8 +99,23 @@ def read_geotiff_full(path):
             raise ValueError("%s: predictor %d is not supported" % (path, pred))
         return a
 
-    out = np.empty((height, width), dtype=dtype.newbyteorder("="))
-    if 322 in t:                                    # tiled
+    if spp != 1:                                    # band-separate strips: PlanarConfiguration 2
+        if 322 in t:
+            raise ValueError("%s: tiled multi-band rasters are not supported" % path)
+        rps = t.get(278, (height,))[0]
+        per_band = (height + rps - 1) // rps
+        offs, cnts = t[273], t[279]
+        out = np.empty((spp, height, width), dtype=dtype.newbyteorder("="))
+        for k, (o, c) in enumerate(zip(offs, cnts)):
+            b, ks = divmod(k, per_band)
+            y0 = ks * rps
+            h = min(rps, height - y0)
+            out[b, y0:y0 + h] = decode(buf[o:o + c], h, width)
+    else:
+        out = np.empty((height, width), dtype=dtype.newbyteorder("="))
+    if spp != 1:
+        pass
+    elif 322 in t:                                  # tiled
         tw, tl = t[322][0], t[323][0]
         offs, cnts = t[324], t[325]
         across = (width + tw - 1) // tw
@@ -139,19 +156,22 @@ def read_geotiff_full(path):
 def write_geotiff(path, array, geo_transform=None, nodata=None, geokeys=None):
     """Write a single-band little-endian classic TIFF (one uncompressed strip).
 
-    array: 2-D, any of the dtypes read_geotiff accepts (float64 grids are
-    stored as given; pass ``array.astype('f4')`` for compact output).
+    array: (rows, cols) or (bands, rows, cols) - bands are stored as separate
+    planes, one strip each; any of the dtypes read_geotiff accepts (float64
+    grids are stored as given; pass ``array.astype('f4')`` for compact output).
     geo_transform: GDAL 6-tuple; axis-aligned transforms become
     ModelPixelScale + ModelTiepoint, rotated ones ModelTransformation."""
     a = np.ascontiguousarray(array)
-    if a.ndim != 2:
-        raise ValueError("write_geotiff: single-band 2-D arrays only")
+    if a.ndim not in (2, 3):
+        raise ValueError("write_geotiff: (rows, cols) or (bands, rows, cols) arrays only")
+    bands = 1 if a.ndim == 2 else a.shape[0]
     kind = {"u": 1, "i": 2, "f": 3}.get(a.dtype.kind)
     if kind is None or a.dtype.itemsize not in (1, 2, 4, 8) or \
             (kind == 3 and a.dtype.itemsize < 4):
         raise ValueError("write_geotiff: unsupported dtype %s" % a.dtype)
     a = a.astype(a.dtype.newbyteorder("<"), copy=False)
-    h, w = a.shape
+    h, w = a.shape[-2:]
+    band_bytes = h * w * a.dtype.itemsize
     entries = []                                    # (tag, type, count, bytes)
 
     def add(tag, typ, values):
@@ -166,15 +186,17 @@ def write_geotiff(path, array, geo_transform=None, nodata=None, geokeys=None):
 
     add(256, 4, [w])
     add(257, 4, [h])
-    add(258, 3, [a.dtype.itemsize * 8])
+    add(258, 3, [a.dtype.itemsize * 8] * bands)
     add(259, 3, [1])
     add(262, 3, [1])                                # BlackIsZero
-    add(273, 4, [0])                                # strip offset, patched below
-    add(277, 3, [1])
+    add(273, 4, [8 + b * band_bytes for b in range(bands)])    # one strip per band, data at 8
+    add(277, 3, [bands])
     add(278, 4, [h])
-    add(279, 4, [a.nbytes])
-    add(284, 3, [1])
-    add(339, 3, [kind])
+    add(279, 4, [band_bytes] * bands)
+    add(284, 3, [1 if bands == 1 else 2])           # band-separate planes
+    if bands > 1:
+        add(338, 3, [0] * (bands - 1))              # ExtraSamples: unspecified data
+    add(339, 3, [kind] * bands)
     if geo_transform is not None:
         x0, dx, rx, y0, ry, dy = [float(v) for v in geo_transform]
         if rx == 0.0 and ry == 0.0 and dx > 0 and dy < 0:
@@ -202,8 +224,6 @@ def write_geotiff(path, array, geo_transform=None, nodata=None, geokeys=None):
     ifd = struct.pack("<H", len(entries))
     extra = b""
     for tag, typ, cnt, data in entries:
-        if tag == 273:
-            data = struct.pack("<I", data_off)
         if len(data) <= 4:
             field = data.ljust(4, b"\0")
         else:

@@ -54,24 +54,41 @@ def test_c5_grandcanyon_channel_readme_example(gpu_ctx):
     assert chk["n_bad"] == 0, chk
 
 
-def test_c5_grandcanyon_channel_five_widths(gpu_ctx):
-    """configs[4]: Channel (Ricker) plugin, 5 wavelet widths x orientations in
-    ONE device fold (every third degree here so the oracle stack stays small;
-    the 181-orientation grid of a single width is the test above)."""
+def test_c5_grandcanyon_channel_five_scales(gpu_ctx):
+    """configs[4] as SURVEY.md section 8(d) defines it: Channel (Ricker) plugin, f = 0.1,
+    scales {5, 10, 20, 40, 80}, one result set per scale (every sixth degree here so
+    the oracle stacks stay small; the full 181-orientation grid is the test above)."""
+    z, dx, dy = dem_fixture("dem_grandcanyon.npz")
+    angles = _plan.angle_grid()[::6]
+    for scale in (5., 10., 20., 40., 80.):
+        a_st, s_st = orc.snr_stack(z, dx, dy, orc.RICKER, scale, [0.1], angles, workers=4)
+        T = len(angles)
+        for method in ("fft", "direct") if scale <= 10. else ("fft",):
+            m = sl.Matcher(grid(z, dx, dy), ctx=gpu_ctx)
+            res = m.search(WT.Channel, scale, [0.1], angles, method=method).result()
+            chk = orc.check_fold(res, a_st.reshape(T, *z.shape), s_st.reshape(T, *z.shape),
+                                 np.repeat([0.1], T), angles,
+                                 tie_rtol=TIE_RTOL, amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
+                                 snr_tol=(SNR_RTOL, SNR_ATOL * np.max(s_st)))
+            assert chk["n_bad"] == 0, (scale, method, chk["n_bad"])
+
+
+def test_channel_several_widths_in_one_fold(gpu_ctx):
+    """The second constructor argument of Ricker is the wavelet frequency: several of
+    them fold in one device search like ages do for Scarp."""
     z, dx, dy = dem_fixture("dem_grandcanyon.npz")
     widths = [0.05, 0.1, 0.2, 0.4, 0.8]
-    angles = _plan.angle_grid()[::3]
+    angles = _plan.angle_grid()[::6]
     a_st, s_st = orc.snr_stack(z, dx, dy, orc.RICKER, 10., widths, angles, workers=4)
     T = len(widths) * len(angles)
-    for method in ("fft", "direct"):
-        m = sl.Matcher(grid(z, dx, dy), ctx=gpu_ctx)
-        res = m.search(WT.Channel, 10., widths, angles, method=method).result()
-        chk = orc.check_fold(res, a_st.reshape(T, *z.shape), s_st.reshape(T, *z.shape),
-                             np.repeat(widths, len(angles)), np.tile(angles, len(widths)),
-                             tie_rtol=TIE_RTOL, amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
-                             snr_tol=(SNR_RTOL, SNR_ATOL * np.max(s_st)))
-        assert chk["n_bad"] == 0, (method, chk["n_bad"])
-        assert len(np.unique(res[1][res[3] > 0])) > 1     # more than one width wins somewhere
+    m = sl.Matcher(grid(z, dx, dy), ctx=gpu_ctx)
+    res = m.search(WT.Channel, 10., widths, angles, method="fft").result()
+    chk = orc.check_fold(res, a_st.reshape(T, *z.shape), s_st.reshape(T, *z.shape),
+                         np.repeat(widths, len(angles)), np.tile(angles, len(widths)),
+                         tie_rtol=TIE_RTOL, amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
+                         snr_tol=(SNR_RTOL, SNR_ATOL * np.max(s_st)))
+    assert chk["n_bad"] == 0, chk["n_bad"]
+    assert len(np.unique(res[1][res[3] > 0])) > 1     # more than one width wins somewhere
 
 
 def test_c2_synthetic_2048_ten_ages_91_orientations(gpu_ctx):
@@ -84,7 +101,7 @@ def test_c2_synthetic_2048_ten_ages_91_orientations(gpu_ctx):
     n = 2048
     g = synthetic.synthetic_scarp(n)
     z = g._griddata
-    ages = _plan.age_grid()[0:30:3]
+    ages = _plan.age_grid()[np.round(np.linspace(0, 34, 10)).astype(int)]
     angles = _plan.angle_grid(-np.pi / 4, np.pi / 4)
     assert len(ages) == 10 and len(angles) == 91
     m = sl.Matcher(g, ctx=gpu_ctx)
@@ -93,7 +110,7 @@ def test_c2_synthetic_2048_ten_ages_91_orientations(gpu_ctx):
     assert np.isin(age[snr > 0], ages).all() and np.isin(ang[snr > 0], angles).all()
 
     won = 0
-    for ia, ib in [(0, 0), (3, 45), (5, 45), (9, 90), (7, 20), (2, 70)]:
+    for ia, ib in [(0, 0), (3, 45), (4, 45), (9, 90), (7, 20), (2, 70)]:
         o_amp, _, _, o_snr = orc.match_template(z, 1.0, 1.0, orc.SCARP, 100, ages[ia], angles[ib], workers=4)
         tol_s = SNR_RTOL * o_snr + SNR_ATOL * np.max(o_snr)
         assert (snr >= o_snr * (1 - TIE_RTOL) - tol_s).all(), (ia, ib)

@@ -1,5 +1,6 @@
 """GeoTIFF reading without GDAL and the DEMGrid duck type (host side)."""
 import numpy as np
+import pytest
 
 import scarplet_amd as sl
 from scarplet_amd import tiff
@@ -68,3 +69,19 @@ def test_write_geotiff_dtypes_and_rotated_transform(tmp_path):
         b, gt2, nd = tiff.read_geotiff(out)
         assert b.dtype == a.dtype and (a == b).all()
         assert np.allclose(gt, gt2) and nd == -1.0
+
+
+def test_four_band_result_raster_round_trip(tmp_path):
+    """4-band result rasters (CHANGELOG.md:20-24): amplitude, age, orientation, SNR as
+    band-separate float32 planes with the DEM's georeferencing."""
+    g = sl.DEMGrid(golden("grandcanyon_crop.tif"))
+    rng = np.random.default_rng(5)
+    res = rng.standard_normal((4,) + g._griddata.shape)
+    out = str(tmp_path / "res.tif")
+    g.save_results(out, res)
+    arr, gt, nodata = tiff.read_geotiff(out)
+    assert arr.shape == res.shape and arr.dtype == np.float32
+    assert np.array_equal(arr, res.astype(np.float32))
+    assert np.allclose(gt, g._georef_info.geo_transform) and nodata is None
+    with pytest.raises(ValueError):
+        g.save_results(out, res[:3])
