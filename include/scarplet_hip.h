@@ -235,6 +235,18 @@ typedef struct sc_xfer {
 int sc_halo_exchange(sc_ctx* ctx, const double* core, int core_h, int core_w,
                      int hy_lo, int hy_hi, int hx_lo, int hx_hi,
                      const sc_xfer* x, int n, void** z_dev);
+/*
+ * Final gather of a tiled search (results are disjoint rectangles): every rank
+ * converts its record like sc_get_result and sends the four float64 planes of its
+ * core to `root` over RCCL; root places them in out = 4 x ny x nx doubles (host).
+ *   cores   nranks x 4 ints: [cy0, cy1, cx0, cx1) of every rank, same on all ranks
+ *   out     root only (ignored elsewhere)
+ * Collective: all ranks of the communicator call it.  Without a communicator
+ * (single context) it is sc_get_result into the core's place.
+ */
+int sc_gather_result(sc_ctx* ctx, int root, const int32_t* cores, int ny, int nx,
+                     const double* param_of_id, const double* angle_of_id, int n_ids,
+                     double* out);
 int sc_comm_destroy(sc_ctx* ctx);
 
 #ifdef __cplusplus

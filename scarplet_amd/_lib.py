@@ -98,6 +98,8 @@ SIGNATURES = {
     "sc_device_bytes": (C.c_size_t, [_P]),
     "sc_comm_unique_id": (C.c_int, [_P]),
     "sc_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "sc_gather_result": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int,
+                                   _dp, _dp, C.c_int, _dp]),
     "sc_halo_exchange": (C.c_int, [_P, _dp] + [C.c_int] * 6
                          + [C.POINTER(sc_xfer), C.c_int, C.POINTER(_P)]),
     "sc_comm_destroy": (C.c_int, [_P]),
@@ -314,6 +316,18 @@ class Context(object):
         buf = C.create_string_buffer(bytes(uid), COMM_ID_BYTES)
         self._check(self.lib.sc_comm_init(self._h, buf, rank, nranks),
                     "sc_comm_init")
+
+    def gather_result(self, root, cores, shape, param_of_id, angle_of_id, is_root):
+        """Collective final gather over RCCL; returns (4, ny, nx) on root."""
+        cores = np.ascontiguousarray(cores, dtype=np.int32)
+        par = np.ascontiguousarray(param_of_id, dtype=np.float64)
+        ang = np.ascontiguousarray(angle_of_id, dtype=np.float64)
+        out = np.zeros((4,) + tuple(shape), dtype=np.float64) if is_root else None
+        self._check(self.lib.sc_gather_result(
+            self._h, int(root), cores.ctypes.data_as(C.POINTER(C.c_int32)), int(shape[0]),
+            int(shape[1]), _as(par, _dp), _as(ang, _dp), len(par),
+            _as(out, _dp) if is_root else None), "sc_gather_result")
+        return out
 
     def halo_exchange(self, core, halo, xfers):
         core = np.ascontiguousarray(core, dtype=np.float64)

@@ -550,9 +550,9 @@ k_result(const float* __restrict__ amp, const float* __restrict__ snr,
     }
 }
 
-extern "C" int sc_get_result(sc_ctx* ctx, const double* param_of_id, const double* angle_of_id,
-                             int n_ids, double* out) {
-    if (!ctx || !param_of_id || !angle_of_id || n_ids <= 0 || !out) return SC_ERR_INVALID;
+// the record of this context's core as four float64 planes in ctx->res (device)
+int sc_result_planes(sc_ctx* ctx, const double* param_of_id, const double* angle_of_id, int n_ids,
+                     double** planes_out, size_t* nc_out) {
     if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
     SC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
@@ -567,6 +567,18 @@ extern "C" int sc_get_result(sc_ctx* ctx, const double* param_of_id, const doubl
                        (const float*)ctx->best_snr.p, (const uint32_t*)ctx->best_id.p,
                        (const double*)tab, (const double*)(tab + n_ids), (uint32_t)n_ids, nc, planes);
     SC_HIP(ctx, hipGetLastError());
+    *planes_out = planes;
+    *nc_out = nc;
+    return SC_OK;
+}
+
+extern "C" int sc_get_result(sc_ctx* ctx, const double* param_of_id, const double* angle_of_id,
+                             int n_ids, double* out) {
+    if (!ctx || !param_of_id || !angle_of_id || n_ids <= 0 || !out) return SC_ERR_INVALID;
+    double* planes = nullptr;
+    size_t nc = 0;
+    int rc = sc_result_planes(ctx, param_of_id, angle_of_id, n_ids, &planes, &nc);
+    if (rc) return rc;
     SC_HIP(ctx, hipMemcpyAsync(out, planes, sizeof(double) * 4 * nc, hipMemcpyDeviceToHost, ctx->stream));
     return sc_sync(ctx);
 }

@@ -135,3 +135,49 @@ extern "C" int sc_halo_exchange(sc_ctx* ctx, const double* core, int core_h, int
     *z_dev = (void*)blk;
     return SC_OK;
 }
+
+extern "C" int sc_gather_result(sc_ctx* ctx, int root, const int32_t* cores, int ny, int nx,
+                                const double* param_of_id, const double* angle_of_id, int n_ids,
+                                double* out) {
+    if (!ctx || !cores || ny <= 0 || nx <= 0 || !param_of_id || !angle_of_id || n_ids <= 0)
+        return SC_ERR_INVALID;
+    const int nranks = ctx->comm ? ctx->nranks : 1, rank = ctx->comm ? ctx->rank : 0;
+    if (root < 0 || root >= nranks || (rank == root && !out)) return SC_ERR_INVALID;
+    const int32_t* mine = cores + 4 * rank;
+    if (mine[0] != ctx->g.cy0 || mine[1] != ctx->g.cy1 || mine[2] != ctx->g.cx0 || mine[3] != ctx->g.cx1)
+        return sc_fail(ctx, SC_ERR_INVALID, "cores[%d] is not this context's core", rank);
+    double* planes = nullptr;
+    size_t nc = 0;
+    int rc = sc_result_planes(ctx, param_of_id, angle_of_id, n_ids, &planes, &nc);
+    if (rc) return rc;
+    const size_t full = (size_t)ny * nx;
+    // a core's planes (contiguous h x w each) into the full host planes
+    auto place = [&](const double* dev, const int32_t* c) -> int {
+        const int h = c[1] - c[0], w = c[3] - c[2];
+        for (int k = 0; k < 4; ++k)
+            SC_HIP(ctx, hipMemcpy2DAsync(out + k * full + (size_t)c[0] * nx + c[2], sizeof(double) * nx,
+                                         dev + (size_t)k * h * w, sizeof(double) * w,
+                                         sizeof(double) * w, h, hipMemcpyDeviceToHost, ctx->stream));
+        return SC_OK;
+    };
+    if (rank != root) {
+        SC_NCCL(ctx, ncclSend(planes, 4 * nc, ncclDouble, root, (ncclComm_t)ctx->comm, ctx->stream));
+        SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return SC_OK;
+    }
+    if ((rc = place(planes, mine))) return rc;
+    for (int r = 0; r < nranks; ++r) {
+        if (r == root) continue;
+        const int32_t* c = cores + 4 * r;
+        const int h = c[1] - c[0], w = c[3] - c[2];
+        if (h <= 0 || w <= 0 || c[0] < 0 || c[1] > ny || c[2] < 0 || c[3] > nx)
+            return sc_fail(ctx, SC_ERR_INVALID, "cores[%d] outside the DEM", r);
+        const size_t n = (size_t)4 * h * w;
+        if ((rc = sc_ensure(ctx, ctx->halo_stage, sizeof(double) * n))) return rc;
+        SC_NCCL(ctx, ncclRecv(ctx->halo_stage.p, n, ncclDouble, r, (ncclComm_t)ctx->comm, ctx->stream));
+        if ((rc = place((const double*)ctx->halo_stage.p, c))) return rc;
+        SC_HIP(ctx, hipStreamSynchronize(ctx->stream));      // the staging buffer is reused
+    }
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SC_OK;
+}

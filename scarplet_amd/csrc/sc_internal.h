@@ -116,6 +116,8 @@ int sc_lds_attr(sc_ctx* ctx, const void* kernel, size_t bytes);
 
 // profiling brackets around kernel launches
 void sc_prof_begin(sc_ctx* ctx, int kernel);
+int sc_result_planes(sc_ctx* ctx, const double* param_of_id, const double* angle_of_id, int n_ids,
+                     double** planes_out, size_t* nc_out);
 void sc_prof_end(sc_ctx* ctx, int n = 1);
 void sc_prof_collect(sc_ctx* ctx);
 

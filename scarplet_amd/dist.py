@@ -230,7 +230,17 @@ class DistMatcher(object):
         return self.m.result()
 
     def gather(self, dst=0):
-        """Assemble the full maps on rank ``dst`` (None elsewhere)."""
+        """Assemble the full maps on rank ``dst`` (None elsewhere): over RCCL
+        (sc_gather_result, device to root's host array) with the 'rccl' backend,
+        over torch.distributed with 'gloo'."""
+        if self.backend == "rccl":
+            lay = Layout(self.ny, self.nx, self.py, self.px, (0, 0, 0, 0))
+            cores = [lay.core(r) for r in range(self.nranks)]
+            m = self.m
+            out = m.ctx.gather_result(dst, cores, (self.ny, self.nx),
+                                      np.repeat(m.params, len(m.angles)),
+                                      np.tile(m.angles, len(m.params)), self.rank == dst)
+            return tuple(out) if self.rank == dst else None
         import torch.distributed as dist
         tiles = [None] * self.nranks if self.rank == dst else None
         dist.gather_object((self.core(), self.result()), tiles, dst=dst)

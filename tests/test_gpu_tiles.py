@@ -82,3 +82,28 @@ def test_rccl_single_rank_halo_exchange():
     res = dm.search(sl.Scarp, 10, params, angles, z, method="fft").result()
     for k in range(4):
         assert np.allclose(res[k], whole[k], rtol=2e-3, atol=1e-6 * np.abs(whole[k]).max() + 1e-12)
+    # final gather (sc_gather_result): with one rank the root places its own planes
+    full = dm.gather(0)
+    for k in range(4):
+        assert np.array_equal(full[k], res[k])
+
+
+def test_gather_result_places_a_core_inside_the_dem():
+    """sc_gather_result without a communicator: a context that owns a sub-rectangle
+    of the DEM gets its four planes at that place of the full arrays, zeros elsewhere."""
+    g = synthetic.synthetic_scarp(150, seed=4, ny=120)
+    z = g._griddata
+    params, angles = [4.0], _plan.angle_grid(-0.2, 0.2)[::5]
+    lay = sd.Layout(120, 150, 1, 2, sd.halo_for_search((-20, 20, -20, 20), 120, 150))
+    core = lay.core(1)
+    m = sl.Matcher()
+    m.set_block(sd.assemble_block_reference(z, lay, 1), lay.block_origin(1), z.shape, core, 1.0, 1.0)
+    res = m.search(sl.Scarp, 8, params, angles, method="fft").result()
+    # rank numbering: pretend to be rank 0 of 1 with that core
+    out = m.ctx.gather_result(0, [core], z.shape, np.repeat(params, len(angles)),
+                              np.tile(angles, len(params)), True)
+    for k in range(4):
+        assert np.array_equal(out[k][core[0]:core[1], core[2]:core[3]], res[k])
+        mask = np.ones(z.shape, bool)
+        mask[core[0]:core[1], core[2]:core[3]] = False
+        assert not out[k][mask].any()
