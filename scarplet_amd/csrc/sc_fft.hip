@@ -2,17 +2,22 @@
 //
 // Data flow for one orientation (all templates of the orientation share it):
 //
-//   F1c  k_fwd_rows_curv   curvature of TWO tiles packed as re/im  -> row FFT
-//   F2   k_fwd_cols        column FFT -> uc, uc2 (spectra of curv, curv^2)
-//   F1t  k_fwd_rows_templ  template tile v = W + iM                -> row FFT
-//   F2   k_fwd_cols        column FFT -> vh
-//   I1   k_inv_cols        FFT(W) = (vh[f]+conj vh[-f])/2, FFT(M) likewise;
-//                          P1 = FFT(W)*uc, P2 = FFT(M)*uc2; inverse column FFT
-//   I2   k_inv_rows        inverse row FFT -> xcorr(A) + i xcorr(B), T3 likewise;
-//                          float64 amp/SNR epilogue, masks, running-best fold
+//   F1c  k_fwd_rows_curv    curvature of TWO tiles packed as re/im  -> row FFT
+//   F2   k_fwd_cols         column FFT -> uc, uc2 (spectra of curv, curv^2)
+//   F1t  k_fwd_rows_templ   template tile v = alpha*W + iM          -> row FFT
+//   F2   k_fwd_cols         column FFT -> vh
+//   S    k_split_templ_sym  Scarp / Ricker: FFT(W) = {i} a P, FFT(M) = b P with a, b
+//                           real (flip symmetry of the template): store a, b only
+//        k_split_templ      any other template: FFT(W), FFT(M) as complex half planes
+//   I1   k_inv_cols_sym     Y = a * (X P {i}) per column block, inverse column FFT;
+//        k_inv_cols         the same with complex spectra
+//   I2   k_inv_rows_fast    inverse row FFT -> xcorr(A) + i xcorr(B), T3 likewise;
+//        k_inv_rows         float32 amp/SNR epilogue, masks, running-best fold
+//                           (fast: T in {512, 1024, 2048}; generic: the rest)
 //
 // Two real tiles ride in one complex transform (the template is real), so no
-// real-to-complex bookkeeping is needed anywhere.
+// real-to-complex bookkeeping is needed anywhere; an unpaired tile carries two
+// templates instead (template parameter PT of I1 / I2).
 //
 // Layouts (all complex float32):
 //   "spectrum"  [fx][fy]: a column of the 2-D spectrum is contiguous; written
@@ -25,10 +30,11 @@
 //
 //   "rows2"     hand-off between I1 and I2: 128-byte blocks of 2 rows x 8
 //               columns, cell (r, c) at ((r/2)*(Tx/8) + c/8)*16 + (c%8)*2 + r%2.
-//               I1 (4 columns) writes 64-byte half blocks; I2 owns whole row
-//               pairs, i.e. one contiguous 2*Tx run per plane.
+//               I1 (4 columns) writes 64-byte half blocks; I2 reads whole rows,
+//               the two rows of a pair from sibling workgroups on one XCD.
 //
-// The in-LDS FFT is a Stockham autosort with radices 16,16,..,r (see below).
+// The in-LDS FFT is a Stockham autosort with radices 16,16,..,r (see below);
+// complex arithmetic is packed (namespace pk).
 #include "sc_internal.h"
 #include <math.h>
 #include <type_traits>
@@ -53,8 +59,9 @@ struct TileDev {
 __host__ __device__ constexpr int fft_threads(int T) {
     return (T / 4) >= 512 ? 512 : ((T / 4) < 64 ? 64 : (T / 4));
 }
-// waves per SIMD the kernels are compiled for: two 512-thread workgroups per
-// CU (LDS allows it up to T = 2048), i.e. at most 128 VGPRs
+// minimum waves per SIMD the forward kernels are compiled for (the second
+// __launch_bounds__ argument of hipcc): 4 = at most 128 VGPRs, i.e. two
+// 512-thread workgroups per CU where LDS allows it (T <= 2048)
 __host__ __device__ constexpr int fft_waves(int T) { return T >= 4096 ? 2 : 4; }
 // padded line: one pad per 16 elements, plus 8 so that consecutive lines start
 // 16 banks apart (lanes of one wave may alternate between two lines)
