@@ -1163,8 +1163,8 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
 template <int TX>
 __host__ __device__ constexpr bool inv_rows_fast_ok() { return TX == 512 || TX == 1024 || TX == 2048; }
 
-// Byte-offset access to the best-record planes: one 32-bit offset per cell on
-// top of the (uniform) plane pointer.
+// Byte-offset access to the best-record planes: one 32-bit offset per lane on
+// top of a workgroup-uniform row pointer.
 template <typename V>
 __device__ __forceinline__ V& at_bytes(V* base, uint32_t off) {
     return *reinterpret_cast<V*>(reinterpret_cast<char*>(base) + off);
@@ -1274,9 +1274,11 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     int cj0 = rem3 - ra.Qx;
     const int cmask = ra.circ_x ? TX - 1 : -1;
     auto col_of = [&](int c) { return (cj0 + (c / R3) * 2 * S + 256 * (c % R3)) & cmask; };
-    // byte offset of tile column 0 of this thread's row in the best-record planes
-    const uint32_t offA = (uint32_t)(((size_t)(tA.i0 + ri - ra.cy0) * ra.cw + (tA.j0 - ra.cx0)) * 4);
-    const uint32_t offB = (uint32_t)(((size_t)(tB.i0 + ri - ra.cy0) * ra.cw + (tB.j0 - ra.cx0)) * 4);
+    // element offset of tile column 0 of this workgroup's row in the best-record planes
+    // (the row is the same for the whole workgroup: a scalar 64-bit element offset;
+    //  the column adds a 32-bit byte offset per lane)
+    const size_t offA = (size_t)(tA.i0 + ri - ra.cy0) * ra.cw + (tA.j0 - ra.cx0);
+    const size_t offB = (size_t)(tB.i0 + ri - ra.cy0) * ra.cw + (tB.j0 - ra.cx0);
     // The two halves ("parts") of a packed output: tiles A and B under one
     // template, or - PT, the pair's second tile is empty - templates 2k and 2k+1
     // on tile A (see k_inv_cols_sym).  Everything below is written per part.
@@ -1302,7 +1304,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
 #pragma unroll
         for (int part = 0; part < (PT ? 1 : 2); ++part) {
             const bool ok = !MAPS && row_of(part) && cj >= 0 && cj < tile_of(part).vx;
-            b_snr[best_of(c, part)] = ok ? at_bytes(best_snr, off_of(part) + 4u * (uint32_t)cj) : 0.f;
+            b_snr[best_of(c, part)] = ok ? at_bytes(best_snr + off_of(part), 4u * (uint32_t)cj) : 0.f;
             b_amp[best_of(c, part)] = 0.f;
         }
     }
@@ -1424,9 +1426,8 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                                 snr = 0.f;
                             }
                             if (MAPS) {
-                                const uint32_t o = off_of(part) + 4u * (uint32_t)cj;
-                                at_bytes(map_amp, o) = amp;
-                                at_bytes(map_snr, o) = snr;
+                                at_bytes(map_amp + off_of(part), 4u * (uint32_t)cj) = amp;
+                                at_bytes(map_snr + off_of(part), 4u * (uint32_t)cj) = snr;
                             }
                         } else {
                             snr = 0.f;
@@ -1453,10 +1454,10 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             const uint32_t ix = (b_ix[k >> 2] >> (8 * (k & 3))) & 0xFFu;
             if (ix != 0xFFu) {
                 const int c = PT ? k : k >> 1, part = PT ? 0 : (k & 1);
-                const uint32_t o = off_of(part) + 4u * (uint32_t)col_of(c);
-                at_bytes(best_snr, o) = b_snr[k];
-                at_bytes(best_amp, o) = b_amp[k];
-                at_bytes(best_id, o) = templ[ra.first + ix].id;
+                const uint32_t o = 4u * (uint32_t)col_of(c);
+                at_bytes(best_snr + off_of(part), o) = b_snr[k];
+                at_bytes(best_amp + off_of(part), o) = b_amp[k];
+                at_bytes(best_id + off_of(part), o) = templ[ra.first + ix].id;
             }
         }
     }
@@ -1656,9 +1657,6 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         rp_hi = std::min(fg.Ty - 1, fg.Py + fg.Vy - 1) / 2;
     }
     const int rp_n = rp_hi - rp_lo + 1;
-    // the row kernels address the best-record planes with 32-bit byte offsets
-    if ((size_t)(ctx->g.cy1 - ctx->g.cy0) * (size_t)(ctx->g.cx1 - ctx->g.cx0) >= ((size_t)1 << 30))
-        return sc_fail(ctx, SC_ERR_UNSUPPORTED, "core block of 2^30 cells or more");
     if (group > SC_MAX_GROUP)
         return sc_fail(ctx, SC_ERR_INVALID, "group %d exceeds %d", group, SC_MAX_GROUP);
     const int pb = std::max(1, ctx->fft_pb);
