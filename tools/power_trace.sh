@@ -3,11 +3,11 @@
 cd $GRAFT_REPO_ROOT
 python bench.py --no-cpu-baseline "$@" > gpurun_out/pt_bench.json 2>/dev/null &
 BP=$!
-for i in $(seq 1 60); do
+for i in $(seq 1 80); do
   if ! kill -0 $BP 2>/dev/null; then break; fi
-  rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|mclk|fclk|Power" | tr -s ' \t' ' ' | tr '\n' '|'
+  rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|fclk|Power|junction|memory" | sed -E 's/.*: //' | tr '\n' ' '
   echo
-  sleep 0.5
+  sleep 0.7
 done
 wait $BP
 python -c "
