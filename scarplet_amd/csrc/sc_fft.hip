@@ -559,6 +559,21 @@ k_fwd_rows_curv(const float* __restrict__ curv, Geom g,
     }
 }
 
+// Tile rows 4rb .. 4rb+3 hold template rows (tile row r holds template row p = r
+// for p >= 0, r - Ty for p < 0)?  The row kernel does not write blocks outside the
+// support and the column kernel does not read them: 85 % of a template tile at
+// C3 is zero rows.
+__device__ __forceinline__ bool templ_rowblock_used(const TemplDev& t, int rb, int Ty) {
+    bool any = false;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        int r = 4 * rb + rr;
+        int p = (r <= t.pmax) ? r : r - Ty;
+        any |= p >= t.pmin && p <= t.pmax;
+    }
+    return any;
+}
+
 // ---- F1t: template tile v = W + iM -> row FFT -> blocked ---------------------
 // grid = (Ty/4, n_templates)
 template <int TX>
@@ -587,11 +602,7 @@ k_fwd_rows_templ(const TemplDev* __restrict__ templ, int first,
         prow[rr] = (p >= t.pmin && p <= t.pmax) ? p : INT_MIN;
         any |= prow[rr] != INT_MIN;
     }
-    if (!any) {                       // block-uniform: rows outside the support
-        for (int e = 2 * threadIdx.x; e < 4 * TX; e += 2 * NT)
-            *reinterpret_cast<float4*>(out + e) = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
+    if (!any) return;                 // block-uniform: rows outside the support (templ_rowblock_used)
     for (int e = threadIdx.x; e < 4 * TX; e += NT) {
         int rr = e / TX, s = e - rr * TX;
         int q = (s <= t.qmax) ? s : s - TX;
@@ -618,7 +629,8 @@ k_fwd_rows_templ(const TemplDev* __restrict__ templ, int first,
 template <int TY>
 __global__ void __launch_bounds__(fft_threads(TY), fft_waves(TY))
 k_fwd_cols(const float2* __restrict__ blk, int Tx, const float2* __restrict__ tw,
-           float2* __restrict__ out0, float2* __restrict__ out1, int split2) {
+           float2* __restrict__ out0, float2* __restrict__ out1, int split2,
+           const TemplDev* __restrict__ templ) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     FftTw<TY> twr;
     twr.load(tw);
@@ -627,10 +639,16 @@ k_fwd_cols(const float2* __restrict__ blk, int Tx, const float2* __restrict__ tw
     const size_t plane = (size_t)TY * Tx;
     const float2* in = blk + (size_t)q * plane;
     const int nbx = Tx >> 2;
+    // template planes (templ != nullptr, plane q = template q of the chunk): row
+    // blocks outside the template's support were not written - they are zero
+    TemplDev t{};
+    if (templ) t = templ[q];
 #pragma unroll 4
     for (int e = 2 * threadIdx.x; e < 4 * TY; e += 2 * NT) {      // 2 cells = 16 B per lane
         int rbk = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
-        float4 x = *reinterpret_cast<const float4*>(in + ((size_t)rbk * nbx + cb) * 16 + (e & 15));
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!templ || templ_rowblock_used(t, rbk, TY))
+            x = *reinterpret_cast<const float4*>(in + ((size_t)rbk * nbx + cb) * 16 + (e & 15));
         sm[lidx<TY>(cc, 4 * rbk + rr)] = make_float2(x.x, x.y);
         sm[lidx<TY>(cc + 1, 4 * rbk + rr)] = make_float2(x.z, x.w);
     }
@@ -1565,7 +1583,8 @@ static int set_lds(sc_ctx* ctx, K kernel, size_t bytes) {
     }
 
 static int launch_fwd_cols(sc_ctx* ctx, const FftGeom& fg, int nplanes,
-                           float2* out0, float2* out1, int split2) {
+                           float2* out0, float2* out1, int split2,
+                           const TemplDev* templ = nullptr) {
     size_t lds = fft_lds_bytes(fg.Ty);
     dim3 grid(fg.Tx / 4, nplanes);
     sc_prof_begin(ctx, SC_K_FWD_COLS);
@@ -1575,7 +1594,8 @@ static int launch_fwd_cols(sc_ctx* ctx, const FftGeom& fg, int nplanes,
         if (rc) return rc;                                                     \
         hipLaunchKernelGGL(k_fwd_cols<T>, grid, dim3(fft_threads(T)), lds,     \
                            ctx->stream, (const float2*)ctx->blk.p, fg.Tx,      \
-                           (const float2*)ctx->tw_y.p, out0, out1, split2);    \
+                           (const float2*)ctx->tw_y.p, out0, out1, split2,     \
+                           templ);                                             \
     }
     DISPATCH_T(fg.Ty, FN)
 #undef FN
@@ -1632,7 +1652,8 @@ int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n, int 
 #undef FN
     sc_prof_end(ctx);
     SC_HIP(ctx, hipGetLastError());
-    int rc = launch_fwd_cols(ctx, fg, n, (float2*)ctx->vh.p, nullptr, 0);
+    int rc = launch_fwd_cols(ctx, fg, n, (float2*)ctx->vh.p, nullptr, 0,
+                             (const TemplDev*)ctx->templ.p + first);
     if (rc) return rc;
     size_t cells = half_plane(fg.Ty, fg.Tx);
     dim3 grid_s((unsigned)((cells / 2 + 255) / 256), n);
