@@ -223,13 +223,25 @@ template <bool INV>
 __device__ __forceinline__ v2 mulj(v2 a) { return INV ? v2{-a.y, a.x} : v2{a.y, -a.x}; }
 template <bool INV>
 __device__ __forceinline__ v2 cw(float c, float s) { return v2{c, INV ? s : -s}; }
+// a + j*d and a - j*d in one instruction each: the swap of d's halves and the sign
+// ride on the modifiers (written out, the compiler spends an extra v_xor per j)
+__device__ __forceinline__ v2 add_jd(v2 a, v2 d) {           // (a.x - d.y, a.y + d.x)
+    v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+}
+__device__ __forceinline__ v2 sub_jd(v2 a, v2 d) {           // (a.x + d.y, a.y - d.x)
+    v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+}
 template <bool INV>
 __device__ __forceinline__ void dft4(v2& a0, v2& a1, v2& a2, v2& a3) {
-    v2 apc = a0 + a2, amc = a0 - a2, bpd = a1 + a3, bmd = mulj<INV>(a1 - a3);
+    const v2 apc = a0 + a2, amc = a0 - a2, bpd = a1 + a3, d = a1 - a3;
     a0 = apc + bpd;
-    a1 = amc + bmd;
     a2 = apc - bpd;
-    a3 = amc - bmd;
+    a1 = INV ? add_jd(amc, d) : sub_jd(amc, d);
+    a3 = INV ? sub_jd(amc, d) : add_jd(amc, d);
 }
 // radix-R butterfly on v[0..R-1] (natural order in); X[m] ends up in v[pos(m)]
 template <int R, bool INV>
