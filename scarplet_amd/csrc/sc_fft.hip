@@ -1327,14 +1327,16 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     // end, and only where a template of this launch won.  A stored NaN SNR
     // stays: nothing compares greater than it (sc_fold's sticky NaN); a NaN score
     // never wins here - it cannot arise from the finite DEMs the host lets through.
-    // The winner is remembered as its index in the launch, one byte per cell
-    // (0xFF: unchanged), four cells to a register.
+    // The winner is remembered as its index in the launch (NONE: unchanged) and by
+    // its raw transform output; its amplitude xr * ka[winner] is formed at the
+    // write-back (the kernel is VALU-bound: every instruction per cell counts).
     constexpr int NBEST = PT ? NC : 2 * NC;
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
     auto best_of = [](int c, int part) { return PT ? c : 2 * c + part; };
-    float b_snr[NBEST], b_amp[NBEST];
-    uint32_t b_ix[NBEST / 4];
+    float b_snr[NBEST], b_xr[NBEST];
+    uint32_t b_ix[NBEST];
 #pragma unroll
-    for (int c = 0; c < NBEST / 4; ++c) b_ix[c] = 0xFFFFFFFFu;
+    for (int c = 0; c < NBEST; ++c) b_ix[c] = NONE;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int cj = col_of(c);
@@ -1342,7 +1344,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         for (int part = 0; part < (PT ? 1 : 2); ++part) {
             const bool ok = !MAPS && row_of(part) && cj >= 0 && cj < tile_of(part).vx;
             b_snr[best_of(c, part)] = ok ? at_bytes(best_snr + off_of(part), 4u * (uint32_t)cj) : 0.f;
-            b_amp[best_of(c, part)] = 0.f;
+            b_xr[best_of(c, part)] = 0.f;
         }
     }
 
@@ -1403,7 +1405,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         float ka[2], kt[2], kx2[2], fl0[2], inv_n[2];
         unsigned span[2];
         int base[2];
-        uint32_t ix4[2];
+        uint32_t tix[2];
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
             const int tg = PT ? 2 * gi_ + part : gi_;
@@ -1414,7 +1416,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             const float* e = epi + EPI_FLOATS * tgc;
             tpp[part] = tp;
             ka[part] = e[0]; kt[part] = e[1]; kx2[part] = e[2]; fl0[part] = e[3]; inv_n[part] = e[4];
-            ix4[part] = (uint32_t)tgc * 0x01010101u;
+            tix[part] = (uint32_t)tgc;
             int lo = 0, hi = t.vx - 1;
             bool r = row_of(part) && have;
             if (!FULL && !MAPS) {
@@ -1451,8 +1453,8 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                     const float d = fmaxf(fmaf(tr, scale, -T1), fmaf(fabsf(xr), kx2[part], fl0[part]));
                     float snr = fabsf(T1 * __builtin_amdgcn_rcpf(fmaf(d, inv_n[part], (float)SC_EPS)));
                     const bool in = (unsigned)(cj - base[part]) <= span[part];
-                    float amp = xr * ka[part];
                     if (MAPS || FULL) {
+                        float amp = xr * ka[part];
                         // `in` is the tile's valid extent here; masks per cell
                         if (in) {
                             if (FULL)
@@ -1469,16 +1471,14 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                         } else {
                             snr = 0.f;
                         }
-                    } else {
-                        snr = in ? snr : 0.f;
                     }
                     if (!MAPS) {
-                        // sc_fold: take if greater, ties keep the incumbent
-                        const bool won = snr > b_snr[k];
+                        // sc_fold: take if greater, ties keep the incumbent; a cell outside
+                        // the range (lean variant) or masked to 0 never wins
+                        const bool won = (FULL || in) && snr > b_snr[k];
                         b_snr[k] = won ? snr : b_snr[k];
-                        b_amp[k] = won ? amp : b_amp[k];
-                        const uint32_t bm = 0xFFu << (8 * (k & 3));
-                        b_ix[k >> 2] = won ? ((b_ix[k >> 2] & ~bm) | (ix4[part] & bm)) : b_ix[k >> 2];
+                        b_xr[k] = won ? xr : b_xr[k];
+                        b_ix[k] = won ? tix[part] : b_ix[k];
                     }
                 }
             }
@@ -1488,12 +1488,12 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     if (!MAPS) {
 #pragma unroll
         for (int k = 0; k < NBEST; ++k) {
-            const uint32_t ix = (b_ix[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-            if (ix != 0xFFu) {
+            const uint32_t ix = b_ix[k];
+            if (ix != NONE) {
                 const int c = PT ? k : k >> 1, part = PT ? 0 : (k & 1);
                 const uint32_t o = 4u * (uint32_t)col_of(c);
                 at_bytes(best_snr + off_of(part), o) = b_snr[k];
-                at_bytes(best_amp + off_of(part), o) = b_amp[k];
+                at_bytes(best_amp + off_of(part), o) = b_xr[k] * epi[EPI_FLOATS * ix];
                 at_bytes(best_id + off_of(part), o) = templ[ra.first + ix].id;
             }
         }
