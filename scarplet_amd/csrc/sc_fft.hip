@@ -431,7 +431,9 @@ __device__ __forceinline__ void fft_stage(float2* s, const FftTw<T>& twr) {
         int id = threadIdx.x + u * NT;
         if (id < 4 * S) set_load<T>(s + (id / S) * fft_line(T), id % S, a[u]);
     }
-    lds_barrier();
+    // the last stage works in place: butterfly bt reads the elements bt + k*T/R and
+    // writes bt + m*T/R, the same cells - no other thread is waiting for them
+    if constexpr ((R << LST) != T) lds_barrier();
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         int id = threadIdx.x + u * NT;
