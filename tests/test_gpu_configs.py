@@ -160,3 +160,25 @@ def test_odd_tile_count_and_odd_template_count(gpu_ctx):
     chk = fold_check(res, g._griddata, 1.0, 1.0, orc.SCARP, 30, ages, angles)
     assert chk["n_bad"] == 0, (p, chk)
     assert chk["n_strict"] > 0.9 * chk["n"], chk
+
+
+def test_paired_templates_agree_with_paired_tiles(monkeypatch):
+    """Device self-consistency on a DEM too large for the oracle stack: the
+    paired-template mode of an unpaired tile (default) against the same search
+    with that tile in a half-empty tile pair (SC_VARIANT=5 switches the mode off)."""
+    g = synthetic.synthetic_scarp(1700, ny=1650, seed=11)
+    ages, angles = _plan.age_grid()[::5], _plan.angle_grid()[::30]
+    out = {}
+    for variant in ("0", "5"):
+        monkeypatch.setenv("SC_VARIANT", variant)
+        m = sl.Matcher(g)                     # a fresh context reads the variable
+        out[variant] = m.search(sl.Scarp, 100, ages, angles, method="fft").result()
+        assert (m.plan.nty * m.plan.ntx) % 2 == 1, m.plan
+        del m
+    a, b = out["0"], out["5"]
+    same = (a[1] == b[1]) & (a[2] == b[2])
+    assert same.mean() > 0.999, float(same.mean())
+    assert np.allclose(a[3][same], b[3][same], rtol=2e-4, atol=1e-7 * b[3].max())
+    assert np.allclose(a[0][same], b[0][same], rtol=2e-4, atol=1e-7 * np.abs(b[0]).max())
+    # where the winner differs the two SNRs are a near-tie
+    assert np.allclose(a[3][~same], b[3][~same], rtol=TIE_RTOL)
