@@ -182,3 +182,24 @@ def test_paired_templates_agree_with_paired_tiles(monkeypatch):
     assert np.allclose(a[0][same], b[0][same], rtol=2e-4, atol=1e-7 * np.abs(b[0]).max())
     # where the winner differs the two SNRs are a near-tie
     assert np.allclose(a[3][~same], b[3][~same], rtol=TIE_RTOL)
+
+
+def test_symmetric_spectrum_path_agrees_with_complex_path(monkeypatch):
+    """The real-coefficient path of Scarp / Ricker templates (k_split_templ_sym,
+    k_inv_cols_sym) against the complex-spectrum path every other template takes
+    (SC_VARIANT=8 forces it), on several tiles of an even x odd DEM."""
+    g = synthetic.synthetic_scarp(2600, ny=2301, seed=12)
+    ages, angles = _plan.age_grid()[2::8], _plan.angle_grid()[7::40]
+    out = {}
+    for variant in ("0", "8"):
+        monkeypatch.setenv("SC_VARIANT", variant)
+        m = sl.Matcher(g)
+        out[variant] = m.search(sl.Scarp, 100, ages, angles, method="fft").result()
+        assert m.plan.nty * m.plan.ntx > 1
+        del m
+    a, b = out["0"], out["8"]
+    same = (a[1] == b[1]) & (a[2] == b[2])
+    assert same.mean() > 0.999, float(same.mean())
+    assert np.allclose(a[3][same], b[3][same], rtol=2e-4, atol=1e-7 * b[3].max())
+    assert np.allclose(a[0][same], b[0][same], rtol=2e-4, atol=1e-7 * np.abs(b[0]).max())
+    assert np.allclose(a[3][~same], b[3][~same], rtol=TIE_RTOL)
