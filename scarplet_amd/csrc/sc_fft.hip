@@ -1195,6 +1195,9 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
 // small LDS tables.  The two rows of a rows2 pair share their 128-byte lines:
 // their workgroups are given block ids 8 apart, i.e. the same XCD at the same
 // time, so the second reader hits in that XCD's L2.
+#ifndef SC_I2_WAVES
+#define SC_I2_WAVES 4      // waves per SIMD the fast row kernel is compiled for (LDS fits 4 workgroups per CU)
+#endif
 #ifndef SC_I2_FETCH_AT
 #define SC_I2_FETCH_AT 0
 #endif
@@ -1208,19 +1211,19 @@ template <typename V>
 __device__ __forceinline__ V& at_bytes(V* base, uint32_t off) {
     return *reinterpret_cast<V*>(reinterpret_cast<char*>(base) + off);
 }
-constexpr int EPI_FLOATS = 8;                  // per-template scalars staged in LDS
-// LDS: 4 lines | per-template scalars | stage-1 twiddle bases (4 per set index)
+constexpr int EPI_FLOATS = 5;                  // per-template scalars staged in LDS
+// LDS: 2 lines | per-template scalars | stage-1 twiddle bases (w^tt, w^8tt per set index)
 //      | stage-2 twiddles (16 per p = 0 .. S/16-1)
 template <int TX>
 __host__ __device__ constexpr int inv_rows_fast_threads() { return TX / 8; }
 template <int TX>
 __host__ __device__ constexpr size_t inv_rows_fast_lds() {
     return fft_lds_bytes(TX) / 2 + (size_t)SC_MAX_GROUP * EPI_FLOATS * sizeof(float) +
-           (size_t)(TX / 16) * 4 * sizeof(float2) + (size_t)(TX / 256) * 16 * sizeof(float2);
+           (size_t)(TX / 16) * 2 * sizeof(float2) + (size_t)(TX / 256) * 16 * sizeof(float2);
 }
 
 template <int TX, bool FULL, bool MAPS, bool PT>
-__global__ void __launch_bounds__(inv_rows_fast_threads<TX>(), 3)
+__global__ void __launch_bounds__(inv_rows_fast_threads<TX>(), SC_I2_WAVES)
 k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 RowArgs ra, Geom g, const TileDev* __restrict__ tiles,
                 const TemplDev* __restrict__ templ, const double* __restrict__ sums,
@@ -1255,7 +1258,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
 
     float* epi = reinterpret_cast<float*>(sm + 2 * LINE);
     v2* tw1 = reinterpret_cast<v2*>(epi + SC_MAX_GROUP * EPI_FLOATS);
-    v2* tw2 = tw1 + 4 * S;
+    v2* tw2 = tw1 + 2 * S;
     // per-template scalars of the epilogue (float64 arithmetic on the template
     // sums) are the same for every cell: thread t prepares template t once and
     // parks the five floats in LDS.  xcorr = xr*scale_w, T3 = tr*scale
@@ -1277,8 +1280,8 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     // twiddle tables (inverse transform: conjugates of the forward table):
     //   stage 1 (stride 1):  set tt multiplies output m by w^(tt*m); bases m = 1,2,4,8
     //   stage 2 (stride 16): set tt multiplies output m by w^(16*(tt>>4)*m)
-    for (int i = id; i < 4 * S; i += NT) {
-        float2 w = tw[(i >> 2) << (i & 3)];
+    for (int i = id; i < 2 * S; i += NT) {                       // bases w^tt and w^(8 tt) per set tt
+        float2 w = tw[(i >> 1) << (3 * (i & 1))];
         tw1[i] = v2{w.x, -w.y};
     }
     for (int i = id; i < S; i += NT) {
@@ -1336,9 +1339,9 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     auto best_of = [](int c, int part) { return PT ? c : 2 * c + part; };
     float b_snr[NBEST], b_xr[NBEST];
-    uint32_t b_ix[NBEST];
+    uint32_t b_ix[NBEST / 4];                  // one byte per cell (0xFF: unchanged)
 #pragma unroll
-    for (int c = 0; c < NBEST; ++c) b_ix[c] = NONE;
+    for (int c = 0; c < NBEST / 4; ++c) b_ix[c] = NONE;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int cj = col_of(c);
@@ -1368,7 +1371,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         // ---- stage 1 (radix 16, stride 1) from registers: outputs 16 tt1 + m
         {
             pk::B<16, true>::run(a);
-            const v2 w1 = tw1[4 * tt1], w2 = tw1[4 * tt1 + 1], w4 = tw1[4 * tt1 + 2], w8 = tw1[4 * tt1 + 3];
+            const v2 w1 = tw1[2 * tt1], w8 = tw1[2 * tt1 + 1], w2 = pk::cmul(w1, w1), w4 = pk::cmul(w2, w2);
             line1[0] = a[pk::B<16, true>::pos(0)];
             line1[8] = pk::cmul(a[pk::B<16, true>::pos(8)], w8);
 #pragma unroll
@@ -1418,7 +1421,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             const float* e = epi + EPI_FLOATS * tgc;
             tpp[part] = tp;
             ka[part] = e[0]; kt[part] = e[1]; kx2[part] = e[2]; fl0[part] = e[3]; inv_n[part] = e[4];
-            tix[part] = (uint32_t)tgc;
+            tix[part] = (uint32_t)tgc * 0x01010101u;
             int lo = 0, hi = t.vx - 1;
             bool r = row_of(part) && have;
             if (!FULL && !MAPS) {
@@ -1480,7 +1483,8 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                         const bool won = (FULL || in) && snr > b_snr[k];
                         b_snr[k] = won ? snr : b_snr[k];
                         b_xr[k] = won ? xr : b_xr[k];
-                        b_ix[k] = won ? tix[part] : b_ix[k];
+                        const uint32_t bm = 0xFFu << (8 * (k & 3));
+                        b_ix[k >> 2] = won ? ((b_ix[k >> 2] & ~bm) | (tix[part] & bm)) : b_ix[k >> 2];
                     }
                 }
             }
@@ -1490,8 +1494,8 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     if (!MAPS) {
 #pragma unroll
         for (int k = 0; k < NBEST; ++k) {
-            const uint32_t ix = b_ix[k];
-            if (ix != NONE) {
+            const uint32_t ix = (b_ix[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            if (ix != 0xFFu) {
                 const int c = PT ? k : k >> 1, part = PT ? 0 : (k & 1);
                 const uint32_t o = 4u * (uint32_t)col_of(c);
                 at_bytes(best_snr + off_of(part), o) = b_snr[k];
