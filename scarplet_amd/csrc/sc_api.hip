@@ -72,7 +72,14 @@ void sc_prof_begin(sc_ctx* ctx, int kernel) {
     ctx->prof_kernel = kernel;
     const long long b = ctx->k_brackets[kernel]++;
     if (!ctx->prof) return;
-    if (b % ctx->prof) return;
+    // one bracket in `prof`, chosen by a hash of the counter: the launches of a
+    // kernel come in periodic patterns (curvature / template forward passes, first
+    // / second chunk of an orientation) that a fixed stride would alias with
+    uint32_t h = (uint32_t)b * 2654435761u;
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    if (ctx->prof > 1 && h % (uint32_t)ctx->prof) return;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (!ctx->ev_pool.empty()) {
         ev = ctx->ev_pool.back();
