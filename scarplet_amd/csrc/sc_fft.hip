@@ -1187,10 +1187,11 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
 //     no LDS write of the result, no read back;
 //   * the running best record of a thread's 16 cells stays in registers across
 //     the G templates of the launch and is written back once.
-// Small workgroups on purpose: three of them share a CU (3 waves per SIMD, 168
-// VGPRs each), so one computes while another sits in a barrier or waits for LDS
-// or HBM; a 512-thread workgroup per row pair left the SIMDs idle two thirds of
-// the time.  Complex values are native 2-vectors (v_pk_add/mul/fma_f32: one
+// Small workgroups on purpose: four of them share a CU (39 KB of LDS and at most
+// 128 VGPRs each - hence the packed winner index and the two-entry twiddle
+// table), so one computes while another sits in a barrier or waits for LDS or
+// HBM; a 512-thread workgroup per row pair left the SIMDs idle two thirds of the
+// time, three workgroups per CU were 6 % slower than four.  Complex values are native 2-vectors (v_pk_add/mul/fma_f32: one
 // instruction per complex add, two per complex product) and twiddles come from
 // small LDS tables.  The two rows of a rows2 pair share their 128-byte lines:
 // their workgroups are given block ids 8 apart, i.e. the same XCD at the same
