@@ -14,7 +14,7 @@ from scarplet_amd import _plan, synthetic, _lib, dist as sd
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--halo", default="gloo")
-ap.add_argument("--n", type=int, default=700)
+ap.add_argument("--size", dest="n", type=int, default=700)
 a = ap.parse_args()
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
