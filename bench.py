@@ -11,8 +11,24 @@ rank exchanges halos over RCCL and searches its tile: total work is fixed, so
 scaling is "strong".  torch is used for the launcher contract only (rank
 rendezvous, barrier, max-reduce of the timings); the product path is
 ctypes -> libscarplet_hip.so.
+
+Besides the contract's fields the JSON line carries
+  roofline       dominant kernel against the 28-B / 8 TB/s HBM roofline; its
+                 `traffic` is the PMC-measured bytes per launch, printed only
+                 when profiles/traffic.json was measured on this very .so
+  cpu_baseline   the oracle timed on this box's host cores:
+                 whole-DEM templates, process-pool fan-out like core.py:180-183
+  end_to_end     sl.match() wall time (H2D of the DEM, descriptors, search,
+                 result conversion and D2H) as Mpx.template/s
+  verified       a window of the result checked against the oracle after the
+                 timed loop (every template of the search, near-tie policy)
+
+Other workloads: --config C1|C2|C5 (BASELINE.json configs as SURVEY.md 8d
+defines them), --emulate-ranks R (the R rank blocks of the tiled search run one
+after the other on this GPU: per-block times, their max and sum).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -25,9 +41,8 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_UNIT = 28.0        # bytes per px.template
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
-# profiling slot of the library -> kernel symbols as rocprofv3 lists them (Scarp / Ricker
-# searches at T = 512..2048; each tile pair takes one launch of either instantiation)
-KERNEL_SYMBOLS = {"k_inv_cols": "k_inv_cols_sym<T,false|true,false>", "k_inv_rows": "k_inv_rows_fast<T,false,false,false>"}
+# profiling slot of the library -> kernel symbols as rocprofv3 lists them
+KERNEL_SYMBOLS = {"k_inv_cols": "k_inv_cols_sym<T,...>", "k_inv_rows": "k_inv_rows_fast<T,false,false,false>"}
 
 
 def parse():
@@ -35,90 +50,256 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", dest="n", type=int, default=10000, help="DEM size (default: C3)")
-    ap.add_argument("--ages", type=int, default=35)
-    ap.add_argument("--angles", type=int, default=181)
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C5"])
+    ap.add_argument("--size", dest="n", type=int, default=0, help="synthetic DEM size (default: the config's)")
+    ap.add_argument("--ages", type=int, default=0, help="ages of the grid (default: the config's)")
+    ap.add_argument("--angles", type=int, default=0, help="orientations (default: the config's)")
     ap.add_argument("--method", default="fft")
     ap.add_argument("--group", type=int, default=0, help="templates per inverse launch (0: auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--prof-stride", type=int, default=16)
-    ap.add_argument("--halo", default="rccl", choices=["rccl", "gloo"],
-                    help="halo exchange executor for --gpus > 1 (gloo: host arrays, for bring-up)")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="run the R blocks of the R-rank tiled search sequentially on this GPU")
+    ap.add_argument("--halo", default="rccl", choices=["rccl", "host", "gloo"],
+                    help="halo exchange executor for --gpus > 1 (host: host arrays over gloo, for bring-up)")
     return ap.parse_args()
 
 
-def _cpu_one(args):
-    z, age, ang = args
+# ----------------------------------------------------------------------------- workloads
+def workload(a):
+    """(DEMGrid, Template, [scales], params, angles, label, oracle kind) of a BASELINE config
+    (SURVEY.md section 8(d) definitions)."""
+    import scarplet_amd as sl
+    from scarplet_amd import _plan, synthetic
+    ages35, ang181 = _plan.age_grid(), _plan.angle_grid()
+
+    def pick(arr, k):
+        return arr if not k or k >= len(arr) else arr[np.round(np.linspace(0, len(arr) - 1, k)).astype(int)]
+    if a.config == "C3":
+        n = a.n or 10000
+        ages, angles = pick(ages35, a.ages), pick(ang181, a.angles)
+        full = n == 10000 and len(ages) == 35 and len(angles) == 181
+        label = "%s: %dx%d synthetic erf-scarp DEM (BASELINE.md s3), Scarp, scale=100, %d ages x %d orientations" % (
+            "C3" if full else "reduced C3", n, n, len(ages), len(angles))
+        return synthetic.synthetic_scarp(n), sl.Scarp, [100.0], ages, angles, label, "scarp"
+    if a.config == "C2":
+        n = a.n or 2048
+        ages = ages35[np.round(np.linspace(0, 34, 10)).astype(int)]
+        angles = pick(_plan.angle_grid(-np.pi / 4, np.pi / 4), a.angles)
+        label = "C2: %dx%d synthetic DEM, Scarp, scale=100, %d ages x %d orientations" % (n, n, len(ages), len(angles))
+        return synthetic.synthetic_scarp(n), sl.Scarp, [100.0], ages, angles, label, "scarp"
+    f = np.load(os.path.join(ROOT, "tests", "golden",
+                             "dem_carrizo.npz" if a.config == "C1" else "dem_grandcanyon.npz"))
+    g = sl.DEMGrid.from_array(f["z"].astype(float), float(f["dx"]), float(f["dy"]))
+    if a.config == "C1":
+        lim = 17 * np.pi / 180
+        angles = _plan.angle_grid(-lim, lim)
+        return g, sl.Scarp, [100.0], np.array([10.0]), angles, \
+            "C1: load_carrizo() 900x505 lidar DEM at 2 m, Scarp, scale=100, age=10, 35 orientations", "scarp"
+    return g, sl.Channel, [5.0, 10.0, 20.0, 40.0, 80.0], np.array([0.1]), pick(ang181, a.angles), \
+        "C5: load_grandcanyon() 512x512 (dx=1, dy=-1), Channel f=0.1, 5 scales x 181 orientations", "ricker"
+
+
+# ----------------------------------------------------------------------------- CPU baseline
+def _cpu_one(job):
+    age, ang = job
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import scarplet_oracle as orc
-    orc.match_template(z, 1.0, 1.0, orc.SCARP, 100, age, ang, workers=1)
-    return 1
+    z, dx, dy, kind, scale = _CPU_CTX
+    t0 = time.time()
+    orc.match_template(z, dx, dy, kind, scale, age, ang, workers=1)
+    return time.time() - t0
 
 
-def cpu_baseline(z_full, ages, angles, budget_s=25.0):
-    """The oracle (float64 FFT restatement of core.py:297-377) timed on this
-    box's host cores the way the reference runs it: a process pool over
-    templates (core.py:180-183), one single-threaded FFT convolution per
-    process.  Bounded sample: a 2048 x 2048 crop of the DEM, one template per
-    worker drawn across the (age, angle) grid."""
+_CPU_CTX = None
+
+
+def mem_available_bytes():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 64 << 30
+
+
+def cpu_baseline(g, kind, scale, params, angles, max_workers=48):
+    """The oracle (float64 restatement of core.py:297-377, scipy.fft/pocketfft
+    because pyfftw is not in the image) on THIS box's host cores, run the way
+    the reference runs a search: a process pool over templates
+    (core.py:180-183), every worker one whole-DEM template with
+    single-threaded FFTs.  Bounded sample: one template per worker, stratified
+    over the (age, orientation) grid (small and large supports, all quadrants);
+    workers = min(cores, available RAM / 12 GB per 10000 x 10000 template, 48).
+    The figure is units-per-second of the sample, i.e. the full search's rate
+    by extrapolation (every template costs the same FFTs)."""
+    global _CPU_CTX
     import multiprocessing as mp
+    z = np.ascontiguousarray(g._griddata, dtype=np.float64)
+    ny, nx = z.shape
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-    workers = max(1, min(cores, 64))
-    c = min(2048, z_full.shape[0])
-    z = np.ascontiguousarray(z_full[:c, :c], dtype=np.float64)
-    rng = np.random.default_rng(0)
-    picks = [(z, float(ages[rng.integers(len(ages))]), float(angles[rng.integers(len(angles))]))
-             for _ in range(workers)]
+    per_worker = 120.0 * ny * nx + (64 << 20)         # ~11 GB transient at 10000^2 (SURVEY.md 8a, row a7)
+    workers = int(max(1, min(cores, max_workers, 0.6 * mem_available_bytes() // per_worker)))
+    n_all = len(params) * len(angles)
+    n_s = max(min(8, n_all), min(workers, n_all))
+    # stratified: spread over the flattened (age-major) grid with a stride coprime to both axes
+    idx = np.unique(np.round(np.linspace(0, n_all - 1, n_s)).astype(int))
+    jobs = [(float(params[i // len(angles)]), float(angles[(i * 7) % len(angles)])) for i in idx]
+    _CPU_CTX = (z, float(g._georef_info.dx), float(g._georef_info.dy), kind, float(scale))
     ctx = mp.get_context("fork")
-    with ctx.Pool(workers) as pool:
-        pool.map(_cpu_one, picks[:workers])          # warm the workers (imports, FFT plans)
-        t0 = time.time()
-        done = sum(pool.map(_cpu_one, picks, chunksize=1))
-        dt = time.time() - t0
-    return {"value": round(c * c * done / dt / 1e6, 3), "unit": "Mpx.template/s", "cores": int(workers),
-            "kind": "port", "sample": "%d templates of the 35x181 grid on a %dx%d crop of the DEM, "
-            "oracle/scarplet_oracle.py, process pool of %d single-threaded workers (%d cores visible), %.1f s"
-            % (done, c, c, workers, cores, dt)}
+    t0 = time.time()
+    with ctx.Pool(min(workers, len(jobs))) as pool:
+        per = pool.map(_cpu_one, jobs, chunksize=1)
+    dt = time.time() - t0
+    _CPU_CTX = None
+    value = ny * nx * len(jobs) / dt / 1e6
+    return {"value": round(value, 3), "unit": "Mpx.template/s", "cores": int(min(workers, len(jobs))), "kind": "port",
+            "sample": "%d of the %d templates (stratified over ages and orientations) on the full %dx%d DEM, "
+                      "oracle/scarplet_oracle.py (float64, scipy.fft single-threaded per template), process pool of "
+                      "%d workers like core.py:180-183 (%d cores visible, %.0f GB RAM available), wall %.1f s, "
+                      "mean %.1f s per template per worker; the full search's rate is this figure by extrapolation "
+                      "(x%d templates)" % (len(jobs), n_all, ny, nx, min(workers, len(jobs)), cores,
+                                           mem_available_bytes() / 1e9, dt, float(np.mean(per)), n_all)}
 
 
+# ----------------------------------------------------------------------------- verification
+def verify_window(res, g, kind, scale, params, angles, plan):
+    """A window of the finished search against the oracle, every template of the
+    grid (oracle.snr_stack_window + check_fold, tolerances oracle.PARITY).  The
+    window straddles the corner where four FFT tiles meet when the plan is tiled."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import scarplet_oracle as orc
+    ny, nx = g._griddata.shape
+    w = 48 if min(ny, nx) >= 512 else 16
+    reach = max(abs(v) for v in plan.bbox) + 3
+    ci = plan.Vy if getattr(plan, "nty", 1) > 1 else ny // 2
+    cj = plan.Vx if getattr(plan, "ntx", 1) > 1 else nx // 3
+    i0, j0 = max(0, min(ny - w, ci - w // 2)), max(0, min(nx - w, cj - w // 2))
+    win = (i0, i0 + w + (ny % 2), j0, j0 + w + (nx % 2))        # crop parity = DEM parity
+    if 2 * reach + w >= min(ny, nx):
+        return {"ok": None, "note": "DEM too small for a windowed check"}
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    t0 = time.time()
+    a_st, s_st = orc.snr_stack_window(g._griddata, float(g._georef_info.dx), float(g._georef_info.dy), kind, scale,
+                                      params, angles, win, reach, procs=max(1, min(cores, 64)))
+    T = len(params) * len(angles)
+    h, wd = win[1] - win[0], win[3] - win[2]
+    sub = tuple(np.asarray(r)[win[0]:win[1], win[2]:win[3]] for r in res)
+    P = orc.PARITY
+    chk = orc.check_fold(sub, a_st.reshape(T, h, wd), s_st.reshape(T, h, wd), np.repeat(params, len(angles)),
+                         np.tile(angles, len(params)), tie_rtol=P["tie_rtol"],
+                         amp_tol=(P["amp"][0], P["amp"][1] * np.max(np.abs(a_st))),
+                         snr_tol=(P["snr"][0], P["snr"][1] * np.max(s_st)))
+    return {"ok": chk["n_bad"] == 0, "window": list(win), "templates": T, "cells": chk["n"], "bad": chk["n_bad"],
+            "exact_argmax_frac": round(chk["exact_frac"], 5), "near_tie_cells": chk["n_tie"],
+            "max_rel_snr_err": float("%.3g" % chk["snr_err"]), "max_rel_amp_err": float("%.3g" % chk["amp_err"]),
+            "tie_rtol": P["tie_rtol"], "oracle_s": round(time.time() - t0, 1)}
+
+
+def so_sha256():
+    from scarplet_amd import _lib
+    h = hashlib.sha256()
+    with open(_lib.LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def measured_traffic(dom, default_workload):
+    """PMC bytes per launch of the dominant kernel from profiles/traffic.json -
+    only if that file was measured (tools/prof_run.sh) on this very library."""
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if not (default_workload and os.path.exists(tf)):
+        return None
+    try:
+        t = json.load(open(tf))
+        if t.get("so_sha256") != so_sha256():
+            return None
+        return t.get("bytes_per_launch", {}).get(dom)
+    except Exception:
+        return None
+
+
+# ----------------------------------------------------------------------------- main
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    transport = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo")
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from torch_transport import TorchTransport
+        transport = TorchTransport()
 
     import scarplet_amd as sl
-    from scarplet_amd import _plan, synthetic, _lib
+    from scarplet_amd import _lib
     from scarplet_amd import dist as sd
     ndev = max(1, _lib.load().sc_device_count())
     device = local % ndev                      # one rank per GPU; wraps only in bring-up runs
 
-    ages = _plan.age_grid()[np.round(np.linspace(0, 34, a.ages)).astype(int)]
-    angles = _plan.angle_grid()[np.round(np.linspace(0, 180, a.angles)).astype(int)]
-    g = synthetic.synthetic_scarp(a.n)                 # same seed on every rank
-    n_templates = len(ages) * len(angles)
-    units = float(a.n) * a.n * n_templates             # px.template per step
+    g, Template, scales, params, angles, label, kind = workload(a)     # same seed on every rank
+    ny, nx = g._griddata.shape
+    n_templates = len(params) * len(angles) * len(scales)
+    units = float(ny) * nx * n_templates               # px.template per step
+    emu = None
 
-    if world == 1:
-        m = sl.Matcher(g, device=device)
-        arr, bbox, area = m.describe(sl.Scarp, 100, ages, angles)
-        plan, sp = m.plan_for(bbox, area, a.method, a.group or None, n_params=len(ages))
+    if world == 1 and a.emulate_ranks > 1:
+        # the R blocks of the R-rank search, one after the other on this GPU
+        R = a.emulate_ranks
+        m = sl.Matcher(device=device)
+        m.ny, m.nx, m.de = ny, nx, float(g._georef_info.dx)
+        arr, bbox, area = m.describe(Template, scales[0], params, angles)
+        halo = sd.halo_for_search(bbox, ny, nx)
+        py, px = sd.grid_dims(R, ny, nx)
+        lay = sd.Layout(ny, nx, py, px, halo)
+        blocks = [np.ascontiguousarray(sd.assemble_block_reference(g._griddata, lay, r)) for r in range(R)]
+        halo_bytes = [8 * (blocks[r].size - (lay.core(r)[1] - lay.core(r)[0]) * (lay.core(r)[3] - lay.core(r)[2]))
+                      for r in range(R)]
+        per_block = np.zeros(R)
+        plans = []
 
         def step():
-            m.ctx.reset_best()
-            m.ctx.match(arr, sp, sync=True)
+            for r in range(R):
+                t0 = time.perf_counter()
+                m.set_block(blocks[r], lay.block_origin(r), (ny, nx), lay.core(r),
+                            float(g._georef_info.dx), float(g._georef_info.dy))
+                plan, sp = m.plan_for(bbox, area, a.method, a.group or None, n_params=len(params))
+                m.ctx.reset_best()
+                m.ctx.match(arr, sp, sync=True)
+                per_block[r] += time.perf_counter() - t0
+                if len(plans) < R:
+                    plans.append(plan)
         ctx = m.ctx
+        emu = (R, py, px, per_block, halo_bytes, plans)
+    elif world == 1:
+        m = sl.Matcher(g, device=device)
+        descs = []
+        for sc in scales:
+            arr, bbox, area = m.describe(Template, sc, params, angles)
+            plan, sp = m.plan_for(bbox, area, a.method, a.group or None, n_params=len(params))
+            descs.append((arr, sp, plan))
+
+        def step():
+            for (arr_, sp_, _) in descs:               # one result set per scale (C5)
+                m.ctx.reset_best()
+                m.ctx.match(arr_, sp_, sync=True)
+        ctx = m.ctx
+        plan = descs[-1][2]
     else:
-        dm = sd.DistMatcher(rank, world, (a.n, a.n), 1.0, 1.0, device=device, backend=a.halo)
+        dm = sd.DistMatcher(rank, world, (ny, nx), float(g._georef_info.dx), float(g._georef_info.dy),
+                            device=device, backend=a.halo, transport=transport)
         c = dm.core()
         z_core = np.ascontiguousarray(g._griddata[c[0]:c[1], c[2]:c[3]])
-        arr, bbox, area = dm.m.describe(sl.Scarp, 100, ages, angles)
+        arr, bbox, area = dm.m.describe(Template, scales[0], params, angles)
         dm.load(z_core, bbox)                          # halo exchange over RCCL
-        plan, sp = dm.m.plan_for(bbox, area, a.method, a.group or None, n_params=len(ages))
+        plan, sp = dm.m.plan_for(bbox, area, a.method, a.group or None, n_params=len(params))
 
         def step():
             dm.load(z_core, bbox)                      # the exchange is part of a search
@@ -133,6 +314,8 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    if emu:
+        emu[3][:] = 0.0
     ctx.profile(a.prof_stride)
     barrier()
     t0 = time.perf_counter()
@@ -146,6 +329,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     prof = ctx.profile_get()
+    ctx.profile(0)
 
     if rank == 0:
         ms = 1e3 * dt / a.steps
@@ -154,42 +338,77 @@ def main():
         # = 28 B x the px.templates one launch serves (DESIGN.md "Roofline")
         dom = max(prof, key=lambda k: prof[k][1])
         launches, total_ms = prof[dom]
-        core = ctx.core
-        core_px = (core[1] - core[0]) * (core[3] - core[2])
-        per_launch_units = core_px * n_templates * a.steps / max(launches, 1)
+        per_launch_units = units * a.steps / max(launches, 1) / (world if world > 1 else 1)
         avg_s = total_ms / 1e3 / max(launches, 1)
         achieved = ALGO_BYTES_PER_UNIT * per_launch_units / avg_s / 1e9 if avg_s > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        default_workload = (world == 1 and a.n == 10000 and len(ages) == 35 and len(angles) == 181
+        default_workload = (world == 1 and not emu and a.config == "C3" and label.startswith("C3:")
                             and a.method == "fft")
-        if os.path.exists(tf) and default_workload:      # measured on exactly this workload
-            try:
-                traffic = json.load(open(tf)).get(dom)
-            except Exception:
-                traffic = None
+        if emu:
+            plan = emu[5][0]
         out = {
             "metric": "Mpixel·template/s (DEM pixels × ages × orientations / s)",
             "value": round(value, 1), "unit": "Mpx·template/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %dx%d synthetic erf-scarp DEM (BASELINE.md s3), Scarp, "
-                       "scale=100, %d ages x %d orientations" % (
-                           "C3" if (a.n == 10000 and len(ages) == 35 and len(angles) == 181) else "reduced",
-                           a.n, a.n, len(ages), len(angles)),
-                       "method": a.method, "tiles": "%dx%d of %dx%d" % (plan.nty, plan.ntx, plan.Ty, plan.Tx),
-                       "ranks": "%d (%s tile grid)" % (world, "x".join(map(str, sd.grid_dims(world, a.n, a.n))))},
+            "dtype": "f32", "data": "synthetic" if a.config in ("C2", "C3") else "reference sample DEM (tests/golden)",
+            "config": {"workload": label, "method": a.method,
+                       "tiles": ("%dx%d of %dx%d" % (plan.nty, plan.ntx, plan.Ty, plan.Tx)) if a.method == "fft" else "-",
+                       "group": int(getattr(plan, "group", 0)),
+                       "ranks": "%d (%s tile grid)" % (world, "x".join(map(str, sd.grid_dims(world, ny, nx))))},
             "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOLS.get(dom, dom) if a.method == "fft" else dom,
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "launches": int(launches),
+                         "traffic": measured_traffic(dom, default_workload), "launches": int(launches),
                          "avg_launch_us": round(1e6 * avg_s, 2),
-                         "pipeline_frac": round(value * 1e6 * ALGO_BYTES_PER_UNIT / (HBM_PEAK_GBS * 1e9 * world), 4)},
+                         "pipeline_frac": round(value * 1e6 * ALGO_BYTES_PER_UNIT / (HBM_PEAK_GBS * 1e9 * world), 4),
+                         "note": "frac follows the prescribed formula (28 B x the launch's px.templates / its "
+                                 "duration) and credits the dominant kernel with the whole path's bytes; "
+                                 "pipeline_frac is the whole search against 8 TB/s / 28 B"},
             "kernels_ms_per_step": {k: round(v[1] / a.steps, 2) for k, v in prof.items() if v[0]},
         }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(g._griddata, ages, angles)
+        if emu:
+            R, py, px, per_block, halo_bytes, plans = emu
+            pb = per_block / a.steps
+            out["emulated_ranks"] = {
+                "ranks": R, "grid": "%dx%d" % (py, px),
+                "block_ms": [round(1e3 * v, 1) for v in pb],
+                "max_block_ms": round(1e3 * float(pb.max()), 1), "sum_block_ms": round(1e3 * float(pb.sum()), 1),
+                "halo_bytes_per_rank": int(max(halo_bytes)),
+                "tiles_per_block": "%dx%d of %dx%d" % (plans[0].nty, plans[0].ntx, plans[0].Ty, plans[0].Tx),
+                "predicted_value_at_%d_gpus" % R: round(units / float(pb.max()) / 1e6, 1),
+                "note": "PREDICTED, not measured: every block (core + torus halo, upload and curvature planes "
+                        "included) searched alone on one GPU; the slowest block bounds the %d-GPU step, the halo "
+                        "exchange (halo_bytes_per_rank over xGMI) comes on top" % R}
+        if world == 1 and not emu:
+            if not a.no_verify:
+                # the record the timed loop left behind (the last scale's, for C5)
+                res = ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
+                ver = verify_window(res, g, kind, scales[-1], params, angles, plan)
+                del res
+                out["verified"] = ver["ok"]
+                out["verification"] = ver
+            if not a.no_e2e and len(scales) == 1:
+                # the whole call a user makes: upload of z, curvature planes, descriptors, search,
+                # float64 result planes, D2H
+                ctx.sync()
+                t1 = time.perf_counter()
+                if default_workload:
+                    sl.match(g, Template, scale=scales[0], device=device, method=a.method)
+                elif len(params) == 1:
+                    sl.match(g, Template, scale=scales[0], age=float(params[0]), ang_min=float(angles[0]),
+                             ang_max=float(angles[-1]), device=device, method=a.method)
+                else:
+                    sl.Matcher(g, device=device).search(Template, scales[0], params, angles, method=a.method,
+                                                        group=a.group or None).result()
+                e2e = time.perf_counter() - t1
+                out["end_to_end"] = {"value": round(units / e2e / 1e6, 1), "unit": "Mpx·template/s",
+                                     "seconds": round(e2e, 3),
+                                     "call": "sl.match(data, Template, scale=...)" if (default_workload or len(params) == 1)
+                                             else "Matcher(data).search(...).result()",
+                                     "includes": "H2D of the float64 DEM, curvature planes, template descriptors, "
+                                                 "search, float64 (4,ny,nx) result conversion and D2H"}
+            if not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(g, kind, scales[0], params, angles)
         print(json.dumps(out, ensure_ascii=False))
     if dist is not None:
         dist.barrier()

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 1
+#define SC_ABI_VERSION 2
 
 #define SC_OK               0
 #define SC_ERR_INVALID     -1   /* bad argument                                */
@@ -138,14 +138,39 @@ int sc_set_masks(sc_ctx* ctx, int slot, const uint8_t* limits,
                  const uint8_t* err);
 int sc_clear_windows(sc_ctx* ctx);
 
+/*
+ * Engine options, set explicitly (nothing is read from the environment):
+ *   "kappa"    float32 resolution floor of the FFT epilogue in units of eps32
+ *              (default 4; 0 switches the floor off; sc_internal.h sc_epi_floor)
+ *   "variant"  alternative kernel paths kept for cross-checks in the tests:
+ *              0 default, 5 no paired-template mode, 8 complex-spectrum I1 for
+ *              symmetric templates, 9 generic row kernel at every tile size
+ *   "y_gb"     memory budget of the column -> row pass hand-off buffers in GB
+ *              (0: a quarter of the free memory, at most 32)
+ */
+int sc_set_option(sc_ctx* ctx, const char* name, double value);
+
 /* ---- the hot path ------------------------------------------------------ */
 /* Zero the running-best record (compare() start state, core.py:222-225). */
 int sc_reset_best(sc_ctx* ctx);
 
 /* Match n templates and fold them, in the order given, into the running
- * best (core.py:227-240 semantics: strict compares, tie -> zero record,
- * NaN sticky).  Templates with equal (cc, sc2, ss) share one curvature
- * plane; send them adjacent. */
+ * best record (snr, amp, id), float32 per cell.  Fold rule (compare(),
+ * core.py:227-240, as far as it is meaningful in float32):
+ *   - a template takes a cell when its SNR is strictly greater than the
+ *     record's; cells it masks (window limits, error mask) score 0 and never
+ *     take a cell;
+ *   - an exact SNR tie KEEPS THE INCUMBENT.  The reference's two strict
+ *     compares zero the record on a tie; in its float64 arithmetic that is a
+ *     rounding accident, in float32 it is systematic (an even or odd template
+ *     gives bit-identical SNR at -pi/2 and +pi/2) and the zeroed record would
+ *     be overtaken by an arbitrary later template.  The literal float64 rule,
+ *     ties and sticky NaNs included, is sc_compare_*;
+ *   - the order of the fold is the order of t[]; it matters on ties only;
+ *   - NaN cannot arise: sc_set_dem's elevations must be finite (the host layer
+ *     answers a DEM with NaNs the way the reference does, without the device).
+ * Templates with equal (cc, sc2, ss) share one curvature plane; send them
+ * adjacent. */
 int sc_match(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* plan);
 int sc_match_async(sc_ctx* ctx, const sc_template* t, int n,
                    const sc_plan* plan);
@@ -175,6 +200,11 @@ int sc_get_result(sc_ctx* ctx, const double* param_of_id, const double* angle_of
 int sc_compare_begin(sc_ctx* ctx, int ny, int nx);
 int sc_compare_fold(sc_ctx* ctx, const double* amp, const double* snr,
                     double age, double angle);
+/* The same step for a result whose age and angle are per-cell planes - the
+ * output of an earlier fold, as match() feeds calculate_best_fit_parameters'
+ * (4, ny, nx) arrays to compare() (core.py:288-292). */
+int sc_compare_fold_planes(sc_ctx* ctx, const double* amp, const double* age,
+                           const double* angle, const double* snr);
 int sc_compare_end(sc_ctx* ctx, double* amp, double* age, double* angle,
                    double* snr);
 

@@ -285,6 +285,114 @@ def snr_stack(z, dx, dy, kind, scale, ages, angles, workers=1):
     return amp, snr
 
 
+def window_limit_axes(nx, ny, de, alpha, c, d):
+    """WindowedTemplate.py:66-84 again, as the two 1-D conditions the mask is
+    made of: ``lim[i, j] = ymask[i] | xmask[j]`` (X and Y are meshgrids of the
+    centred axes, so each comparison depends on one index only).  Lets the
+    window tests below evaluate the mask of a 10000 x 10000 grid at a few
+    cells; tests/test_oracle.py checks it against window_limits()."""
+    x4 = d * np.cos(alpha - np.pi / 2)
+    y4 = d * np.sin(alpha - np.pi / 2)
+    x1 = d * np.cos(alpha)
+    y1 = d * np.sin(alpha)
+    an_y = abs((x4 - x1) + 2 * c * np.cos(alpha - np.pi / 2))
+    an_x = abs((y1 - y4) + 2 * c * np.sin(alpha - np.pi / 2))
+    x, y = grid_axes(nx, ny, de)
+    xmask = (x < (min(x) + an_x)) | (x > (max(x) - an_x))
+    ymask = (y < (min(y) + an_y)) | (y > (max(y) - an_y))
+    return xmask, ymask
+
+
+_WIN = None      # crop shared with forked pool workers (snr_stack_window)
+
+
+def _window_job(job):
+    """One template of snr_stack_window (module level: runs in pool workers,
+    which inherit the crop through _WIN when the pool is forked)."""
+    age, angle = job
+    (zc, gi, gj, ny, nx, dx, dy, kind, scale, margin, workers) = _WIN
+    # dem.py:68-107 on the crop, with the zero borders of the FULL grid
+    # (dem.py:88-101: A is zero in the first/last column, B in the first row
+    # and column, C in the first/last row); interior stencils never reach
+    # across the wrap, so differencing the wrapped crop is the full DEM's value
+    A, B, C = curvature_components(zc, dx, dy)
+    A[:, (gj == 0) | (gj == nx - 1)] = 0
+    B[:, gj == 0] = 0
+    B[gi == 0, :] = 0
+    C[(gi == 0) | (gi == ny - 1), :] = 0
+    curv = A * np.cos(angle) ** 2 - 2 * B * np.sin(angle) * np.cos(angle) \
+        + C * np.sin(angle) ** 2
+    cy, cx = zc.shape
+    # the template on the crop's grid: same values around the centre as on the
+    # full grid when the sizes have the same parity (the centred axes agree)
+    W, _, err = template_arrays(kind, scale, age, angle, cx, cy, dx)
+    none = np.zeros((cy, cx), dtype=bool)
+    amp, snr = match_arrays(curv, W, none, None, workers=workers)
+    inner = (slice(margin, cy - margin), slice(margin, cx - margin))
+    amp, snr = amp[inner].copy(), snr[inner].copy()
+    gi_in, gj_in = gi[margin:cy - margin], gj[margin:cx - margin]
+    alpha = -angle
+    if kind in (RIGHT_UPPER, LEFT_UPPER):
+        x, y = grid_axes(nx, ny, dx)
+        xr = x[gj_in][None, :] * np.cos(alpha) + y[gi_in][:, None] * np.sin(alpha)
+        snr[(xr <= 0) if kind == RIGHT_UPPER else (xr >= 0)] = 0
+    if kind != RICKER:
+        xm, ym = window_limit_axes(nx, ny, dx, alpha, scarp_c(age), scale)
+        lim = ym[gi_in][:, None] | xm[gj_in][None, :]
+        amp[lim] = 0
+        snr[lim] = 0
+    return amp, snr
+
+
+def snr_stack_window(z, dx, dy, kind, scale, ages, angles, win, margin,
+                     workers=1, procs=1):
+    """Per-template (amp, snr) of the FULL periodic DEM ``z`` over the window
+    ``win = (i0, i1, j0, j1)`` only, shape (n_ages, n_angles, i1-i0, j1-j0).
+
+    For DEMs too large to run match_template on (10000 x 10000 takes 11 GB and
+    a minute per template): the window plus ``margin`` cells on every side is
+    cut out of the periodic DEM (indices wrap, as the reference's circular
+    convolution does), correlated with the template on the crop's own grid,
+    and masked with the FULL grid's window limits (window_limit_axes) and zero
+    curvature borders.  Exact for the inner window when ``margin`` covers the
+    template reach plus one cell and the crop has the DEM's size parity
+    (tests/test_oracle.py compares it with snr_stack on whole small DEMs).
+    ``procs`` > 1 spreads the templates over a forked process pool."""
+    global _WIN
+    z = np.asarray(z)
+    ny, nx = z.shape
+    i0, i1, j0, j1 = win
+    gi = np.arange(i0 - margin, i1 + margin) % ny
+    gj = np.arange(j0 - margin, j1 + margin) % nx
+    if (len(gi) - ny) % 2 or (len(gj) - nx) % 2:
+        raise ValueError("crop and DEM sizes must have the same parity")
+    zc = np.asarray(z[np.ix_(gi, gj)], dtype=float)
+    _WIN = (zc, gi, gj, ny, nx, dx, dy, kind, scale, margin, workers)
+    jobs = [(age, ang) for age in ages for ang in angles]
+    try:
+        if procs > 1:
+            import multiprocessing as mp
+            with mp.get_context("fork").Pool(min(procs, len(jobs))) as pool:
+                out = pool.map(_window_job, jobs, chunksize=1)
+        else:
+            out = [_window_job(j) for j in jobs]
+    finally:
+        _WIN = None
+    amp = np.array([o[0] for o in out]).reshape(len(ages), len(angles), i1 - i0, j1 - j0)
+    snr = np.array([o[1] for o in out]).reshape(amp.shape)
+    return amp, snr
+
+
+# Stated parity tolerances of the float32 device path against this float64
+# oracle (DESIGN.md "Parity"); shared by tests/, smoke() and bench.py's check:
+#   amp : |d| <= rtol*|amp| + atol*max|amp|      snr likewise
+#   tie : a device winner other than the oracle's argmax is accepted only if its
+#         oracle SNR is within tie_rtol of the maximum - twice the largest
+#         relative SNR error measured on the device (1.2e-4, check_fold's
+#         snr_err over the GPU suite), because two candidates are each off by it
+PARITY = dict(amp=(2e-4, 2e-6), snr=(2e-3, 2e-6), tie_rtol=3e-4)
+
+
 def xcorr_direct(curv, W):
     """Real-space closed form of core.py:359 (and l.363 with W -> M,
     curv -> curv**2), SURVEY.md section 7:
@@ -337,7 +445,10 @@ def check_fold(res, amp_stack, snr_stack, ages, angles, tie_rtol=1e-6,
 
     ``amp_stack``/``snr_stack``: (T, ny, nx) in any order; ``ages``/``angles``:
     length-T parameter values.  Returns a dict with the boolean ``ok`` map and
-    counts; ``n_strict`` is the number of pixels decided without the tie rule.
+    counts: ``n_strict`` pixels have no second candidate inside the tie window
+    (a property of the data), ``n_exact`` pixels carry exactly the oracle's
+    argmax (age, angle) (a property of the result), ``snr_err`` / ``amp_err``
+    are the largest relative deviations measured on those.
     """
     amp, age, ang, snr = [np.asarray(a, dtype=float) for a in res]
     snr_stack = np.asarray(snr_stack)
@@ -358,5 +469,20 @@ def check_fold(res, amp_stack, snr_stack, ages, angles, tie_rtol=1e-6,
     zero = (amp == 0) & (age == 0) & (ang == 0) & (snr == 0)
     ok |= zero & ((smax == 0) | (ncand >= 2))
     strict |= zero & (smax == 0)
+    # cells whose (age, angle) is the oracle's own argmax (first maximum; all-zero
+    # where every template is masked) - "bit-exact index" in the plain sense
+    tmax = np.argmax(snr_stack, axis=0)
+    exact = np.where(smax > 0, (age == np.asarray(ages)[tmax]) & (ang == np.asarray(angles)[tmax]),
+                     zero)
+    # largest relative SNR / amp deviation on the exact cells: the measured error
+    # the tie window has to cover (twice: two candidates, each off by this much)
+    s_at = np.take_along_axis(snr_stack, tmax[None], 0)[0]
+    a_at = np.take_along_axis(np.asarray(amp_stack), tmax[None], 0)[0]
+    sel = exact & (smax > 0)
+    snr_err = float(np.max(np.abs(snr[sel] - s_at[sel]) / s_at[sel])) if sel.any() else 0.0
+    amp_err = float(np.max(np.abs(amp[sel] - a_at[sel]) / (np.abs(a_at[sel]) + 1e-3 * np.max(np.abs(a_at)))
+                           )) if sel.any() else 0.0
     return dict(ok=ok, n_bad=int(np.sum(~ok)), n_strict=int(np.sum(strict)),
-                n_tie=int(np.sum(ok & ~strict)), n=int(ok.size))
+                n_tie=int(np.sum(ok & ~strict)), n=int(ok.size),
+                n_exact=int(np.sum(exact)), exact_frac=float(np.mean(exact)),
+                snr_err=snr_err, amp_err=amp_err)

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscarplet_hip.so")
 
 SC_OK = 0
-ABI_VERSION = 1
+ABI_VERSION = 2
 ID_NONE = 0xFFFFFFFF
 COMM_ID_BYTES = 128
 
@@ -89,7 +89,9 @@ SIGNATURES = {
     "sc_get_result": (C.c_int, [_P, _dp, _dp, C.c_int, _dp]),
     "sc_compare_begin": (C.c_int, [_P, C.c_int, C.c_int]),
     "sc_compare_fold": (C.c_int, [_P, _dp, _dp, C.c_double, C.c_double]),
+    "sc_compare_fold_planes": (C.c_int, [_P, _dp, _dp, _dp, _dp]),
     "sc_compare_end": (C.c_int, [_P, _dp, _dp, _dp, _dp]),
+    "sc_set_option": (C.c_int, [_P, C.c_char_p, C.c_double]),
     "sc_curvature": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, _fp]),
     "sc_get_template_sums": (C.c_int, [_P, C.c_int, _dp, _dp]),
     "sc_profile": (C.c_int, [_P, C.c_int]),
@@ -172,6 +174,12 @@ class Context(object):
             self.close()
         except Exception:
             pass
+
+    def set_option(self, name, value):
+        """Engine options (include/scarplet_hip.h sc_set_option): 'kappa',
+        'variant', 'y_gb'."""
+        self._check(self.lib.sc_set_option(self._h, name.encode(), float(value)),
+                    "sc_set_option(%s)" % name)
 
     # -- DEM ----------------------------------------------------------------
     def _dem_args(self, ly, lx, origin, shape, core, wrap):

@@ -164,6 +164,15 @@ class Plan(object):
                    self.circ_y, self.circ_x, (self.bbox,)))
 
 
+# real-space kernel (k_direct): a 64-cell wide patch plus the template window must
+# fit 16 rows of its 36 K-float LDS slab (sc_kernels.hip direct_window_fits)
+DIRECT_MAX_WINDOW = 2304 - 64
+
+
+def direct_window_fits(ww):
+    return ((64 + ww - 1) | 1) * 16 <= 36 * 1024
+
+
 def direct_cost(n_taps):
     """Relative cost per output cell of the real-space path."""
     return 2.0 * n_taps

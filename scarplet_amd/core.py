@@ -22,8 +22,9 @@ Differences a caller can observe (DESIGN.md "Parity"):
   * templates are folded orientation-major (the reference's ``match`` folds
     age-major); the two orders differ only where two templates tie exactly,
     which in float arithmetic is rounding noise in the reference as well;
-  * a DEM with NaNs is rejected with ValueError (the reference returns
-    all-NaN maps): call ``data._fill_nodata()`` first, as ``load`` does.
+  * a DEM with NaNs gives the reference's all-NaN maps (NaN spreads to every
+    cell through its whole-grid FFTs) with a warning and without a device
+    pass: call ``data._fill_nodata()`` first, as ``load`` does.
 """
 
 import numpy as np
@@ -72,10 +73,22 @@ class Matcher(object):
     # -- DEM ------------------------------------------------------------------
     def set_data(self, data):
         z, dx, dy = _grid_of(data)
-        if np.isnan(z).any():
-            raise ValueError("DEM contains NaN cells; fill them first "
-                             "(DEMGrid._fill_nodata)")
+        # A NaN anywhere in the DEM turns every reference output into NaN: the
+        # curvature keeps the NaN (dem.py:85-86, 105) and the whole-grid FFTs
+        # spread it to every cell (core.py:349-363).  Nothing is left to
+        # compute, so such a DEM never reaches the device; the drivers answer
+        # with the maps the reference returns (_nan_maps / _nan_fold).
+        self.nan_dem = bool(np.isnan(z).any())
         self.ny, self.nx = z.shape
+        if self.nan_dem:
+            import warnings
+            warnings.warn("DEM contains NaN cells: every template's amplitude and SNR are "
+                          "NaN (as in the reference); fill them first (DEMGrid._fill_nodata)")
+            self.de = dx
+            self.dx, self.dy = dx, dy
+            self.core = (0, self.ny, 0, self.nx)
+            self.whole = True
+            return
         self.de = dx
         self.dx, self.dy = dx, dy
         self.core = (0, self.ny, 0, self.nx)
@@ -101,9 +114,37 @@ class Matcher(object):
             self.ctx.set_dem_device(z_dev_or_host, ly, lx, dx, dy, xa, ya,
                                     origin, shape, core)
 
+    # -- DEMs with NaN cells: the reference's (degenerate) outputs --------------
+    def _nan_maps(self, t):
+        """match_template() on a DEM with NaNs (core.py:348-375): amp and snr
+        are NaN everywhere, then snr[err_mask] = 0, amp[lim] = snr[lim] = 0."""
+        amp = np.full((self.ny, self.nx), np.nan)
+        snr = np.full((self.ny, self.nx), np.nan)
+        if hasattr(t, "get_err_mask"):
+            snr[np.asarray(t.get_err_mask(), dtype=bool)] = 0
+        lim = np.asarray(t.get_window_limits(), dtype=bool)
+        amp[lim] = 0
+        snr[lim] = 0
+        return amp, snr
+
+    def _nan_fold(self, Template, scale, params, angles, **kwargs):
+        """compare() over such maps (core.py:228-240): 0*NaN poisons amp and
+        snr of every cell some template leaves unmasked; age and angle stay 0
+        (0 * finite); fully masked cells keep the zero record."""
+        amp = np.zeros((self.ny, self.nx))
+        snr = np.zeros((self.ny, self.nx))
+        for ang in angles:
+            for par in params:
+                a, s = self._nan_maps(Template(scale, par, ang, self.nx, self.ny, self.de, **kwargs))
+                amp[np.isnan(a)] = np.nan
+                snr[np.isnan(s)] = np.nan
+        zero = np.zeros((self.ny, self.nx))
+        return np.stack([amp, zero, zero.copy(), snr])
+
     # -- templates --------------------------------------------------------------
-    def describe(self, Template, scale, params, angles, **kwargs):
+    def describe(self, Template, scale, params, angles, id_base=0, **kwargs):
         """Descriptors for the (param, angle) grid, orientation-major.
+        Template (param ia, angle ib) gets id ``id_base + ia * n_angles + ib``.
         Returns (ctypes array, support bbox union, max taps)."""
         n_par, n_ang = len(params), len(angles)
         arr = (_lib.sc_template * (n_par * n_ang))()
@@ -126,7 +167,7 @@ class Matcher(object):
                 s.cc, s.sc2, s.ss = cc, sc2, ss
                 s.ilo, s.ihi, s.jlo, s.jhi = desc["limits"]
                 s.pmin, s.pmax, s.qmin, s.qmax = desc["bbox"]
-                s.id = ia * n_ang + ib
+                s.id = id_base + ia * n_ang + ib
                 s.window = desc.get("window", -1)
                 if s.pmax < s.pmin or s.qmax < s.qmin:
                     # empty support: a 1-cell box of zeros keeps the kernels
@@ -184,11 +225,17 @@ class Matcher(object):
     # -- planning -----------------------------------------------------------------
     def plan_for(self, bbox, max_area, method="auto", group=None, n_params=1):
         if method == "auto":
-            fft = _plan.Plan(self.ny, self.nx, self.core, bbox,
-                             whole=self.whole, method=_plan.METHOD_FFT)
+            direct_ok = _plan.direct_window_fits(bbox[3] - bbox[2] + 1)
+            try:
+                fft = _plan.Plan(self.ny, self.nx, self.core, bbox,
+                                 whole=self.whole, method=_plan.METHOD_FFT)
+            except ValueError:
+                if not direct_ok:         # larger than the largest tile AND the LDS slab
+                    raise
+                fft = None
             n_cells = (self.core[1] - self.core[0]) * (self.core[3] - self.core[2])
-            method = "direct" if _plan.direct_cost(max_area) \
-                < _plan.fft_cost(fft, n_cells) else "fft"
+            method = "direct" if fft is None or (
+                direct_ok and _plan.direct_cost(max_area) < _plan.fft_cost(fft, n_cells)) else "fft"
         m = _plan.METHOD_DIRECT if method == "direct" else _plan.METHOD_FFT
         p = _plan.Plan(self.ny, self.nx, self.core, bbox, whole=self.whole,
                        method=m)
@@ -209,8 +256,17 @@ class Matcher(object):
         """Fold every (param, angle) template into the running best."""
         params = np.atleast_1d(np.asarray(params, dtype=float))
         angles = np.atleast_1d(np.asarray(angles, dtype=float))
+        if getattr(self, "nan_dem", False):
+            self._nan_result = self._nan_fold(Template, scale, params, angles, **kwargs)
+            self.params, self.angles = params, angles
+            return self
+        self._nan_result = None
+        # ids are cumulative over the searches folded into one record: a later
+        # search with another grid must not re-use the ids cells already hold
+        if reset or getattr(self, "_id_par", None) is None:
+            self._id_par, self._id_ang = np.empty(0), np.empty(0)
         arr, bbox, max_area = self.describe(Template, scale, params, angles,
-                                            **kwargs)
+                                            id_base=len(self._id_par), **kwargs)
         self.plan, sp = self.plan_for(bbox, max_area, method, group,
                                       n_params=len(params))
         if reset:
@@ -218,6 +274,8 @@ class Matcher(object):
         self.ctx.match(arr, sp, sync=sync)
         self.params, self.angles = params, angles
         self.n_templates = len(arr)
+        self._id_par = np.concatenate([self._id_par, np.repeat(params, len(angles))])
+        self._id_ang = np.concatenate([self._id_ang, np.tile(angles, len(params))])
         return self
 
     def result(self):
@@ -230,11 +288,18 @@ class Matcher(object):
 
     def result_array(self):
         """The same as one (4, h, w) float64 array."""
-        return self.ctx.get_result(np.repeat(self.params, len(self.angles)),
-                                   np.tile(self.angles, len(self.params)))
+        if getattr(self, "_nan_result", None) is not None:
+            return self._nan_result
+        if getattr(self, "_id_par", None) is None or not len(self._id_par):
+            # descriptors were sent by hand (ctx.match): one grid, ids from 0
+            return self.ctx.get_result(np.repeat(self.params, len(self.angles)),
+                                       np.tile(self.angles, len(self.params)))
+        return self.ctx.get_result(self._id_par, self._id_ang)
 
     def match_template(self, Template, scale, age, angle, method="auto",
                        **kwargs):
+        if getattr(self, "nan_dem", False):
+            return self._nan_maps(Template(scale, age, angle, self.nx, self.ny, self.de, **kwargs))
         arr, bbox, max_area = self.describe(Template, scale, [age], [angle],
                                             **kwargs)
         self.plan, sp = self.plan_for(bbox, max_area, method)

@@ -137,14 +137,30 @@ extern "C" int sc_create(int device, sc_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return SC_ERR_HIP;
     sc_ctx* c = new sc_ctx();
     c->device = device;
+#ifdef SC_ABLATE
     if (const char* d = getenv("SC_DBG")) c->dbg = atoi(d);
-    if (const char* d = getenv("SC_VARIANT")) c->variant = atoi(d);
-    if (const char* d = getenv("SC_KAPPA")) c->kappa = (float)atof(d);
+#endif
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return SC_ERR_HIP;
     }
     *out = c;
+    return SC_OK;
+}
+
+extern "C" int sc_set_option(sc_ctx* ctx, const char* name, double value) {
+    if (!ctx || !name) return SC_ERR_INVALID;
+    if (!strcmp(name, "kappa")) {
+        if (!(value >= 0.0)) return sc_fail(ctx, SC_ERR_INVALID, "kappa must be >= 0");
+        ctx->kappa = (float)value;
+    } else if (!strcmp(name, "variant")) {
+        ctx->variant = (int)value;
+    } else if (!strcmp(name, "y_gb")) {
+        if (!(value >= 0.0)) return sc_fail(ctx, SC_ERR_INVALID, "y_gb must be >= 0");
+        ctx->y_gb = value;
+    } else {
+        return sc_fail(ctx, SC_ERR_INVALID, "unknown option '%s'", name);
+    }
     return SC_OK;
 }
 
@@ -179,7 +195,7 @@ extern "C" void sc_destroy(sc_ctx* c) {
                      &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res};
     for (DevBuf* b : arr) buf_free(*b);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp[k]);
-    for (int k = 0; k < 2; ++k) buf_free(c->cmp_in[k]);
+    for (int k = 0; k < 4; ++k) buf_free(c->cmp_in[k]);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -357,6 +373,9 @@ static int check_templates(sc_ctx* ctx, const sc_template* t, int n, const sc_pl
             if (w.h != s.pmax - s.pmin + 1 || w.wd != s.qmax - s.qmin + 1)
                 return sc_fail(ctx, SC_ERR_INVALID, "template %d: window size mismatch", i);
         }
+        if (plan->method == SC_METHOD_DIRECT && !direct_window_fits(s.qmax - s.qmin + 1))
+            return sc_fail(ctx, SC_ERR_UNSUPPORTED, "template %d: a %d-cell wide window exceeds the "
+                           "real-space kernel's LDS slab; use SC_METHOD_FFT", i, s.qmax - s.qmin + 1);
         if (plan->method == SC_METHOD_FFT) {
             if (s.pmax > plan->Py || s.qmax > plan->Qx ||
                 plan->Py - s.pmin > plan->Ty - plan->Vy + (plan->circ_y ? plan->Ty : 0) ||
@@ -621,17 +640,36 @@ extern "C" int sc_compare_begin(sc_ctx* ctx, int ny, int nx) {
     return SC_OK;
 }
 
-extern "C" int sc_compare_fold(sc_ctx* ctx, const double* amp, const double* snr,
-                               double age, double angle) {
+static int compare_fold_impl(sc_ctx* ctx, const double* amp, const double* snr,
+                             const double* age_p, const double* angle_p, double age, double angle) {
     if (!ctx || !amp || !snr || ctx->cmp_n == 0) return SC_ERR_INVALID;
     SC_HIP(ctx, hipSetDevice(ctx->device));
     size_t bytes = sizeof(double) * ctx->cmp_n;
+    const bool planes = age_p && angle_p;
     SC_HIP(ctx, hipMemcpyAsync(ctx->cmp_in[0].p, amp, bytes, hipMemcpyHostToDevice, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(ctx->cmp_in[1].p, snr, bytes, hipMemcpyHostToDevice, ctx->stream));
-    int rc = launch_compare_fold(ctx, age, angle);
+    if (planes) {
+        int rc;
+        for (int k = 2; k < 4; ++k)
+            if ((rc = sc_ensure(ctx, ctx->cmp_in[k], bytes))) return rc;
+        SC_HIP(ctx, hipMemcpyAsync(ctx->cmp_in[2].p, age_p, bytes, hipMemcpyHostToDevice, ctx->stream));
+        SC_HIP(ctx, hipMemcpyAsync(ctx->cmp_in[3].p, angle_p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    int rc = launch_compare_fold(ctx, age, angle, planes);
     if (rc) return rc;
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SC_OK;
+}
+
+extern "C" int sc_compare_fold(sc_ctx* ctx, const double* amp, const double* snr,
+                               double age, double angle) {
+    return compare_fold_impl(ctx, amp, snr, nullptr, nullptr, age, angle);
+}
+
+extern "C" int sc_compare_fold_planes(sc_ctx* ctx, const double* amp, const double* age,
+                                      const double* angle, const double* snr) {
+    if (!age || !angle) return SC_ERR_INVALID;
+    return compare_fold_impl(ctx, amp, snr, age, angle, 0.0, 0.0);
 }
 
 extern "C" int sc_compare_end(sc_ctx* ctx, double* amp, double* age, double* angle, double* snr) {

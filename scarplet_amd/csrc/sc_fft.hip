@@ -516,12 +516,12 @@ k_fwd_rows_curv(const float* __restrict__ curv, Geom g,
     // two workgroups per CU.
     for (int pl = 0; pl < 2; ++pl) {
         float va[E], vb[E];
-        if (!(dbg & 8)) { load_tile(ta, va); load_tile(tb, vb); }
+        if (!SC_DBGBIT(dbg, 8)) { load_tile(ta, va); load_tile(tb, vb); }
         else {
 #pragma unroll
             for (int u = 0; u < E; ++u) va[u] = vb[u] = 1.f + u;
         }
-        if (pl == 0 && !(dbg & 1)) {  // |curv|_2^2 and |curv^2|_2^2 of the tile pair (resolution floor, sc_epi_floor)
+        if (pl == 0 && !SC_DBGBIT(dbg, 1)) {  // |curv|_2^2 and |curv^2|_2^2 of the tile pair (resolution floor, sc_epi_floor)
             double s2 = 0.0, s4 = 0.0;
 #pragma unroll
             for (int u = 0; u < E; ++u) {
@@ -560,9 +560,9 @@ k_fwd_rows_curv(const float* __restrict__ curv, Geom g,
                                               : make_float2(va[u], vb[u]);
         }
         lds_barrier();
-        if (!(dbg & 2)) fft4_lines<TX, false>(sm, twr);
+        if (!SC_DBGBIT(dbg, 2)) fft4_lines<TX, false>(sm, twr);
         float2* out = blk + (size_t)(pair * 2 + pl) * plane + (size_t)rb * 4 * TX;
-        if (!(dbg & 4))
+        if (!SC_DBGBIT(dbg, 4))
 #pragma unroll 4
         for (int e = 2 * threadIdx.x; e < 4 * TX; e += 2 * NT) {
             int cb = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
@@ -816,7 +816,7 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
             for (int u = 0; u < EP; ++u)
                 hreg[u] = *reinterpret_cast<const float4*>(p + 2 * (threadIdx.x + u * NT));
         };
-        if (!(dbg & 16)) {
+        if (!SC_DBGBIT(dbg, 16)) {
             if (PARK) {
 #pragma unroll
                 for (int u = 0; u < EP; ++u) xs[threadIdx.x + u * NT] = uu[threadIdx.x + u * NT];
@@ -851,13 +851,13 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                 }
             }
             lds_barrier();
-            if (gi_ + 1 < G && !(dbg & 16)) fetch(gi_ + 1);
-            if (!(dbg & 32)) fft4_lines<TY, true>(sm, twr);
+            if (gi_ + 1 < G && !SC_DBGBIT(dbg, 16)) fetch(gi_ + 1);
+            if (!SC_DBGBIT(dbg, 32)) fft4_lines<TY, true>(sm, twr);
             // rows2 layout: this block's 4 columns x 2 rows of a row pair are 64
             // contiguous bytes; a thread stores (row 2rp, row 2rp+1) of one column
             float2* o = (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)(cb >> 1) * 16 + (cb & 1) * 8;
             const int e_lo = 4 * rp_lo, e_hi = 4 * (rp_hi + 1);
-            if (!(dbg & 64))
+            if (!SC_DBGBIT(dbg, 64))
 #pragma unroll 2
             for (int e = e_lo + threadIdx.x; e < e_hi; e += NT) {
                 int rp = e >> 2, k = e & 3;
@@ -1075,11 +1075,11 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
             bool okB = ri >= 0 && ri < tB.vy && cj >= 0 && cj < tB.vx;
             if (okA) valid |= 1u << (2 * u);
             if (okB) valid |= 2u << (2 * u);
-            const bool rd = !map_amp && !(ra.dbg & 8);
+            const bool rd = !map_amp && !SC_DBGBIT(ra.dbg, 8);
             b_snr[2 * u] = (okA && rd) ? best_snr[(size_t)(tA.i0 + ri - ra.cy0) * ra.cw + (tA.j0 + cj - ra.cx0)] : 0.f;
             b_snr[2 * u + 1] = (okB && rd) ? best_snr[(size_t)(tB.i0 + ri - ra.cy0) * ra.cw + (tB.j0 + cj - ra.cx0)] : 0.f;
         }
-        if (!(ra.dbg & 1)) fetch(0);
+        if (!SC_DBGBIT(ra.dbg, 1)) fetch(0);
         for (int gi_ = 0; gi_ < ra.G; ++gi_) {
             const TemplDev* tp = templ + ra.first + gi_;
             EpiScal es = sc_epi_scalars(sums, ra.first + gi_);
@@ -1100,9 +1100,9 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 sm[lidx<TX>(3, c)] = make_float2(yreg[u].z, yreg[u].w);
             }
             lds_barrier();
-            if (gi_ + 1 < ra.G && !(ra.dbg & 1)) fetch(gi_ + 1);
-            if (!(ra.dbg & 2)) fft4_lines<TX, true>(sm, twr);
-            if (!(ra.dbg & 4)) {
+            if (gi_ + 1 < ra.G && !SC_DBGBIT(ra.dbg, 1)) fetch(gi_ + 1);
+            if (!SC_DBGBIT(ra.dbg, 2)) fft4_lines<TX, true>(sm, twr);
+            if (!SC_DBGBIT(ra.dbg, 4)) {
                 // branch-free scoring of the 2E slots, then the (rare) stores
                 float t_amp[2 * E], t_snr[2 * E];
 #pragma unroll
@@ -1147,7 +1147,7 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
                         if (take || poison) won |= 1u << c;
                     }
                 }
-                if (won && !(ra.dbg & 8)) {
+                if (won && !SC_DBGBIT(ra.dbg, 8)) {
 #pragma unroll
                     for (int u = 0; u < E; ++u) {
                         int ri, cj;
@@ -1567,14 +1567,14 @@ int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group) {
     if ((rc = sc_ensure(ctx, ctx->wh, hplane * n_templ_chunk))) return rc;
     if ((rc = sc_ensure(ctx, ctx->mh, hplane * n_templ_chunk))) return rc;
     // Y blocks of several tile pairs per inverse launch (see RowArgs): as many as
-    // a quarter of the free device memory (at most 32 GB, SC_Y_GB overrides) holds
+    // a quarter of the free device memory (at most 32 GB; sc_set_option "y_gb" overrides) holds
     int pb = 1;
     {
         size_t free_b = 0, total_b = 0;
         double budget = 0.0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
             budget = std::min(32e9, 0.25 * (double)(free_b + ctx->yw.cap + ctx->ym.cap));
-        if (const char* e = getenv("SC_Y_GB")) budget = atof(e) * 1e9;
+        if (ctx->y_gb > 0.0) budget = ctx->y_gb * 1e9;
         double per_pair = 2.0 * (double)plane * group;
         pb = (int)std::max(1.0, std::min((double)np, floor(budget / per_pair)));
     }

@@ -9,6 +9,15 @@
 #include "../../include/scarplet_hip.h"
 
 #define SC_EPS 2.220446049250313e-16      // np.spacing(1), core.py:340
+
+// Timing-only ablation bits (skip loads / transforms / stores of a kernel; the
+// results are wrong while one is set).  They exist only in a -DSC_ABLATE build
+// (tools/ablate.sh); in the shipped library the tests fold to constants.
+#ifdef SC_ABLATE
+#define SC_DBGBIT(d, b) (((d) & (b)) != 0)
+#else
+#define SC_DBGBIT(d, b) false
+#endif
 #define SC_EXP_UNDERFLOW 745.1332191019412 // exp(-u) != 0  <=>  u < 1075 ln 2
 
 // Device-side view of one template of the current batch.
@@ -68,7 +77,7 @@ struct sc_ctx {
     const double* z_dev = nullptr;
     DevBuf best_snr, best_amp, best_id;
     DevBuf map_amp, map_snr;
-    DevBuf cmp[4], cmp_in[2];   // sc_compare_*: amp, age, angle, snr (float64)
+    DevBuf cmp[4], cmp_in[4];   // sc_compare_*: amp, age, angle, snr (float64); inputs amp, snr, age, angle
     size_t cmp_n = 0;
     DevBuf templ, sums, wl1, norms, win_w, win_m;   // wl1: sum|W| per template; norms: per tile pair
     DevBuf tw_y, tw_x;
@@ -77,9 +86,10 @@ struct sc_ctx {
     DevBuf blk, uc, uc2, vh, wh, mh, yw, ym, tiles;
     std::vector<WindowSlot> windows;
     int last_batch = 0;
-    float kappa = 4.f;         // float32 resolution floor of the FFT path, in units of eps
-    int variant = 0;           // SC_VARIANT: kernel variant under evaluation
-    int dbg = 0;               // SC_DBG: timing-only ablation bits (wrong results)
+    float kappa = 4.f;         // float32 resolution floor of the FFT path, in units of eps (sc_set_option "kappa")
+    int variant = 0;           // sc_set_option "variant": alternative kernel paths kept for cross-checks
+    double y_gb = 0.0;         // sc_set_option "y_gb": memory budget of the I1 -> I2 hand-off (0: automatic)
+    int dbg = 0;               // timing-only ablation bits; only an SC_ABLATE build reads them (tools/ablate.sh)
     // profiling
     int prof = 0;              // 0 off, k: time every k-th launch of a kernel
     int prof_cur = -1;         // kernel being bracketed (-1: not sampled)
@@ -126,7 +136,8 @@ int launch_curv_planes(sc_ctx* ctx);
 int launch_curv_alpha(sc_ctx* ctx, float cc, float sc2, float ss);
 int launch_windows(sc_ctx* ctx, int first, int n, int wh_max, int ww_max);
 int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps);
-int launch_compare_fold(sc_ctx* ctx, double age, double angle);
+bool direct_window_fits(int ww);     // template window width the real-space kernel can stage in LDS
+int launch_compare_fold(sc_ctx* ctx, double age, double angle, bool planes);
 
 // ---- launchers implemented in sc_fft.hip ------------------------------------
 int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group);

@@ -280,15 +280,18 @@ __global__ void __launch_bounds__(256)
 k_compare_fold(double* __restrict__ b_amp, double* __restrict__ b_age,
                double* __restrict__ b_ang, double* __restrict__ b_snr,
                const double* __restrict__ t_amp, const double* __restrict__ t_snr,
+               const double* __restrict__ t_age, const double* __restrict__ t_ang,
                double age, double angle, size_t n) {
+    // t_age / t_ang: per-cell planes (results of an earlier fold, as match()
+    // feeds them to compare(), core.py:288-292) or null for scalar age / angle
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         double bs = b_snr[i], ts = t_snr[i];
         double keep = (bs > ts) ? 1.0 : 0.0, take = (bs < ts) ? 1.0 : 0.0;
         b_amp[i] = __dadd_rn(__dmul_rn(keep, b_amp[i]), __dmul_rn(take, t_amp[i]));
-        b_age[i] = __dadd_rn(__dmul_rn(keep, b_age[i]), __dmul_rn(take, age));
-        b_ang[i] = __dadd_rn(__dmul_rn(keep, b_ang[i]), __dmul_rn(take, angle));
+        b_age[i] = __dadd_rn(__dmul_rn(keep, b_age[i]), __dmul_rn(take, t_age ? t_age[i] : age));
+        b_ang[i] = __dadd_rn(__dmul_rn(keep, b_ang[i]), __dmul_rn(take, t_ang ? t_ang[i] : angle));
         b_snr[i] = __dadd_rn(__dmul_rn(keep, bs), __dmul_rn(take, ts));
     }
 }
@@ -296,14 +299,15 @@ k_compare_fold(double* __restrict__ b_amp, double* __restrict__ b_age,
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-int launch_compare_fold(sc_ctx* ctx, double age, double angle) {
+int launch_compare_fold(sc_ctx* ctx, double age, double angle, bool planes) {
     size_t n = ctx->cmp_n;
     size_t blocks = std::min<size_t>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(k_compare_fold, dim3((unsigned)std::max<size_t>(blocks, 1)), dim3(256), 0,
                        ctx->stream, (double*)ctx->cmp[0].p, (double*)ctx->cmp[1].p,
                        (double*)ctx->cmp[2].p, (double*)ctx->cmp[3].p,
                        (const double*)ctx->cmp_in[0].p, (const double*)ctx->cmp_in[1].p,
-                       age, angle, n);
+                       planes ? (const double*)ctx->cmp_in[2].p : nullptr,
+                       planes ? (const double*)ctx->cmp_in[3].p : nullptr, age, angle, n);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
 }
@@ -348,6 +352,12 @@ int launch_windows(sc_ctx* ctx, int first, int n, int wh_max, int ww_max) {
     sc_prof_end(ctx);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
+}
+
+// widest template window the real-space kernel can stage: a slab holds at least
+// DR_TY rows of DR_TX + ww - 1 cells (odd pitch) in its DR_LDS_FLOATS floats
+bool direct_window_fits(int ww) {
+    return (long long)(((DR_TX + ww - 1) | 1)) * DR_TY <= DR_LDS_FLOATS;
 }
 
 int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps) {

@@ -13,10 +13,23 @@ Nothing else is exchanged: results are disjoint tiles, so the "argmax
 all-reduce" of a replicated design degenerates to a gather of tiles.
 
 This module is pure host logic plus two executors for the same transfer list:
-  * ``exchange_gloo``  - torch.distributed point-to-point on host arrays
-    (CPU tests, and machines without xGMI);
+  * ``exchange_host`` - point-to-point on host arrays through a caller-supplied
+    *transport* (CPU tests and bring-up on machines without xGMI);
   * ``Context.halo_exchange`` (sc_halo_exchange) - grouped ncclSend/ncclRecv
     on device buffers over RCCL.
+
+The package itself depends on no process-group library.  Whoever launches the
+ranks (bench.py, the tests, a user's MPI or torchrun script) passes a transport:
+
+    class Transport:                      # duck-typed
+        def broadcast_bytes(self, payload):     # rank 0's bytes -> every rank
+        def exchange(self, sends, recvs):       # sends: [(peer, tag, ndarray)],
+                                                # recvs: [(peer, tag, shape)]
+                                                # -> list of received float64 arrays
+        def gather(self, obj, dst):             # -> list of objects on dst, else None
+
+The RCCL path needs ``broadcast_bytes`` only (the 128-byte communicator id);
+tools/torch_transport.py implements all three over torch.distributed.
 """
 
 import numpy as np
@@ -135,30 +148,24 @@ def assemble_block_reference(z, layout, rank):
     return np.asarray(z)[np.ix_(ii, jj)]
 
 
-def exchange_gloo(core, layout, rank, group=None):
-    """Host executor of the transfer list over torch.distributed (any
-    backend that supports CPU point-to-point; gloo in the tests)."""
-    import torch
-    import torch.distributed as dist
+def exchange_host(core, layout, rank, transport):
+    """Host executor of the transfer list: this rank's sends and receives go
+    through ``transport.exchange`` (see the module docstring), periodic images
+    of the rank's own core are copied in place."""
     bh, bw = layout.block_shape(rank)
     hy, _, hx, _ = layout.halo
     blk = np.zeros((bh, bw), dtype=np.float64)
     c = layout.core(rank)
     blk[hy:hy + c[1] - c[0], hx:hx + c[3] - c[2]] = core
-    reqs, recvs = [], []
     mine = layout.rank_transfers(rank, with_tag=True)
-    for (peer, kind, sy0, sx0, dy0, dx0, h, w, tag) in mine:
-        if kind == _lib.XFER_SEND:
-            t = torch.from_numpy(np.ascontiguousarray(blk[sy0:sy0 + h, sx0:sx0 + w]))
-            reqs.append(dist.isend(t, dst=peer, group=group, tag=tag))
-        elif kind == _lib.XFER_RECV:
-            t = torch.empty((h, w), dtype=torch.float64)
-            reqs.append(dist.irecv(t, src=peer, group=group, tag=tag))
-            recvs.append((t, dy0, dx0, h, w))
-    for r in reqs:
-        r.wait()
-    for (t, dy0, dx0, h, w) in recvs:
-        blk[dy0:dy0 + h, dx0:dx0 + w] = t.numpy()
+    sends = [(peer, tag, np.ascontiguousarray(blk[sy0:sy0 + h, sx0:sx0 + w]))
+             for (peer, kind, sy0, sx0, dy0, dx0, h, w, tag) in mine if kind == _lib.XFER_SEND]
+    rinfo = [(peer, tag, dy0, dx0, h, w)
+             for (peer, kind, sy0, sx0, dy0, dx0, h, w, tag) in mine if kind == _lib.XFER_RECV]
+    got = transport.exchange(sends, [(peer, tag, (h, w)) for (peer, tag, _, _, h, w) in rinfo]) \
+        if (sends or rinfo) else []
+    for (peer, tag, dy0, dx0, h, w), arr in zip(rinfo, got):
+        blk[dy0:dy0 + h, dx0:dx0 + w] = arr
     for (peer, kind, sy0, sx0, dy0, dx0, h, w, tag) in mine:
         if kind == _lib.XFER_LOCAL:
             blk[dy0:dy0 + h, dx0:dx0 + w] = blk[sy0:sy0 + h, sx0:sx0 + w]
@@ -169,22 +176,34 @@ class DistMatcher(object):
     """Per-rank driver of a tiled search.
 
     ``z_core`` is this rank's rectangle of the DEM (layout.core(rank)).
-    ``backend`` 'rccl' exchanges halos on the GPUs; 'gloo' on the host."""
+    ``backend`` 'rccl' exchanges halos on the GPUs (needs
+    ``transport.broadcast_bytes`` - or the bare ``broadcast_bytes`` callable -
+    for the communicator id when nranks > 1); 'host' moves host arrays through
+    ``transport`` ('gloo' is accepted as an alias of 'host')."""
 
     def __init__(self, rank, nranks, shape, dx, dy, device=0, backend="rccl",
-                 broadcast_bytes=None):
+                 broadcast_bytes=None, transport=None):
         from scarplet_amd.core import Matcher
         self.rank, self.nranks = rank, nranks
         self.ny, self.nx = shape
         self.dx, self.dy = dx, dy
-        self.backend = backend
+        self.backend = "host" if backend == "gloo" else backend
+        backend = self.backend
+        self.transport = transport
+        if backend not in ("rccl", "host"):
+            raise ValueError("backend must be 'rccl' or 'host'")
+        if backend == "host" and nranks > 1 and transport is None:
+            raise ValueError("the host backend needs a transport (scarplet_amd/dist.py docstring)")
         self.py, self.px = grid_dims(nranks, self.ny, self.nx)
         self.m = Matcher(device=device)
         # describe() only needs the grid geometry
         self.m.ny, self.m.nx, self.m.de = self.ny, self.nx, dx
         if backend == "rccl" and nranks > 1:
             if broadcast_bytes is None:
-                broadcast_bytes = _torch_broadcast_bytes
+                if transport is None:
+                    raise ValueError("RCCL with more than one rank needs broadcast_bytes= or "
+                                     "transport= to share the communicator id")
+                broadcast_bytes = transport.broadcast_bytes
             uid = self.m.ctx.comm_unique_id() if rank == 0 else None
             uid = broadcast_bytes(uid)
             self.m.ctx.comm_init(uid, rank, nranks)
@@ -208,7 +227,7 @@ class DistMatcher(object):
             self.m.set_block(z_dev, origin, (self.ny, self.nx), core, self.dx,
                              self.dy, block_shape=bshape)
         else:
-            blk = exchange_gloo(z_core, self.layout, self.rank)
+            blk = exchange_host(z_core, self.layout, self.rank, self.transport)
             self.m.set_block(blk, origin, (self.ny, self.nx), core, self.dx, self.dy)
         return self
 
@@ -232,7 +251,7 @@ class DistMatcher(object):
     def gather(self, dst=0):
         """Assemble the full maps on rank ``dst`` (None elsewhere): over RCCL
         (sc_gather_result, device to root's host array) with the 'rccl' backend,
-        over torch.distributed with 'gloo'."""
+        through ``transport.gather`` with the host backend."""
         if self.backend == "rccl":
             lay = Layout(self.ny, self.nx, self.py, self.px, (0, 0, 0, 0))
             cores = [lay.core(r) for r in range(self.nranks)]
@@ -241,9 +260,10 @@ class DistMatcher(object):
                                       np.repeat(m.params, len(m.angles)),
                                       np.tile(m.angles, len(m.params)), self.rank == dst)
             return tuple(out) if self.rank == dst else None
-        import torch.distributed as dist
-        tiles = [None] * self.nranks if self.rank == dst else None
-        dist.gather_object((self.core(), self.result()), tiles, dst=dst)
+        if self.nranks == 1:
+            tiles = [(self.core(), self.result())]
+        else:
+            tiles = self.transport.gather((self.core(), self.result()), dst)
         if self.rank != dst:
             return None
         out = [np.zeros((self.ny, self.nx)) for _ in range(4)]
@@ -251,10 +271,3 @@ class DistMatcher(object):
             for k in range(4):
                 out[k][core[0]:core[1], core[2]:core[3]] = res[k]
         return tuple(out)
-
-
-def _torch_broadcast_bytes(payload):
-    import torch.distributed as dist
-    box = [payload]
-    dist.broadcast_object_list(box, src=0)
-    return box[0]

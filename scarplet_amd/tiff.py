@@ -94,7 +94,11 @@ def read_geotiff_full(path):
             raise ValueError("%s: compression %d is not supported" % (path, comp))
         a = np.frombuffer(raw, dtype=dtype, count=rows * cols).reshape(rows, cols)
         if pred == 2:
-            a = np.cumsum(a, axis=1, dtype=dtype)
+            # horizontal differencing is defined on the sample WORDS (libtiff
+            # / GDAL PREDICTOR=2 on Float32 differences the raw integers):
+            # accumulate as unsigned integers with wraparound, then view back
+            u = np.dtype(bo + "u" + str(bits // 8))
+            a = np.cumsum(a.view(u), axis=1, dtype=u).view(dtype)
         elif pred != 1:
             raise ValueError("%s: predictor %d is not supported" % (path, pred))
         return a
@@ -153,8 +157,12 @@ def read_geotiff_full(path):
     return out, gt, nodata, geokeys
 
 
-def write_geotiff(path, array, geo_transform=None, nodata=None, geokeys=None):
-    """Write a single-band little-endian classic TIFF (one uncompressed strip).
+def write_geotiff(path, array, geo_transform=None, nodata=None, geokeys=None,
+                  compress=False, predictor=1):
+    """Write a little-endian classic TIFF, one strip per band; uncompressed by
+    default, ``compress=True`` deflates the strips, ``predictor=2`` stores
+    horizontal differences of the sample words (integer wraparound, also for
+    float samples - what libtiff / GDAL's PREDICTOR=2 do).
 
     array: (rows, cols) or (bands, rows, cols) - bands are stored as separate
     planes, one strip each; any of the dtypes read_geotiff accepts (float64
@@ -171,7 +179,18 @@ def write_geotiff(path, array, geo_transform=None, nodata=None, geokeys=None):
         raise ValueError("write_geotiff: unsupported dtype %s" % a.dtype)
     a = a.astype(a.dtype.newbyteorder("<"), copy=False)
     h, w = a.shape[-2:]
-    band_bytes = h * w * a.dtype.itemsize
+    if predictor not in (1, 2):
+        raise ValueError("write_geotiff: predictor 1 or 2")
+    strips = []
+    for b in range(bands):
+        plane = a if a.ndim == 2 else a[b]
+        if predictor == 2:
+            u = plane.view(np.dtype("<u%d" % a.dtype.itemsize))
+            d = u.copy()
+            d[:, 1:] = u[:, 1:] - u[:, :-1]          # modulo 2**bits
+            plane = d
+        raw = plane.tobytes()
+        strips.append(zlib.compress(raw, 6) if compress else raw)
     entries = []                                    # (tag, type, count, bytes)
 
     def add(tag, typ, values):
@@ -187,15 +206,22 @@ def write_geotiff(path, array, geo_transform=None, nodata=None, geokeys=None):
     add(256, 4, [w])
     add(257, 4, [h])
     add(258, 3, [a.dtype.itemsize * 8] * bands)
-    add(259, 3, [1])
+    add(259, 3, [8 if compress else 1])
     add(262, 3, [1])                                # BlackIsZero
-    add(273, 4, [8 + b * band_bytes for b in range(bands)])    # one strip per band, data at 8
+    offs, o = [], 8                                 # one strip per band, data at 8
+    for st in strips:
+        offs.append(o)
+        o += len(st) + (len(st) & 1)
+    data_bytes = o - 8
+    add(273, 4, offs)
     add(277, 3, [bands])
     add(278, 4, [h])
-    add(279, 4, [band_bytes] * bands)
+    add(279, 4, [len(st) for st in strips])
     add(284, 3, [1 if bands == 1 else 2])           # band-separate planes
     if bands > 1:
         add(338, 3, [0] * (bands - 1))              # ExtraSamples: unspecified data
+    if predictor == 2:
+        add(317, 3, [2])
     add(339, 3, [kind] * bands)
     if geo_transform is not None:
         x0, dx, rx, y0, ry, dy = [float(v) for v in geo_transform]
@@ -216,10 +242,9 @@ def write_geotiff(path, array, geo_transform=None, nodata=None, geokeys=None):
         add(42113, 2, repr(float(nodata)))
     entries.sort(key=lambda e: e[0])
 
-    if a.nbytes + 4096 + sum(len(e[3]) for e in entries) >= 2 ** 32:
+    if data_bytes + 4096 + sum(len(e[3]) for e in entries) >= 2 ** 32:
         raise ValueError("write_geotiff: raster too large for classic TIFF")
-    data_off = 8
-    ifd_off = data_off + a.nbytes + (a.nbytes & 1)
+    ifd_off = 8 + data_bytes
     extra_off = ifd_off + 2 + 12 * len(entries) + 4
     ifd = struct.pack("<H", len(entries))
     extra = b""
@@ -233,8 +258,9 @@ def write_geotiff(path, array, geo_transform=None, nodata=None, geokeys=None):
     ifd += struct.pack("<I", 0)
     with open(path, "wb") as f:
         f.write(b"II" + struct.pack("<HI", 42, ifd_off))
-        f.write(a.tobytes())
-        if a.nbytes & 1:
-            f.write(b"\0")
+        for st in strips:
+            f.write(st)
+            if len(st) & 1:
+                f.write(b"\0")
         f.write(ifd)
         f.write(extra)

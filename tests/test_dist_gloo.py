@@ -4,10 +4,14 @@ import multiprocessing as mp
 import os
 import socket
 
+import sys
+
 import numpy as np
 import pytest
 
 from scarplet_amd import dist as sd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_layout_tiles_the_dem():
@@ -66,13 +70,15 @@ def _free_port():
 def _worker(rank, world, port, ny, nx, halo, q):
     try:
         import torch.distributed as dist
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from torch_transport import TorchTransport
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
                                 rank=rank, world_size=world)
         z = np.random.default_rng(9).standard_normal((ny, nx))
         py, px = sd.grid_dims(world, ny, nx)
         lay = sd.Layout(ny, nx, py, px, halo)
         c = lay.core(rank)
-        blk = sd.exchange_gloo(z[c[0]:c[1], c[2]:c[3]], lay, rank)
+        blk = sd.exchange_host(z[c[0]:c[1], c[2]:c[3]], lay, rank, TorchTransport())
         ok = np.array_equal(blk, sd.assemble_block_reference(z, lay, rank))
         dist.barrier()
         dist.destroy_process_group()
@@ -93,6 +99,19 @@ def test_halo_exchange_over_gloo(world, ny, nx, halo):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(r, True) for r in range(world)], res
+
+
+def test_package_imports_no_process_group_library():
+    """north_star: host code is Python over ctypes, no PyTorch in the product."""
+    import subprocess
+    code = ("import sys; import scarplet_amd, scarplet_amd.dist, scarplet_amd.core; "
+            "assert 'torch' not in sys.modules, 'torch imported by the package'")
+    subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "scarplet_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import torch" not in src, f
 
 
 def test_halo_for_search_covers_the_reach():

@@ -6,8 +6,10 @@ Stated tolerances (float32 device arithmetic vs the float64 reference):
   amp : |d| <= AMP_RTOL * |amp| + AMP_ATOL * max|amp|
   snr : |d| <= SNR_RTOL * snr  + SNR_ATOL * max(snr)
   argmax (age, angle): exact, except where the oracle's best and the chosen
-  template's SNR differ by less than TIE_RTOL (near-tie policy, see
-  oracle.check_fold and DESIGN.md "Parity").
+  template's SNR differ by less than TIE_RTOL = 3e-4 - twice the largest SNR
+  error measured on the device (near-tie policy, see oracle.check_fold and
+  DESIGN.md "Parity").  Every fold test prints and asserts the fraction of
+  cells that carry exactly the oracle's argmax (EXACT_MIN).
 """
 import numpy as np
 import pytest
@@ -20,9 +22,17 @@ from conftest import golden, load_cases
 
 pytestmark = pytest.mark.gpu
 
-AMP_RTOL, AMP_ATOL = 2e-4, 2e-6
-SNR_RTOL, SNR_ATOL = 2e-3, 2e-6
-TIE_RTOL = 4e-3
+AMP_RTOL, AMP_ATOL = orc.PARITY["amp"]
+SNR_RTOL, SNR_ATOL = orc.PARITY["snr"]
+TIE_RTOL = orc.PARITY["tie_rtol"]      # twice the measured SNR error (oracle.PARITY)
+EXACT_MIN = 0.99                       # cells that must carry the oracle's own argmax
+
+
+def report(name, chk):
+    """One line per fold check in the test log (pytest -s / GPUTEST output)."""
+    print("fold %-44s bad=%d exact=%.4f strict=%d tie=%d of %d snr_err=%.2e amp_err=%.2e"
+          % (name, chk["n_bad"], chk["exact_frac"], chk["n_strict"], chk["n_tie"], chk["n"],
+             chk["snr_err"], chk["amp_err"]))
 
 CLS = {"scarp": WT.Scarp, "ricker": WT.Ricker,
        "right_upper_break": WT.RightFacingUpperBreakScarp,
@@ -124,8 +134,9 @@ def test_fold_against_oracle_stack(gpu_ctx, method):
     m = sl.Matcher(grid(z, 1.0), ctx=gpu_ctx)
     res = m.search(WT.Scarp, 10, params, angles, method=method).result()
     chk = fold_check(res, z, 1.0, 1.0, orc.SCARP, 10, params, angles)
+    report("oracle stack 96x90 %s" % method, chk)
     assert chk["n_bad"] == 0, chk
-    assert chk["n_strict"] > 0.85 * chk["n"], chk
+    assert chk["exact_frac"] >= EXACT_MIN, chk
 
 
 @pytest.mark.parametrize("method", ["direct", "fft"])
@@ -139,7 +150,12 @@ def test_fold_channel_even_template(gpu_ctx, method):
     m = sl.Matcher(grid(z, 1.0, -1.0), ctx=gpu_ctx)
     res = m.search(WT.Channel, 6, params, angles, method=method).result()
     chk = fold_check(res, z, 1.0, -1.0, orc.RICKER, 6, params, angles)
+    report("channel (even template: -90/+90 tie) %s" % method, chk)
     assert chk["n_bad"] == 0, chk
+    # -pi/2 and +pi/2 are the same template: the oracle's first maximum is -pi/2,
+    # the device may hold either; everything else must be exact
+    amb = (np.abs(res[2]) == np.pi / 2)
+    assert (chk["n_exact"] + int(amb.sum())) >= EXACT_MIN * chk["n"], chk
 
 
 def test_small_searches_reference(gpu_ctx):
@@ -152,11 +168,13 @@ def test_small_searches_reference(gpu_ctx):
         angles = _plan.angle_grid(kw["ang_min"], kw["ang_max"])
         params = [kw["age"]] if "age" in kw else list(_plan.age_grid())
         chk = fold_check(res, c["z"], float(c["dx"]), float(c["dy"]), kind, kw["scale"], params, angles)
+        report("reference sl.match capture (%s)" % kind, chk)
         assert chk["n_bad"] == 0, (kind, chk)
         if kind != "ricker":
             # (ages: numpy's 10**x differs by an ulp between the numpy that wrote the fixture and this one)
             same = np.isclose(res[1], c["res"][1], rtol=1e-9) & (np.asarray(res[2]) == c["res"][2])
-            assert same.mean() > 0.9, float(same.mean())
+            print("     same (age, angle) as the reference's output: %.4f" % same.mean())
+            assert same.mean() >= EXACT_MIN, float(same.mean())
 
 
 def golden_check(res, gold):
@@ -180,8 +198,9 @@ def test_synthetic_single_age_golden(gpu_ctx):
     res = sl.match(grid(z, 1.0), sl.Scarp, scale=100, age=10, ang_max=np.pi / 2, ang_min=-np.pi / 2)
     assert res.shape == (4, 200, 200) and res.dtype == np.float64
     ok_same, near = golden_check(res, gold)
+    print("golden synthetic_match2: same (age, angle) and values %.4f, near-tie %.4f" % (ok_same.mean(), near.mean()))
     assert (ok_same | near).all()
-    assert ok_same.mean() > 0.99
+    assert ok_same.mean() >= EXACT_MIN
 
 
 def test_synthetic_full_grid_golden(gpu_ctx):
@@ -193,8 +212,9 @@ def test_synthetic_full_grid_golden(gpu_ctx):
     assert isinstance(res, tuple) and len(res) == 4
     ok_same, near = golden_check(res, gold)
     bad = ~(ok_same | near)
+    print("golden synthetic_match1: same (age, angle) and values %.4f, near-tie %.4f" % (ok_same.mean(), near.mean()))
     assert not bad.any(), (int(bad.sum()), np.argwhere(bad)[:5])
-    assert ok_same.mean() > 0.97, float(ok_same.mean())
+    assert ok_same.mean() >= EXACT_MIN, float(ok_same.mean())
 
 
 # ------------------------------------------------------------------ plugin API
@@ -265,11 +285,91 @@ def test_compare_is_the_reference_fold(gpu_ctx):
         assert np.array_equal(a, b)
 
 
-def test_nan_dem_is_rejected(gpu_ctx):
-    z = np.zeros((40, 40))
+def test_compare_folds_plane_valued_results_like_match(gpu_ctx):
+    """match() feeds compare() the (4, ny, nx) arrays of
+    calculate_best_fit_parameters (core.py:288-292): age and angle are per-cell
+    planes there, and docs/examples/multiprocessing_example.ipynb calls
+    sl.compare([best, results], nx, ny) the same way."""
+    rng = np.random.default_rng(2)
+    ny, nx = 21, 34
+    rs = []
+    for k in range(5):
+        amp, snr = rng.standard_normal((ny, nx)), np.abs(rng.standard_normal((ny, nx)))
+        age = np.where(snr > 0.5, 10.0 ** k, 0.0)                # planes, zeros where nothing won
+        ang = rng.choice(np.linspace(-1.5, 1.5, 7), size=(ny, nx))
+        rs.append(np.stack([amp, age, ang, snr]))                # (4, ny, nx) arrays
+    rs[3][3][4, 4] = rs[1][3][4, 4]
+    rs.insert(2, (rng.standard_normal((ny, nx)), 3.0, 0.25, np.abs(rng.standard_normal((ny, nx)))))  # scalars mixed in
+    mine = sl.compare(iter(rs), ny, nx)
+    ref = orc.compare(iter(rs), ny, nx)
+    for a, b in zip(mine, ref):
+        assert np.array_equal(a, b)
+
+
+def test_second_search_with_another_grid_keeps_its_winners(gpu_ctx):
+    """Matcher.search(reset=False) folds a second parameter grid into the same
+    record: cells won by the first search must still decode to ITS (age, angle)."""
+    rng = np.random.default_rng(31)
+    z = (np.cumsum(rng.standard_normal((80, 84)), 1) * 0.05 + rng.standard_normal((80, 84)) * 0.03).astype(np.float32)
+    p1, a1 = [2.0, 20.0], np.array([-0.5, 0.1])
+    p2, a2 = [5.0, 8.0, 50.0], np.array([0.7, -1.1, 1.3])
+    m = sl.Matcher(grid(z, 1.0), ctx=gpu_ctx)
+    m.search(WT.Scarp, 10, p1, a1, method="fft")
+    m.search(WT.Scarp, 10, p2, a2, method="fft", reset=False)
+    res = m.result()
+    a_1, s_1 = orc.snr_stack(z, 1.0, 1.0, orc.SCARP, 10, p1, a1)
+    a_2, s_2 = orc.snr_stack(z, 1.0, 1.0, orc.SCARP, 10, p2, a2)
+    A = np.concatenate([a_1.reshape(-1, 80, 84), a_2.reshape(-1, 80, 84)])
+    S = np.concatenate([s_1.reshape(-1, 80, 84), s_2.reshape(-1, 80, 84)])
+    ages = np.concatenate([np.repeat(p1, len(a1)), np.repeat(p2, len(a2))])
+    angs = np.concatenate([np.tile(a1, len(p1)), np.tile(a2, len(p2))])
+    chk = orc.check_fold(res, A, S, ages, angs, tie_rtol=TIE_RTOL,
+                         amp_tol=(AMP_RTOL, AMP_ATOL * np.abs(A).max()), snr_tol=(SNR_RTOL, SNR_ATOL * S.max()))
+    report("two searches, two grids, one record", chk)
+    assert chk["n_bad"] == 0 and chk["exact_frac"] >= EXACT_MIN, chk
+    assert np.isin(res[1][res[3] > 0], ages).all()
+    assert (np.isin(res[1], p1) & (res[3] > 0)).any() and (np.isin(res[1], p2) & (res[3] > 0)).any()
+
+
+def test_direct_path_rejects_windows_wider_than_its_lds_slab(gpu_ctx):
+    """k_direct stages a 64-cell patch plus the window width per LDS row: a window
+    wider than the slab must come back as SC_ERR_UNSUPPORTED, not corrupt LDS."""
+    z = np.zeros((64, 3000), np.float32)
+    z[:, ::7] = 1.0
+    m = sl.Matcher(grid(z, 1.0), ctx=gpu_ctx)
+
+    class Wide(WT.Scarp):
+        def _device_descriptor(self):
+            return None
+
+        def template(self):
+            W = np.zeros((self.ny, self.nx))
+            W[self.ny // 2, 100:2900] = 1.0
+            return W
+    try:
+        with pytest.raises(sl._lib.ScarpletHipError, match="real-space"):
+            m.match_template(Wide, 10, 1.0, 0.0, method="direct")
+        amp, snr = m.match_template(Wide, 10, 1.0, 0.0, method="auto")     # FFT takes it
+        assert np.isfinite(amp).all()
+    finally:
+        m.ctx.clear_windows()
+
+
+def test_nan_dem_gives_the_reference_nan_maps(gpu_ctx):
+    """dem.py:85-86,105 + core.py:349-375: one NaN cell turns every output cell NaN
+    (the FFT spreads it), masks then zero their cells; compare() keeps age/angle 0."""
+    rng = np.random.default_rng(4)
+    z = rng.standard_normal((40, 44))
     z[3, 4] = np.nan
-    with pytest.raises(ValueError):
-        sl.match(grid(z, 1.0), sl.Scarp, scale=5, age=10.)
+    with pytest.warns(UserWarning, match="NaN"):
+        amp, age, ang, snr = sl.match_template(grid(z, 1.0), sl.Scarp, 5, 10., 0.3)
+    o_amp, _, _, o_snr = orc.match_template(z, 1.0, 1.0, orc.SCARP, 5, 10., 0.3)
+    assert np.array_equal(amp, o_amp, equal_nan=True) and np.array_equal(snr, o_snr, equal_nan=True)
+    assert np.isnan(amp).any() and (amp == 0).any()
+    with pytest.warns(UserWarning):
+        res = sl.match(grid(z, 1.0), sl.RightFacingUpperBreakScarp, scale=5, age=10., ang_min=-0.05, ang_max=0.05)
+    ref = orc.match(z, 1.0, 1.0, orc.RIGHT_UPPER, scale=5, age=10., ang_min=-0.05, ang_max=0.05)
+    assert np.array_equal(res, ref, equal_nan=True)
 
 
 # ------------------------------------------------------------------ full size

@@ -85,3 +85,23 @@ def test_four_band_result_raster_round_trip(tmp_path):
     assert np.allclose(gt, g._georef_info.geo_transform) and nodata is None
     with pytest.raises(ValueError):
         g.save_results(out, res[:3])
+
+
+def test_predictor2_on_float_samples_is_integer_differencing(tmp_path):
+    """GDAL's -co PREDICTOR=2 on Float32 / Float64 differences the raw sample
+    words (libtiff horAcc32/64), not the float values: decoding with a float
+    cumsum would return wrong elevations without any error."""
+    rng = np.random.default_rng(8)
+    for dt in ("f4", "f8", "i2", "u4"):
+        a = (rng.standard_normal((9, 13)) * 1e3).astype(dt)
+        out = str(tmp_path / ("p2_%s.tif" % dt))
+        tiff.write_geotiff(out, a, compress=True, predictor=2)
+        b, _, _ = tiff.read_geotiff(out)
+        assert b.dtype == a.dtype and np.array_equal(a, b)
+    # the stored words really are integer differences of the float bit patterns
+    a = np.array([[1.5, 2.25, -3.0]], dtype="f4")
+    out = str(tmp_path / "p2_words.tif")
+    tiff.write_geotiff(out, a, predictor=2)
+    raw = open(out, "rb").read()[8:8 + 12]
+    u = a.view("<u4")[0]
+    assert np.array_equal(np.frombuffer(raw, "<u4"), np.array([u[0], u[1] - u[0], u[2] - u[1]], dtype="<u4"))

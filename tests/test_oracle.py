@@ -124,3 +124,32 @@ def test_real_space_closed_form():
         _, _, det = orc.match_arrays(curv, W, np.zeros((ny, nx), bool), details=True)
         assert np.allclose(orc.xcorr_direct(curv, W), det["xcorr"], atol=1e-12)
         assert np.allclose(orc.xcorr_direct(curv ** 2, (W != 0).astype(float)), det["T3"], atol=1e-12)
+
+
+def test_window_limit_axes_is_the_mask():
+    # the separable restatement equals WindowedTemplate.py:66-84 cell for cell
+    for (nx, ny, de, alpha, c, d) in [(60, 50, 1.0, 0.3, 4.0, 9.0), (61, 47, 2.0, -np.pi / 4, 7.0, 20.0),
+                                      (40, 40, 1.0, np.pi / 2, 2.0, 6.0)]:
+        xm, ym = orc.window_limit_axes(nx, ny, de, alpha, c, d)
+        assert np.array_equal(ym[:, None] | xm[None, :], orc.window_limits(nx, ny, de, alpha, c, d))
+
+
+@pytest.mark.parametrize("shape", [(170, 160), (171, 161)])
+def test_window_stack_equals_whole_dem_stack(shape):
+    """snr_stack_window (used at 10000 x 10000, where whole-DEM templates are
+    out of reach) against snr_stack on DEMs small enough for both: interior,
+    border and wrap-corner windows, with the full grid's masks."""
+    ny, nx = shape
+    o = ny % 2
+    rng = np.random.default_rng(3)
+    z = np.cumsum(rng.standard_normal((ny, nx)), 1) * 0.05 + rng.standard_normal((ny, nx)) * 0.03
+    angles = [-np.pi / 4, 0.3, np.pi / 2]
+    for kind, scale, pars, margin in ((orc.SCARP, 8, [1.0, 10.0], 40), (orc.RICKER, 5, [0.2], 60),
+                                      (orc.RIGHT_UPPER, 8, [4.0], 40)):
+        a, s = orc.snr_stack(z, 1.0, 1.0, kind, scale, pars, angles)
+        for win in [(0, 20 + o, 0, 24 + o), (ny - 20 - o, ny, nx - 22 - o, nx), (60, 90 + o, 50, 80 + o)]:
+            aw, sw = orc.snr_stack_window(z, 1.0, 1.0, kind, scale, pars, angles, win, margin)
+            i0, i1, j0, j1 = win
+            assert np.allclose(aw, a[:, :, i0:i1, j0:j1], rtol=1e-9, atol=1e-12 * np.abs(a).max())
+            assert np.allclose(sw, s[:, :, i0:i1, j0:j1], rtol=1e-7, atol=1e-10 * s.max())
+            assert np.array_equal(sw == 0, s[:, :, i0:i1, j0:j1] == 0)

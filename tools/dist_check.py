@@ -11,6 +11,8 @@ sys.path.insert(0, ROOT)
 import torch.distributed as dist
 import scarplet_amd as sl
 from scarplet_amd import _plan, synthetic, _lib, dist as sd
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from torch_transport import TorchTransport
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--halo", default="gloo")
@@ -22,7 +24,7 @@ ndev = max(1, _lib.load().sc_device_count())
 g = synthetic.synthetic_scarp(a.n, ny=a.n - 60)
 z = g._griddata
 ages, angles = [3.0, 30.0, 300.0], _plan.angle_grid(-1.0, 1.0)[::10]
-dm = sd.DistMatcher(rank, world, z.shape, 1.0, 1.0, device=int(os.environ.get("LOCAL_RANK", 0)) % ndev, backend=a.halo)
+dm = sd.DistMatcher(rank, world, z.shape, 1.0, 1.0, device=int(os.environ.get("LOCAL_RANK", 0)) % ndev, backend=a.halo, transport=TorchTransport())
 c = dm.core()
 dm.search(sl.Scarp, 30, ages, angles, np.ascontiguousarray(z[c[0]:c[1], c[2]:c[3]]), method="fft")
 full = dm.gather(0)

@@ -3,8 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/sq_$1
 rm -rf $OUT; mkdir -p $OUT; cd $GRAFT_REPO_ROOT
-export SC_VARIANT=$1
-timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU --output-format csv -d $OUT/pmc -- python3 tools/time_search.py --n 10000 --angles 2 --reps 1 --prof 0 > $OUT/log.txt 2>&1
+timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU --output-format csv -d $OUT/pmc -- python3 tools/time_search.py --n 10000 --angles 2 --reps 1 --prof 0 --variant $1 > $OUT/log.txt 2>&1
 python3 - <<PY
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
