@@ -113,60 +113,85 @@ def _cpu_one(job):
     return time.time() - t0
 
 
-_CPU_CTX = None
+_CPU_CTX = None       # (z float64, dx, dy, kind, scale): set BEFORE the pool is forked
+
+
+def host_cores():
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
 def mem_available_bytes():
+    """min(MemAvailable, cgroup limit - usage): what this container may still take."""
+    avail = 64 << 30
     try:
         for line in open("/proc/meminfo"):
             if line.startswith("MemAvailable:"):
-                return int(line.split()[1]) * 1024
+                avail = int(line.split()[1]) * 1024
     except OSError:
         pass
-    return 64 << 30
+    for lim, use in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            v = open(lim).read().strip()
+            if v != "max" and int(v) < (1 << 60):
+                avail = min(avail, int(v) - int(open(use).read().strip()))
+        except (OSError, ValueError):
+            pass
+    return max(avail, 0)
 
 
-def cpu_baseline(g, kind, scale, params, angles, max_workers=48):
+def make_pool(g, kind, scale):
+    """The host-side process pool (oracle verification + CPU baseline), forked
+    HERE - before this process makes its first HIP call: a process that has
+    initialised the GPU must neither fork nor exec on the GPU boxes.  The workers
+    inherit the float64 DEM copy-on-write and only ever run numpy / scipy."""
+    global _CPU_CTX
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import scarplet_oracle  # noqa: F401  (inherited by the workers)
+    _CPU_CTX = (np.ascontiguousarray(g._griddata, dtype=np.float64), float(g._georef_info.dx),
+                float(g._georef_info.dy), kind, float(scale))
+    return mp.get_context("fork").Pool(max(1, min(host_cores(), 64)))
+
+
+def cpu_baseline(pool, g, params, angles, max_workers=32):
     """The oracle (float64 restatement of core.py:297-377, scipy.fft/pocketfft
     because pyfftw is not in the image) on THIS box's host cores, run the way
     the reference runs a search: a process pool over templates
     (core.py:180-183), every worker one whole-DEM template with
     single-threaded FFTs.  Bounded sample: one template per worker, stratified
     over the (age, orientation) grid (small and large supports, all quadrants);
-    workers = min(cores, available RAM / 12 GB per 10000 x 10000 template, 48).
-    The figure is units-per-second of the sample, i.e. the full search's rate
-    by extrapolation (every template costs the same FFTs)."""
-    global _CPU_CTX
-    import multiprocessing as mp
-    z = np.ascontiguousarray(g._griddata, dtype=np.float64)
-    ny, nx = z.shape
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    workers = min(cores, a third of the available RAM / 12 GB per 10000 x 10000
+    template, 32).  The figure is units-per-second of the sample, i.e. the full
+    search's rate by extrapolation (every template costs the same FFTs)."""
+    ny, nx = g._griddata.shape
+    cores = host_cores()
     per_worker = 120.0 * ny * nx + (64 << 20)         # ~11 GB transient at 10000^2 (SURVEY.md 8a, row a7)
-    workers = int(max(1, min(cores, max_workers, 0.6 * mem_available_bytes() // per_worker)))
+    avail = mem_available_bytes()
+    workers = int(max(1, min(cores, max_workers, (avail / 3.0) // per_worker)))
     n_all = len(params) * len(angles)
     n_s = max(min(8, n_all), min(workers, n_all))
     # stratified: spread over the flattened (age-major) grid with a stride coprime to both axes
     idx = np.unique(np.round(np.linspace(0, n_all - 1, n_s)).astype(int))
     jobs = [(float(params[i // len(angles)]), float(angles[(i * 7) % len(angles)])) for i in idx]
-    _CPU_CTX = (z, float(g._georef_info.dx), float(g._georef_info.dy), kind, float(scale))
-    ctx = mp.get_context("fork")
+    conc = min(workers, len(jobs))
     t0 = time.time()
-    with ctx.Pool(min(workers, len(jobs))) as pool:
-        per = pool.map(_cpu_one, jobs, chunksize=1)
+    per = []
+    for k in range(0, len(jobs), conc):               # at most `conc` templates in flight (memory)
+        per += pool.map(_cpu_one, jobs[k:k + conc], chunksize=1)
     dt = time.time() - t0
-    _CPU_CTX = None
     value = ny * nx * len(jobs) / dt / 1e6
-    return {"value": round(value, 3), "unit": "Mpx.template/s", "cores": int(min(workers, len(jobs))), "kind": "port",
+    return {"value": round(value, 3), "unit": "Mpx.template/s", "cores": int(conc), "kind": "port",
             "sample": "%d of the %d templates (stratified over ages and orientations) on the full %dx%d DEM, "
-                      "oracle/scarplet_oracle.py (float64, scipy.fft single-threaded per template), process pool of "
-                      "%d workers like core.py:180-183 (%d cores visible, %.0f GB RAM available), wall %.1f s, "
-                      "mean %.1f s per template per worker; the full search's rate is this figure by extrapolation "
-                      "(x%d templates)" % (len(jobs), n_all, ny, nx, min(workers, len(jobs)), cores,
-                                           mem_available_bytes() / 1e9, dt, float(np.mean(per)), n_all)}
+                      "oracle/scarplet_oracle.py (float64, scipy.fft single-threaded per template), process pool: "
+                      "%d templates at a time like core.py:180-183 (%d cores visible, %.0f GB RAM available, "
+                      "12 GB per template), wall %.1f s, mean %.1f s per template per worker; the full search's "
+                      "rate is this figure by extrapolation (x%d templates)" % (
+                          len(jobs), n_all, ny, nx, conc, cores, avail / 1e9, dt, float(np.mean(per)), n_all)}
 
 
 # ----------------------------------------------------------------------------- verification
-def verify_window(res, g, kind, scale, params, angles, plan):
+def verify_window(pool, res, g, kind, scale, params, angles, plan):
     """A window of the finished search against the oracle, every template of the
     grid (oracle.snr_stack_window + check_fold, tolerances oracle.PARITY).  The
     window straddles the corner where four FFT tiles meet when the plan is tiled."""
@@ -181,10 +206,9 @@ def verify_window(res, g, kind, scale, params, angles, plan):
     win = (i0, i0 + w + (ny % 2), j0, j0 + w + (nx % 2))        # crop parity = DEM parity
     if 2 * reach + w >= min(ny, nx):
         return {"ok": None, "note": "DEM too small for a windowed check"}
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
     t0 = time.time()
     a_st, s_st = orc.snr_stack_window(g._griddata, float(g._georef_info.dx), float(g._georef_info.dy), kind, scale,
-                                      params, angles, win, reach, procs=max(1, min(cores, 64)))
+                                      params, angles, win, reach, pool=pool)
     T = len(params) * len(angles)
     h, wd = win[1] - win[0], win[3] - win[2]
     sub = tuple(np.asarray(r)[win[0]:win[1], win[2]:win[3]] for r in res)
@@ -241,11 +265,14 @@ def main():
     import scarplet_amd as sl
     from scarplet_amd import _lib
     from scarplet_amd import dist as sd
-    ndev = max(1, _lib.load().sc_device_count())
-    device = local % ndev                      # one rank per GPU; wraps only in bring-up runs
 
     g, Template, scales, params, angles, label, kind = workload(a)     # same seed on every rank
     ny, nx = g._griddata.shape
+    pool = None
+    if rank == 0 and world == 1 and not a.emulate_ranks and not (a.no_verify and a.no_cpu_baseline):
+        pool = make_pool(g, kind, scales[0])   # forked before the first HIP call below
+    ndev = max(1, _lib.load().sc_device_count())
+    device = local % ndev                      # one rank per GPU; wraps only in bring-up runs
     n_templates = len(params) * len(angles) * len(scales)
     units = float(ny) * nx * n_templates               # px.template per step
     emu = None
@@ -383,7 +410,7 @@ def main():
             if not a.no_verify:
                 # the record the timed loop left behind (the last scale's, for C5)
                 res = ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
-                ver = verify_window(res, g, kind, scales[-1], params, angles, plan)
+                ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan)
                 del res
                 out["verified"] = ver["ok"]
                 out["verification"] = ver
@@ -408,7 +435,10 @@ def main():
                                      "includes": "H2D of the float64 DEM, curvature planes, template descriptors, "
                                                  "search, float64 (4,ny,nx) result conversion and D2H"}
             if not a.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(g, kind, scales[0], params, angles)
+                out["cpu_baseline"] = cpu_baseline(pool, g, params, angles)
+            if pool is not None:
+                pool.terminate()
+                pool.join()
         print(json.dumps(out, ensure_ascii=False))
     if dist is not None:
         dist.barrier()

@@ -303,14 +303,9 @@ def window_limit_axes(nx, ny, de, alpha, c, d):
     return xmask, ymask
 
 
-_WIN = None      # crop shared with forked pool workers (snr_stack_window)
-
-
-def _window_job(job):
-    """One template of snr_stack_window (module level: runs in pool workers,
-    which inherit the crop through _WIN when the pool is forked)."""
-    age, angle = job
-    (zc, gi, gj, ny, nx, dx, dy, kind, scale, margin, workers) = _WIN
+def _window_one(ctx, age, angle):
+    """One template of snr_stack_window."""
+    (zc, gi, gj, ny, nx, dx, dy, kind, scale, margin, workers) = ctx
     # dem.py:68-107 on the crop, with the zero borders of the FULL grid
     # (dem.py:88-101: A is zero in the first/last column, B in the first row
     # and column, C in the first/last row); interior stencils never reach
@@ -344,8 +339,15 @@ def _window_job(job):
     return amp, snr
 
 
+def _window_chunk(job):
+    """A run of templates of one window (module level: runs in pool workers;
+    the job carries the crop, so the pool may predate it)."""
+    ctx, pairs = job
+    return [_window_one(ctx, age, ang) for (age, ang) in pairs]
+
+
 def snr_stack_window(z, dx, dy, kind, scale, ages, angles, win, margin,
-                     workers=1, procs=1):
+                     workers=1, procs=1, pool=None):
     """Per-template (amp, snr) of the FULL periodic DEM ``z`` over the window
     ``win = (i0, i1, j0, j1)`` only, shape (n_ages, n_angles, i1-i0, j1-j0).
 
@@ -357,8 +359,11 @@ def snr_stack_window(z, dx, dy, kind, scale, ages, angles, win, margin,
     curvature borders.  Exact for the inner window when ``margin`` covers the
     template reach plus one cell and the crop has the DEM's size parity
     (tests/test_oracle.py compares it with snr_stack on whole small DEMs).
-    ``procs`` > 1 spreads the templates over a forked process pool."""
-    global _WIN
+
+    ``pool``: a multiprocessing pool to spread the templates over.  Callers
+    that use a GPU create it BEFORE the first HIP call (a process that has
+    initialised the GPU must not fork or exec on the GPU boxes); ``procs`` > 1
+    forks a pool here instead (CPU-only callers)."""
     z = np.asarray(z)
     ny, nx = z.shape
     i0, i1, j0, j1 = win
@@ -367,17 +372,23 @@ def snr_stack_window(z, dx, dy, kind, scale, ages, angles, win, margin,
     if (len(gi) - ny) % 2 or (len(gj) - nx) % 2:
         raise ValueError("crop and DEM sizes must have the same parity")
     zc = np.asarray(z[np.ix_(gi, gj)], dtype=float)
-    _WIN = (zc, gi, gj, ny, nx, dx, dy, kind, scale, margin, workers)
-    jobs = [(age, ang) for age in ages for ang in angles]
+    ctx = (zc, gi, gj, ny, nx, dx, dy, kind, scale, margin, workers)
+    pairs = [(age, ang) for age in ages for ang in angles]
+    own = None
+    if pool is None and procs > 1:
+        import multiprocessing as mp
+        own = pool = mp.get_context("fork").Pool(min(procs, len(pairs)))
     try:
-        if procs > 1:
-            import multiprocessing as mp
-            with mp.get_context("fork").Pool(min(procs, len(jobs))) as pool:
-                out = pool.map(_window_job, jobs, chunksize=1)
+        if pool is not None:
+            nproc = getattr(pool, "_processes", None) or procs or 1
+            per = max(1, -(-len(pairs) // (4 * nproc)))
+            jobs = [(ctx, pairs[k:k + per]) for k in range(0, len(pairs), per)]
+            out = [r for chunk in pool.map(_window_chunk, jobs, chunksize=1) for r in chunk]
         else:
-            out = [_window_job(j) for j in jobs]
+            out = [_window_one(ctx, age, ang) for (age, ang) in pairs]
     finally:
-        _WIN = None
+        if own is not None:
+            own.terminate()
     amp = np.array([o[0] for o in out]).reshape(len(ages), len(angles), i1 - i0, j1 - j0)
     snr = np.array([o[1] for o in out]).reshape(amp.shape)
     return amp, snr

@@ -17,23 +17,41 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: takes more than ~20 s on CPU")
 
 
-def _gpu_available():
-    try:
-        from scarplet_amd import _lib
-        return _lib.load().sc_device_count() > 0
-    except Exception:
-        return False
+def _gpu_box():
+    """A GPU box, judged WITHOUT a HIP call: collection must not initialise the
+    GPU in this process (tests fork pools and start subprocesses later, and a
+    process that has initialised the GPU must not fork or exec on the GPU boxes)."""
+    lib = os.path.join(ROOT, "scarplet_amd", "libscarplet_hip.so")
+    return os.path.exists("/dev/kfd") and os.path.exists(lib)
 
 
 def pytest_collection_modifyitems(config, items):
     """Without a device (or without the built library) the gpu-marked tests
     are skipped rather than failed; `-m "not gpu"` deselects them anyway."""
-    if _gpu_available():
+    if _gpu_box():
         return
     skip = pytest.mark.skip(reason="needs an MI355X and the built libscarplet_hip.so")
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def oracle_pool(request):
+    """Process pool for the oracle stacks of the gpu tests.  Created at session
+    start, before any test can create a GPU context: the workers are forked from
+    a process that has not touched HIP and only ever run numpy."""
+    want = _gpu_box() and any("gpu" in item.keywords for item in request.session.items)
+    if not want:
+        yield None
+        return
+    import multiprocessing as mp
+    import scarplet_oracle  # noqa: F401  (workers inherit the module)
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    pool = mp.get_context("fork").Pool(max(1, min(n, 48)))
+    yield pool
+    pool.terminate()
+    pool.join()
 
 
 def golden(name):
@@ -55,6 +73,6 @@ def load_cases(name):
 
 
 @pytest.fixture(scope="session")
-def gpu_ctx():
+def gpu_ctx(oracle_pool):
     from scarplet_amd import _lib
     return _lib.Context(0)

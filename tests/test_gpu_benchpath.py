@@ -8,8 +8,6 @@ result against oracle.snr_stack_window: inside a tile, across the corner
 where four tiles (two tile pairs, two tile rows) meet, on the DEM's wrap
 edges and in the partial last tiles.  The exact-argmax fraction and the
 measured SNR error are printed and asserted (run with -s to see them)."""
-import os
-
 import numpy as np
 import pytest
 
@@ -21,13 +19,8 @@ pytestmark = pytest.mark.gpu
 P = orc.PARITY
 
 
-def procs():
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    return max(1, min(n, 48))
-
-
-def check_window(res, z, kind, scale, ages, angles, win, margin):
-    a_st, s_st = orc.snr_stack_window(z, 1.0, 1.0, kind, scale, ages, angles, win, margin, procs=procs())
+def check_window(res, z, kind, scale, ages, angles, win, margin, pool):
+    a_st, s_st = orc.snr_stack_window(z, 1.0, 1.0, kind, scale, ages, angles, win, margin, pool=pool)
     T = len(ages) * len(angles)
     i0, i1, j0, j1 = win
     sub = tuple(np.asarray(r)[i0:i1, j0:j1] for r in res)
@@ -37,7 +30,7 @@ def check_window(res, z, kind, scale, ages, angles, win, margin):
                           snr_tol=(P["snr"][0], P["snr"][1] * np.max(s_st)))
 
 
-def test_bench_plan_windows_against_oracle(gpu_ctx):
+def test_bench_plan_windows_against_oracle(gpu_ctx, oracle_pool):
     n = 10000
     g = synthetic.synthetic_scarp(n)
     ages = _plan.age_grid()                                     # all 35: one inverse launch each
@@ -59,7 +52,7 @@ def test_bench_plan_windows_against_oracle(gpu_ctx):
     }
     worst = 0.0
     for name, win in wins.items():
-        chk = check_window(res, g._griddata, orc.SCARP, 100, ages, angles, win, 160)
+        chk = check_window(res, g._griddata, orc.SCARP, 100, ages, angles, win, 160, oracle_pool)
         print("bench-plan window %-40s bad=%d exact=%.4f strict=%d tie=%d of %d  snr_err=%.2e amp_err=%.2e"
               % (name, chk["n_bad"], chk["exact_frac"], chk["n_strict"], chk["n_tie"], chk["n"],
                  chk["snr_err"], chk["amp_err"]))
