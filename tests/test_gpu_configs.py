@@ -173,7 +173,9 @@ def test_paired_templates_agree_with_paired_tiles():
     paired-template mode of an unpaired tile (default) against the same search
     with that tile in a half-empty tile pair (option variant=5 switches the mode off)."""
     g = synthetic.synthetic_scarp(1700, ny=1650, seed=11)
-    ages, angles = _plan.age_grid()[::5], _plan.angle_grid()[::30]
+    # (+pi/2 left out: Scarp at -pi/2 and +pi/2 is one template up to the sign of W, their
+    #  SNRs tie to an ulp and the two modes may keep either)
+    ages, angles = _plan.age_grid()[::5], _plan.angle_grid()[:-1:30]
     out = {}
     for variant in ("0", "5"):
         ctx = sl._lib.Context(0)
