@@ -161,16 +161,16 @@ def cpu_baseline(pool, g, params, angles, max_workers=32):
     (core.py:180-183), every worker one whole-DEM template with
     single-threaded FFTs.  Bounded sample: one template per worker, stratified
     over the (age, orientation) grid (small and large supports, all quadrants);
-    workers = min(cores, a third of the available RAM / 12 GB per 10000 x 10000
-    template, 32).  The figure is units-per-second of the sample, i.e. the full
+    workers = min(cores, 0.6 x the container's available RAM / 12 GB per
+    10000 x 10000 template, 32).  The figure is units-per-second of the sample, i.e. the full
     search's rate by extrapolation (every template costs the same FFTs)."""
     ny, nx = g._griddata.shape
     cores = host_cores()
     per_worker = 120.0 * ny * nx + (64 << 20)         # ~11 GB transient at 10000^2 (SURVEY.md 8a, row a7)
     avail = mem_available_bytes()
-    workers = int(max(1, min(cores, max_workers, (avail / 3.0) // per_worker)))
+    workers = int(max(1, min(cores, max_workers, (0.6 * avail) // per_worker)))
     n_all = len(params) * len(angles)
-    n_s = max(min(8, n_all), min(workers, n_all))
+    n_s = max(min(8, n_all), min(2 * workers, n_all))     # two rounds of the pool
     # stratified: spread over the flattened (age-major) grid with a stride coprime to both axes
     idx = np.unique(np.round(np.linspace(0, n_all - 1, n_s)).astype(int))
     jobs = [(float(params[i // len(angles)]), float(angles[(i * 7) % len(angles)])) for i in idx]
