@@ -162,11 +162,14 @@ def main():
             (WT.Channel, orc.RICKER, 64, 72, 1., 5, 0.1, 0.8),
             (WT.Ricker, orc.RICKER, 63, 64, 1., 8, 0.2, -0.3),
             (WT.RightFacingUpperBreakScarp, orc.RIGHT_UPPER, 64, 64, 1., 10, 10., 0.2),
-            (WT.LeftFacingUpperBreakScarp, orc.LEFT_UPPER, 60, 66, 1., 10, 5., -0.6)]:
+            (WT.LeftFacingUpperBreakScarp, orc.LEFT_UPPER, 60, 66, 1., 10, 5., -0.6),
+            (WT.Scarp, "scarp_negdy", 58, 62, 2., 16, 12., 0.9)]:
         z = np.cumsum(np.cumsum(rng.standard_normal((ny, nx)), 0), 1) * 0.01 \
             + rng.standard_normal((ny, nx)) * 0.05
         z = z.astype(np.float32)
         dy = de if kind != orc.RICKER else -de      # channels notebook uses dy=-dx
+        if kind == "scarp_negdy":                   # north-up GeoTIFFs load with dy < 0 (dem.py:331-332)
+            kind, dy = orc.SCARP, -de
         g = ref_grid(dem, z, de, dy)
         r_amp, r_age, r_ang, r_snr = sl.match_template(g, cls, scale, age, ang)
         o_amp, _, _, o_snr, det = orc.match_template(z, de, dy, kind, scale, age,
@@ -253,6 +256,61 @@ def main():
                         amps=np.stack([x[0] for x in a]), ages=np.array([x[1] for x in a]),
                         angs=np.array([x[2] for x in a]), snrs=np.stack([x[3] for x in a]),
                         res=np.stack(r))
+
+    # ------------------------------------------------------------------ f1
+    print("Shifted templates (WindowedTemplate.py:307-431): reference captures")
+    sh = []
+    for (cls, name, ny, nx, de, scale, age, ang, sdx, sdy) in [
+            (WT.ShiftedLeftFacingUpperBreakScarp, "shifted_left", 52, 60, 1., 8, 6., 0.3, 3, -2),
+            (WT.ShiftedRightFacingUpperBreakScarp, "shifted_right", 57, 49, 1., 7, 3., -0.8, -4, 1),
+            (WT.ShiftedLeftFacingUpperBreakScarp, "shifted_left", 48, 48, 2., 14, 20., 1.2, 0, 5)]:
+        z = (np.cumsum(rng.standard_normal((ny, nx)), 1) * 0.05
+             + rng.standard_normal((ny, nx)) * 0.02).astype(np.float32)
+        t = cls(scale, age, ang, nx, ny, de, dx=sdx, dy=sdy)
+        W, lim, err = t.template(), t.get_window_limits(), t.get_err_mask()
+        g = ref_grid(dem, z, de, de)
+        r_amp, _, _, r_snr = sl.match_template(g, cls, scale, age, ang, dx=sdx, dy=sdy)
+        curv = orc.directional_curvature(z, de, de, ang)
+        o_amp, o_snr = orc.match_arrays(curv, W, lim, err)
+        tag = "%s %dx%d shift (%d,%d)" % (name, ny, nx, sdx, sdy)
+        close(o_amp, r_amp, rtol=1e-9, atol=1e-13, what="amp " + tag)
+        close(o_snr, r_snr, rtol=1e-7, atol=1e-10, what="snr " + tag)
+        sh.append(dict(name=name, z=z, de=de, scale=scale, age=age, ang=ang, sdx=sdx, sdy=sdy,
+                       W=W, lim=lim, err=err, amp=r_amp, snr=r_snr))
+    np.savez_compressed(
+        os.path.join(OUT, "ref_shifted.npz"), n=len(sh),
+        **{"%s_%d" % (k, i): np.array(v) for i, c in enumerate(sh) for k, v in c.items()})
+
+    # ------------------------------------------------------------------ sample DEMs
+    print("sample DEM fixtures (rasters of scarplet/datasets/data as arrays; crops as TIFF)")
+    DATA = os.path.join(REF, "scarplet/datasets/data")
+    car = tifffile.imread(os.path.join(DATA, "carrizo.tif"))
+    gc = tifffile.imread(os.path.join(DATA, "grandcanyon.tif"))
+    assert car.shape == (900, 505) and car.dtype == np.float32
+    assert gc.shape == (512, 512) and gc.dtype == np.int16
+    np.savez_compressed(os.path.join(OUT, "dem_carrizo.npz"), z=car, dx=2.0, dy=2.0,
+                        source="scarplet/datasets/data/carrizo.tif (B4 lidar, Wallace Creek); "
+                               "900x505 float32, 2 m")
+    np.savez_compressed(os.path.join(OUT, "dem_grandcanyon.npz"), z=gc, dx=1.0, dy=-1.0,
+                        source="scarplet/datasets/data/grandcanyon.tif (AWS terrain tiles); 512x512 "
+                               "int16; dx=1, dy=-1 as in docs/source/examples/channels.ipynb")
+    # crops re-encoded the way the originals are (the GeoTIFF reader's cases):
+    # carrizo: uncompressed float32 strips; grandcanyon: 32x32 tiles, deflate,
+    # horizontal predictor, ModelPixelScale / ModelTiepoint / GDAL_NODATA tags
+    cc = np.ascontiguousarray(car[100:150, 200:260])
+    tifffile.imwrite(os.path.join(OUT, "carrizo_crop.tif"), cc, rowsperstrip=4)
+    np.save(os.path.join(OUT, "carrizo_crop.npy"), cc)
+    with tifffile.TiffFile(os.path.join(DATA, "grandcanyon.tif")) as tf:
+        tags = tf.pages[0].tags
+        scale_tag = tuple(tags["ModelPixelScaleTag"].value)
+        tie = tuple(tags["ModelTiepointTag"].value)
+        nod = tags["GDAL_NODATA"].value
+    gcc = np.ascontiguousarray(gc[200:296, 300:380])
+    tifffile.imwrite(os.path.join(OUT, "grandcanyon_crop.tif"), gcc, tile=(32, 32),
+                     compression="adobe_deflate", predictor=True,
+                     extratags=[(33550, "d", 3, scale_tag, False), (33922, "d", 6, tie, False),
+                                (42113, "s", 0, str(nod), False)])
+    np.save(os.path.join(OUT, "grandcanyon_crop.npy"), gcc)
 
     print("search grids")
     for lo, hi in [(-np.pi / 2, np.pi / 2), (-np.pi / 4, np.pi / 4),

@@ -250,6 +250,20 @@ def test_upper_break_err_masks(gpu_ctx):
             assert (snr[o_snr == 0] == 0).all()
 
 
+def test_shifted_templates_reference_outputs(gpu_ctx):
+    """Shifted UpperBreak templates (WindowedTemplate.py:307-431) through the generic
+    window path, against amp / snr captured from the reference's match_template."""
+    from test_templates import SHIFTED
+    for c in load_cases("ref_shifted.npz"):
+        g = grid(c["z"], float(c["de"]))
+        for method in ("direct", "fft"):
+            amp, _, _, snr = sl.match_template(g, SHIFTED[str(c["name"])], float(c["scale"]), float(c["age"]),
+                                               float(c["ang"]), dx=int(c["sdx"]), dy=int(c["sdy"]), method=method)
+            ok, err = close_maps(amp, snr, c["amp"], c["snr"])
+            assert ok, (str(c["name"]), method, err)
+            assert (snr[c["snr"] == 0] == 0).all()
+
+
 def test_serial_driver_forwards_kwargs(gpu_ctx):
     """calculate_best_fit_parameters_serial is the one route to the Shifted
     templates (core.py:65-136 forwards **kwargs)."""

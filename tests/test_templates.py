@@ -68,3 +68,21 @@ def test_shifted_template_quirks():
     assert np.array_equal(out[:3, 2:], W[:3, :3]) and not out[3].any() and not out[:, :2].any()
     out = t.shift_template(W, -1, -1)
     assert np.array_equal(out[1:, :4], W[1:, 1:]) and not out[0].any() and not out[:, 4].any()
+
+
+SHIFTED = {"shifted_left": WT.ShiftedLeftFacingUpperBreakScarp,
+           "shifted_right": WT.ShiftedRightFacingUpperBreakScarp}
+
+
+def test_shifted_templates_match_reference_captures():
+    """WindowedTemplate.py:307-431: template(), window limits and error mask of the
+    Shifted classes against arrays captured from the reference's own objects."""
+    for c in load_cases("ref_shifted.npz"):
+        ny, nx = c["z"].shape
+        t = SHIFTED[str(c["name"])](float(c["scale"]), float(c["age"]), float(c["ang"]), nx, ny,
+                                    float(c["de"]), dx=int(c["sdx"]), dy=int(c["sdy"]))
+        W = t.template()
+        assert np.allclose(W, c["W"], rtol=1e-13, atol=0)
+        assert np.array_equal(W != 0, c["W"] != 0)
+        assert np.array_equal(t.get_window_limits(), c["lim"])
+        assert np.array_equal(t.get_err_mask(), c["err"])
