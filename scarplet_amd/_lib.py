@@ -10,7 +10,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscarplet_hip.so")
+# SCARPLET_HIP_LIB: developer hook of the tools/ scripts to load another build of the
+# same library (the -DSC_ABLATE timing build); the engine itself reads no environment
+LIB_PATH = os.environ.get("SCARPLET_HIP_LIB") or os.path.join(_HERE, "libscarplet_hip.so")
 
 SC_OK = 0
 ABI_VERSION = 2

@@ -92,6 +92,18 @@ __device__ __forceinline__ void store_stream(float2* dst, float2 a, float2 b) {
     const f4 v = {a.x, a.y, b.x, b.y};
     __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dst));
 }
+#ifdef SC_ABLATE
+// store flavours for the ablation build (tools/ablate.sh): 0 non-temporal (production),
+// 1 plain, 2 sc1 (write-through, line dropped from L2), 3 sc0 sc1
+__device__ __forceinline__ void store_flavour(float2* dst, float2 a, float2 b, int mode) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = {a.x, a.y, b.x, b.y};
+    if (mode == 1) { *reinterpret_cast<f4*>(dst) = v; return; }
+    if (mode == 2) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory"); return; }
+    if (mode == 3) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory"); return; }
+    __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dst));
+}
+#endif
 template <int T>
 __device__ __forceinline__ int lidx(int line, int i) { return line * fft_line(T) + ph(i); }
 
@@ -888,7 +900,11 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
                int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, int ky, int kx,
                int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
-               float2* __restrict__ ym, int ystride) {
+               float2* __restrict__ ym, int ystride, int dbg) {
+    // dbg: timing-only ablation bits of an SC_ABLATE build (tools/ablate.sh), folded away otherwise:
+    //   1 no coefficient fetch in mirrored launches   2 no coefficient fetch at all   4 no stores
+    //   8 no transform   16 stores paired into whole 128-byte lines (a bijection onto the same plane)
+    //   32 plain stores   64 sc1 stores   128 one contiguous run per workgroup and template   256 sc0 sc1 stores
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     static_assert(inv_cols_park<TY>(), "symmetric I1 parks the spectrum");
     FftTw<TY> twr;
@@ -949,6 +965,10 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
             }
             xs[threadIdx.x + u * NT] = make_float4(xv[0].x, xv[0].y, xv[1].x, xv[1].y);
         }
+        if (SC_DBGBIT(dbg, 2) || (mirrored && SC_DBGBIT(dbg, 1))) {
+#pragma unroll
+            for (int u = 0; u < EP; ++u) hreg[u] = make_float2(1.f + u, 2.f);
+        } else
         fetch(0);
         if (mirrored) lds_barrier();      // mirrored fills read other threads' cells of xs
         for (int gi_ = 0; gi_ < NG; ++gi_) {
@@ -977,15 +997,195 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                 }
             }
             lds_barrier();
-            if (gi_ + 1 < NG) fetch(gi_ + 1);
-            fft4_lines<TY, true>(sm, twr);
+            if (gi_ + 1 < NG && !SC_DBGBIT(dbg, 2) && !(mirrored && SC_DBGBIT(dbg, 1))) fetch(gi_ + 1);
+            if (!SC_DBGBIT(dbg, 8)) fft4_lines<TY, true>(sm, twr);
             float2* o = (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)(cb >> 1) * 16 + (cb & 1) * 8;
             const int e_lo = 4 * rp_lo, e_hi = 4 * (rp_hi + 1);
+            if (!SC_DBGBIT(dbg, 4))
 #pragma unroll 2
             for (int e = e_lo + threadIdx.x; e < e_hi; e += NT) {
                 int rp = e >> 2, k = e & 3;
                 float2 x0 = sm[lidx<TY>(k, 2 * rp)], x1 = sm[lidx<TY>(k, 2 * rp + 1)];
+#ifdef SC_ABLATE
+                if (dbg & (16 | 32 | 64 | 128 | 256)) {
+                    float2* dst = o + (size_t)rp * (Tx >> 3) * 16 + 2 * k;
+                    if (dbg & 16)        // row pairs (2q, 2q+1) of this block -> one whole line in row pair 2q + (cb & 1)
+                        dst = (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)(cb >> 1) * 16 +
+                              (size_t)((rp & ~1) + (cb & 1)) * (Tx >> 3) * 16 + (rp & 1) * 8 + 2 * k;
+                    if (dbg & 128)       // the workgroup's cells of this template as one contiguous run
+                        dst = (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)cb * (TY * 4) + 2 * (size_t)e;
+                    store_flavour(dst, x0, x1, (dbg & 32) ? 1 : (dbg & 64) ? 2 : (dbg & 256) ? 3 : 0);
+                    continue;
+                }
+#endif
                 store_stream(o + (size_t)rp * (Tx >> 3) * 16 + 2 * k, x0, x1);
+            }
+            lds_barrier();
+        }
+    }
+}
+
+// ---- in-LDS FFT of NL lines by NT threads (general form) -------------------------
+// The transform above is fixed at 4 lines and fft_threads(T) threads.  The
+// register-parked I1 below runs other shapes (8 lines by 512 threads, 4 lines by
+// 256): U = NL*S/NT sets per thread and stage; with NT a multiple of S a thread's
+// sets share their set index tt, so one set of twiddle bases serves all of them.
+template <int T, int NL, int NT>
+struct FftTwG {
+    static constexpr int S = T / 16;
+    static constexpr int U = NL * S / NT;
+    static constexpr int LOGT = __builtin_ctz(T);
+    static constexpr int NST = (LOGT + 3) / 4;
+    static constexpr int NTW = NST - 1;
+    static_assert((NL * S) % NT == 0 && NT % S == 0, "sets divide evenly; one tt per thread");
+    float2 w[NTW > 0 ? NTW : 1][4];
+    __device__ __forceinline__ void load(const float2* __restrict__ tw) {
+#pragma unroll
+        for (int k = 0; k < NTW; ++k) {
+            const int tt = threadIdx.x % S;
+            const int e = (tt >> (4 * k)) << (4 * k);
+            w[k][0] = tw[e];
+            w[k][1] = tw[2 * e];
+            w[k][2] = tw[4 * e];
+            w[k][3] = tw[8 * e];
+        }
+    }
+};
+
+template <int T, int NL, int NT, int R, int LST, bool INV>
+__device__ __forceinline__ void fft_stage_g(float2* s, const FftTwG<T, NL, NT>& twr) {
+    constexpr int S = T / 16;
+    constexpr int U = NL * S / NT;
+    float2 a[U][16];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int id = threadIdx.x + u * NT;
+        set_load<T>(s + (id / S) * fft_line(T), id % S, a[u]);
+    }
+    if constexpr ((R << LST) != T) lds_barrier();      // the last stage works in place
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int id = threadIdx.x + u * NT;
+        set_compute_store<T, R, LST, INV>(s + (id / S) * fft_line(T), id % S, a[u],
+                                          twr.w[(LST / 4) < FftTwG<T, NL, NT>::NTW ? LST / 4 : 0]);
+    }
+    lds_barrier();
+}
+
+template <int T, int NL, int NT, int LST, bool INV>
+__device__ __forceinline__ void fft_stages_g(float2* s, const FftTwG<T, NL, NT>& twr) {
+    if constexpr ((1 << LST) < T) {
+        constexpr int REM = T >> LST;
+        constexpr int R = REM >= 16 ? 16 : REM;
+        fft_stage_g<T, NL, NT, R, LST, INV>(s, twr);
+        fft_stages_g<T, NL, NT, LST + __builtin_ctz(R), INV>(s, twr);
+    }
+}
+
+// ---- I1, register-parked ("r") form --------------------------------------------
+// Same arithmetic as k_inv_cols_sym - every cell of Y comes out bit-identical -
+// with the work of a workgroup laid out differently:
+//   * the phase-multiplied curvature spectrum X' of the workgroup's columns is
+//     parked in REGISTERS (each thread keeps the cells its coefficient loads
+//     pair with), not in 64 KB of LDS: a 4-column workgroup needs 70 KB and two
+//     of them share a CU; an 8-column one (140 KB) emits whole 128-byte lines of
+//     the rows2 hand-off (8 columns x 2 rows) instead of 64-byte halves;
+//   * a mirrored block (fx >= Tx/2) pairs coefficient cell (sc, m) with target
+//     cell (NC-1-sc, -m mod TY), so its X' registers are loaded in that order once
+//     and the fill is a plain product like the direct block's;
+//   * the coefficient stream is read as 16-byte pieces (4 cells of a column).
+// NC columns and NT threads per workgroup: (4, 512) two workgroups per CU at
+// <= 128 VGPRs, (4, 256) two per CU with two 16-point sets per thread and stage,
+// (8, 512) one per CU.  Paired-template tiles stay with k_inv_cols_sym.
+template <int TY, int NC>
+__host__ __device__ constexpr size_t inv_cols_r_lds() { return (size_t)NC * fft_line(TY) * sizeof(float2); }
+template <int NC, int NT>
+__host__ __device__ constexpr int inv_cols_r_waves() { return (NC == 4 && NT == 512) ? 4 : 2; }
+
+template <int TY, bool MIRROR, int NC, int NT>
+__global__ void __launch_bounds__(NT, (inv_cols_r_waves<NC, NT>()))
+k_inv_cols_r(const float2* __restrict__ uc, const float2* __restrict__ uc2,
+             const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
+             int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, int ky, int kx,
+             int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
+             float2* __restrict__ ym, int ystride) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    FftTwG<TY, NC, NT> twr;
+    twr.load(tw);
+    constexpr int EQ = NC * TY / (4 * NT);     // 4-cell (16-byte) coefficient loads per thread
+    static_assert((NC * TY) % (4 * NT) == 0 && TY % 4 == 0, "whole 4-cell pieces");
+    const int cb = cb0 + blockIdx.x;           // block of NC columns: NC*cb .. NC*cb + NC-1
+    pair += blockIdx.y;
+    yw += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
+    ym += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
+    const size_t plane = (size_t)TY * Tx;
+    const size_t hplane = half_plane(TY, Tx);
+    // coefficient run of the block: its own columns, or (mirrored) the stored
+    // columns Tx - fx: a contiguous NC-column run read in storage order
+    const size_t crun = MIRROR ? (size_t)(Tx - NC * cb - (NC - 1)) * TY : (size_t)cb * NC * TY;
+    // cell q of this thread's piece u: coefficient cell (sc, m) -> target line / row
+    int line_of[EQ], row0_of[EQ];
+#pragma unroll
+    for (int u = 0; u < EQ; ++u) {
+        const int e = 4 * (threadIdx.x + u * NT);
+        const int sc = e / TY, m = e - sc * TY;
+        line_of[u] = MIRROR ? NC - 1 - sc : sc;
+        row0_of[u] = m;                        // rows m .. m+3 (direct) or -m .. -(m+3) mod TY (mirrored)
+    }
+    float4 areg[EQ];
+    for (int pl = 0; pl < 2; ++pl) {
+        const float2* uu = (pl ? uc2 : uc) + (size_t)pair * plane + (size_t)cb * NC * TY;
+        const float* hsrc = (pl ? mb : wa) + (size_t)vfirst * hplane + crun;
+        auto fetch = [&](int gi_) {
+            const float* p = hsrc + (size_t)gi_ * hplane;
+#pragma unroll
+            for (int u = 0; u < EQ; ++u)
+                areg[u] = *reinterpret_cast<const float4*>(p + 4 * (threadIdx.x + u * NT));
+        };
+        fetch(0);
+        // park X' = X * P {* i}: the factors of k_inv_cols_sym, cell by cell
+        const bool rot = pl == 0 && parity == 1;
+        float2 xr[EQ][4];
+#pragma unroll
+        for (int u = 0; u < EQ; ++u) {
+            const int cc = line_of[u], fx = NC * cb + cc;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int f = MIRROR ? ((TY - row0_of[u] - k) & (TY - 1)) : row0_of[u] + k;
+                float ang;
+                if (!MIRROR)
+                    ang = (float)(ky * f) / (float)TY + (float)(kx * fx) / (float)Tx;
+                else
+                    ang = -((float)(ky * ((TY - f) & (TY - 1))) / (float)TY +
+                            (float)(kx * ((Tx - fx) & (Tx - 1))) / (float)Tx);
+                float2 v = cmul(uu[(size_t)cc * TY + f], phase_pi(ang));
+                if (rot) v = MIRROR ? make_float2(v.y, -v.x) : make_float2(-v.y, v.x);
+                xr[u][k] = v;
+            }
+        }
+        for (int gi_ = 0; gi_ < G; ++gi_) {
+#pragma unroll
+            for (int u = 0; u < EQ; ++u) {
+                float2* ln = sm + line_of[u] * fft_line(TY);
+                const float a4[4] = {areg[u].x, areg[u].y, areg[u].z, areg[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int f = MIRROR ? ((TY - row0_of[u] - k) & (TY - 1)) : row0_of[u] + k;
+                    ln[ph(f)] = make_float2(a4[k] * xr[u][k].x, a4[k] * xr[u][k].y);
+                }
+            }
+            lds_barrier();
+            if (gi_ + 1 < G) fetch(gi_ + 1);
+            fft_stages_g<TY, NC, NT, 0, true>(sm, twr);
+            // rows2 layout: column c of row pair rp at ((rp*(Tx/8) + c/8)*16 + (c%8)*2);
+            // a thread stores (row 2rp, row 2rp+1) of one column, NC lanes one run
+            float2* o = (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)((NC * cb) >> 3) * 16 + ((NC * cb) & 7) * 2;
+            const int e_lo = NC * rp_lo, e_hi = NC * (rp_hi + 1);
+#pragma unroll 2
+            for (int e = e_lo + threadIdx.x; e < e_hi; e += NT) {
+                const int rp = e / NC, k = e % NC;
+                const float2* ln = sm + k * fft_line(TY);
+                store_stream(o + (size_t)rp * (Tx >> 3) * 16 + 2 * k, ln[ph(2 * rp)], ln[ph(2 * rp + 1)]);
             }
             lds_barrier();
         }
@@ -1738,6 +1938,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float*)ctx->wh.p, \
         (const float*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, 1 - ctx->g.oy,     \
         1 - ctx->g.ox, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group
+#define SYM_ARGS_D(CB0) SYM_ARGS(CB0), ctx->dbg
 #define FN_SYM(T)                                                              \
     {                                                                          \
         int rc = set_lds(ctx, k_inv_cols_sym<T, false, PTV>, inv_cols_lds<T>());    \
@@ -1746,10 +1947,10 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         if (rc) return rc;                                                     \
         const int nlo = fg.Tx / 8, nhi = fg.Tx / 4 - nlo;                      \
         hipLaunchKernelGGL((k_inv_cols_sym<T, false, PTV>), dim3(nlo, pcc), dim3(fft_threads(T)), \
-                           inv_cols_lds<T>(), SYM_ARGS(0));                    \
+                           inv_cols_lds<T>(), SYM_ARGS_D(0));                  \
         if (nhi > 0)                                                           \
             hipLaunchKernelGGL((k_inv_cols_sym<T, true, PTV>), dim3(nhi, pcc), dim3(fft_threads(T)), \
-                               inv_cols_lds<T>(), SYM_ARGS(nlo));              \
+                               inv_cols_lds<T>(), SYM_ARGS_D(nlo));            \
     }
 #define FN(T)                                                                  \
     {                                                                          \
@@ -1764,7 +1965,23 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             hipLaunchKernelGGL((k_inv_cols<T, true>), dim3(nhi, pcc), dim3(fft_threads(T)), \
                                inv_cols_lds<T>(), COL_ARGS(nlo));              \
     }
-            if (sym) {
+#define FN_R(T, NCV, NTV)                                                      \
+    {                                                                          \
+        int rc = set_lds(ctx, k_inv_cols_r<T, false, NCV, NTV>, inv_cols_r_lds<T, NCV>()); \
+        if (rc) return rc;                                                     \
+        rc = set_lds(ctx, k_inv_cols_r<T, true, NCV, NTV>, inv_cols_r_lds<T, NCV>()); \
+        if (rc) return rc;                                                     \
+        const int nb = fg.Tx / (2 * NCV);                                      \
+        hipLaunchKernelGGL((k_inv_cols_r<T, false, NCV, NTV>), dim3(nb, pcc), dim3(NTV), \
+                           (inv_cols_r_lds<T, NCV>()), SYM_ARGS(0));           \
+        hipLaunchKernelGGL((k_inv_cols_r<T, true, NCV, NTV>), dim3(nb, pcc), dim3(NTV), \
+                           (inv_cols_r_lds<T, NCV>()), SYM_ARGS(nb));          \
+    }
+            const int i1r = (sym && !PTV && fg.Ty == 2048) ? ctx->i1_form : 0;
+            if (i1r == 1) FN_R(2048, 4, 512)
+            else if (i1r == 2) FN_R(2048, 8, 512)
+            else if (i1r == 3) FN_R(2048, 4, 256)
+            else if (sym) {
                 switch (fg.Ty) {
                     case 64: FN_SYM(64); break;
                     case 128: FN_SYM(128); break;
@@ -1778,6 +1995,8 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             }
 #undef FN
 #undef FN_SYM
+#undef FN_R
+#undef SYM_ARGS_D
 #undef SYM_ARGS
 #undef COL_ARGS
             }
