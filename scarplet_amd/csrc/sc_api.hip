@@ -159,9 +159,6 @@ extern "C" int sc_set_option(sc_ctx* ctx, const char* name, double value) {
     } else if (!strcmp(name, "dbg")) {
         ctx->dbg = (int)value;
 #endif
-    } else if (!strcmp(name, "i1_form")) {
-        if (value < 0 || value > 9) return sc_fail(ctx, SC_ERR_INVALID, "i1_form 0..9");
-        ctx->i1_form = (int)value;
     } else if (!strcmp(name, "y_gb")) {
         if (!(value >= 0.0)) return sc_fail(ctx, SC_ERR_INVALID, "y_gb must be >= 0");
         ctx->y_gb = value;

@@ -1025,439 +1025,6 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
     }
 }
 
-// ---- in-LDS FFT of NL lines by NT threads (general form) -------------------------
-// The transform above is fixed at 4 lines and fft_threads(T) threads.  The
-// register-parked I1 below runs other shapes (8 lines by 512 threads, 4 lines by
-// 256): U = NL*S/NT sets per thread and stage; with NT a multiple of S a thread's
-// sets share their set index tt, so one set of twiddle bases serves all of them.
-template <int T, int NL, int NT>
-struct FftTwG {
-    static constexpr int S = T / 16;
-    static constexpr int U = NL * S / NT;
-    static constexpr int LOGT = __builtin_ctz(T);
-    static constexpr int NST = (LOGT + 3) / 4;
-    static constexpr int NTW = NST - 1;
-    static_assert((NL * S) % NT == 0 && NT % S == 0, "sets divide evenly; one tt per thread");
-    float2 w[NTW > 0 ? NTW : 1][4];
-    __device__ __forceinline__ void bases(int k, float2 (&o)[4]) const {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = w[k][j];
-    }
-    __device__ __forceinline__ void load(const float2* __restrict__ tw) {
-#pragma unroll
-        for (int k = 0; k < NTW; ++k) {
-            const int tt = threadIdx.x % S;
-            const int e = (tt >> (4 * k)) << (4 * k);
-            w[k][0] = tw[e];
-            w[k][1] = tw[2 * e];
-            w[k][2] = tw[4 * e];
-            w[k][3] = tw[8 * e];
-        }
-    }
-};
-
-// The same bases kept in LDS (set-major tables: 4 bases per set index and twiddled
-// stage), fetched per stage: 16 registers less across a template loop.
-template <int T, int NL, int NT>
-struct FftTwLds {
-    static constexpr int S = T / 16;
-    static constexpr int LOGT = __builtin_ctz(T);
-    static constexpr int NST = (LOGT + 3) / 4;
-    static constexpr int NTW = NST - 1;
-    static constexpr int CELLS = (NTW > 0 ? NTW : 1) * 4 * S;     // float2 cells of LDS
-    const float2* tab;
-    __device__ __forceinline__ void fill(float2* lds, const float2* __restrict__ tw) {
-        for (int i = threadIdx.x; i < NTW * S; i += NT) {
-            const int k = i / S, tt = i - k * S;
-            const int e = (tt >> (4 * k)) << (4 * k);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) lds[(k * 4 + j) * S + tt] = tw[e << j];
-        }
-        tab = lds;
-    }
-    __device__ __forceinline__ void bases(int k, float2 (&w)[4]) const {
-        const int tt = threadIdx.x % S;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = tab[(k * 4 + j) * S + tt];
-    }
-};
-
-template <int T, int NL, int NT, int R, int LST, bool INV, typename TW>
-__device__ __forceinline__ void fft_stage_g(float2* s, const TW& twr) {
-    constexpr int S = T / 16;
-    constexpr int U = NL * S / NT;
-    float2 a[U][16];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int id = threadIdx.x + u * NT;
-        set_load<T>(s + (id / S) * fft_line(T), id % S, a[u]);
-    }
-    float2 w[4];
-    if constexpr ((R << LST) != T) twr.bases(LST / 4, w);
-    if constexpr ((R << LST) != T) lds_barrier();      // the last stage works in place
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int id = threadIdx.x + u * NT;
-        set_compute_store<T, R, LST, INV>(s + (id / S) * fft_line(T), id % S, a[u], w);
-    }
-    lds_barrier();
-}
-
-template <int T, int NL, int NT, int LST, bool INV, typename TW>
-__device__ __forceinline__ void fft_stages_g(float2* s, const TW& twr) {
-    if constexpr ((1 << LST) < T) {
-        constexpr int REM = T >> LST;
-        constexpr int R = REM >= 16 ? 16 : REM;
-        fft_stage_g<T, NL, NT, R, LST, INV>(s, twr);
-        fft_stages_g<T, NL, NT, LST + __builtin_ctz(R), INV>(s, twr);
-    }
-}
-
-// ---- I1 for symmetric templates, NC columns by NT threads -----------------------
-// k_inv_cols_sym with the workgroup shape as a parameter (no paired-template mode): the
-// LDS-parked spectrum and the NC lines take NC * 33.5 KB at TY = 2048, so a 2-column
-// workgroup of 256 threads (67 KB) shares a CU with a second one that is in another
-// phase of its template loop - loads, transforms and stores of the two overlap where
-// one 512-thread workgroup per CU runs them one after the other.  Cell for cell the
-// same arithmetic: Y is bit-identical.
-template <int TY, int NC>
-__host__ __device__ constexpr size_t inv_cols_sym2_lds() {
-    return (size_t)NC * fft_line(TY) * sizeof(float2) + (size_t)NC * TY * sizeof(float2);
-}
-template <int TY, bool MIRROR, int NC, int NT, bool DEEP, int VW>
-__global__ void __launch_bounds__(NT, 2)
-k_inv_cols_sym2(const float2* __restrict__ uc, const float2* __restrict__ uc2,
-                const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
-                int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, int ky, int kx,
-                int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
-                float2* __restrict__ ym, int ystride) {
-    // VW: cells per coefficient load (2: 8-byte, 4: 16-byte pieces of a column)
-    // DEEP: the coefficients are fetched TWO templates ahead (two register sets taking turns):
-    // a fetch then has two template periods to land instead of one
-    extern __shared__ __attribute__((aligned(16))) float2 sm[];
-    FftTwG<TY, NC, NT> twr;
-    twr.load(tw);
-    constexpr int EP = NC * TY / (VW * NT);    // VW-cell loads per thread per stream
-    static_assert((NC * TY) % (VW * NT) == 0 && (VW == 2 || VW == 4), "whole pieces");
-    typedef float hv __attribute__((ext_vector_type(VW)));
-    float2* xs = sm + NC * fft_line(TY);       // parked spectrum, linear [column][row]
-    const int cb = cb0 + blockIdx.x;           // columns NC*cb .. NC*cb + NC-1
-    pair += blockIdx.y;
-    yw += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
-    ym += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
-    constexpr bool mirrored = MIRROR;
-    const size_t plane = (size_t)TY * Tx;
-    const size_t col = (size_t)cb * NC * TY;
-    const size_t hplane = half_plane(TY, Tx);
-    hv hreg[EP], hreg2[DEEP ? EP : 1];
-    for (int pl = 0; pl < 2; ++pl) {
-        const float2* uu = (pl ? uc2 : uc) + (size_t)pair * plane + col;
-        const float* hsrc = (pl ? mb : wa) + (size_t)vfirst * hplane +
-                            (mirrored ? (size_t)(Tx - NC * cb - (NC - 1)) * TY : col);
-        auto fetch_to = [&](int gi_, hv (&h)[EP]) {
-            const float* p = hsrc + (size_t)gi_ * hplane;
-#pragma unroll
-            for (int u = 0; u < EP; ++u)
-                h[u] = *reinterpret_cast<const hv*>(p + VW * (threadIdx.x + u * NT));
-        };
-        const bool rot = pl == 0 && parity == 1;          // odd W: factor i (direct) / -i (mirrored)
-        for (int e = 2 * threadIdx.x; e < NC * TY; e += 2 * NT) {
-            const int cc = e / TY, fy = e - cc * TY, fx = NC * cb + cc;
-            float4 x = *reinterpret_cast<const float4*>(uu + e);
-            float2 xv[2] = {make_float2(x.x, x.y), make_float2(x.z, x.w)};
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                float ang;
-                if (!mirrored)
-                    ang = (float)(ky * (fy + k)) / (float)TY + (float)(kx * fx) / (float)Tx;
-                else
-                    ang = -((float)(ky * ((TY - fy - k) & (TY - 1))) / (float)TY +
-                            (float)(kx * ((Tx - fx) & (Tx - 1))) / (float)Tx);
-                float2 v = cmul(xv[k], phase_pi(ang));
-                if (rot) v = mirrored ? make_float2(v.y, -v.x) : make_float2(-v.y, v.x);
-                xv[k] = v;
-            }
-            *reinterpret_cast<float4*>(xs + e) = make_float4(xv[0].x, xv[0].y, xv[1].x, xv[1].y);
-        }
-        fetch_to(0, hreg);
-        if constexpr (DEEP) { if (G > 1) fetch_to(1, reinterpret_cast<hv (&)[EP]>(hreg2)); }
-        lds_barrier();                    // fills read other threads' cells of xs
-        auto step = [&](int gi_, hv (&h)[EP]) {
-#pragma unroll
-            for (int u = 0; u < EP; ++u) {
-                const int e = VW * (threadIdx.x + u * NT);
-                const int sc = e / TY, m = e - sc * TY;
-                const int cc = mirrored ? NC - 1 - sc : sc;
-#pragma unroll
-                for (int k = 0; k < VW; ++k) {
-                    const int f = mirrored ? ((TY - m - k) & (TY - 1)) : m + k;
-                    const float2 x = xs[cc * TY + f];
-                    sm[lidx<TY>(cc, f)] = make_float2(h[u][k] * x.x, h[u][k] * x.y);
-                }
-            }
-            lds_barrier();
-            if constexpr (DEEP) { if (gi_ + 2 < G) fetch_to(gi_ + 2, h); }
-            else { if (gi_ + 1 < G) fetch_to(gi_ + 1, h); }
-            fft_stages_g<TY, NC, NT, 0, true>(sm, twr);
-            float2* o = (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)((NC * cb) >> 3) * 16 + ((NC * cb) & 7) * 2;
-            const int e_lo = NC * rp_lo, e_hi = NC * (rp_hi + 1);
-#pragma unroll 2
-            for (int e = e_lo + threadIdx.x; e < e_hi; e += NT) {
-                int rp = e / NC, k = e % NC;
-                float2 x0 = sm[lidx<TY>(k, 2 * rp)], x1 = sm[lidx<TY>(k, 2 * rp + 1)];
-                store_stream(o + (size_t)rp * (Tx >> 3) * 16 + 2 * k, x0, x1);
-            }
-            lds_barrier();
-        };
-        if constexpr (DEEP) {
-            for (int gi_ = 0; gi_ < G; gi_ += 2) {
-                step(gi_, hreg);
-                if (gi_ + 1 < G) step(gi_ + 1, reinterpret_cast<hv (&)[EP]>(hreg2));
-            }
-        } else {
-            for (int gi_ = 0; gi_ < G; ++gi_) step(gi_, hreg);
-        }
-    }
-}
-
-// ---- I1 for symmetric templates, double-buffered ("db") -------------------------
-// The ablation of k_inv_cols_sym on the sustained C3 run (profiles/r02_i1_ablation.txt)
-// prices its parts: transforms alone 281 us per launch, with the coefficient loads 289,
-// with the Y stores as well 391 - the loads hide behind the transforms, the stores do
-// not: all eight waves of the one workgroup on a CU reach the store loop together, the
-// 59 KB burst backs up into the store queue and nothing else is left to run meanwhile.
-// Here the four LDS lines exist twice.  Template g is transformed in one set while the
-// finished columns of template g-1 are stored from the other, a third of them after each
-// transform stage, so the store stream runs beside the LDS / VALU work of the same waves.
-// The lines take 140 KB, so the phase-multiplied curvature spectrum is parked in
-// registers (32 per thread; each thread keeps the cells its coefficient loads pair with,
-// a mirrored block in mirrored order).  Arithmetic and results are those of
-// k_inv_cols_sym, cell for cell.
-template <int TY>
-__host__ __device__ constexpr size_t inv_cols_db_lds() {
-    return ((size_t)8 * fft_line(TY) + FftTwLds<TY, 4, 512>::CELLS) * sizeof(float2);
-}
-
-template <int TY, bool MIRROR>
-__global__ void __launch_bounds__(512, 2)
-k_inv_cols_db(const float2* __restrict__ uc, const float2* __restrict__ uc2,
-              const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
-              int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, int ky, int kx,
-              int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
-              float2* __restrict__ ym, int ystride) {
-    extern __shared__ __attribute__((aligned(16))) float2 sm[];
-    constexpr int NT = 512, NC = 4;
-    static_assert(TY == 2048, "stage sequence written out for 2048 = 16 * 16 * 8");
-    constexpr int EP = NC * TY / (2 * NT);     // 2-cell coefficient loads per thread (8)
-    constexpr int LBUF = NC * fft_line(TY);    // one set of lines, in cells
-    FftTwLds<TY, NC, NT> twr;
-    twr.fill(sm + 2 * LBUF, tw);               // read first behind the fill barrier of the first template
-    const int cb = cb0 + blockIdx.x;
-    pair += blockIdx.y;
-    yw += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
-    ym += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
-    const size_t plane = (size_t)TY * Tx;
-    const size_t col = (size_t)cb * NC * TY;
-    const size_t hplane = half_plane(TY, Tx);
-    const int e_lo = NC * rp_lo, e_hi = NC * (rp_hi + 1);
-    // a third of the store loop of one template: iterations [3s, 3s+3) of e = e_lo + tid + it*NT
-    // (tid: the thread index behind an empty asm, refreshed per template, so that the fill
-    //  and store addresses are recomputed where they are used instead of being hoisted out
-    //  of the template loop into sixty-odd registers)
-    auto store_slice = [&](const float2* buf, float2* o, int s, int tid) {
-#pragma unroll
-        for (int it = 3 * s; it < 3 * s + 3; ++it) {
-            const int e = e_lo + tid + it * NT;
-            if (e < e_hi) {
-                const int rp = e >> 2, k = e & 3;
-                const float2* ln = buf + k * fft_line(TY);
-                store_stream(o + (size_t)rp * (Tx >> 3) * 16 + 2 * k, ln[ph(2 * rp)], ln[ph(2 * rp + 1)]);
-            }
-        }
-    };
-    float2 hreg[EP];
-    int cur = 0;                               // line set that receives the next template
-    for (int pl = 0; pl < 2; ++pl) {
-        const float2* uu = (pl ? uc2 : uc) + (size_t)pair * plane + col;
-        const float* hsrc = (pl ? mb : wa) + (size_t)vfirst * hplane +
-                            (MIRROR ? (size_t)(Tx - NC * cb - (NC - 1)) * TY : col);
-        float2* ybase = (pl ? ym : yw) + (size_t)(cb >> 1) * 16 + (cb & 1) * 8;
-        auto fetch = [&](int gi_) {
-            const float* p = hsrc + (size_t)gi_ * hplane;
-#pragma unroll
-            for (int u = 0; u < EP; ++u)
-                hreg[u] = *reinterpret_cast<const float2*>(p + 2 * (threadIdx.x + u * NT));
-        };
-        fetch(0);
-        // park X' = X * P {* i}: coefficient cell (sc, m) pairs with target cell (cc, f)
-        const bool rot = pl == 0 && parity == 1;
-        float2 xr[EP][2];
-#pragma unroll
-        for (int u = 0; u < EP; ++u) {
-            const int e = 2 * (threadIdx.x + u * NT);
-            const int sc = e / TY, m = e - sc * TY;
-            const int cc = MIRROR ? NC - 1 - sc : sc, fx = NC * cb + cc;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int f = MIRROR ? ((TY - m - k) & (TY - 1)) : m + k;
-                float ang;
-                if (!MIRROR)
-                    ang = (float)(ky * f) / (float)TY + (float)(kx * fx) / (float)Tx;
-                else
-                    ang = -((float)(ky * ((TY - f) & (TY - 1))) / (float)TY +
-                            (float)(kx * ((Tx - fx) & (Tx - 1))) / (float)Tx);
-                float2 v = cmul(uu[(size_t)cc * TY + f], phase_pi(ang));
-                if (rot) v = MIRROR ? make_float2(v.y, -v.x) : make_float2(-v.y, v.x);
-                xr[u][k] = v;
-            }
-        }
-        for (int gi_ = 0; gi_ < G; ++gi_) {
-            float2* buf = sm + cur * LBUF;
-            const float2* prev = sm + (cur ^ 1) * LBUF;
-            float2* oprev = ybase + (size_t)(gi_ - 1) * plane;
-            const bool have_prev = gi_ > 0;            // uniform
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));
-#pragma unroll
-            for (int u = 0; u < EP; ++u) {
-                const int e = 2 * (tid + u * NT);
-                const int sc = e / TY, m = e - sc * TY;
-                float2* ln = buf + (MIRROR ? NC - 1 - sc : sc) * fft_line(TY);
-                const int f0 = MIRROR ? ((TY - m) & (TY - 1)) : m, f1 = MIRROR ? ((TY - m - 1) & (TY - 1)) : m + 1;
-                ln[ph(f0)] = make_float2(hreg[u].x * xr[u][0].x, hreg[u].x * xr[u][0].y);
-                ln[ph(f1)] = make_float2(hreg[u].y * xr[u][1].x, hreg[u].y * xr[u][1].y);
-            }
-            lds_barrier();
-            if (gi_ + 1 < G) fetch(gi_ + 1);
-            fft_stage_g<TY, NC, NT, 16, 0, true>(buf, twr);
-            if (have_prev) store_slice(prev, oprev, 0, tid);
-            fft_stage_g<TY, NC, NT, 16, 4, true>(buf, twr);
-            if (have_prev) store_slice(prev, oprev, 1, tid);
-            fft_stage_g<TY, NC, NT, 8, 8, true>(buf, twr);
-            if (have_prev) store_slice(prev, oprev, 2, tid);
-            cur ^= 1;
-        }
-        // the plane's last template (its set is not refilled before the barrier of the next fill)
-        {
-            const float2* prev = sm + (cur ^ 1) * LBUF;
-            float2* oprev = ybase + (size_t)(G - 1) * plane;
-            store_slice(prev, oprev, 0, threadIdx.x);
-            store_slice(prev, oprev, 1, threadIdx.x);
-            store_slice(prev, oprev, 2, threadIdx.x);
-        }
-    }
-}
-
-// ---- I1, register-parked ("r") form --------------------------------------------
-// Same arithmetic as k_inv_cols_sym - every cell of Y comes out bit-identical -
-// with the work of a workgroup laid out differently:
-//   * the phase-multiplied curvature spectrum X' of the workgroup's columns is
-//     parked in REGISTERS (each thread keeps the cells its coefficient loads
-//     pair with), not in 64 KB of LDS: a 4-column workgroup needs 70 KB and two
-//     of them share a CU; an 8-column one (140 KB) emits whole 128-byte lines of
-//     the rows2 hand-off (8 columns x 2 rows) instead of 64-byte halves;
-//   * a mirrored block (fx >= Tx/2) pairs coefficient cell (sc, m) with target
-//     cell (NC-1-sc, -m mod TY), so its X' registers are loaded in that order once
-//     and the fill is a plain product like the direct block's;
-//   * the coefficient stream is read as 16-byte pieces (4 cells of a column).
-// NC columns and NT threads per workgroup: (4, 512) two workgroups per CU at
-// <= 128 VGPRs, (4, 256) two per CU with two 16-point sets per thread and stage,
-// (8, 512) one per CU.  Paired-template tiles stay with k_inv_cols_sym.
-template <int TY, int NC>
-__host__ __device__ constexpr size_t inv_cols_r_lds() { return (size_t)NC * fft_line(TY) * sizeof(float2); }
-template <int NC, int NT>
-__host__ __device__ constexpr int inv_cols_r_waves() { return (NC == 4 && NT == 512) ? 4 : 2; }
-
-template <int TY, bool MIRROR, int NC, int NT>
-__global__ void __launch_bounds__(NT, (inv_cols_r_waves<NC, NT>()))
-k_inv_cols_r(const float2* __restrict__ uc, const float2* __restrict__ uc2,
-             const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
-             int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, int ky, int kx,
-             int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
-             float2* __restrict__ ym, int ystride) {
-    extern __shared__ __attribute__((aligned(16))) float2 sm[];
-    FftTwG<TY, NC, NT> twr;
-    twr.load(tw);
-    constexpr int EQ = NC * TY / (4 * NT);     // 4-cell (16-byte) coefficient loads per thread
-    static_assert((NC * TY) % (4 * NT) == 0 && TY % 4 == 0, "whole 4-cell pieces");
-    const int cb = cb0 + blockIdx.x;           // block of NC columns: NC*cb .. NC*cb + NC-1
-    pair += blockIdx.y;
-    yw += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
-    ym += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
-    const size_t plane = (size_t)TY * Tx;
-    const size_t hplane = half_plane(TY, Tx);
-    // coefficient run of the block: its own columns, or (mirrored) the stored
-    // columns Tx - fx: a contiguous NC-column run read in storage order
-    const size_t crun = MIRROR ? (size_t)(Tx - NC * cb - (NC - 1)) * TY : (size_t)cb * NC * TY;
-    // cell q of this thread's piece u: coefficient cell (sc, m) -> target line / row
-    int line_of[EQ], row0_of[EQ];
-#pragma unroll
-    for (int u = 0; u < EQ; ++u) {
-        const int e = 4 * (threadIdx.x + u * NT);
-        const int sc = e / TY, m = e - sc * TY;
-        line_of[u] = MIRROR ? NC - 1 - sc : sc;
-        row0_of[u] = m;                        // rows m .. m+3 (direct) or -m .. -(m+3) mod TY (mirrored)
-    }
-    float4 areg[EQ];
-    for (int pl = 0; pl < 2; ++pl) {
-        const float2* uu = (pl ? uc2 : uc) + (size_t)pair * plane + (size_t)cb * NC * TY;
-        const float* hsrc = (pl ? mb : wa) + (size_t)vfirst * hplane + crun;
-        auto fetch = [&](int gi_) {
-            const float* p = hsrc + (size_t)gi_ * hplane;
-#pragma unroll
-            for (int u = 0; u < EQ; ++u)
-                areg[u] = *reinterpret_cast<const float4*>(p + 4 * (threadIdx.x + u * NT));
-        };
-        fetch(0);
-        // park X' = X * P {* i}: the factors of k_inv_cols_sym, cell by cell
-        const bool rot = pl == 0 && parity == 1;
-        float2 xr[EQ][4];
-#pragma unroll
-        for (int u = 0; u < EQ; ++u) {
-            const int cc = line_of[u], fx = NC * cb + cc;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int f = MIRROR ? ((TY - row0_of[u] - k) & (TY - 1)) : row0_of[u] + k;
-                float ang;
-                if (!MIRROR)
-                    ang = (float)(ky * f) / (float)TY + (float)(kx * fx) / (float)Tx;
-                else
-                    ang = -((float)(ky * ((TY - f) & (TY - 1))) / (float)TY +
-                            (float)(kx * ((Tx - fx) & (Tx - 1))) / (float)Tx);
-                float2 v = cmul(uu[(size_t)cc * TY + f], phase_pi(ang));
-                if (rot) v = MIRROR ? make_float2(v.y, -v.x) : make_float2(-v.y, v.x);
-                xr[u][k] = v;
-            }
-        }
-        for (int gi_ = 0; gi_ < G; ++gi_) {
-#pragma unroll
-            for (int u = 0; u < EQ; ++u) {
-                float2* ln = sm + line_of[u] * fft_line(TY);
-                const float a4[4] = {areg[u].x, areg[u].y, areg[u].z, areg[u].w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int f = MIRROR ? ((TY - row0_of[u] - k) & (TY - 1)) : row0_of[u] + k;
-                    ln[ph(f)] = make_float2(a4[k] * xr[u][k].x, a4[k] * xr[u][k].y);
-                }
-            }
-            lds_barrier();
-            if (gi_ + 1 < G) fetch(gi_ + 1);
-            fft_stages_g<TY, NC, NT, 0, true>(sm, twr);
-            // rows2 layout: column c of row pair rp at ((rp*(Tx/8) + c/8)*16 + (c%8)*2);
-            // a thread stores (row 2rp, row 2rp+1) of one column, NC lanes one run
-            float2* o = (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)((NC * cb) >> 3) * 16 + ((NC * cb) & 7) * 2;
-            const int e_lo = NC * rp_lo, e_hi = NC * (rp_hi + 1);
-#pragma unroll 2
-            for (int e = e_lo + threadIdx.x; e < e_hi; e += NT) {
-                const int rp = e / NC, k = e % NC;
-                const float2* ln = sm + k * fft_line(TY);
-                store_stream(o + (size_t)rp * (Tx >> 3) * 16 + 2 * k, ln[ph(2 * rp)], ln[ph(2 * rp + 1)]);
-            }
-            lds_barrier();
-        }
-    }
-}
-
 // ---- I2: inverse row FFT -> epilogue -> fold ---------------------------------
 // grid = (valid row blocks): one workgroup per block of 4 tile rows.  The rows
 // are done as two sub-batches of 2 rows x {W plane, M plane} = 4 LDS lines, so
@@ -2231,51 +1798,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             hipLaunchKernelGGL((k_inv_cols<T, true>), dim3(nhi, pcc), dim3(fft_threads(T)), \
                                inv_cols_lds<T>(), COL_ARGS(nlo));              \
     }
-#define FN_R(T, NCV, NTV)                                                      \
-    {                                                                          \
-        int rc = set_lds(ctx, k_inv_cols_r<T, false, NCV, NTV>, inv_cols_r_lds<T, NCV>()); \
-        if (rc) return rc;                                                     \
-        rc = set_lds(ctx, k_inv_cols_r<T, true, NCV, NTV>, inv_cols_r_lds<T, NCV>()); \
-        if (rc) return rc;                                                     \
-        const int nb = fg.Tx / (2 * NCV);                                      \
-        hipLaunchKernelGGL((k_inv_cols_r<T, false, NCV, NTV>), dim3(nb, pcc), dim3(NTV), \
-                           (inv_cols_r_lds<T, NCV>()), SYM_ARGS(0));           \
-        hipLaunchKernelGGL((k_inv_cols_r<T, true, NCV, NTV>), dim3(nb, pcc), dim3(NTV), \
-                           (inv_cols_r_lds<T, NCV>()), SYM_ARGS(nb));          \
-    }
-#define FN_S2(T, NCV, NTV, DEEPV, VWV)                                                   \
-    {                                                                          \
-        int rc = set_lds(ctx, k_inv_cols_sym2<T, false, NCV, NTV, DEEPV, VWV>, inv_cols_sym2_lds<T, NCV>()); \
-        if (rc) return rc;                                                     \
-        rc = set_lds(ctx, k_inv_cols_sym2<T, true, NCV, NTV, DEEPV, VWV>, inv_cols_sym2_lds<T, NCV>()); \
-        if (rc) return rc;                                                     \
-        const int nb = fg.Tx / (2 * NCV);                                      \
-        hipLaunchKernelGGL((k_inv_cols_sym2<T, false, NCV, NTV, DEEPV, VWV>), dim3(nb, pcc), dim3(NTV), \
-                           (inv_cols_sym2_lds<T, NCV>()), SYM_ARGS(0));        \
-        hipLaunchKernelGGL((k_inv_cols_sym2<T, true, NCV, NTV, DEEPV, VWV>), dim3(nb, pcc), dim3(NTV), \
-                           (inv_cols_sym2_lds<T, NCV>()), SYM_ARGS(nb));       \
-    }
-            const int i1r = (sym && !PTV && fg.Ty == 2048) ? ctx->i1_form : 0;
-            if (i1r == 1) FN_R(2048, 4, 512)
-            else if (i1r == 2) FN_R(2048, 8, 512)
-            else if (i1r == 3) FN_R(2048, 4, 256)
-            else if (i1r == 4) FN_S2(2048, 2, 256, false, 2)
-            else if (i1r == 5) FN_S2(2048, 4, 512, false, 2)
-            else if (i1r == 7) FN_S2(2048, 4, 512, true, 2)
-            else if (i1r == 8) FN_S2(2048, 4, 512, false, 4)
-            else if (i1r == 9) FN_S2(2048, 4, 512, true, 4)
-            else if (i1r == 6) {
-                int rc = set_lds(ctx, k_inv_cols_db<2048, false>, inv_cols_db_lds<2048>());
-                if (rc) return rc;
-                rc = set_lds(ctx, k_inv_cols_db<2048, true>, inv_cols_db_lds<2048>());
-                if (rc) return rc;
-                const int nb = fg.Tx / 8;
-                hipLaunchKernelGGL((k_inv_cols_db<2048, false>), dim3(nb, pcc), dim3(512),
-                                   inv_cols_db_lds<2048>(), SYM_ARGS(0));
-                hipLaunchKernelGGL((k_inv_cols_db<2048, true>), dim3(nb, pcc), dim3(512),
-                                   inv_cols_db_lds<2048>(), SYM_ARGS(nb));
-            }
-            else if (sym) {
+            if (sym) {
                 switch (fg.Ty) {
                     case 64: FN_SYM(64); break;
                     case 128: FN_SYM(128); break;
@@ -2289,8 +1812,6 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             }
 #undef FN
 #undef FN_SYM
-#undef FN_R
-#undef FN_S2
 #undef SYM_ARGS_D
 #undef SYM_ARGS
 #undef COL_ARGS

@@ -88,7 +88,6 @@ struct sc_ctx {
     int last_batch = 0;
     float kappa = 4.f;         // float32 resolution floor of the FFT path, in units of eps (sc_set_option "kappa")
     int variant = 0;           // sc_set_option "variant": alternative kernel paths kept for cross-checks
-    int i1_form = 0;           // sc_set_option "i1_form": 0 LDS-parked I1, 1..3 register-parked forms (sc_fft.hip)
     double y_gb = 0.0;         // sc_set_option "y_gb": memory budget of the I1 -> I2 hand-off (0: automatic)
     int dbg = 0;               // timing-only ablation bits; only an SC_ABLATE build reads them (tools/ablate.sh)
     // profiling

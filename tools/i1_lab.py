@@ -4,7 +4,7 @@ engine option sets, in ONE process (the DEM is synthesised once).  Prints the st
 per-kernel breakdown per option set, and checks every set's best record against the first set's
 (bit for bit) unless an ablation option ("dbg") makes its results meaningless.
 
-  python tools/i1_lab.py "i1_form=0" "i1_form=1" "i1_form=2"
+  python tools/i1_lab.py "variant=0" "variant=8"
   SCARPLET_HIP_LIB=scarplet_amd/libscarplet_hip_ablate.so python tools/i1_lab.py "dbg=0" "dbg=4" ...
 """
 import argparse, os, sys, time
@@ -20,7 +20,7 @@ ap.add_argument("--n", type=int, default=10000)
 ap.add_argument("--angles", type=int, default=181)
 ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--warmup", type=int, default=1)
-ap.add_argument("--reset", default="i1_form=0,variant=0", help="options restored before every set")
+ap.add_argument("--reset", default="variant=0", help="options restored before every set")
 a = ap.parse_args()
 
 g = synthetic.synthetic_scarp(a.n)
