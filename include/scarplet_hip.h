@@ -145,6 +145,9 @@ int sc_clear_windows(sc_ctx* ctx);
  *   "variant"  alternative kernel paths kept for cross-checks in the tests:
  *              0 default, 5 no paired-template mode, 8 complex-spectrum I1 for
  *              symmetric templates, 9 generic row kernel at every tile size
+ *   "batch"    1 (default): searches whose single orientation does not fill the
+ *              chip send several orientations through every launch; 0: one
+ *              orientation per launch sequence.  Results are bit-identical.
  *   "y_gb"     memory budget of the column -> row pass hand-off buffers in GB
  *              (0: a quarter of the free memory, at most 32)
  */

@@ -159,6 +159,8 @@ extern "C" int sc_set_option(sc_ctx* ctx, const char* name, double value) {
     } else if (!strcmp(name, "dbg")) {
         ctx->dbg = (int)value;
 #endif
+    } else if (!strcmp(name, "batch")) {
+        ctx->batch_off = value == 0.0;
     } else if (!strcmp(name, "y_gb")) {
         if (!(value >= 0.0)) return sc_fail(ctx, SC_ERR_INVALID, "y_gb must be >= 0");
         ctx->y_gb = value;
@@ -417,7 +419,6 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
             return sc_fail(ctx, SC_ERR_INVALID, "circular axis needs T == n and the whole DEM");
         if ((long long)fg.nty * fg.Vy < g.cy1 - g.cy0 || (long long)fg.ntx * fg.Vx < g.cx1 - g.cx0)
             return sc_fail(ctx, SC_ERR_INVALID, "tiles do not cover the core");
-        if ((rc = fft_prepare(ctx, fg, std::min(n, CHUNK), group))) return rc;
     }
     if (to_maps) {
         size_t nc = (size_t)(g.cy1 - g.cy0) * (g.cx1 - g.cx0);
@@ -425,16 +426,16 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
         if ((rc = sc_ensure(ctx, ctx->map_snr, sizeof(float) * nc))) return rc;
     }
 
-    // device descriptors for the whole batch; windows are laid out per chunk
+    // Orientation runs: consecutive templates with equal (cc, sc2, ss) share one curvature
+    // plane (at most CHUNK of them per run).
     std::vector<TemplDev> h(n);
     std::vector<double> sums(2 * (size_t)n, 0.0), wl1(n, 0.0);
-    struct Chunk { int first, n, wh, ww; size_t cells; };
-    std::vector<Chunk> chunks;
-    size_t max_cells = 0;
+    struct Run { int first, n, parity; bool full; };
+    std::vector<Run> runs;
     for (int i = 0; i < n;) {
         int j = i;
-        size_t off = 0;
-        int wh = 0, ww = 0;
+        int parity = -1;
+        bool full = false;
         while (j < n && j - i < CHUNK && t[j].cc == t[i].cc && t[j].sc2 == t[i].sc2 &&
                t[j].ss == t[i].ss) {
             const sc_template& s = t[j];
@@ -448,7 +449,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
             d.id = s.id;
             d.wh = s.pmax - s.pmin + 1;
             d.ww = s.qmax - s.qmin + 1;
-            d.win_off = (long long)off;
+            d.win_off = 0;
             d.mask_lim = nullptr; d.mask_err = nullptr;
             if (s.kind == SC_KIND_WINDOW) {
                 d.mask_lim = ctx->windows[s.window].mask_lim;
@@ -457,16 +458,49 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
                 sums[2 * (size_t)j + 1] = s.p1;
                 wl1[j] = ctx->windows[s.window].l1;
             }
-            off += (size_t)d.wh * d.ww;
-            off = (off + 3) & ~(size_t)3;
-            wh = std::max(wh, d.wh);
-            ww = std::max(ww, d.ww);
+            // flip symmetry of the built-in templates (k_split_templ_sym): the same parity
+            // for the whole run, and support boxes that map onto themselves
+            int pj = s.kind == SC_KIND_SCARP ? 1 : (s.kind == SC_KIND_RICKER ? 2 : 0);
+            if (s.pmin + s.pmax != -(1 - g.oy) || s.qmin + s.qmax != -(1 - g.ox)) pj = 0;
+            parity = (parity == -1 || parity == pj) ? pj : 0;
+            full |= (d.flags & (SC_FLAG_ERR_XR_LE0 | SC_FLAG_ERR_XR_GE0)) != 0 ||
+                    d.mask_lim != nullptr || d.mask_err != nullptr;
             ++j;
         }
-        chunks.push_back({i, j - i, wh, ww, off});
-        max_cells = std::max(max_cells, off);
+        runs.push_back({i, j - i, parity < 0 ? 0 : parity, full});
         i = j;
     }
+    // Chunks: one run, or - small FFT searches - nb consecutive runs of equal length, parity
+    // and mask kind sent through every launch together (sc_fft.hip, "Orientation batching")
+    struct Chunk { int first, n, nb, wh, ww, parity; bool full; size_t cells; };
+    std::vector<Chunk> chunks;
+    size_t max_cells = 0;
+    int nb_max = 1;
+    for (size_t r = 0; r < runs.size();) {
+        int nb = 1;
+        if (plan->method == SC_METHOD_FFT && !to_maps) {
+            const int want = fft_batch_orientations(ctx, fg, runs[r].n, group);
+            while (nb < want && r + nb < runs.size() && runs[r + nb].n == runs[r].n &&
+                   runs[r + nb].parity == runs[r].parity && runs[r + nb].full == runs[r].full)
+                ++nb;
+        }
+        size_t off = 0;
+        int wh = 0, ww = 0;
+        for (int j = runs[r].first; j < runs[r].first + nb * runs[r].n; ++j) {
+            h[j].win_off = (long long)off;
+            off += (size_t)h[j].wh * h[j].ww;
+            off = (off + 3) & ~(size_t)3;
+            wh = std::max(wh, h[j].wh);
+            ww = std::max(ww, h[j].ww);
+        }
+        chunks.push_back({runs[r].first, runs[r].n, nb, wh, ww, runs[r].parity, runs[r].full, off});
+        max_cells = std::max(max_cells, off);
+        nb_max = std::max(nb_max, nb);
+        r += nb;
+    }
+    if (plan->method == SC_METHOD_FFT &&
+        (rc = fft_prepare(ctx, fg, std::min(n, CHUNK), group, nb_max)))
+        return rc;
     if ((rc = sc_ensure(ctx, ctx->templ, sizeof(TemplDev) * n))) return rc;
     if ((rc = sc_ensure(ctx, ctx->sums, sizeof(double) * 2 * n))) return rc;
     if ((rc = sc_ensure(ctx, ctx->wl1, sizeof(double) * n))) return rc;
@@ -484,14 +518,24 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
     double cur[3] = {0, 0, 0};
     bool have_curv = false;
     for (const Chunk& c : chunks) {
-        const sc_template& s0 = t[c.first];
-        if (!have_curv || s0.cc != cur[0] || s0.sc2 != cur[1] || s0.ss != cur[2]) {
-            if ((rc = launch_curv_alpha(ctx, (float)s0.cc, (float)s0.sc2, (float)s0.ss))) return rc;
-            if (plan->method == SC_METHOD_FFT && (rc = fft_forward_curv(ctx, fg))) return rc;
-            cur[0] = s0.cc; cur[1] = s0.sc2; cur[2] = s0.ss;
-            have_curv = true;
+        const int n_all = c.nb * c.n;
+        if (c.nb > 1) {
+            for (int b = 0; b < c.nb; ++b) {
+                const sc_template& sb = t[c.first + b * c.n];
+                if ((rc = launch_curv_alpha(ctx, (float)sb.cc, (float)sb.sc2, (float)sb.ss, b))) return rc;
+            }
+            if ((rc = fft_forward_curv(ctx, fg, c.nb))) return rc;
+            have_curv = false;                    // plane 0 no longer belongs to a single run
+        } else {
+            const sc_template& s0 = t[c.first];
+            if (!have_curv || s0.cc != cur[0] || s0.sc2 != cur[1] || s0.ss != cur[2]) {
+                if ((rc = launch_curv_alpha(ctx, (float)s0.cc, (float)s0.sc2, (float)s0.ss))) return rc;
+                if (plan->method == SC_METHOD_FFT && (rc = fft_forward_curv(ctx, fg, 1))) return rc;
+                cur[0] = s0.cc; cur[1] = s0.sc2; cur[2] = s0.ss;
+                have_curv = true;
+            }
         }
-        for (int j = c.first; j < c.first + c.n; ++j) {
+        for (int j = c.first; j < c.first + n_all; ++j) {
             if (t[j].kind != SC_KIND_WINDOW) continue;
             const WindowSlot& w = ctx->windows[t[j].window];
             size_t cells = (size_t)w.h * w.wd;
@@ -500,26 +544,12 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
             SC_HIP(ctx, hipMemcpyAsync((uint8_t*)ctx->win_m.p + h[j].win_off, w.m, cells,
                                        hipMemcpyDeviceToDevice, ctx->stream));
         }
-        if ((rc = launch_windows(ctx, c.first, c.n, c.wh, c.ww))) return rc;
+        if ((rc = launch_windows(ctx, c.first, n_all, c.wh, c.ww))) return rc;
         if (plan->method == SC_METHOD_DIRECT) {
             if ((rc = launch_direct(ctx, c.first, c.n, to_maps))) return rc;
         } else {
-            // flip symmetry of the built-in templates (k_split_templ_sym): the same
-            // parity for the whole chunk, and support boxes that map onto themselves
-            int parity = -1;
-            for (int j = c.first; j < c.first + c.n; ++j) {
-                int pj = t[j].kind == SC_KIND_SCARP ? 1 : (t[j].kind == SC_KIND_RICKER ? 2 : 0);
-                if (t[j].pmin + t[j].pmax != -(1 - ctx->g.oy) || t[j].qmin + t[j].qmax != -(1 - ctx->g.ox))
-                    pj = 0;
-                parity = (parity == -1 || parity == pj) ? pj : 0;
-            }
-            if (parity < 0) parity = 0;
-            if ((rc = fft_forward_templates(ctx, fg, c.first, c.n, parity))) return rc;
-            bool full = false;
-            for (int j = c.first; j < c.first + c.n; ++j)
-                full |= (h[j].flags & (SC_FLAG_ERR_XR_LE0 | SC_FLAG_ERR_XR_GE0)) != 0 ||
-                        h[j].mask_lim != nullptr || h[j].mask_err != nullptr;
-            if ((rc = fft_inverse_fold(ctx, fg, c.first, c.n, group, to_maps, full, parity))) return rc;
+            if ((rc = fft_forward_templates(ctx, fg, c.first, n_all, c.parity))) return rc;
+            if ((rc = fft_inverse_fold(ctx, fg, c.first, c.n, group, to_maps, c.full, c.parity, c.nb))) return rc;
         }
     }
     return SC_OK;

@@ -479,13 +479,18 @@ __global__ void __launch_bounds__(fft_threads(TX), 4)
 k_fwd_rows_curv(const float* __restrict__ curv, Geom g,
                 const TileDev* __restrict__ tiles, int Ty,
                 const float2* __restrict__ tw, float2* __restrict__ blk,
-                double* __restrict__ norms, int dbg) {
+                double* __restrict__ norms, int dbg, int np, size_t curv_stride) {
+    // blockIdx.y = b * np + p: tile pair p of the b-th orientation of the launch (its
+    // curvature plane lies curv_stride floats further on); small searches batch several
+    // orientations per launch (sc_api.hip, "orientation batching")
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     FftTw<TX> twr;
     twr.load(tw);
     constexpr int NT = fft_threads(TX);
     const int rb = blockIdx.x, pair = blockIdx.y;
-    const TileDev ta = tiles[2 * pair], tb = tiles[2 * pair + 1];
+    const int ob = pair / np, ptile = pair - ob * np;
+    curv += (size_t)ob * curv_stride;
+    const TileDev ta = tiles[2 * ptile], tb = tiles[2 * ptile + 1];
     const size_t plane = (size_t)Ty * TX;
     constexpr int E = 4 * TX / NT;
     static_assert(TX % NT == 0, "a thread's cell u lies in row (u*NT)/TX, column (u*NT)%TX + tid");
@@ -791,7 +796,7 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
            const float2* __restrict__ wh, const float2* __restrict__ mh, int Tx,
            int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, int dbg,
            const float2* __restrict__ tw, float2* __restrict__ yw,
-           float2* __restrict__ ym, int ystride) {
+           float2* __restrict__ ym, int ystride, int np, int pcj, int tstride) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     FftTw<TY> twr;
     twr.load(tw);
@@ -804,8 +809,14 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
     //                 columns Tx-fx <= Tx/2; Tx/2 mirrors onto itself).
     // Two launches instead of one branchy kernel: the branch cost registers.
     const int cb = cb0 + blockIdx.x;
-    // several tile pairs per launch (grid.y): pair + blockIdx.y, its Y block ystride planes on
-    pair += blockIdx.y;
+    // several jobs per launch (grid.y): job j = ob * pcj + q is tile pair `pair + q` of the
+    // ob-th orientation of the launch (curvature spectra of an orientation: np planes; its
+    // templates start tstride further on); the job's Y block lies j * ystride planes on
+    {
+        const int ob = blockIdx.y / pcj, q = blockIdx.y - ob * pcj;
+        pair += ob * np + q;
+        vfirst += ob * tstride;
+    }
     yw += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
     ym += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
     constexpr bool mirrored = MIRROR;
@@ -900,7 +911,7 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
                int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, int ky, int kx,
                int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
-               float2* __restrict__ ym, int ystride, int dbg) {
+               float2* __restrict__ ym, int ystride, int dbg, int np, int pcj, int tstride) {
     // dbg: timing-only ablation bits of an SC_ABLATE build (tools/ablate.sh), folded away otherwise:
     //   1 no coefficient fetch in mirrored launches   2 no coefficient fetch at all   4 no stores
     //   8 no transform   16 stores paired into whole 128-byte lines (a bijection onto the same plane)
@@ -913,8 +924,12 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
     constexpr int EP = 4 * TY / (2 * NT);     // 2-cell loads per thread per stream
     float4* xs = reinterpret_cast<float4*>(sm + 4 * fft_line(TY));   // parked spectrum, linear
     const int cb = cb0 + blockIdx.x;
-    // several tile pairs per launch (grid.y): pair + blockIdx.y, its Y block ystride planes on
-    pair += blockIdx.y;
+    // several jobs per launch (grid.y), see k_inv_cols
+    {
+        const int ob = blockIdx.y / pcj, q = blockIdx.y - ob * pcj;
+        pair += ob * np + q;
+        vfirst += ob * tstride;
+    }
     yw += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
     ym += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
     constexpr bool mirrored = MIRROR;
@@ -1042,7 +1057,11 @@ struct RowArgs {
     int pair, first, G;
     int rp_lo, rp_n;                    // valid row pairs of the tile: [rp_lo, rp_lo + rp_n)
     int dbg;                            // diagnostic ablation bits (SC_DBG), 0 in production
-    int ystride;                        // planes between the Y blocks of consecutive tile pairs
+    int ystride;                        // planes between the Y blocks of consecutive jobs
+    // orientation batching (fast kernel): the launch folds nb orientations of G templates each
+    // (templates first + b*G + g, consecutive); the Y block of (orientation b, pair q of the
+    // chunk) is job b*pcj + q, its tile norms are entry b*np + pair
+    int nb, np, pcj;
 };
 // One launch may serve several tile pairs (grid.y): pair = ra.pair + blockIdx.y,
 // its Y planes ystride planes further on.  More workgroups per launch fill the
@@ -1285,8 +1304,10 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     const int rp = ra.rp_lo + pi;
     const size_t plane = (size_t)ra.Ty * TX;
     ra.pair += blockIdx.y;
+    // job of orientation b: b * pcj + blockIdx.y (RowArgs); orientation 0 here, fetch() adds the rest
     yw += (size_t)blockIdx.y * ra.ystride * plane;
     ym += (size_t)blockIdx.y * ra.ystride * plane;
+    const int GT = ra.nb * ra.G;               // templates folded by this launch, first + 0 .. GT-1
     const TileDev tA = tiles[2 * ra.pair], tB = tiles[2 * ra.pair + 1];
     const float scale = 1.0f / ((float)ra.Ty * (float)TX);
 
@@ -1297,11 +1318,12 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     // sums) are the same for every cell: thread t prepares template t once and
     // parks the five floats in LDS.  xcorr = xr*scale_w, T3 = tr*scale
     //   =>  amp = xr*ka, T1 = xr^2*kt, floor = |xr|*kx2 + fl0
-    if (id < ra.G) {
+    if (id < GT) {
         const int it = ra.first + id;
+        const int nrm = (id / ra.G) * ra.np + ra.pair;      // tile-pair norms of the template's orientation
         EpiScal es = sc_epi_scalars(sums, it);
-        sc_epi_floor(es, sums[2 * it], sums[2 * it + 1], wl1[it], norms[2 * ra.pair],
-                     norms[2 * ra.pair + 1], (double)ra.Ty * TX, kappa);
+        sc_epi_floor(es, sums[2 * it], sums[2 * it + 1], wl1[it], norms[2 * nrm],
+                     norms[2 * nrm + 1], (double)ra.Ty * TX, kappa);
         const float scale_w = scale / sc_fft_alpha(sums, it);
         const float ka = scale_w * es.inv_ts;
         float* e = epi + EPI_FLOATS * id;
@@ -1387,16 +1409,24 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         }
     }
 
-    const int NG = PT ? (ra.G + 1) / 2 : ra.G;                   // transforms of the launch
+    const int NGO = PT ? (ra.G + 1) / 2 : ra.G;                  // transforms per orientation
+    const int NG = ra.nb * NGO;                                  // transforms of the launch
+    const size_t ostep = ((size_t)ra.pcj * ra.ystride - NGO) * plane * sizeof(float2);   // last plane of a job -> first of the next
     v2 a[16];
-    auto fetch = [&](int gi_) {
-        const char* p = src1 + (size_t)gi_ * plane * sizeof(float2);
+    // transforms are fetched in order: fp walks the planes of a job, then steps to the same
+    // pair's job of the next orientation (uniform scalars; nb = 1: a plain plane walk)
+    const char* fp = src1;
+    int fk = 0;
+    auto fetch = [&]() {
 #pragma unroll
         for (int j = 0; j < 16; ++j)                             // column tt1 + j*S
-            a[j] = *reinterpret_cast<const v2*>(p + (size_t)j * 2 * S * sizeof(float2) + voff1);
+            a[j] = *reinterpret_cast<const v2*>(fp + (size_t)j * 2 * S * sizeof(float2) + voff1);
+        fp += plane * sizeof(float2);
+        if (++fk == NGO) { fk = 0; fp += ostep; }
     };
-    fetch(0);
+    fetch();
     lds_barrier();                                               // tables and scalars are in place
+    int ob = 0, ok_ = 0;                                         // orientation / transform within it of gi_
     for (int gi_ = 0; gi_ < NG; ++gi_) {
         // the columns are two instructions away from cj0: keep them out of the
         // loop-invariant registers (eight of them would not fit)
@@ -1420,7 +1450,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             }
         }
         lds_barrier();
-        if (FETCH_AT == 0 && gi_ + 1 < NG) fetch(gi_ + 1);       // in flight through stages 2-3
+        if (FETCH_AT == 0 && gi_ + 1 < NG) fetch();              // in flight through stages 2-3
         // ---- stage 2 (radix 16, stride 16): elements tt2 + j*S -> o + 16 m
         {
             v2 b[16];
@@ -1432,7 +1462,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
 #pragma unroll
             for (int m = 1; m < 16; ++m) wr2[17 * m] = pk::cmul(b[pk::B<16, true>::pos(m)], twp2[m]);
         }
-        if (FETCH_AT == 1 && gi_ + 1 < NG) fetch(gi_ + 1);       // in flight through stage 3
+        if (FETCH_AT == 1 && gi_ + 1 < NG) fetch();              // in flight through stage 3
         lds_barrier();
         // ---- stage 3 (radix R3, stride 256) fused with the epilogue: every
         // output is scored as soon as its two butterflies have produced it.
@@ -1447,9 +1477,9 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         uint32_t tix[2];
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
-            const int tg = PT ? 2 * gi_ + part : gi_;
-            const bool have = !PT || tg < ra.G;
-            const int tgc = have ? tg : 2 * gi_;
+            const int tgo = PT ? 2 * ok_ + part : ok_;            // template within its orientation
+            const bool have = !PT || tgo < ra.G;
+            const int tgc = ob * ra.G + (have ? tgo : 2 * ok_);   // template of the launch
             const TemplDev* tp = templ + ra.first + tgc;
             const TileDev& t = tile_of(part);
             const float* e = epi + EPI_FLOATS * tgc;
@@ -1524,6 +1554,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             }
         }
         lds_barrier();
+        if (++ok_ == NGO) { ok_ = 0; ++ob; }
     }
     if (!MAPS) {
 #pragma unroll
@@ -1564,7 +1595,8 @@ static int upload_twiddles(sc_ctx* ctx, DevBuf& buf, int& have, int T) {
 
 static int npairs_of(const FftGeom& fg) { return (fg.ntiles + 1) / 2; }
 
-int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group) {
+int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group, int nb) {
+    // nb: orientations batched per launch (fft_batch_orientations); 1 for the large searches
     if (!fft_size_supported(fg.Ty) || !fft_size_supported(fg.Tx))
         return sc_fail(ctx, SC_ERR_UNSUPPORTED, "FFT tile %dx%d not supported", fg.Ty, fg.Tx);
     int rc;
@@ -1590,11 +1622,12 @@ int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group) {
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SC_HIP(ctx, hipMemcpy(ctx->tiles.p, h.data(), sizeof(TileDev) * h.size(), hipMemcpyHostToDevice));
     size_t plane = (size_t)fg.Ty * fg.Tx * sizeof(float2);
-    size_t nblk = std::max((size_t)2 * np, (size_t)n_templ_chunk);
+    size_t nblk = std::max((size_t)2 * np * nb, (size_t)n_templ_chunk);
     if ((rc = sc_ensure(ctx, ctx->blk, plane * nblk))) return rc;
-    if ((rc = sc_ensure(ctx, ctx->norms, sizeof(double) * 2 * np))) return rc;
-    if ((rc = sc_ensure(ctx, ctx->uc, plane * np))) return rc;
-    if ((rc = sc_ensure(ctx, ctx->uc2, plane * np))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->norms, sizeof(double) * 2 * np * nb))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->uc, plane * np * nb))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->uc2, plane * np * nb))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->curv, sizeof(float) * (size_t)ctx->g.ly * ctx->g.lx * nb))) return rc;
     if ((rc = sc_ensure(ctx, ctx->vh, plane * n_templ_chunk))) return rc;
     size_t hplane = half_plane(fg.Ty, fg.Tx) * sizeof(float2);
     if ((rc = sc_ensure(ctx, ctx->wh, hplane * n_templ_chunk))) return rc;
@@ -1608,13 +1641,32 @@ int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group) {
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
             budget = std::min(32e9, 0.25 * (double)(free_b + ctx->yw.cap + ctx->ym.cap));
         if (ctx->y_gb > 0.0) budget = ctx->y_gb * 1e9;
-        double per_pair = 2.0 * (double)plane * group;
+        double per_pair = 2.0 * (double)plane * group * nb;      // a pair's Y blocks of all batched orientations
         pb = (int)std::max(1.0, std::min((double)np, floor(budget / per_pair)));
     }
     ctx->fft_pb = pb;
-    if ((rc = sc_ensure(ctx, ctx->yw, plane * group * pb))) return rc;
-    if ((rc = sc_ensure(ctx, ctx->ym, plane * group * pb))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->yw, plane * group * pb * nb))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->ym, plane * group * pb * nb))) return rc;
     return SC_OK;
+}
+
+// Orientation batching.  A search whose single orientation does not fill the chip (one or
+// two tiles, one age: BASELINE configs C1, C2, C5) is launch-bound: ten launches of a few
+// microseconds of work per orientation.  Such searches send nb orientations through every
+// launch: nb curvature planes and spectra, the templates of all of them in one forward pass,
+// the inverse column pass with one job per (orientation, tile pair), and the row pass folding
+// nb * n templates in the order the orientations come - the same cells in the same order as
+// orientation by orientation, so the result is bit-identical.  Conditions: the fast row
+// kernel (its scalar table and winner byte hold SC_MAX_GROUP templates), all templates of an
+// orientation in one inverse launch (group >= n), and at most ~2048 column workgroups.
+int fft_batch_orientations(const sc_ctx* ctx, const FftGeom& fg, int n_per, int group) {
+    if (ctx->batch_off || n_per < 1 || n_per > group) return 1;
+    const bool fast = (fg.Tx == 512 || fg.Tx == 1024 || fg.Tx == 2048) && ctx->variant != 9;
+    if (!fast) return 1;
+    const int np = (fg.ntiles + 1) / 2;
+    const int by_table = SC_MAX_GROUP / n_per;
+    const int by_fill = 2048 / std::max(1, np * (fg.Tx / 8));
+    return std::max(1, std::min(std::min(by_table, by_fill), 32));
 }
 
 template <typename K>
@@ -1656,11 +1708,11 @@ static int launch_fwd_cols(sc_ctx* ctx, const FftGeom& fg, int nplanes,
     return SC_OK;
 }
 
-int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg) {
+int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg, int nb) {
     int np = npairs_of(fg);
-    SC_HIP(ctx, hipMemsetAsync(ctx->norms.p, 0, sizeof(double) * 2 * np, ctx->stream));
+    SC_HIP(ctx, hipMemsetAsync(ctx->norms.p, 0, sizeof(double) * 2 * np * nb, ctx->stream));
     size_t lds = fft_lds_bytes(fg.Tx);
-    dim3 grid(fg.Ty / 4, np);
+    dim3 grid(fg.Ty / 4, np * nb);
     sc_prof_begin(ctx, SC_K_FWD_ROWS);
 #define FN(T)                                                                  \
     {                                                                          \
@@ -1670,13 +1722,14 @@ int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg) {
                            lds, ctx->stream, (const float*)ctx->curv.p,        \
                            ctx->g, (const TileDev*)ctx->tiles.p, fg.Ty,        \
                            (const float2*)ctx->tw_x.p, (float2*)ctx->blk.p,    \
-                           (double*)ctx->norms.p, ctx->dbg);                   \
+                           (double*)ctx->norms.p, ctx->dbg, np,                \
+                           (size_t)ctx->g.ly * ctx->g.lx);                     \
     }
     DISPATCH_T(fg.Tx, FN)
 #undef FN
     sc_prof_end(ctx);
     SC_HIP(ctx, hipGetLastError());
-    return launch_fwd_cols(ctx, fg, 2 * np, (float2*)ctx->uc.p, (float2*)ctx->uc2.p, 1);
+    return launch_fwd_cols(ctx, fg, 2 * np * nb, (float2*)ctx->uc.p, (float2*)ctx->uc2.p, 1);
 }
 
 // Symmetric fast path (k_split_templ_sym / k_inv_cols_sym): all templates of the
@@ -1726,7 +1779,9 @@ int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n, int 
 // planes [0, n).  For every tile pair: inverse transforms in groups of `group`
 // templates, folded in template order.
 int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
-                     int group, bool to_maps, bool full_masks, int parity) {
+                     int group, bool to_maps, bool full_masks, int parity, int nb) {
+    // nb > 1: templates [first, first + nb*n) are nb orientations of n templates each
+    // (fft_batch_orientations); n <= group then, and the row kernel is the fast one
     const bool sym = fft_use_sym(ctx, fg, parity);
     int np = npairs_of(fg);
     size_t lds_r = fft_lds_bytes(fg.Tx);
@@ -1742,6 +1797,8 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     const int pb = std::max(1, ctx->fft_pb);
     const size_t yblock = (size_t)fg.Ty * fg.Tx * group;          // cells per pair in yw / ym
     const bool fast = (fg.Tx == 512 || fg.Tx == 1024 || fg.Tx == 2048) && ctx->variant != 9;
+    if (nb > 1 && (!fast || n > group || nb * n > SC_MAX_GROUP))
+        return sc_fail(ctx, SC_ERR_INVALID, "orientation batching outside its conditions");
     // One chunk = pc tile pairs through I1 and I2, group by group.  PTV: the chunk is a
     // single pair whose second tile is empty; templates ride in pairs instead (see
     // k_inv_cols_sym) - the symmetric I1 and the fast I2 know that mode.
@@ -1754,7 +1811,9 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             const size_t lds_c = (size_t)4 * fft_line(fg.Ty) * sizeof(float2) +
                                  (fg.Ty <= 2048 ? (size_t)4 * fg.Ty * sizeof(float2) : 0);
             const int slots = 256 * (int)std::max<size_t>(1, (size_t)(160 * 1024) / lds_c);
-            const int pi1 = std::max(1, std::min(pc, (slots + fg.Tx / 8 - 1) / (fg.Tx / 8)));
+            // (nb > 1, batched orientations: every job of the chunk in one launch - job
+            //  ob * pc + q, the numbering the row kernel expects)
+            const int pi1 = nb > 1 ? pc : std::max(1, std::min(pc, (slots + fg.Tx / 8 - 1) / (fg.Tx / 8)));
             sc_prof_begin(ctx, SC_K_INV_COLS);
             int n_i1 = 0;
             for (int pl0 = 0; pl0 < pc; pl0 += pi1) {
@@ -1766,12 +1825,12 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
 #define COL_ARGS(CB0)                                                          \
     ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float2*)ctx->wh.p, \
         (const float2*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, ctx->dbg,        \
-        (const float2*)ctx->tw_y.p, ywp, ymp, group
+        (const float2*)ctx->tw_y.p, ywp, ymp, group, np, pcc, n
 #define SYM_ARGS(CB0)                                                          \
     ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float*)ctx->wh.p, \
         (const float*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, 1 - ctx->g.oy,     \
         1 - ctx->g.ox, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group
-#define SYM_ARGS_D(CB0) SYM_ARGS(CB0), ctx->dbg
+#define SYM_ARGS_D(CB0) SYM_ARGS(CB0), ctx->dbg, np, pcc, n
 #define FN_SYM(T)                                                              \
     {                                                                          \
         int rc = set_lds(ctx, k_inv_cols_sym<T, false, PTV>, inv_cols_lds<T>());    \
@@ -1779,10 +1838,10 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         rc = set_lds(ctx, k_inv_cols_sym<T, true, PTV>, inv_cols_lds<T>());         \
         if (rc) return rc;                                                     \
         const int nlo = fg.Tx / 8, nhi = fg.Tx / 4 - nlo;                      \
-        hipLaunchKernelGGL((k_inv_cols_sym<T, false, PTV>), dim3(nlo, pcc), dim3(fft_threads(T)), \
+        hipLaunchKernelGGL((k_inv_cols_sym<T, false, PTV>), dim3(nlo, nb * pcc), dim3(fft_threads(T)), \
                            inv_cols_lds<T>(), SYM_ARGS_D(0));                  \
         if (nhi > 0)                                                           \
-            hipLaunchKernelGGL((k_inv_cols_sym<T, true, PTV>), dim3(nhi, pcc), dim3(fft_threads(T)), \
+            hipLaunchKernelGGL((k_inv_cols_sym<T, true, PTV>), dim3(nhi, nb * pcc), dim3(fft_threads(T)), \
                                inv_cols_lds<T>(), SYM_ARGS_D(nlo));            \
     }
 #define FN(T)                                                                  \
@@ -1792,10 +1851,10 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         rc = set_lds(ctx, k_inv_cols<T, true>, inv_cols_lds<T>());             \
         if (rc) return rc;                                                     \
         const int nlo = fg.Tx / 8, nhi = fg.Tx / 4 - nlo;                      \
-        hipLaunchKernelGGL((k_inv_cols<T, false>), dim3(nlo, pcc), dim3(fft_threads(T)), \
+        hipLaunchKernelGGL((k_inv_cols<T, false>), dim3(nlo, nb * pcc), dim3(fft_threads(T)), \
                            inv_cols_lds<T>(), COL_ARGS(0));                    \
         if (nhi > 0)                                                           \
-            hipLaunchKernelGGL((k_inv_cols<T, true>), dim3(nhi, pcc), dim3(fft_threads(T)), \
+            hipLaunchKernelGGL((k_inv_cols<T, true>), dim3(nhi, nb * pcc), dim3(fft_threads(T)), \
                                inv_cols_lds<T>(), COL_ARGS(nlo));              \
     }
             if (sym) {
@@ -1819,7 +1878,8 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             sc_prof_end(ctx, n_i1);                   // direct + mirrored launches
             const int pair = pair0;
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
-                       ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg, group};
+                       ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg, group,
+                       nb, np, pc};
                         dim3 gridr(fast ? ((rp_n + 7) / 8) * 16 : (rp_n + 1) / 2, pc);
             sc_prof_begin(ctx, SC_K_INV_ROWS);
 #define ROW_ARGS lds_r, FAST_ARGS

@@ -88,6 +88,7 @@ struct sc_ctx {
     int last_batch = 0;
     float kappa = 4.f;         // float32 resolution floor of the FFT path, in units of eps (sc_set_option "kappa")
     int variant = 0;           // sc_set_option "variant": alternative kernel paths kept for cross-checks
+    int batch_off = 0;         // sc_set_option "batch" = 0: no orientation batching (cross-check in the tests)
     double y_gb = 0.0;         // sc_set_option "y_gb": memory budget of the I1 -> I2 hand-off (0: automatic)
     int dbg = 0;               // timing-only ablation bits; only an SC_ABLATE build reads them (tools/ablate.sh)
     // profiling
@@ -133,18 +134,19 @@ void sc_prof_collect(sc_ctx* ctx);
 
 // ---- launchers implemented in sc_kernels.hip --------------------------------
 int launch_curv_planes(sc_ctx* ctx);
-int launch_curv_alpha(sc_ctx* ctx, float cc, float sc2, float ss);
+int launch_curv_alpha(sc_ctx* ctx, float cc, float sc2, float ss, int plane = 0);
 int launch_windows(sc_ctx* ctx, int first, int n, int wh_max, int ww_max);
 int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps);
 bool direct_window_fits(int ww);     // template window width the real-space kernel can stage in LDS
 int launch_compare_fold(sc_ctx* ctx, double age, double angle, bool planes);
 
 // ---- launchers implemented in sc_fft.hip ------------------------------------
-int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group);
-int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg);
+int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group, int nb);
+int fft_batch_orientations(const sc_ctx* ctx, const FftGeom& fg, int n_per, int group);
+int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg, int nb);
 int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n, int parity);
 int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
-                     int group, bool to_maps, bool full_masks, int parity);
+                     int group, bool to_maps, bool full_masks, int parity, int nb);
 bool fft_size_supported(int T);
 
 // ---- device helpers shared by both paths -------------------------------------

@@ -324,7 +324,8 @@ int launch_curv_planes(sc_ctx* ctx) {
     return SC_OK;
 }
 
-int launch_curv_alpha(sc_ctx* ctx, float cc, float sc2, float ss) {
+int launch_curv_alpha(sc_ctx* ctx, float cc, float sc2, float ss, int plane) {
+    // plane: which of the context's curvature planes receives it (batched orientations)
     size_t n = (size_t)ctx->g.ly * ctx->g.lx;
     size_t blocks = (n / 4 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -333,7 +334,7 @@ int launch_curv_alpha(sc_ctx* ctx, float cc, float sc2, float ss) {
     hipLaunchKernelGGL(k_curv_alpha, dim3((unsigned)blocks), dim3(256), 0,
                        ctx->stream, (const float*)ctx->A.p,
                        (const float*)ctx->B.p, (const float*)ctx->C.p, cc, sc2,
-                       ss, (float*)ctx->curv.p, n);
+                       ss, (float*)ctx->curv.p + (size_t)plane * n, n);
     sc_prof_end(ctx);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;

@@ -215,3 +215,40 @@ def test_symmetric_spectrum_path_agrees_with_complex_path():
     assert np.allclose(a[3][same], b[3][same], rtol=2e-4, atol=1e-7 * b[3].max())
     assert np.allclose(a[0][same], b[0][same], rtol=2e-4, atol=1e-7 * np.abs(b[0]).max())
     assert np.allclose(a[3][~same], b[3][~same], rtol=TIE_RTOL)
+
+
+def test_orientation_batching_is_bit_identical():
+    """Small searches send several orientations through every launch (sc_fft.hip "Orientation
+    batching"): same cells, same fold order - the record must equal the one-orientation-per-
+    launch path bit for bit.  Covers one- and two-tile plans, paired-template tiles, single and
+    several ages, the masked (UpperBreak) and the generic complex-spectrum (Shifted) paths."""
+    rng = np.random.default_rng(77)
+
+    def dem(ny, nx):
+        return (np.cumsum(np.cumsum(rng.standard_normal((ny, nx)), 0), 1) * 0.01
+                + rng.standard_normal((ny, nx)) * 0.05).astype(np.float32)
+    gc = dem_fixture("dem_grandcanyon.npz")
+    cases = [
+        (grid(dem(900, 505), 2.0), WT.Scarp, 100, [10.0], _plan.angle_grid(-0.3, 0.3), {}),          # C1 shape: 2 tiles
+        (grid(gc[0], gc[1], gc[2]), WT.Channel, 10., [0.1], _plan.angle_grid()[::3], {}),             # C5: one tile, one template
+        (grid(gc[0], gc[1], gc[2]), WT.Channel, 20., [0.05, 0.1, 0.2], _plan.angle_grid()[::7], {}),  # odd template count
+        (synthetic.synthetic_scarp(1024, seed=5), WT.Scarp, 60, _plan.age_grid()[::4], _plan.angle_grid()[::9], {}),
+        (grid(dem(600, 700), 1.0), WT.RightFacingUpperBreakScarp, 20, [3.0, 30.0], _plan.angle_grid()[::10], {}),
+        (grid(dem(520, 530), 1.0), WT.ShiftedLeftFacingUpperBreakScarp, 12, [4.0], _plan.angle_grid()[::12],
+         dict(dx=3, dy=-2)),
+    ]
+    for (g, cls, scale, params, angles, kw) in cases:
+        out = []
+        for batch in (1, 0):
+            ctx = sl._lib.Context(0)
+            ctx.set_option("batch", batch)
+            m = sl.Matcher(g, ctx=ctx)
+            m.search(cls, scale, params, angles, method="fft", **kw)
+            out.append(m.ctx.get_best())
+            plan = m.plan
+            m.ctx.clear_windows()
+            del m
+            ctx.close()
+        for a, b, name in zip(out[0], out[1], ("amp", "snr", "id")):
+            assert np.array_equal(a, b), (cls.__name__, str(plan), name, int((a != b).sum()))
+        assert (out[0][1] > 0).any()
