@@ -774,6 +774,92 @@ k_split_templ_sym(const float2* __restrict__ vh, int Ty, int Tx, int ky, int kx,
     *reinterpret_cast<float2*>(mb + (size_t)blockIdx.y * hplane + e) = make_float2(rb[0], rb[1]);
 }
 
+// ---- F2 + S fused for symmetric templates ----------------------------------------
+// k_fwd_cols followed by k_split_templ_sym writes the full complex spectrum of every
+// template (8 B per cell), reads it back and its mirror, and keeps 2 x 4 B per cell of half
+// the plane: 86 MB of traffic per 2048^2 template for 17 MB of result.  Large searches
+// amortise that over their tile pairs; a one-tile search (BASELINE config C2) spent a third
+// of its time there.  Here one workgroup transforms the four mirror columns Tx - fx first,
+// keeps the cells it will pair with in registers (16 complex values per thread), transforms
+// its own four columns in the same LDS lines and writes the real coefficients a, b straight
+// away.  Same transforms, same split arithmetic: the coefficients are bit-identical.
+// grid = (Tx/8 + 1, n_templates): column blocks up to the one holding Tx/2.
+template <int TY>
+__global__ void __launch_bounds__(fft_threads(TY), fft_waves(TY))
+k_fwd_cols_tsym(const float2* __restrict__ blk, int Tx, const float2* __restrict__ tw,
+                const TemplDev* __restrict__ templ, int ky, int kx, int parity,
+                float* __restrict__ wa, float* __restrict__ mb) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    FftTw<TY> twr;
+    twr.load(tw);
+    constexpr int NT = fft_threads(TY);
+    constexpr int EP = (4 * TY + 2 * NT - 1) / (2 * NT);     // 2-cell pieces per thread
+    const int cb = blockIdx.x, q = blockIdx.y;
+    const size_t plane = (size_t)TY * Tx, hplane = half_plane(TY, Tx);
+    const float2* in = blk + (size_t)q * plane;
+    const int nbx = Tx >> 2;
+    const TemplDev t = templ[q];
+    // ---- mirror columns: line c holds column (Tx - (4cb + c)) mod Tx
+    for (int e = threadIdx.x; e < 4 * TY; e += NT) {
+        const int c = e / TY, r = e - c * TY;
+        const int col = (Tx - (4 * cb + c)) & (Tx - 1);
+        float2 v = make_float2(0.f, 0.f);
+        if (templ_rowblock_used(t, r >> 2, TY))
+            v = in[((size_t)(r >> 2) * nbx + (col >> 2)) * 16 + (r & 3) * 4 + (col & 3)];
+        sm[lidx<TY>(c, r)] = v;
+    }
+    lds_barrier();
+    fft4_lines<TY, false>(sm, twr);
+    float2 vm0[EP], vm1[EP];
+#pragma unroll
+    for (int u = 0; u < EP; ++u) {
+        const int e = 2 * (threadIdx.x + u * NT);
+        if (e < 4 * TY) {
+            const int cc = e / TY, fy = e - cc * TY;          // fy even
+            vm0[u] = sm[lidx<TY>(cc, (TY - fy) & (TY - 1))];
+            vm1[u] = sm[lidx<TY>(cc, TY - fy - 1)];
+        }
+    }
+    lds_barrier();
+    // ---- own columns 4cb .. 4cb+3 (k_fwd_cols' fill)
+#pragma unroll 4
+    for (int e = 2 * threadIdx.x; e < 4 * TY; e += 2 * NT) {      // 2 cells = 16 B per lane
+        int rbk = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (templ_rowblock_used(t, rbk, TY))
+            x = *reinterpret_cast<const float4*>(in + ((size_t)rbk * nbx + cb) * 16 + (e & 15));
+        sm[lidx<TY>(cc, 4 * rbk + rr)] = make_float2(x.x, x.y);
+        sm[lidx<TY>(cc + 1, 4 * rbk + rr)] = make_float2(x.z, x.w);
+    }
+    lds_barrier();
+    fft4_lines<TY, false>(sm, twr);
+    // ---- split (k_split_templ_sym, cell for cell) and store
+#pragma unroll
+    for (int u = 0; u < EP; ++u) {
+        const int e = 2 * (threadIdx.x + u * NT);
+        if (e >= 4 * TY) continue;
+        const int cc = e / TY, fy = e - cc * TY, fx = 4 * cb + cc;
+        const float2 a0 = sm[lidx<TY>(cc, fy)], a1 = sm[lidx<TY>(cc, fy + 1)];
+        const float2 b0 = vm0[u], b1 = vm1[u];
+        float2 w[2] = {make_float2(0.5f * (a0.x + b0.x), 0.5f * (a0.y - b0.y)),
+                       make_float2(0.5f * (a1.x + b1.x), 0.5f * (a1.y - b1.y))};
+        float2 m[2] = {make_float2(0.5f * (a0.y + b0.y), -0.5f * (a0.x - b0.x)),
+                       make_float2(0.5f * (a1.y + b1.y), -0.5f * (a1.x - b1.x))};
+        float ra[2], rb[2];
+        const float ax = (float)(kx * fx) / (float)Tx;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float2 ph_ = phase_pi((float)(ky * (fy + k)) / (float)TY + ax);
+            float wr = w[k].x * ph_.x + w[k].y * ph_.y, wi = w[k].y * ph_.x - w[k].x * ph_.y;
+            ra[k] = parity == 1 ? wi : wr;
+            rb[k] = m[k].x * ph_.x + m[k].y * ph_.y;
+        }
+        const size_t o = (size_t)q * hplane + (size_t)cb * 4 * TY + e;
+        *reinterpret_cast<float2*>(wa + o) = make_float2(ra[0], ra[1]);
+        *reinterpret_cast<float2*>(mb + o) = make_float2(rb[0], rb[1]);
+    }
+}
+
 // ---- I1: spectra product -> inverse column FFT -> blocked --------------------
 // grid = (Tx/4): one workgroup per block of 4 columns.  For each plane (W: xcorr,
 // M: T3) the block's 4 columns of the curvature spectrum are parked in LDS once
@@ -1757,6 +1843,33 @@ int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n, int 
 #undef FN
     sc_prof_end(ctx);
     SC_HIP(ctx, hipGetLastError());
+    if (fft_use_sym(ctx, fg, parity) && ctx->variant != 7) {
+        // symmetric templates: column transform and split in one kernel (k_fwd_cols_tsym)
+        size_t ldsc = fft_lds_bytes(fg.Ty);
+        dim3 gridc(fg.Tx / 8 + 1, n);
+        sc_prof_begin(ctx, SC_K_FWD_COLS);
+#define FN(T)                                                                  \
+    {                                                                          \
+        int rc = set_lds(ctx, k_fwd_cols_tsym<T>, ldsc);                       \
+        if (rc) return rc;                                                     \
+        hipLaunchKernelGGL(k_fwd_cols_tsym<T>, gridc, dim3(fft_threads(T)), ldsc, ctx->stream, \
+                           (const float2*)ctx->blk.p, fg.Tx, (const float2*)ctx->tw_y.p, \
+                           (const TemplDev*)ctx->templ.p + first, 1 - ctx->g.oy, 1 - ctx->g.ox, \
+                           parity, (float*)ctx->wh.p, (float*)ctx->mh.p);      \
+    }
+        switch (fg.Ty) {
+            case 64: FN(64); break;
+            case 128: FN(128); break;
+            case 256: FN(256); break;
+            case 512: FN(512); break;
+            case 1024: FN(1024); break;
+            default: FN(2048); break;
+        }
+#undef FN
+        sc_prof_end(ctx);
+        SC_HIP(ctx, hipGetLastError());
+        return SC_OK;
+    }
     int rc = launch_fwd_cols(ctx, fg, n, (float2*)ctx->vh.p, nullptr, 0,
                              (const TemplDev*)ctx->templ.p + first);
     if (rc) return rc;

@@ -252,3 +252,34 @@ def test_orientation_batching_is_bit_identical():
         for a, b, name in zip(out[0], out[1], ("amp", "snr", "id")):
             assert np.array_equal(a, b), (cls.__name__, str(plan), name, int((a != b).sum()))
         assert (out[0][1] > 0).any()
+
+
+def test_fused_template_split_is_bit_identical():
+    """k_fwd_cols_tsym (column transform + split of symmetric templates in one kernel) against
+    the two-kernel sequence it replaces (option variant=7): identical coefficients, so an
+    identical record; on an even x odd DEM and on a circular single tile."""
+    for g, scale, ages in ((synthetic.synthetic_scarp(1300, ny=1201, seed=21), 60, _plan.age_grid()[3::9]),
+                           (synthetic.synthetic_scarp(1024, seed=22), 40, _plan.age_grid()[::6])):
+        out = []
+        for variant in (0, 7):
+            ctx = sl._lib.Context(0)
+            ctx.set_option("variant", variant)
+            m = sl.Matcher(g, ctx=ctx)
+            m.search(sl.Scarp, scale, ages, _plan.angle_grid()[::16], method="fft")
+            out.append(m.ctx.get_best())
+            del m
+            ctx.close()
+        for a, b, name in zip(out[0], out[1], ("amp", "snr", "id")):
+            assert np.array_equal(a, b), (name, int((a != b).sum()))
+    gc = dem_fixture("dem_grandcanyon.npz")
+    out = []
+    for variant in (0, 7):
+        ctx = sl._lib.Context(0)
+        ctx.set_option("variant", variant)
+        m = sl.Matcher(grid(gc[0], gc[1], gc[2]), ctx=ctx)
+        m.search(WT.Channel, 10., [0.1, 0.2], _plan.angle_grid()[::9], method="fft")
+        out.append(m.ctx.get_best())
+        del m
+        ctx.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
