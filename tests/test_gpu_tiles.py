@@ -109,3 +109,40 @@ def test_gather_result_places_a_core_inside_the_dem():
         mask = np.ones(z.shape, bool)
         mask[core[0]:core[1], core[2]:core[3]] = False
         assert not out[k][mask].any()
+
+
+def test_c4_eight_rank_blocks_at_full_size():
+    """BASELINE config C4 on one GPU: the 10000 x 10000 DEM cut into the 2 x 4 rank grid, every
+    rank's block (5000 x 2500 core + torus halo, as sc_halo_exchange assembles it) searched on
+    its own with all 35 ages, the tiles stitched and compared with the whole-DEM search.  The
+    two runs tile differently (blocks: 3 x 4 tiles of 2048 x 1024, whole DEM: 6 x 6 of 2048^2),
+    so they differ by float32 rounding: winners must agree except inside the tie window."""
+    n = 10000
+    g = synthetic.synthetic_scarp(n)
+    z = g._griddata
+    ages = _plan.age_grid()
+    angles = _plan.angle_grid()[[3, 30, 61, 88, 117, 150, 176]]
+    m = sl.Matcher(g)
+    whole = m.search(sl.Scarp, 100, ages, angles, method="fft").result_array()
+    arr, bbox, area = m.describe(sl.Scarp, 100, ages, angles)
+    halo = sd.halo_for_search(bbox, n, n)
+    py, px = sd.grid_dims(8, n, n)
+    assert (py, px) in ((2, 4), (4, 2))
+    lay = sd.Layout(n, n, py, px, halo)
+    tiled = np.zeros_like(whole)
+    for r in range(8):
+        c = lay.core(r)
+        blk = np.ascontiguousarray(sd.assemble_block_reference(z, lay, r))
+        m.set_block(blk, lay.block_origin(r), (n, n), c, 1.0, 1.0)
+        plan, sp = m.plan_for(bbox, area, "fft", None, n_params=len(ages))
+        m.ctx.reset_best()
+        m.ctx.match(arr, sp)
+        tiled[:, c[0]:c[1], c[2]:c[3]] = m.ctx.get_result(np.repeat(ages, len(angles)), np.tile(angles, len(ages)))
+    same = (whole[1] == tiled[1]) & (whole[2] == tiled[2])
+    tie = orc.PARITY["tie_rtol"]
+    print("C4 blocks vs whole DEM: same (age, angle) %.6f of %d cells; the rest within the tie window: %s"
+          % (same.mean(), same.size, bool(np.allclose(whole[3][~same], tiled[3][~same], rtol=tie))))
+    assert same.mean() > 0.999, float(same.mean())
+    assert np.allclose(whole[3][~same], tiled[3][~same], rtol=tie)
+    assert np.allclose(whole[0][same], tiled[0][same], rtol=2e-4, atol=2e-6 * np.abs(whole[0]).max())
+    assert np.allclose(whole[3][same], tiled[3][same], rtol=2e-3, atol=2e-6 * whole[3].max())
