@@ -154,6 +154,21 @@ int sc_clear_windows(sc_ctx* ctx);
  */
 int sc_set_option(sc_ctx* ctx, const char* name, double value);
 
+/*
+ * One pass of the nodata fill that precedes the matcher (DEMGrid._fill_nodata,
+ * dem.py:388-414: rasterio.fill.fillnodata -> GDALFillNodata).  z: ny x nx
+ * float64 host array, NaN = nodata, filled in place: every nodata cell takes the
+ * inverse-distance mean of the nearest valid cells of its four quadrants within
+ * max_search_distance (searching the columns x +- step, step <= floor(distance)),
+ * then smoothing_iterations 3x3 means over the filled cells.  *remaining = cells
+ * still nodata (no source within reach); the host repeats with a new distance as
+ * the reference does.  Independent of the DEM held by the context.
+ * GDAL itself is not available to check against: the algorithm is restated from
+ * its published description (oracle/scarplet_oracle.py fill_nodata_pass).
+ */
+int sc_fill_nodata(sc_ctx* ctx, double* z, int ny, int nx, double max_search_distance,
+                   int smoothing_iterations, long long* remaining);
+
 /* ---- the hot path ------------------------------------------------------ */
 /* Zero the running-best record (compare() start state, core.py:222-225). */
 int sc_reset_best(sc_ctx* ctx);

@@ -268,6 +268,95 @@ def match_serial(z, dx, dy, kind, scale, ang_max=np.pi / 2,
 
 
 # ----------------------------------------------------------------------------
+# nodata fill                                               dem.py:388-414
+# ----------------------------------------------------------------------------
+def fill_nodata_pass(z, max_search_distance, smoothing_iterations=0):
+    """One call of GDAL's GDALFillNodata as rasterio.fill.fillnodata reaches it
+    (dem.py:408-410).  PARITY UNPINNED: GDAL is an un-vendored dependency
+    (setup.py / requirements.txt: rasterio, unpinned) and neither it nor
+    rasterio is installed here, so this restates the algorithm GDAL publishes
+    (gdal/alg/rasterfill.cpp, "a four direction conic search ... using inverse
+    distance weighting ... then smoothing iterations of a 3x3 average filter on
+    interpolated pixels") and has not been checked against GDAL output:
+
+      * for a nodata cell (x, y) and every column x' with |x' - x| <=
+        floor(max_search_distance), take the nearest valid cell of that column
+        at or above row y (top quadrants) and at or below it (bottom
+        quadrants); x' <= x feeds the left quadrant, x' >= x the right one
+        (the cell's own column feeds both);
+      * per quadrant keep the candidate of smallest Euclidean distance (first
+        found on a tie, scanning outwards from x);
+      * value = sum(v_q / d_q) / sum(1 / d_q) over the quadrants whose
+        distance is <= max_search_distance; none: the cell stays nodata;
+      * only original valid cells are sources (fills do not feed fills);
+      * smoothing: ``smoothing_iterations`` passes replacing each FILLED cell
+        by the mean of its 3x3 neighbourhood's non-nodata cells.
+    Returns a new float64 array."""
+    z = np.array(z, dtype=float)
+    ny, nx = z.shape
+    valid = ~np.isnan(z)
+    big = 1 << 30
+    up = np.full((ny, nx), -big, dtype=np.int64)     # nearest valid row at or above
+    dn = np.full((ny, nx), big, dtype=np.int64)      # nearest valid row at or below
+    last = np.full(nx, -big, dtype=np.int64)
+    for y in range(ny):
+        last = np.where(valid[y], y, last)
+        up[y] = last
+    last = np.full(nx, big, dtype=np.int64)
+    for y in range(ny - 1, -1, -1):
+        last = np.where(valid[y], y, last)
+        dn[y] = last
+    out = z.copy()
+    R = int(np.floor(max_search_distance))
+    for (y, x) in np.argwhere(~valid):
+        qd = [np.inf] * 4          # TL, TR, BL, BR
+        qv = [0.0] * 4
+        for step in range(R + 1):
+            for side, xx in ((0, x - step), (1, x + step)):
+                if xx < 0 or xx >= nx:
+                    continue
+                for vert, yy in ((0, up[y, xx]), (2, dn[y, xx])):
+                    if yy < 0 or yy >= ny:
+                        continue
+                    d = np.sqrt(float((xx - x) ** 2 + (yy - y) ** 2))
+                    q = vert + side
+                    if d < qd[q]:
+                        qd[q], qv[q] = d, z[yy, xx]
+        ws = vs = 0.0
+        for q in range(4):
+            if qd[q] <= max_search_distance:
+                ws += 1.0 / qd[q]
+                vs += qv[q] / qd[q]
+        if ws > 0:
+            out[y, x] = vs / ws
+    filled = ~valid & ~np.isnan(out)
+    for _ in range(int(smoothing_iterations)):
+        src = out.copy()
+        for (y, x) in np.argwhere(filled):
+            win = src[max(y - 1, 0):y + 2, max(x - 1, 0):x + 2]
+            out[y, x] = np.nanmean(win)
+    return out
+
+
+def fill_nodata(z, max_passes=64):
+    """DEMGrid._fill_nodata, dem.py:388-414: repeat fillnodata with
+    max_search_distance = max(most nodata cells in a row, in a column) / 2
+    until no nodata is left (bounded here: the reference loops forever when a
+    pass makes no progress)."""
+    z = np.array(z, dtype=float)
+    for _ in range(max_passes):
+        mask = np.isnan(z)
+        if not mask.any():
+            break
+        dist = max(np.sum(mask, axis=1).max(), np.sum(mask, axis=0).max()) / 2
+        before = int(mask.sum())
+        z = fill_nodata_pass(z, dist)
+        if int(np.isnan(z).sum()) == before:
+            break
+    return z
+
+
+# ----------------------------------------------------------------------------
 # helpers for the parity tests (not in the reference)
 # ----------------------------------------------------------------------------
 def snr_stack(z, dx, dy, kind, scale, ages, angles, workers=1):

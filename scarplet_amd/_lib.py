@@ -94,6 +94,8 @@ SIGNATURES = {
     "sc_compare_fold_planes": (C.c_int, [_P, _dp, _dp, _dp, _dp]),
     "sc_compare_end": (C.c_int, [_P, _dp, _dp, _dp, _dp]),
     "sc_set_option": (C.c_int, [_P, C.c_char_p, C.c_double]),
+    "sc_fill_nodata": (C.c_int, [_P, _dp, C.c_int, C.c_int, C.c_double, C.c_int,
+                                 C.POINTER(C.c_longlong)]),
     "sc_curvature": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, _fp]),
     "sc_get_template_sums": (C.c_int, [_P, C.c_int, _dp, _dp]),
     "sc_profile": (C.c_int, [_P, C.c_int]),
@@ -182,6 +184,16 @@ class Context(object):
         'variant', 'y_gb'."""
         self._check(self.lib.sc_set_option(self._h, name.encode(), float(value)),
                     "sc_set_option(%s)" % name)
+
+    def fill_nodata(self, z, max_search_distance, smoothing_iterations=0):
+        """One GDALFillNodata-style pass over ``z`` (float64, NaN = nodata), in
+        place; returns the number of cells still nodata."""
+        assert z.dtype == np.float64 and z.flags.c_contiguous and z.ndim == 2
+        left = C.c_longlong(0)
+        self._check(self.lib.sc_fill_nodata(self._h, _as(z, _dp), z.shape[0], z.shape[1],
+                                            float(max_search_distance), int(smoothing_iterations),
+                                            C.byref(left)), "sc_fill_nodata")
+        return int(left.value)
 
     # -- DEM ----------------------------------------------------------------
     def _dem_args(self, ly, lx, origin, shape, core, wrap):

@@ -202,6 +202,7 @@ extern "C" void sc_destroy(sc_ctx* c) {
     for (DevBuf* b : arr) buf_free(*b);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp[k]);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp_in[k]);
+    for (int k = 0; k < 4; ++k) buf_free(c->fill[k]);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -653,6 +654,33 @@ extern "C" int sc_get_template_sums(sc_ctx* ctx, int n, double* n_out, double* t
         n_out[i] = h[2 * (size_t)i] + SC_EPS;
         ts_out[i] = h[2 * (size_t)i + 1];
     }
+    return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// nodata fill (pre-step of the matcher: DEMGrid._fill_nodata)
+// ---------------------------------------------------------------------------
+extern "C" int sc_fill_nodata(sc_ctx* ctx, double* z, int ny, int nx, double max_search_distance,
+                              int smoothing_iterations, long long* remaining) {
+    if (!ctx || !z || ny <= 0 || nx <= 0 || !(max_search_distance >= 0.0) || smoothing_iterations < 0)
+        return SC_ERR_INVALID;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)ny * nx;
+    int rc;
+    if ((rc = sc_ensure(ctx, ctx->fill[0], sizeof(double) * n))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->fill[1], sizeof(double) * n))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->fill[2], sizeof(int) * 2 * n + 16))) return rc;      // up | down, contiguous
+    if ((rc = sc_ensure(ctx, ctx->fill[3], 16))) return rc;
+    SC_HIP(ctx, hipMemcpyAsync(ctx->fill[0].p, z, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    int* up = (int*)ctx->fill[2].p;
+    rc = launch_fill_nodata(ctx, (double*)ctx->fill[0].p, (double*)ctx->fill[1].p, up, up + n, ny, nx,
+                            max_search_distance, smoothing_iterations, (unsigned long long*)ctx->fill[3].p);
+    if (rc) return rc;
+    unsigned long long left = 0;
+    SC_HIP(ctx, hipMemcpyAsync(z, ctx->fill[0].p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(&left, ctx->fill[3].p, sizeof(left), hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (remaining) *remaining = (long long)left;
     return SC_OK;
 }
 

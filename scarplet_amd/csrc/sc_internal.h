@@ -109,6 +109,7 @@ struct sc_ctx {
     int rank = 0, nranks = 1;
     DevBuf halo_z, halo_stage;
     DevBuf res;                // sc_get_result: four float64 planes + the id tables
+    DevBuf fill[4];            // sc_fill_nodata: z, result, up / down tables (+ the counter)
 };
 
 int sc_fail(sc_ctx* ctx, int code, const char* fmt, ...);
@@ -137,7 +138,9 @@ int launch_curv_planes(sc_ctx* ctx);
 int launch_curv_alpha(sc_ctx* ctx, float cc, float sc2, float ss, int plane = 0);
 int launch_windows(sc_ctx* ctx, int first, int n, int wh_max, int ww_max);
 int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps);
-bool direct_window_fits(int ww);     // template window width the real-space kernel can stage in LDS
+bool direct_window_fits(int ww);
+int launch_fill_nodata(sc_ctx* ctx, double* zdev, double* tmp, int* up, int* dn, int ny, int nx,
+                       double maxd, int smoothing, unsigned long long* remaining_dev);     // template window width the real-space kernel can stage in LDS
 int launch_compare_fold(sc_ctx* ctx, double age, double angle, bool planes);
 
 // ---- launchers implemented in sc_fft.hip ------------------------------------

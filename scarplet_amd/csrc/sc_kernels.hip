@@ -297,6 +297,126 @@ k_compare_fold(double* __restrict__ b_amp, double* __restrict__ b_age,
 }
 
 // ---------------------------------------------------------------------------
+// Nodata fill (DEMGrid._fill_nodata, dem.py:388-414 -> rasterio.fill.fillnodata ->
+// GDALFillNodata): four-quadrant inverse-distance interpolation from the nearest valid
+// cell of every column within the search distance, as restated in
+// the oracle's fill_nodata_pass (parity unpinned: GDAL is not in the image).
+// float64 throughout, the oracle's operation order.
+//   k_fill_scan : per column, the nearest valid row at or above / at or below every row
+//   k_fill_idw  : per nodata cell, the search over columns x +- step and the weighted mean
+//   k_fill_smooth: optional 3x3 means over filled cells
+// ---------------------------------------------------------------------------
+#define SC_FILL_NONE_UP (-(1 << 30))
+#define SC_FILL_NONE_DN (1 << 30)
+
+__global__ void __launch_bounds__(256)
+k_fill_scan(const double* __restrict__ z, int ny, int nx, int* __restrict__ up, int* __restrict__ dn) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nx) return;
+    int last = SC_FILL_NONE_UP;
+    for (int y = 0; y < ny; ++y) {
+        const double v = z[(size_t)y * nx + x];
+        if (v == v) last = y;
+        up[(size_t)y * nx + x] = last;
+    }
+    last = SC_FILL_NONE_DN;
+    for (int y = ny - 1; y >= 0; --y) {
+        const double v = z[(size_t)y * nx + x];
+        if (v == v) last = y;
+        dn[(size_t)y * nx + x] = last;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_fill_idw(const double* __restrict__ z, int ny, int nx, const int* __restrict__ up,
+           const int* __restrict__ dn, double maxd, int R, double* __restrict__ out,
+           unsigned long long* __restrict__ remaining) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= nx) return;
+    const size_t o = (size_t)y * nx + x;
+    const double v0 = z[o];
+    if (v0 == v0) { out[o] = v0; return; }
+    double qd[4] = {1e300, 1e300, 1e300, 1e300}, qv[4] = {0, 0, 0, 0};     // TL, TR, BL, BR
+    for (int step = 0; step <= R; ++step) {
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int xx = side ? x + step : x - step;
+            if (xx < 0 || xx >= nx) continue;
+#pragma unroll
+            for (int vert = 0; vert < 2; ++vert) {
+                const int yy = vert ? dn[(size_t)y * nx + xx] : up[(size_t)y * nx + xx];
+                if (yy < 0 || yy >= ny) continue;
+                const double ddx = (double)(xx - x), ddy = (double)(yy - y);
+                const double d = __dsqrt_rn(__dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddy, ddy)));
+                const int q = 2 * vert + side;
+                if (d < qd[q]) { qd[q] = d; qv[q] = z[(size_t)yy * nx + xx]; }
+            }
+        }
+    }
+    double ws = 0.0, vs = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (qd[q] <= maxd) {
+            ws = __dadd_rn(ws, __ddiv_rn(1.0, qd[q]));
+            vs = __dadd_rn(vs, __ddiv_rn(qv[q], qd[q]));
+        }
+    if (ws > 0.0) {
+        out[o] = __ddiv_rn(vs, ws);
+    } else {
+        out[o] = v0;                                  // stays nodata
+        atomicAdd(remaining, 1ull);
+    }
+}
+
+// mean of the non-nodata cells of the 3x3 neighbourhood, filled cells only (row-major sum
+// like numpy's nanmean over the window)
+__global__ void __launch_bounds__(256)
+k_fill_smooth(const double* __restrict__ src, const double* __restrict__ orig, int ny, int nx,
+              double* __restrict__ dst) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= nx) return;
+    const size_t o = (size_t)y * nx + x;
+    const double v = src[o], z0 = orig[o];
+    if (z0 == z0 || v != v) { dst[o] = v; return; }   // an original cell, or still nodata
+    double sum = 0.0;
+    int cnt = 0;
+    for (int j = max(y - 1, 0); j <= min(y + 1, ny - 1); ++j)
+        for (int i = max(x - 1, 0); i <= min(x + 1, nx - 1); ++i) {
+            const double w = src[(size_t)j * nx + i];
+            if (w == w) { sum = __dadd_rn(sum, w); ++cnt; }
+        }
+    dst[o] = __ddiv_rn(sum, (double)cnt);
+}
+
+int launch_fill_nodata(sc_ctx* ctx, double* zdev, double* tmp, int* up, int* dn, int ny, int nx,
+                       double maxd, int smoothing, unsigned long long* remaining_dev) {
+    SC_HIP(ctx, hipMemsetAsync(remaining_dev, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k_fill_scan, dim3((nx + 255) / 256), dim3(256), 0, ctx->stream,
+                       (const double*)zdev, ny, nx, up, dn);
+    int R = (int)floor(maxd);
+    if (R < 0) R = 0;
+    if (R > nx) R = nx;
+    dim3 grid((nx + 255) / 256, ny);
+    hipLaunchKernelGGL(k_fill_idw, grid, dim3(256), 0, ctx->stream, (const double*)zdev, ny, nx,
+                       (const int*)up, (const int*)dn, maxd, R, tmp, remaining_dev);
+    // result in tmp; smoothing ping-pongs tmp <-> a second buffer carved from `up`/`dn`? no: the
+    // original z (zdev) is still needed as the "filled cells only" mask, so smooth into zdev last
+    double* cur = tmp;
+    if (smoothing > 0) {
+        // needs a third plane: reuse the up/dn storage (2 x int32 per cell = one float64 plane)
+        double* alt = reinterpret_cast<double*>(up);
+        for (int k = 0; k < smoothing; ++k) {
+            hipLaunchKernelGGL(k_fill_smooth, grid, dim3(256), 0, ctx->stream, (const double*)cur,
+                               (const double*)zdev, ny, nx, alt);
+            std::swap(cur, alt);
+        }
+    }
+    SC_HIP(ctx, hipMemcpyAsync(zdev, cur, sizeof(double) * (size_t)ny * nx, hipMemcpyDeviceToDevice, ctx->stream));
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 int launch_compare_fold(sc_ctx* ctx, double age, double angle, bool planes) {

@@ -120,29 +120,27 @@ class DEMGrid(object):
         proj = gi.projection if isinstance(gi.projection, dict) else None
         tiff.write_geotiff(filename, res, gi.geo_transform, geokeys=proj)
 
-    def _fill_nodata(self):
-        """Fill NaN cells so the matcher's NaN-free precondition holds
-        (dem.py:388-414 wraps GDAL's FillNodata; here: iterative mean of the
-        valid 8-neighbours, which reproduces its behaviour for the isolated
-        gaps of the sample datasets but is NOT GDAL's inverse-distance
-        search)."""
-        z = self._griddata
+    def _fill_nodata(self, device=0, max_passes=64):
+        """Fill nodata (NaN) cells by interpolation so that the matcher's NaN-free
+        precondition holds (dem.py:388-414).  Like the reference: repeat
+        fillnodata with max_search_distance = max(most nodata cells in a row, in
+        a column) / 2 until nothing is left.  One pass is ``sc_fill_nodata`` on
+        the GPU (four-quadrant inverse-distance fill; include/scarplet_hip.h).
+        GDAL / rasterio are not available to pin the pass against: it follows
+        GDAL's published algorithm, parity unpinned (oracle fill_nodata_pass).
+        A DEM without nodata cells does not touch the device."""
+        z = np.ascontiguousarray(self._griddata, dtype=np.float64)
         mask = np.isnan(z)
         self.nodata_mask = mask.copy()
-        while mask.any():
-            zp = np.pad(np.where(mask, 0.0, z), 1)
-            vp = np.pad((~mask).astype(float), 1)
-            acc = np.zeros_like(z)
-            cnt = np.zeros_like(z)
-            for di in (0, 1, 2):
-                for dj in (0, 1, 2):
-                    if di == 1 and dj == 1:
-                        continue
-                    acc += zp[di:di + z.shape[0], dj:dj + z.shape[1]]
-                    cnt += vp[di:di + z.shape[0], dj:dj + z.shape[1]]
-            fill = mask & (cnt > 0)
-            if not fill.any():
-                break
-            z[fill] = acc[fill] / cnt[fill]
-            mask = np.isnan(z)
+        if mask.any():
+            from scarplet_amd.core import _context
+            ctx = _context(device)
+            for _ in range(max_passes):
+                dist = max(np.sum(mask, axis=1).max(), np.sum(mask, axis=0).max()) / 2
+                before = int(mask.sum())
+                left = ctx.fill_nodata(z, dist)
+                if left == 0 or left == before:   # done, or no source within reach of the rest
+                    break
+                mask = np.isnan(z)
+        self._griddata = z
         self.is_interpolated = True

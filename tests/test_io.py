@@ -32,14 +32,50 @@ def test_demgrid_load_matches_reference_contract():
     assert h._georef_info.dx == 2.0 and h._georef_info.dy == 2.0 and h.shape == (5, 7)
 
 
-def test_fill_nodata_leaves_no_nan():
+def test_fill_nodata_oracle_on_a_plane():
+    """The restated GDALFillNodata pass (parity unpinned, see its docstring): a planar
+    surface stays planar where sources surround the hole, and nothing is left NaN."""
+    import scarplet_oracle as orc
     z = np.add.outer(np.arange(20.), np.arange(30.))
+    truth = z.copy()
     z[4:7, 10:13] = np.nan
     z[0, 0] = np.nan
+    z[12, 5:9] = np.nan
+    f = orc.fill_nodata(z)
+    assert not np.isnan(f).any()
+    assert abs(f[5, 11] - truth[5, 11]) < 1e-9                           # symmetric sources: exact on a plane
+    assert np.abs(f[4:7, 10:13] - truth[4:7, 10:13]).max() <= 1.0        # inverse distance is not linear-exact
+    assert abs(f[0, 0] - truth[0, 0]) <= 1.0 and np.allclose(f[12, 5:9], truth[12, 5:9], atol=0.5)
+    assert np.array_equal(f[~np.isnan(z)], truth[~np.isnan(z)])          # valid cells untouched
+    # a cell with no source within reach stays nodata in ONE pass
+    one = orc.fill_nodata_pass(z, 0.0)
+    assert np.isnan(one[5, 11])
+
+
+@pytest.mark.gpu
+def test_fill_nodata_device_equals_oracle():
+    """sc_fill_nodata against the oracle's pass, bit for bit (float64, same operation order),
+    and DEMGrid._fill_nodata (the reference's repeat-until-filled loop, dem.py:388-414)."""
+    import scarplet_oracle as orc
+    from scarplet_amd import _lib
+    rng = np.random.default_rng(12)
+    z = np.cumsum(rng.standard_normal((90, 110)), 1) + 50.0
+    z[rng.random(z.shape) < 0.03] = np.nan          # speckle
+    z[20:33, 40:47] = np.nan                         # a hole
+    z[:, 100] = np.nan                               # a dead column
+    z[0:3, 0:4] = np.nan                             # a corner
+    ctx = _lib.Context(0)
+    for dist, smooth in ((1.0, 0), (2.5, 0), (7.0, 0), (7.0, 2)):
+        mine = z.copy()
+        left = ctx.fill_nodata(mine, dist, smooth)
+        ref = orc.fill_nodata_pass(z, dist, smooth)
+        assert np.array_equal(mine, ref, equal_nan=True), (dist, smooth, int(np.sum(mine != ref)))
+        assert left == int(np.isnan(ref).sum())
     g = sl.DEMGrid.from_array(z, 1.0)
     g._fill_nodata()
-    assert not np.isnan(g._griddata).any() and g.is_interpolated
-    assert abs(g._griddata[5, 11] - 16.0) < 1.0          # planar surface: the fill stays on it
+    assert g.is_interpolated and not np.isnan(g._griddata).any()
+    assert np.array_equal(g._griddata, orc.fill_nodata(z))
+    assert np.array_equal(g.nodata_mask, np.isnan(z))
 
 
 def test_save_round_trip_keeps_grid_georeferencing_and_nodata(tmp_path):
