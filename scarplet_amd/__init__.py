@@ -14,3 +14,4 @@ from scarplet_amd.WindowedTemplate import (Scarp, Ricker, Channel,  # noqa: F401
                                            RightFacingUpperBreakScarp,
                                            LeftFacingUpperBreakScarp)
 from scarplet_amd.dem import DEMGrid  # noqa: F401
+from scarplet_amd.plotting import plot_results, Hillshade, hillshade  # noqa: F401

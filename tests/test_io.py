@@ -141,3 +141,19 @@ def test_predictor2_on_float_samples_is_integer_differencing(tmp_path):
     raw = open(out, "rb").read()[8:8 + 12]
     u = a.view("<u4")[0]
     assert np.array_equal(np.frombuffer(raw, "<u4"), np.array([u[0], u[1] - u[0], u[2] - u[1]], dtype="<u4"))
+
+
+def test_plot_results_and_hillshade():
+    """Row f4: the reference's result plot (core.py:380-420) and hillshade (dem.py:433-460)."""
+    import matplotlib
+    matplotlib.use("Agg")
+    g = sl.DEMGrid(golden("grandcanyon_crop.tif"))
+    hs = sl.hillshade(g)
+    assert hs.shape == g._griddata.shape and 0.0 <= hs.min() and hs.max() <= 1.0
+    ls = matplotlib.colors.LightSource(azdeg=315, altdeg=45)
+    assert np.array_equal(hs, ls.hillshade(g._griddata, vert_exag=1, dx=g._georef_info.dx, dy=g._georef_info.dy))
+    res = np.random.default_rng(0).random((4,) + g._griddata.shape)
+    fig = sl.plot_results(g, res, figsize=(3, 6))
+    assert len(fig.axes) == 8                       # four maps + four colour bars
+    sl.Hillshade(g).plot()
+    matplotlib.pyplot.close("all")
