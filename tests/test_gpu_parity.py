@@ -215,6 +215,43 @@ def test_synthetic_full_grid_golden(gpu_ctx):
     assert ok_same.mean() >= EXACT_MIN, float(ok_same.mean())
 
 
+def test_noise_free_surfaces_resolution_floor(gpu_ctx):
+    """The float32 resolution floor of the FFT epilogue (sc_epi_floor, kappa = 4) was calibrated on
+    the reference's synthetic.tif alone.  Three more exactly-flat-away-from-the-feature surfaces,
+    where T3 - T1 of distant templates sinks below the float32 noise of the transforms: a scarp at
+    de = 2 / scale = 20, a channel (Ricker templates), and a scarp crossing a tiled DEM."""
+    from scipy.special import erf
+    cases = []
+    y, x = np.mgrid[-100:100, -100:100].astype(float) * 2.0
+    th = 0.6
+    cases.append((-erf((-x * np.sin(th) + y * np.cos(th)) / (2 * np.sqrt(25.0))), 2.0, 2.0, WT.Scarp, orc.SCARP,
+                  20, [5.0, 25.0, 100.0], _plan.angle_grid()[::15]))
+    y, x = np.mgrid[-128:128, -128:128].astype(float)
+    th = -0.4
+    d = -x * np.sin(th) + y * np.cos(th)
+    cases.append((-np.exp(-(d / 6.0) ** 2), 1.0, -1.0, WT.Channel, orc.RICKER, 10, [0.05, 0.1],
+                  _plan.angle_grid()[::12]))
+    y, x = np.mgrid[-300:300, -330:330].astype(float)
+    cases.append((-erf((-x * np.sin(1.1) + y * np.cos(1.1)) / (2 * np.sqrt(10.0))) + 0.01 * x, 1.0, 1.0,
+                  WT.Scarp, orc.SCARP, 40, [3.0, 10.0, 30.0], _plan.angle_grid()[5::30]))
+    for (z, dx, dy, cls, kind, scale, params, angles) in cases:
+        z = z.astype(np.float32)
+        m = sl.Matcher(grid(z, dx, dy), ctx=gpu_ctx)
+        arr, bbox, area = m.describe(cls, scale, np.asarray(params, float), np.asarray(angles, float))
+        tmax = 256 if z.shape[0] >= 600 else _plan.T_MAX          # the last case in several tiles
+        p = _plan.Plan(m.ny, m.nx, m.core, bbox, whole=True, method=_plan.METHOD_FFT, t_max=tmax)
+        sp = sl._lib.sc_plan(method=1, Ty=p.Ty, Tx=p.Tx, Vy=p.Vy, Vx=p.Vx, nty=p.nty, ntx=p.ntx,
+                             circ_y=int(p.circ_y), circ_x=int(p.circ_x), Py=p.Py, Qx=p.Qx, group=len(params))
+        m.ctx.reset_best()
+        m.ctx.match(arr, sp)
+        res = m.ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
+        chk = fold_check(res, z, dx, dy, kind, scale, params, angles)
+        report("noise-free %s %dx%d de=%g scale=%g tiles %dx%d" % (kind, z.shape[0], z.shape[1], dx, scale,
+                                                                  p.nty, p.ntx), chk)
+        assert chk["n_bad"] == 0, (kind, chk["n_bad"])
+        assert chk["exact_frac"] >= EXACT_MIN, (kind, chk["exact_frac"])
+
+
 # ------------------------------------------------------------------ plugin API
 def test_generic_plugin_goes_through_the_window_path(gpu_ctx):
     """A user subclass with its own template() (docs/source/new_template.rst
