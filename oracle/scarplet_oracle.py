@@ -333,8 +333,13 @@ def fill_nodata_pass(z, max_search_distance, smoothing_iterations=0):
     for _ in range(int(smoothing_iterations)):
         src = out.copy()
         for (y, x) in np.argwhere(filled):
-            win = src[max(y - 1, 0):y + 2, max(x - 1, 0):x + 2]
-            out[y, x] = np.nanmean(win)
+            tot, cnt = 0.0, 0
+            for j in range(max(y - 1, 0), min(y + 1, ny - 1) + 1):       # row-major running sum
+                for i in range(max(x - 1, 0), min(x + 1, nx - 1) + 1):
+                    if not np.isnan(src[j, i]):
+                        tot += src[j, i]
+                        cnt += 1
+            out[y, x] = tot / cnt
     return out
 
 
@@ -528,8 +533,49 @@ def synthetic_dem(n, seed=20260101, kt0=10.0, b=0.01, sigma=0.05,
     return z.astype(dtype)
 
 
+def resolution_floor(z, dx, dy, kind, scale, ages, angles, kappa=16.0, workers=1):
+    """(amp, snr, resolved) stacks, (n_ages, n_angles, ny, nx): snr_stack() plus
+    the float32 resolvability of every (template, cell).
+
+    A float32 FFT convolution over a tile returns every output with an ABSOLUTE
+    error of about eps32 * |kernel|_1 * |data|_2 / sqrt(N): relative to the
+    energy of the whole tile, not to the cell.  The SNR's denominator is the
+    residual T3 - T1 = sum_M curv^2 - xcorr^2 / sum(W^2); where a strong feature
+    shares the tile with ground whose curvature is orders of magnitude smaller
+    (synthetic surfaces stored as float32: quantisation noise only), that
+    residual is below the error of its two terms and float32 cannot produce the
+    float64 value.  The device clamps the residual from below at
+        d3 + 2 |xcorr| dx / ts + dx^2 / ts,
+        d3 = k eps32 n rms(curv^2),  dx = k eps32 |W|_1 rms(curv)
+    with k = 4 and the rms taken over the tile pair (sc_internal.h
+    sc_epi_floor).  Here the same expression is evaluated in float64 with the
+    rms over the whole DEM and ``kappa`` = 16 (four times the device's k: tiles
+    differ from the DEM, and a residual just above the clamp is still noisy);
+    resolved = residual >= that floor.  On DEMs with a noise floor of their own
+    (lidar, the benchmark DEM) every cell is resolved."""
+    z = np.asarray(z, dtype=float)
+    ny, nx = z.shape
+    amp = np.empty((len(ages), len(angles), ny, nx))
+    snr = np.empty_like(amp)
+    res = np.empty(amp.shape, dtype=bool)
+    e = kappa * 5.9604644775390625e-08
+    for ib, ang in enumerate(angles):
+        curv = directional_curvature(z, dx, dy, ang)
+        rms2, rms4 = np.sqrt(np.mean(curv ** 2)), np.sqrt(np.mean(curv ** 4))
+        for ia, age in enumerate(ages):
+            W, lim, err = template_arrays(kind, scale, age, ang, nx, ny, dx)
+            a, s, det = match_arrays(curv, W, lim, err, workers=workers, details=True)
+            ts, n = det["template_sum"], det["n"]
+            d3 = e * n * rms4
+            dxx = e * np.sum(np.abs(W)) * rms2
+            floor = d3 + 2 * np.abs(det["xcorr"]) * dxx / ts + dxx * dxx / ts
+            resid = det["T3"] - det["xcorr"] ** 2 / ts
+            amp[ia, ib], snr[ia, ib], res[ia, ib] = a, s, resid >= floor
+    return amp, snr, res
+
+
 def check_fold(res, amp_stack, snr_stack, ages, angles, tie_rtol=1e-6,
-               amp_tol=(1e-5, 1e-9), snr_tol=(1e-5, 1e-9)):
+               amp_tol=(1e-5, 1e-9), snr_tol=(1e-5, 1e-9), resolved=None):
     """Near-tie aware check of a folded result against per-template stacks.
 
     The reference's fold (core.py:230-240) is an argmax by SNR whose outcome
@@ -546,6 +592,22 @@ def check_fold(res, amp_stack, snr_stack, ages, angles, tie_rtol=1e-6,
           (masked) or at least two templates are within ``tie_rtol`` of the
           maximum (an exact tie is possible).
 
+    Two more rules keep the check to what float32 can decide:
+
+      (c) a cell whose oracle maximum is below the absolute SNR tolerance
+          ``snr_tol[1]`` (flat ground: the float64 "SNR" there is FFT rounding
+          noise over eps, ~1e-18) is accepted when the result's SNR is below
+          that tolerance too, whatever record it carries;
+      (d) ``resolved`` (optional, (T, ny, nx) bool; resolution_floor()) marks
+          the (template, cell) pairs whose residual T3 - T1 lies above the
+          float32 resolution of an FFT convolution over the tile.  Below it the
+          device clamps the residual from below (sc_epi_floor), i.e. reports an
+          SNR that is too SMALL.  A cell is decidable when its best resolved
+          template beats every unresolved one by more than the tie window; the
+          rules above then apply among the resolved templates.  Elsewhere the
+          result only has to stay at or below the oracle's maximum (within
+          tolerance).  ``n_undecided`` counts those cells.
+
     ``amp_stack``/``snr_stack``: (T, ny, nx) in any order; ``ages``/``angles``:
     length-T parameter values.  Returns a dict with the boolean ``ok`` map and
     counts: ``n_strict`` pixels have no second candidate inside the tie window
@@ -554,8 +616,18 @@ def check_fold(res, amp_stack, snr_stack, ages, angles, tie_rtol=1e-6,
     are the largest relative deviations measured on those.
     """
     amp, age, ang, snr = [np.asarray(a, dtype=float) for a in res]
-    snr_stack = np.asarray(snr_stack)
-    T = snr_stack.shape[0]
+    snr_full = np.asarray(snr_stack)
+    T = snr_full.shape[0]
+    smax_all = np.max(snr_full, axis=0)
+    undecided = np.zeros(smax_all.shape, dtype=bool)
+    if resolved is not None:
+        resolved = np.asarray(resolved, dtype=bool)
+        s_res = np.max(np.where(resolved, snr_full, 0.0), axis=0)
+        s_unres = np.max(np.where(resolved, 0.0, snr_full), axis=0)
+        undecided = s_res <= s_unres * (1.0 + tie_rtol)
+        snr_stack = np.where(resolved, snr_full, 0.0)        # candidates: resolved templates only
+    else:
+        snr_stack = snr_full
     smax = np.max(snr_stack, axis=0)
     thr = smax * (1.0 - tie_rtol)
     ncand = np.sum(snr_stack >= thr, axis=0)
@@ -572,6 +644,10 @@ def check_fold(res, amp_stack, snr_stack, ages, angles, tie_rtol=1e-6,
     zero = (amp == 0) & (age == 0) & (ang == 0) & (snr == 0)
     ok |= zero & ((smax == 0) | (ncand >= 2))
     strict |= zero & (smax == 0)
+    # (c) below the absolute tolerance on both sides; (d) undecidable cells: never above the oracle
+    below = (smax_all <= snr_tol[1]) & (np.abs(snr) <= snr_tol[1])
+    capped = undecided & (snr <= smax_all * (1.0 + snr_tol[0]) + snr_tol[1])
+    ok |= below | capped
     # cells whose (age, angle) is the oracle's own argmax - "bit-exact index" in
     # the plain sense.  Templates whose float64 SNRs agree to 1e-9 are one
     # maximum: Scarp at -pi/2 and +pi/2 is the same template up to the sign of W
@@ -579,7 +655,7 @@ def check_fold(res, amp_stack, snr_stack, ages, angles, tie_rtol=1e-6,
     # (~1e-13) and which of the two the reference itself returns depends on its
     # FFT library.  All-zero records count where every template is masked.
     co_thr = smax * (1.0 - 1e-9)
-    exact = zero & (smax == 0)
+    exact = (zero & (smax == 0)) | below | capped
     s_at = np.zeros(smax.shape)
     a_at = np.zeros(smax.shape)
     for t in range(T):
@@ -590,11 +666,12 @@ def check_fold(res, amp_stack, snr_stack, ages, angles, tie_rtol=1e-6,
     # largest SNR / amp deviation on those cells, relative to the cell's value
     # (cells below a thousandth of the map's maximum: to that floor): the measured
     # error the tie window has to cover (twice: two candidates, each off by it)
-    sel = exact & (smax > 0)
+    sel = exact & (smax > 0) & ~below & ~capped
     s_floor, a_floor = 1e-3 * float(np.max(smax)), 1e-3 * float(np.max(np.abs(amp_stack)))
     snr_err = float(np.max(np.abs(snr[sel] - s_at[sel]) / np.maximum(s_at[sel], s_floor))) if sel.any() else 0.0
     amp_err = float(np.max(np.abs(amp[sel] - a_at[sel]) / np.maximum(np.abs(a_at[sel]), a_floor))) if sel.any() else 0.0
     return dict(ok=ok, n_bad=int(np.sum(~ok)), n_strict=int(np.sum(strict)),
                 n_tie=int(np.sum(ok & ~strict)), n=int(ok.size),
                 n_exact=int(np.sum(exact)), exact_frac=float(np.mean(exact)),
+                n_undecided=int(np.sum(undecided & ~below)), n_below=int(np.sum(below)),
                 snr_err=snr_err, amp_err=amp_err)

@@ -216,40 +216,56 @@ def test_synthetic_full_grid_golden(gpu_ctx):
 
 
 def test_noise_free_surfaces_resolution_floor(gpu_ctx):
-    """The float32 resolution floor of the FFT epilogue (sc_epi_floor, kappa = 4) was calibrated on
-    the reference's synthetic.tif alone.  Three more exactly-flat-away-from-the-feature surfaces,
-    where T3 - T1 of distant templates sinks below the float32 noise of the transforms: a scarp at
-    de = 2 / scale = 20, a channel (Ricker templates), and a scarp crossing a tiled DEM."""
+    """Float32 resolution of the FFT path, stated and tested.  On surfaces without a noise floor
+    (synthetic erf scarps stored as float32, a ramp added: the ground away from the feature
+    carries quantisation noise only) a float32 FFT convolution cannot resolve residuals T3 - T1
+    that lie 1e-7 below the tile's energy; the device clamps them (sc_epi_floor) and reports an
+    SNR that is too small there.  oracle.resolution_floor() marks those (template, cell) pairs;
+    check_fold then requires the exact argmax and the stated tolerances wherever the winner is
+    resolved, and "never above the oracle" elsewhere.  The real-space path has no such limit: it
+    must match everywhere.  (The floor constant kappa = 4 was calibrated on the reference's
+    synthetic.tif; these are three further surfaces: de = 2 / scale = 20, a channel under Ricker
+    templates, and a scarp on a ramp crossing several tiles.)"""
     from scipy.special import erf
     cases = []
     y, x = np.mgrid[-100:100, -100:100].astype(float) * 2.0
-    th = 0.6
-    cases.append((-erf((-x * np.sin(th) + y * np.cos(th)) / (2 * np.sqrt(25.0))), 2.0, 2.0, WT.Scarp, orc.SCARP,
-                  20, [5.0, 25.0, 100.0], _plan.angle_grid()[::15]))
+    cases.append((-erf((-x * np.sin(0.6) + y * np.cos(0.6)) / (2 * np.sqrt(25.0))), 2.0, 2.0, WT.Scarp, orc.SCARP,
+                  20, [5.0, 25.0, 100.0], _plan.angle_grid()[::15], _plan.T_MAX))
     y, x = np.mgrid[-128:128, -128:128].astype(float)
-    th = -0.4
-    d = -x * np.sin(th) + y * np.cos(th)
+    d = -x * np.sin(-0.4) + y * np.cos(-0.4)
     cases.append((-np.exp(-(d / 6.0) ** 2), 1.0, -1.0, WT.Channel, orc.RICKER, 10, [0.05, 0.1],
-                  _plan.angle_grid()[::12]))
+                  _plan.angle_grid()[::12], _plan.T_MAX))
     y, x = np.mgrid[-300:300, -330:330].astype(float)
     cases.append((-erf((-x * np.sin(1.1) + y * np.cos(1.1)) / (2 * np.sqrt(10.0))) + 0.01 * x, 1.0, 1.0,
-                  WT.Scarp, orc.SCARP, 40, [3.0, 10.0, 30.0], _plan.angle_grid()[5::30]))
-    for (z, dx, dy, cls, kind, scale, params, angles) in cases:
+                  WT.Scarp, orc.SCARP, 40, [3.0, 10.0, 30.0], _plan.angle_grid()[5::30], 256))
+    for (z, dx, dy, cls, kind, scale, params, angles, tmax) in cases:
         z = z.astype(np.float32)
+        ny, nx = z.shape
+        T = len(params) * len(angles)
+        A, S, R = orc.resolution_floor(z, dx, dy, kind, scale, params, angles, workers=4)
+        A, S, R = A.reshape(T, ny, nx), S.reshape(T, ny, nx), R.reshape(T, ny, nx)
+        ages_t, angs_t = np.repeat(params, len(angles)), np.tile(angles, len(params))
+        tol = dict(tie_rtol=TIE_RTOL, amp_tol=(AMP_RTOL, AMP_ATOL * np.abs(A).max()),
+                   snr_tol=(SNR_RTOL, SNR_ATOL * S.max()))
         m = sl.Matcher(grid(z, dx, dy), ctx=gpu_ctx)
         arr, bbox, area = m.describe(cls, scale, np.asarray(params, float), np.asarray(angles, float))
-        tmax = 256 if z.shape[0] >= 600 else _plan.T_MAX          # the last case in several tiles
         p = _plan.Plan(m.ny, m.nx, m.core, bbox, whole=True, method=_plan.METHOD_FFT, t_max=tmax)
         sp = sl._lib.sc_plan(method=1, Ty=p.Ty, Tx=p.Tx, Vy=p.Vy, Vx=p.Vx, nty=p.nty, ntx=p.ntx,
                              circ_y=int(p.circ_y), circ_x=int(p.circ_x), Py=p.Py, Qx=p.Qx, group=len(params))
         m.ctx.reset_best()
         m.ctx.match(arr, sp)
-        res = m.ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
-        chk = fold_check(res, z, dx, dy, kind, scale, params, angles)
-        report("noise-free %s %dx%d de=%g scale=%g tiles %dx%d" % (kind, z.shape[0], z.shape[1], dx, scale,
-                                                                  p.nty, p.ntx), chk)
-        assert chk["n_bad"] == 0, (kind, chk["n_bad"])
-        assert chk["exact_frac"] >= EXACT_MIN, (kind, chk["exact_frac"])
+        res = m.ctx.get_result(ages_t, angs_t)
+        chk = orc.check_fold(res, A, S, ages_t, angs_t, resolved=R, **tol)
+        name = "noise-free %s %dx%d de=%g tiles %dx%d" % (kind, ny, nx, dx, p.nty, p.ntx)
+        report(name + " fft", chk)
+        print("     float32-resolved (template, cell) pairs %.3f; cells: %d undecidable, %d below the absolute tolerance"
+              % (R.mean(), chk["n_undecided"], chk["n_below"]))
+        assert chk["n_bad"] == 0, (kind, "fft", chk["n_bad"])
+        # the real-space path sums locally: no resolution limit, plain check
+        res_d = m.search(cls, scale, params, angles, method="direct").result()
+        chk_d = orc.check_fold(res_d, A, S, ages_t, angs_t, **tol)
+        report(name + " direct", chk_d)
+        assert chk_d["n_bad"] == 0 and chk_d["exact_frac"] >= EXACT_MIN, (kind, "direct", chk_d["n_bad"])
 
 
 # ------------------------------------------------------------------ plugin API
