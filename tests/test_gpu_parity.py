@@ -220,10 +220,10 @@ def test_noise_free_surfaces_resolution_floor(gpu_ctx):
     (synthetic erf scarps stored as float32, a ramp added: the ground away from the feature
     carries quantisation noise only) a float32 FFT convolution cannot resolve residuals T3 - T1
     that lie 1e-7 below the tile's energy; the device clamps them (sc_epi_floor) and reports an
-    SNR that is too small there.  oracle.resolution_floor() marks those (template, cell) pairs;
-    check_fold then requires the exact argmax and the stated tolerances wherever the winner is
-    resolved, and "never above the oracle" elsewhere.  The real-space path has no such limit: it
-    must match everywhere.  (The floor constant kappa = 4 was calibrated on the reference's
+    SNR that is off by about (float32 resolution of the residual) / (residual).
+    oracle.resolution_floor() evaluates that ratio per (template, cell) as an extra relative
+    tolerance ("slack", 16 f / r); check_fold applies it to the values and to the tie window.
+    The real-space path has no such limit: it must match everywhere with the plain tolerances.  (The floor constant kappa = 4 was calibrated on the reference's
     synthetic.tif; these are three further surfaces: de = 2 / scale = 20, a channel under Ricker
     templates, and a scarp on a ramp crossing several tiles.)"""
     from scipy.special import erf
@@ -242,8 +242,8 @@ def test_noise_free_surfaces_resolution_floor(gpu_ctx):
         z = z.astype(np.float32)
         ny, nx = z.shape
         T = len(params) * len(angles)
-        A, S, R = orc.resolution_floor(z, dx, dy, kind, scale, params, angles, workers=4)
-        A, S, R = A.reshape(T, ny, nx), S.reshape(T, ny, nx), R.reshape(T, ny, nx)
+        A, S, K = orc.resolution_floor(z, dx, dy, kind, scale, params, angles, workers=4)
+        A, S, K = A.reshape(T, ny, nx), S.reshape(T, ny, nx), K.reshape(T, ny, nx)
         ages_t, angs_t = np.repeat(params, len(angles)), np.tile(angles, len(params))
         tol = dict(tie_rtol=TIE_RTOL, amp_tol=(AMP_RTOL, AMP_ATOL * np.abs(A).max()),
                    snr_tol=(SNR_RTOL, SNR_ATOL * S.max()))
@@ -255,11 +255,11 @@ def test_noise_free_surfaces_resolution_floor(gpu_ctx):
         m.ctx.reset_best()
         m.ctx.match(arr, sp)
         res = m.ctx.get_result(ages_t, angs_t)
-        chk = orc.check_fold(res, A, S, ages_t, angs_t, resolved=R, **tol)
+        chk = orc.check_fold(res, A, S, ages_t, angs_t, slack=K, **tol)
         name = "noise-free %s %dx%d de=%g tiles %dx%d" % (kind, ny, nx, dx, p.nty, p.ntx)
         report(name + " fft", chk)
-        print("     float32-resolved (template, cell) pairs %.3f; cells: %d undecidable, %d below the absolute tolerance"
-              % (R.mean(), chk["n_undecided"], chk["n_below"]))
+        print("     (template, cell) pairs with slack > 1e-3: %.3f; cells accepted through the slack: %d, below the "
+              "absolute tolerance: %d" % ((K > 1e-3).mean(), chk["n_slack"], chk["n_below"]))
         assert chk["n_bad"] == 0, (kind, "fft", chk["n_bad"])
         # the real-space path sums locally: no resolution limit, plain check
         res_d = m.search(cls, scale, params, angles, method="direct").result()
