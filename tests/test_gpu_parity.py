@@ -222,7 +222,7 @@ def test_noise_free_surfaces_resolution_floor(gpu_ctx):
     that lie 1e-7 below the tile's energy; the device clamps them (sc_epi_floor) and reports an
     SNR that is off by about (float32 resolution of the residual) / (residual).
     oracle.resolution_floor() evaluates that ratio per (template, cell) as an extra relative
-    tolerance ("slack", 16 f / r); check_fold applies it to the values and to the tie window.
+    tolerance ("slack", 32 f / r); check_fold applies it to the values and to the tie window.
     The real-space path has no such limit: it must match everywhere with the plain tolerances.  (The floor constant kappa = 4 was calibrated on the reference's
     synthetic.tif; these are three further surfaces: de = 2 / scale = 20, a channel under Ricker
     templates, and a scarp on a ramp crossing several tiles.)"""
@@ -238,6 +238,7 @@ def test_noise_free_surfaces_resolution_floor(gpu_ctx):
     y, x = np.mgrid[-300:300, -330:330].astype(float)
     cases.append((-erf((-x * np.sin(1.1) + y * np.cos(1.1)) / (2 * np.sqrt(10.0))) + 0.01 * x, 1.0, 1.0,
                   WT.Scarp, orc.SCARP, 40, [3.0, 10.0, 30.0], _plan.angle_grid()[5::30], 256))
+    failures = []
     for (z, dx, dy, cls, kind, scale, params, angles, tmax) in cases:
         z = z.astype(np.float32)
         ny, nx = z.shape
@@ -260,12 +261,15 @@ def test_noise_free_surfaces_resolution_floor(gpu_ctx):
         report(name + " fft", chk)
         print("     (template, cell) pairs with slack > 1e-3: %.3f; cells accepted through the slack: %d, below the "
               "absolute tolerance: %d" % ((K > 1e-3).mean(), chk["n_slack"], chk["n_below"]))
-        assert chk["n_bad"] == 0, (kind, "fft", chk["n_bad"])
+        if chk["n_bad"]:
+            failures.append((name, "fft", chk["n_bad"]))
         # the real-space path sums locally: no resolution limit, plain check
         res_d = m.search(cls, scale, params, angles, method="direct").result()
         chk_d = orc.check_fold(res_d, A, S, ages_t, angs_t, **tol)
         report(name + " direct", chk_d)
-        assert chk_d["n_bad"] == 0 and chk_d["exact_frac"] >= EXACT_MIN, (kind, "direct", chk_d["n_bad"])
+        if chk_d["n_bad"] or chk_d["exact_frac"] < EXACT_MIN:
+            failures.append((name, "direct", chk_d["n_bad"], chk_d["exact_frac"]))
+    assert not failures, failures
 
 
 # ------------------------------------------------------------------ plugin API
