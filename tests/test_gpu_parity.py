@@ -263,6 +263,13 @@ def test_noise_free_surfaces_resolution_floor(gpu_ctx):
               "absolute tolerance: %d" % ((K > 1e-3).mean(), chk["n_slack"], chk["n_below"]))
         if chk["n_bad"]:
             failures.append((name, "fft", chk["n_bad"]))
+            for (i, j) in np.argwhere(~chk["ok"])[:6]:
+                t_dev = np.nonzero((ages_t == res[1][i, j]) & (angs_t == res[2][i, j]))[0]
+                t_max = int(np.argmax(S[:, i, j]))
+                print("     bad cell (%d,%d): device amp %.6g snr %.6g template %s | oracle at it: amp %s snr %s slack %s | "
+                      "oracle max: t=%d snr %.6g slack %.3g amp %.6g" % (
+                          i, j, res[0][i, j], res[3][i, j], t_dev, A[t_dev, i, j], S[t_dev, i, j], K[t_dev, i, j],
+                          t_max, S[t_max, i, j], K[t_max, i, j], A[t_max, i, j]))
         # the real-space path sums locally: no resolution limit, plain check
         res_d = m.search(cls, scale, params, angles, method="direct").result()
         chk_d = orc.check_fold(res_d, A, S, ages_t, angs_t, **tol)
