@@ -570,8 +570,8 @@ def resolution_floor(z, dx, dy, kind, scale, ages, angles, c_slack=32.0, workers
             f = e * n * rms4 + 2 * np.abs(det["xcorr"]) * dxx / ts + dxx * dxx / ts
             r = np.maximum(det["T3"] - det["xcorr"] ** 2 / ts, 0.0)
             with np.errstate(divide="ignore", invalid="ignore"):
-                sl_ = np.where(r > 0, c_slack * f / r, 1.0)
-            amp[ia, ib], snr[ia, ib], slack[ia, ib] = a, s, np.minimum(sl_, 1.0)
+                sl_ = np.where(r > 0, c_slack * f / r, np.inf)
+            amp[ia, ib], snr[ia, ib], slack[ia, ib] = a, s, sl_
     return amp, snr, slack
 
 
@@ -621,8 +621,10 @@ def check_fold(res, amp_stack, snr_stack, ages, angles, tie_rtol=1e-6,
     thr = smax * (1.0 - tie_rtol)
     ncand = np.sum(snr_stack >= thr, axis=0)
     if slack is not None:
-        slack = np.clip(np.asarray(slack, dtype=float), 0.0, 1.0)
-        thr_s = np.max(snr_stack * (1.0 - slack), axis=0) * (1.0 - tie_rtol)
+        slack = np.clip(np.asarray(slack, dtype=float), 0.0, 1e3)      # upper side: as given
+        slack_lo = np.minimum(slack, 1.0)                               # lower side: down to zero at most
+        low_max = np.max(snr_stack * (1.0 - slack_lo), axis=0)          # what the device is bound to reach
+        thr_s = low_max * (1.0 - tie_rtol)
     ok = np.zeros(smax.shape, dtype=bool)
     ok_plain = np.zeros(smax.shape, dtype=bool)
     strict = np.zeros(smax.shape, dtype=bool)
@@ -636,15 +638,17 @@ def check_fold(res, amp_stack, snr_stack, ages, angles, tie_rtol=1e-6,
         strict |= hit & (ncand == 1)
         if slack is not None:
             hit = mine & (s_t * (1.0 + slack[t]) >= thr_s) & amp_ok & \
-                (np.abs(snr - s_t) <= (snr_tol[0] + slack[t]) * np.abs(s_t) + snr_tol[1])
+                (snr <= (1.0 + snr_tol[0] + slack[t]) * s_t + snr_tol[1]) & \
+                (snr >= (1.0 - snr_tol[0] - slack_lo[t]) * s_t - snr_tol[1])
         ok |= hit
     zero = (amp == 0) & (age == 0) & (ang == 0) & (snr == 0)
     zero_ok = zero & ((smax == 0) | (ncand >= 2))
     ok |= zero_ok
     ok_plain |= zero_ok
     strict |= zero & (smax == 0)
-    # (c) below the absolute tolerance on both sides
-    below = (smax <= snr_tol[1]) & (np.abs(snr) <= snr_tol[1])
+    # (c) below the absolute tolerance on both sides (with slack: nothing the device is bound
+    #     to reach lies above it)
+    below = ((smax if slack is None else low_max) <= snr_tol[1]) & (np.abs(snr) <= snr_tol[1])
     ok |= below
     ok_plain |= below
     n_slack = int(np.sum(ok & ~ok_plain))
