@@ -549,8 +549,8 @@ def resolution_floor(z, dx, dy, kind, scale, ages, angles, c_slack=32.0, workers
     curvature is orders of magnitude smaller - synthetic surfaces stored as
     float32, with quantisation noise only - r comes close to f and the device's
     SNR is off by about f / r (measured on three such surfaces with
-    tools/kappa_lab2.py: median 1 f/r, largest ~20 f/r).  slack =
-    c_slack f / r) with c_slack = 32 and the rms taken over the whole DEM (the
+    tools/kappa_lab2.py: median 1 f/r, largest ~20 f/r).  slack = c_slack f / r
+    with c_slack = 32 and the rms taken over the whole DEM (the
     device takes it over the tile pair).  On DEMs with a noise floor of their own
     (lidar, the benchmark DEM) slack is ~1e-6 everywhere."""
     z = np.asarray(z, dtype=float)
