@@ -882,7 +882,8 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
            const float2* __restrict__ wh, const float2* __restrict__ mh, int Tx,
            int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, int dbg,
            const float2* __restrict__ tw, float2* __restrict__ yw,
-           float2* __restrict__ ym, int ystride, int np, int pcj, int tstride) {
+           float2* __restrict__ ym, int ystride, int np, int pcj, int tstride,
+           const TileDev* __restrict__ tiles, int py_valid) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     FftTw<TY> twr;
     twr.load(tw);
@@ -900,6 +901,12 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
     // templates start tstride further on); the job's Y block lies j * ystride planes on
     {
         const int ob = blockIdx.y / pcj, q = blockIdx.y - ob * pcj;
+        // rows beyond the valid extent of both tiles of the pair (the DEM's last tile row) are
+        // never read by the row pass: do not store them (py_valid < 0: circular axis, all rows)
+        if (py_valid >= 0) {
+            const int vy = max(tiles[2 * (pair + q)].vy, tiles[2 * (pair + q) + 1].vy);
+            rp_hi = min(rp_hi, (py_valid + vy - 1) >> 1);
+        }
         pair += ob * np + q;
         vfirst += ob * tstride;
     }
@@ -997,7 +1004,8 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
                int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, int ky, int kx,
                int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
-               float2* __restrict__ ym, int ystride, int dbg, int np, int pcj, int tstride) {
+               float2* __restrict__ ym, int ystride, int dbg, int np, int pcj, int tstride,
+               const TileDev* __restrict__ tiles, int py_valid) {
     // dbg: timing-only ablation bits of an SC_ABLATE build (tools/ablate.sh), folded away otherwise:
     //   1 no coefficient fetch in mirrored launches   2 no coefficient fetch at all   4 no stores
     //   8 no transform   16 stores paired into whole 128-byte lines (a bijection onto the same plane)
@@ -1013,6 +1021,12 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
     // several jobs per launch (grid.y), see k_inv_cols
     {
         const int ob = blockIdx.y / pcj, q = blockIdx.y - ob * pcj;
+        // rows beyond the valid extent of both tiles of the pair (the DEM's last tile row) are
+        // never read by the row pass: do not store them (py_valid < 0: circular axis, all rows)
+        if (py_valid >= 0) {
+            const int vy = max(tiles[2 * (pair + q)].vy, tiles[2 * (pair + q) + 1].vy);
+            rp_hi = min(rp_hi, (py_valid + vy - 1) >> 1);
+        }
         pair += ob * np + q;
         vfirst += ob * tstride;
     }
@@ -1938,12 +1952,12 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
 #define COL_ARGS(CB0)                                                          \
     ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float2*)ctx->wh.p, \
         (const float2*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, ctx->dbg,        \
-        (const float2*)ctx->tw_y.p, ywp, ymp, group, np, pcc, n
+        (const float2*)ctx->tw_y.p, ywp, ymp, group, np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py
 #define SYM_ARGS(CB0)                                                          \
     ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float*)ctx->wh.p, \
         (const float*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, 1 - ctx->g.oy,     \
         1 - ctx->g.ox, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group
-#define SYM_ARGS_D(CB0) SYM_ARGS(CB0), ctx->dbg, np, pcc, n
+#define SYM_ARGS_D(CB0) SYM_ARGS(CB0), ctx->dbg, np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py
 #define FN_SYM(T)                                                              \
     {                                                                          \
         int rc = set_lds(ctx, k_inv_cols_sym<T, false, PTV>, inv_cols_lds<T>());    \
