@@ -174,13 +174,19 @@ def direct_window_fits(ww):
 
 
 def direct_cost(n_taps):
-    """Relative cost per output cell of the real-space path."""
-    return 2.0 * n_taps
+    """Time per output cell and template of the real-space path, picoseconds
+    (tools/crossover.py at 4096^2, profiles/r02_crossover.txt: 1.04 ms at 46
+    taps, 7.75 ms at 466, 46.7 ms at 1474)."""
+    return 60.0 + 1.9 * n_taps
 
 
 def fft_cost(plan, n_cells):
-    """Relative cost per output cell of the FFT path (same units as
-    direct_cost; the constant is calibrated on MI355X)."""
-    return 24.0 * (math.log2(plan.Ty) + math.log2(plan.Tx)) \
-        * math.sqrt(TILE_PENALTY.get(plan.Ty, 1.0) * TILE_PENALTY.get(plan.Tx, 1.0)) \
+    """The same for the FFT path: ~28 ps per PADDED cell for single-template
+    searches (0.60 - 0.78 ms per template at 4096^2 whatever the support; with
+    many ages per orientation it falls to 4.4), times the tile-size penalty of
+    tiles below 512.  Since orientation batching the FFT path wins at every
+    support size measured; the real-space path is for templates no tile holds
+    and for surfaces without a noise floor (it is exact per
+    cell)."""
+    return 28.0 * math.sqrt(TILE_PENALTY.get(plan.Ty, 1.0) * TILE_PENALTY.get(plan.Tx, 1.0)) \
         * plan.padded_cells() / float(n_cells)
