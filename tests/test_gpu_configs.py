@@ -283,3 +283,28 @@ def test_fused_template_split_is_bit_identical():
         ctx.close()
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+
+
+def test_merged_column_pass_is_bit_identical():
+    """k_inv_cols_msym (a column block and its mirror in one workgroup, permuted upper half of the
+    hand-off) against the two-launch column pass (option variant=6): the same Y cell for cell,
+    so the same record - at T = 2048 with several tile pairs and a partial last tile row, at
+    T = 1024 / 512, and with batched orientations on a circular tile."""
+    cases = [(synthetic.synthetic_scarp(3900, ny=3700, seed=31), sl.Scarp, 100, _plan.age_grid()[::7], _plan.angle_grid()[3::45]),
+             (synthetic.synthetic_scarp(1500, ny=1400, seed=32), sl.Scarp, 40, _plan.age_grid()[1::9], _plan.angle_grid()[::30]),
+             (synthetic.synthetic_scarp(700, seed=33), sl.Scarp, 12, [2.0, 9.0], _plan.angle_grid()[::20]),
+             (synthetic.synthetic_scarp(1024, seed=34), sl.Channel, 15, [0.1], _plan.angle_grid()[::4])]
+    for (g, cls, scale, params, angles) in cases:
+        out = []
+        for variant in (0, 6):
+            ctx = sl._lib.Context(0)
+            ctx.set_option("variant", variant)
+            m = sl.Matcher(g, ctx=ctx)
+            m.search(cls, scale, params, angles, method="fft")
+            out.append(m.ctx.get_best())
+            plan = m.plan
+            del m
+            ctx.close()
+        for a, b, name in zip(out[0], out[1], ("amp", "snr", "id")):
+            assert np.array_equal(a, b), (str(plan), name, int((a != b).sum()))
+        assert (out[0][1] > 0).any()
