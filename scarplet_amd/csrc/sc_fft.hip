@@ -347,36 +347,6 @@ struct FftTw {
     }
 };
 
-// The same bases kept in an LDS table (per twiddled stage and set index: 4 bases) and fetched
-// stage by stage: 16 registers less across a template loop, for kernels that park other data
-// in registers (k_inv_cols_msym).  T >= 256, one set per thread and stage.
-template <int T>
-struct FftTwL {
-    static constexpr int S = T / 16;
-    static constexpr int NT = fft_threads(T);
-    static constexpr int LOGT = __builtin_ctz(T);
-    static constexpr int NST = (LOGT + 3) / 4;
-    static constexpr int NTW = NST - 1;
-    static constexpr int CELLS = (NTW > 0 ? NTW : 1) * 4 * S;     // float2 cells of LDS
-    static_assert(4 * S == NT, "one 16-point set per thread and stage");
-    const float2* tab;
-    __device__ __forceinline__ void fill(float2* lds, const float2* __restrict__ tw) {
-        for (int i = threadIdx.x; i < NTW * S; i += NT) {
-            const int k = i / S, tt = i - k * S;
-            const int e = (tt >> (4 * k)) << (4 * k);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) lds[(k * 4 + j) * S + tt] = tw[e << j];
-        }
-        tab = lds;
-    }
-    __device__ __forceinline__ const float2 (&get(int k, int, float2 (&o)[4]) const)[4] {
-        const int tt = threadIdx.x % S;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = tab[(k * 4 + j) * S + tt];
-        return o;
-    }
-};
-
 // ---- one Stockham stage, per 16-point set -------------------------------------
 // For T >= 256 every LDS address of a stage is (one per-thread base) +
 // (compile-time offset): S = T/16 and the strides are multiples of 16, so the
@@ -1203,8 +1173,8 @@ k_inv_cols_msym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
     constexpr int NT = fft_threads(TY);
     constexpr int EP = 4 * TY / (2 * NT);     // 2-cell loads per thread per stream
     float4* xs = reinterpret_cast<float4*>(sm + 4 * fft_line(TY));   // parked spectrum of the own columns
-    FftTwL<TY> twr;                            // twiddle bases in LDS behind the parked spectrum
-    twr.fill(sm + 4 * fft_line(TY) + 4 * TY, tw);
+    FftTw<TY> twr;
+    twr.load(tw);
     const int cb = blockIdx.x;                 // 0 .. Tx/8 - 1
     {
         const int ob = blockIdx.y / pcj, q = blockIdx.y - ob * pcj;
@@ -1278,13 +1248,15 @@ k_inv_cols_msym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                     if (e < TY) hmid[u] = *reinterpret_cast<const float2*>(p + e);
                 }
             }
-            // the two transforms of the template share one copy of the code (half = 0: own
-            // columns, 1: mirrors); tid behind an empty asm keeps the fill and store addresses
-            // from being hoisted out of the loops into registers the transform needs
-#pragma unroll 1
+            // half 0: own columns, 1: mirrors.  Written out twice on purpose: one shared copy of
+            // the transform with the fill / store addresses recomputed per half (and the twiddle
+            // bases in an LDS table to make room) was 13 % SLOWER on the sustained C3 run
+            // (416 vs 367 us per launch-equivalent; profiles/r02_i1_merged.txt).  The register
+            // spills the compiler reports for this kernel sit in the parking prologue, not in
+            // the template loop.
+#pragma unroll
             for (int half = 0; half < 2; ++half) {
-                int tid = threadIdx.x;
-                asm volatile("" : "+v"(tid));
+                const int tid = threadIdx.x;
                 if (half == 0) {
 #pragma unroll
                     for (int u = 0; u < EP; ++u) {
@@ -2187,11 +2159,10 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     }
 #define FN_MSYM(T)                                                             \
     {                                                                          \
-        const size_t ldsm = inv_cols_lds<T>() + FftTwL<T>::CELLS * sizeof(float2);             \
-        int rc = set_lds(ctx, k_inv_cols_msym<T>, ldsm);                       \
+        int rc = set_lds(ctx, k_inv_cols_msym<T>, inv_cols_lds<T>());          \
         if (rc) return rc;                                                     \
         hipLaunchKernelGGL((k_inv_cols_msym<T>), dim3(fg.Tx / 8, nb * pcc), dim3(fft_threads(T)), \
-                           ldsm, ctx->stream, (const float2*)ctx->uc.p,      \
+                           inv_cols_lds<T>(), ctx->stream, (const float2*)ctx->uc.p,      \
                            (const float2*)ctx->uc2.p, (const float*)ctx->wh.p, (const float*)ctx->mh.p, \
                            fg.Tx, pair, g0, G, rp_lo, rp_hi, 1 - ctx->g.oy, 1 - ctx->g.ox, parity, \
                            (const float2*)ctx->tw_y.p, ywp, ymp, group, np, pcc, n,       \
