@@ -2121,7 +2121,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             const int pair = pair0 + pl0;
             float2* ywp = (float2*)ctx->yw.p + (size_t)pl0 * yblock;
             float2* ymp = (float2*)ctx->ym.p + (size_t)pl0 * yblock;
-            n_i1 += 2;
+            n_i1 += (merged && !PTV) ? 1 : 2;   // one merged launch, or own columns + mirrors
 #define COL_ARGS(CB0)                                                          \
     ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float2*)ctx->wh.p, \
         (const float2*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, ctx->dbg,        \
@@ -2193,7 +2193,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
 #undef SYM_ARGS
 #undef COL_ARGS
             }
-            sc_prof_end(ctx, n_i1);                   // direct + mirrored launches
+            sc_prof_end(ctx, n_i1);
             const int pair = pair0;
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
                        ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg, group,
