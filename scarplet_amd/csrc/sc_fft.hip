@@ -1160,7 +1160,7 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
 // it in the line its column 0 - mirror of itself, already done - leaves idle; it fetches
 // that one coefficient column separately) and the mirrors of columns 1, 2, 3.
 // Cell for cell the arithmetic of k_inv_cols_sym: Y is bit-identical.
-template <int TY, bool PT>
+template <int TY>
 __global__ void __launch_bounds__(fft_threads(TY), 2)
 k_inv_cols_msym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                 const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
@@ -1193,30 +1193,17 @@ k_inv_cols_msym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
     // storage block of the mirrors: Tx/4 - cb, or (cb = 0) the block at Tx/2
     const int mblock = cb ? (Tx >> 2) - cb : (Tx >> 3);
     const int e_lo = 4 * rp_lo, e_hi = 4 * (rp_hi + 1);
-    // PT: the launch serves a tile pair whose second tile is empty; two TEMPLATES ride in every
-    // transform instead (k_inv_cols_sym): coefficient a_2g + i a_2g+1, plane g of Y
-    float2 hreg[EP], hreg2[PT ? EP : 1];
-    const int NG = PT ? (G + 1) / 2 : G;       // inverse transform pairs of the launch
-    auto prod = [&](float2 x, float a, float a2) {
-        return PT ? make_float2(x.x * a - x.y * a2, x.x * a2 + x.y * a) : make_float2(a * x.x, a * x.y);
-    };
+    float2 hreg[EP];
     for (int pl = 0; pl < 2; ++pl) {
         const float2* xplane = (pl ? uc2 : uc) + (size_t)pair * plane;
         const float* hsrc = (pl ? mb : wa) + (size_t)vfirst * hplane + col;
         // coefficient column Tx/2 for line 0 of workgroup 0 (pieces with source column 0)
         const float* hsrc_mid = (pl ? mb : wa) + (size_t)vfirst * hplane + (size_t)(Tx >> 1) * TY;
         auto fetch = [&](int gi_) {
-            const float* p = hsrc + (size_t)(PT ? 2 * gi_ : gi_) * hplane;
+            const float* p = hsrc + (size_t)gi_ * hplane;
 #pragma unroll
             for (int u = 0; u < EP; ++u)
                 hreg[u] = *reinterpret_cast<const float2*>(p + 2 * (threadIdx.x + u * NT));
-            if constexpr (PT) {
-                const bool has2 = 2 * gi_ + 1 < G;
-#pragma unroll
-                for (int u = 0; u < EP; ++u)
-                    hreg2[u] = has2 ? *reinterpret_cast<const float2*>(p + hplane + 2 * (threadIdx.x + u * NT))
-                                    : make_float2(0.f, 0.f);
-            }
         };
         const bool rot = pl == 0 && parity == 1;          // odd W: factor i (own columns) / -i (mirrors)
         // ---- park: own columns in LDS (k_inv_cols_sym, direct), mirrors in registers (mirrored)
@@ -1249,18 +1236,16 @@ k_inv_cols_msym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
             }
         }
         fetch(0);
-        for (int gi_ = 0; gi_ < NG; ++gi_) {
+        for (int gi_ = 0; gi_ < G; ++gi_) {
             // (workgroup 0: the coefficients of column Tx/2, needed by the mirror fill below;
             //  fetched here so that they land behind the first transform)
             float2 hmid[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
-            float2 hmid2[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
             if (cb == 0) {                                 // uniform
-                const float* p = hsrc_mid + (size_t)(PT ? 2 * gi_ : gi_) * hplane;
+                const float* p = hsrc_mid + (size_t)gi_ * hplane;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int e = 2 * (threadIdx.x + u * NT);
                     if (e < TY) hmid[u] = *reinterpret_cast<const float2*>(p + e);
-                    if (PT && e < TY && 2 * gi_ + 1 < G) hmid2[u] = *reinterpret_cast<const float2*>(p + hplane + e);
                 }
             }
             // half 0: own columns, 1: mirrors.  Written out twice on purpose: one shared copy of
@@ -1278,8 +1263,8 @@ k_inv_cols_msym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                         const int e = 2 * (tid + u * NT);
                         const int cc = e / TY, fy = e - cc * TY;
                         const float4 x = xs[tid + u * NT];
-                        sm[lidx<TY>(cc, fy)] = prod(make_float2(x.x, x.y), hreg[u].x, hreg2[PT ? u : 0].x);
-                        sm[lidx<TY>(cc, fy + 1)] = prod(make_float2(x.z, x.w), hreg[u].y, hreg2[PT ? u : 0].y);
+                        sm[lidx<TY>(cc, fy)] = make_float2(hreg[u].x * x.x, hreg[u].x * x.y);
+                        sm[lidx<TY>(cc, fy + 1)] = make_float2(hreg[u].y * x.z, hreg[u].y * x.w);
                     }
                 } else {
                     // line sc <- coefficient column sc (workgroup 0, line 0: column Tx/2), rows reversed
@@ -1288,14 +1273,14 @@ k_inv_cols_msym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                         const int e = 2 * (tid + u * NT);
                         const int sc = e / TY, m = e - sc * TY;
                         const int f0 = (TY - m) & (TY - 1), f1 = (TY - m - 1) & (TY - 1);
-                        float2 h = hreg[u], h2 = hreg2[PT ? u : 0];
-                        if (u < 2 && cb == 0 && sc == 0) { h = hmid[u < 2 ? u : 0]; h2 = hmid2[u < 2 ? u : 0]; }
-                        sm[lidx<TY>(sc, f0)] = prod(xm[u][0], h.x, h2.x);
-                        sm[lidx<TY>(sc, f1)] = prod(xm[u][1], h.y, h2.y);
+                        float2 h = hreg[u];
+                        if (u < 2 && cb == 0 && sc == 0) h = hmid[u < 2 ? u : 0];
+                        sm[lidx<TY>(sc, f0)] = make_float2(h.x * xm[u][0].x, h.x * xm[u][0].y);
+                        sm[lidx<TY>(sc, f1)] = make_float2(h.y * xm[u][1].x, h.y * xm[u][1].y);
                     }
                 }
                 lds_barrier();
-                if (half == 1 && gi_ + 1 < NG) fetch(gi_ + 1);
+                if (half == 1 && gi_ + 1 < G) fetch(gi_ + 1);
                 fft4_lines<TY, true>(sm, twr);
                 const int blk_ = half ? mblock : cb;
                 float2* o = (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)(blk_ >> 1) * 16 + (blk_ & 1) * 8;
@@ -2136,7 +2121,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             const int pair = pair0 + pl0;
             float2* ywp = (float2*)ctx->yw.p + (size_t)pl0 * yblock;
             float2* ymp = (float2*)ctx->ym.p + (size_t)pl0 * yblock;
-            n_i1 += merged ? 1 : 2;             // one merged launch, or own columns + mirrors
+            n_i1 += (merged && !PTV) ? 1 : 2;   // one merged launch, or own columns + mirrors
 #define COL_ARGS(CB0)                                                          \
     ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float2*)ctx->wh.p, \
         (const float2*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, ctx->dbg,        \
@@ -2174,16 +2159,16 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     }
 #define FN_MSYM(T)                                                             \
     {                                                                          \
-        int rc = set_lds(ctx, k_inv_cols_msym<T, PTV>, inv_cols_lds<T>());     \
+        int rc = set_lds(ctx, k_inv_cols_msym<T>, inv_cols_lds<T>());          \
         if (rc) return rc;                                                     \
-        hipLaunchKernelGGL((k_inv_cols_msym<T, PTV>), dim3(fg.Tx / 8, nb * pcc), dim3(fft_threads(T)), \
+        hipLaunchKernelGGL((k_inv_cols_msym<T>), dim3(fg.Tx / 8, nb * pcc), dim3(fft_threads(T)), \
                            inv_cols_lds<T>(), ctx->stream, (const float2*)ctx->uc.p,      \
                            (const float2*)ctx->uc2.p, (const float*)ctx->wh.p, (const float*)ctx->mh.p, \
                            fg.Tx, pair, g0, G, rp_lo, rp_hi, 1 - ctx->g.oy, 1 - ctx->g.ox, parity, \
                            (const float2*)ctx->tw_y.p, ywp, ymp, group, np, pcc, n,       \
                            (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py);         \
     }
-            if (merged) {
+            if (merged && !PTV) {
                 switch (fg.Ty) {
                     case 512: FN_MSYM(512); break;
                     case 1024: FN_MSYM(1024); break;
@@ -2212,7 +2197,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             const int pair = pair0;
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
                        ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg, group,
-                       nb, np, pc, merged ? 1 : 0};
+                       nb, np, pc, (merged && !PTV) ? 1 : 0};
                         dim3 gridr(fast ? ((rp_n + 7) / 8) * 16 : (rp_n + 1) / 2, pc);
             sc_prof_begin(ctx, SC_K_INV_ROWS);
 #define ROW_ARGS lds_r, FAST_ARGS
