@@ -2096,7 +2096,11 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     const bool fast = (fg.Tx == 512 || fg.Tx == 1024 || fg.Tx == 2048) && ctx->variant != 9;
     // a column block and its mirror in one workgroup (k_inv_cols_msym): symmetric templates,
     // the fast row kernel (it reads the permuted upper half) and a column length it is built for
-    const bool merged = sym && fast && (fg.Ty == 512 || fg.Ty == 1024 || fg.Ty == 2048) && ctx->variant != 6;
+    // (and enough templates per launch: its parking prologue - the mirror cells gathered into
+    //  registers - costs more than that of the two plain launches, which single-age searches
+    //  notice: C1 1.03 -> 1.31 ms)
+    const bool merged = sym && fast && (fg.Ty == 512 || fg.Ty == 1024 || fg.Ty == 2048) && n >= 8 &&
+                        ctx->variant != 6;
     if (nb > 1 && (!fast || n > group || nb * n > SC_MAX_GROUP))
         return sc_fail(ctx, SC_ERR_INVALID, "orientation batching outside its conditions");
     // One chunk = pc tile pairs through I1 and I2, group by group.  PTV: the chunk is a
