@@ -290,10 +290,15 @@ def test_merged_column_pass_is_bit_identical():
     hand-off) against the two-launch column pass (option variant=6): the same Y cell for cell,
     so the same record - at T = 2048 with several tile pairs and a partial last tile row, at
     T = 1024 / 512, and with batched orientations on a circular tile."""
-    cases = [(synthetic.synthetic_scarp(3900, ny=3700, seed=31), sl.Scarp, 100, _plan.age_grid()[::7], _plan.angle_grid()[3::45]),
-             (synthetic.synthetic_scarp(1500, ny=1400, seed=32), sl.Scarp, 40, _plan.age_grid()[1::9], _plan.angle_grid()[::30]),
-             (synthetic.synthetic_scarp(700, seed=33), sl.Scarp, 12, [2.0, 9.0], _plan.angle_grid()[::20]),
-             (synthetic.synthetic_scarp(1024, seed=34), sl.Channel, 15, [0.1], _plan.angle_grid()[::4])]
+    a9 = _plan.age_grid()[::4]                          # 9 ages: the merged kernel needs >= 8 templates per launch
+    cases = [(synthetic.synthetic_scarp(3900, ny=3700, seed=31), sl.Scarp, 100, a9, _plan.angle_grid()[3::45]),
+             (synthetic.synthetic_scarp(1500, ny=1400, seed=32), sl.Scarp, 40, a9, _plan.angle_grid()[::30]),
+             (synthetic.synthetic_scarp(700, seed=33), sl.Scarp, 12, list(10 ** np.linspace(0, 1.6, 8)), _plan.angle_grid()[::20]),
+             # non-square tiles: 1024 x 512, 512 x 1024, 2048 x 512 (batched orientations where they fit)
+             (synthetic.synthetic_scarp(505, ny=900, seed=35), sl.Scarp, 50, a9, _plan.angle_grid()[::18]),
+             (synthetic.synthetic_scarp(900, ny=505, seed=36), sl.Scarp, 50, a9, _plan.angle_grid()[::18]),
+             (synthetic.synthetic_scarp(420, ny=3000, seed=37), sl.Scarp, 60, a9, _plan.angle_grid()[::25]),
+             (synthetic.synthetic_scarp(1024, seed=34), sl.Channel, 15, [0.05, 0.07, 0.1, 0.14, 0.2, 0.28, 0.4, 0.56], _plan.angle_grid()[::12])]
     for (g, cls, scale, params, angles) in cases:
         out = []
         for variant in (0, 6):
@@ -305,6 +310,7 @@ def test_merged_column_pass_is_bit_identical():
             plan = m.plan
             del m
             ctx.close()
+        print("merged vs two-launch column pass:", plan)
         for a, b, name in zip(out[0], out[1], ("amp", "snr", "id")):
             assert np.array_equal(a, b), (str(plan), name, int((a != b).sum()))
         assert (out[0][1] > 0).any()
