@@ -21,8 +21,12 @@ def one(job):
     orc.match_template(Z, 1.0, 1.0, orc.SCARP, 100, age, ang, workers=w)
     return time.time() - t0
 
+sys.path.insert(0, ROOT)
+from bench import mem_available_bytes           # min(MemAvailable, cgroup limit - usage)
+max_procs = int(0.6 * mem_available_bytes() // (120.0 * n * n + (64 << 20)))     # ~12 GB per 10000^2 template
+print("memory allows %d whole-DEM templates at a time" % max_procs)
 for procs, thr in [(1, 1), (1, 16), (8, 4), (16, 1), (32, 1)]:
-    if procs * thr > cores:
+    if procs * thr > cores or procs > max_procs:
         continue
     jobs = [(float(ages[(3 * k) % 35]), float(angs[(37 * k) % 181]), thr) for k in range(procs)]
     t0 = time.time()
