@@ -4,8 +4,6 @@ import ctypes as C
 
 import numpy as np
 
-from scarplet_amd import _lib
-
 
 def compare(results, ny, nx, device=0):
     """Reference semantics (core.py:198-243): zeros start state, then for
