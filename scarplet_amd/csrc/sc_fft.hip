@@ -636,15 +636,30 @@ k_fwd_rows_templ(const TemplDev* __restrict__ templ, int first,
         any |= prow[rr] != INT_MIN;
     }
     if (!any) return;                 // block-uniform: rows outside the support (templ_rowblock_used)
-    for (int e = threadIdx.x; e < 4 * TX; e += NT) {
-        int rr = e / TX, s = e - rr * TX;
-        int q = (s <= t.qmax) ? s : s - TX;
-        float2 v = make_float2(0.f, 0.f);
-        if (prow[rr] != INT_MIN && q >= t.qmin && q <= t.qmax) {
-            size_t o = (size_t)t.win_off + (size_t)(prow[rr] - t.pmin) * t.ww + (q - t.qmin);
-            v = make_float2(alpha * win_w[o], win_m[o] ? 1.f : 0.f);
+    {
+        // all window loads first, then the LDS stores (see k_fwd_cols_tsym)
+        constexpr int NF = 4 * TX / NT;
+        float w[NF];
+        uint8_t m[NF];
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            const int e = threadIdx.x + u * NT;
+            const int rr = e / TX, s = e - rr * TX;
+            const int q = (s <= t.qmax) ? s : s - TX;
+            w[u] = 0.f;
+            m[u] = 0;
+            if (prow[rr] != INT_MIN && q >= t.qmin && q <= t.qmax) {
+                size_t o = (size_t)t.win_off + (size_t)(prow[rr] - t.pmin) * t.ww + (q - t.qmin);
+                w[u] = win_w[o];
+                m[u] = win_m[o];
+            }
         }
-        sm[lidx<TX>(rr, s)] = v;
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            const int e = threadIdx.x + u * NT;
+            const int rr = e / TX, s = e - rr * TX;
+            sm[lidx<TX>(rr, s)] = make_float2(alpha * w[u], m[u] ? 1.f : 0.f);
+        }
     }
     lds_barrier();
     fft4_lines<TX, false>(sm, twr);
@@ -741,13 +756,17 @@ k_split_templ(const float2* __restrict__ vh, int Ty, int Tx,
 // phase P is folded into the parked curvature spectrum there.  Taking the real /
 // imaginary part also drops the rounding noise of the transform that breaks the
 // symmetry.  parity: 1 odd, 2 even.
-__device__ __forceinline__ float2 phase_pi(float ang) {       // exp(i pi ang)
-    float s, c;
-    sincospif(ang, &s, &c);
-    return make_float2(c, s);
+// P[fy][fx] = phy[fy] * phx[fx]: the two factors are tabulated behind the twiddles of their
+// axis (upload_twiddles: entries T .. 2T-1 hold exp(i pi k f / T)).  A sincospif per cell cost
+// the template split more instructions than its transforms.
+__device__ __forceinline__ float2 phase_tab(const float2* __restrict__ phy, const float2* __restrict__ phx,
+                                            int fy, int fx) {
+    const float2 a = phy[fy], b = phx[fx];
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 __global__ void __launch_bounds__(256)
-k_split_templ_sym(const float2* __restrict__ vh, int Ty, int Tx, int ky, int kx, int parity,
+k_split_templ_sym(const float2* __restrict__ vh, int Ty, int Tx, const float2* __restrict__ phy,
+                  const float2* __restrict__ phx, int parity,
                   float* __restrict__ wa, float* __restrict__ mb) {
     const size_t plane = (size_t)Ty * Tx, hplane = half_plane(Ty, Tx);
     const float2* v = vh + (size_t)blockIdx.y * plane;
@@ -763,10 +782,9 @@ k_split_templ_sym(const float2* __restrict__ vh, int Ty, int Tx, int ky, int kx,
     float2 m[2] = {make_float2(0.5f * (a.y + b0.y), -0.5f * (a.x - b0.x)),
                    make_float2(0.5f * (a.w + b1.y), -0.5f * (a.z - b1.x))};
     float ra[2], rb[2];
-    const float ax = (float)(kx * fx) / (float)Tx;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        float2 ph_ = phase_pi((float)(ky * (fy + k)) / (float)Ty + ax);
+        float2 ph_ = phase_tab(phy, phx, fy + k, fx);
         // x * conj(P)
         float wr = w[k].x * ph_.x + w[k].y * ph_.y, wi = w[k].y * ph_.x - w[k].x * ph_.y;
         ra[k] = parity == 1 ? wi : wr;
@@ -789,8 +807,9 @@ k_split_templ_sym(const float2* __restrict__ vh, int Ty, int Tx, int ky, int kx,
 template <int TY>
 __global__ void __launch_bounds__(fft_threads(TY), fft_waves(TY))
 k_fwd_cols_tsym(const float2* __restrict__ blk, int Tx, const float2* __restrict__ tw,
-                const TemplDev* __restrict__ templ, int ky, int kx, int parity,
+                const TemplDev* __restrict__ templ, const float2* __restrict__ phx, int parity,
                 float* __restrict__ wa, float* __restrict__ mb) {
+    const float2* phy = tw + TY;
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     FftTw<TY> twr;
     twr.load(tw);
@@ -802,13 +821,26 @@ k_fwd_cols_tsym(const float2* __restrict__ blk, int Tx, const float2* __restrict
     const int nbx = Tx >> 2;
     const TemplDev t = templ[q];
     // ---- mirror columns: line c holds column (Tx - (4cb + c)) mod Tx
-    for (int e = threadIdx.x; e < 4 * TY; e += NT) {
-        const int c = e / TY, r = e - c * TY;
-        const int col = (Tx - (4 * cb + c)) & (Tx - 1);
-        float2 v = make_float2(0.f, 0.f);
-        if (templ_rowblock_used(t, r >> 2, TY))
-            v = in[((size_t)(r >> 2) * nbx + (col >> 2)) * 16 + (r & 3) * 4 + (col & 3)];
-        sm[lidx<TY>(c, r)] = v;
+    // (all loads of a fill are issued before its first LDS store: a load per loop trip, waited
+    //  for before the next, made this kernel a chain of sixteen memory latencies)
+    {
+        constexpr int NM = 4 * TY / NT;
+        float2 v[NM];
+#pragma unroll
+        for (int u = 0; u < NM; ++u) {
+            const int e = threadIdx.x + u * NT;
+            const int c = e / TY, r = e - c * TY;
+            const int col = (Tx - (4 * cb + c)) & (Tx - 1);
+            v[u] = make_float2(0.f, 0.f);
+            if (templ_rowblock_used(t, r >> 2, TY))
+                v[u] = in[((size_t)(r >> 2) * nbx + (col >> 2)) * 16 + (r & 3) * 4 + (col & 3)];
+        }
+#pragma unroll
+        for (int u = 0; u < NM; ++u) {
+            const int e = threadIdx.x + u * NT;
+            const int c = e / TY, r = e - c * TY;
+            sm[lidx<TY>(c, r)] = v[u];
+        }
     }
     lds_barrier();
     fft4_lines<TY, false>(sm, twr);
@@ -824,14 +856,23 @@ k_fwd_cols_tsym(const float2* __restrict__ blk, int Tx, const float2* __restrict
     }
     lds_barrier();
     // ---- own columns 4cb .. 4cb+3 (k_fwd_cols' fill)
-#pragma unroll 4
-    for (int e = 2 * threadIdx.x; e < 4 * TY; e += 2 * NT) {      // 2 cells = 16 B per lane
-        int rbk = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (templ_rowblock_used(t, rbk, TY))
-            x = *reinterpret_cast<const float4*>(in + ((size_t)rbk * nbx + cb) * 16 + (e & 15));
-        sm[lidx<TY>(cc, 4 * rbk + rr)] = make_float2(x.x, x.y);
-        sm[lidx<TY>(cc + 1, 4 * rbk + rr)] = make_float2(x.z, x.w);
+    {
+        float4 x[EP];
+#pragma unroll
+        for (int u = 0; u < EP; ++u) {                                // 2 cells = 16 B per lane
+            const int e = 2 * (threadIdx.x + u * NT);
+            x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < 4 * TY && templ_rowblock_used(t, e >> 4, TY))
+                x[u] = *reinterpret_cast<const float4*>(in + ((size_t)(e >> 4) * nbx + cb) * 16 + (e & 15));
+        }
+#pragma unroll
+        for (int u = 0; u < EP; ++u) {
+            const int e = 2 * (threadIdx.x + u * NT);
+            if (e >= 4 * TY) continue;
+            const int rbk = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
+            sm[lidx<TY>(cc, 4 * rbk + rr)] = make_float2(x[u].x, x[u].y);
+            sm[lidx<TY>(cc + 1, 4 * rbk + rr)] = make_float2(x[u].z, x[u].w);
+        }
     }
     lds_barrier();
     fft4_lines<TY, false>(sm, twr);
@@ -848,10 +889,9 @@ k_fwd_cols_tsym(const float2* __restrict__ blk, int Tx, const float2* __restrict
         float2 m[2] = {make_float2(0.5f * (a0.y + b0.y), -0.5f * (a0.x - b0.x)),
                        make_float2(0.5f * (a1.y + b1.y), -0.5f * (a1.x - b1.x))};
         float ra[2], rb[2];
-        const float ax = (float)(kx * fx) / (float)Tx;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            float2 ph_ = phase_pi((float)(ky * (fy + k)) / (float)TY + ax);
+            float2 ph_ = phase_tab(phy, phx, fy + k, fx);
             float wr = w[k].x * ph_.x + w[k].y * ph_.y, wi = w[k].y * ph_.x - w[k].x * ph_.y;
             ra[k] = parity == 1 ? wi : wr;
             rb[k] = m[k].x * ph_.x + m[k].y * ph_.y;
@@ -1004,7 +1044,7 @@ template <int TY, bool MIRROR, bool PT>
 __global__ void __launch_bounds__(fft_threads(TY), 2)
 k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
-               int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, int ky, int kx,
+               int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
                int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
                float2* __restrict__ ym, int ystride, int dbg, int np, int pcj, int tstride,
                const TileDev* __restrict__ tiles, int py_valid) {
@@ -1070,13 +1110,14 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
             float2 xv[2] = {make_float2(x.x, x.y), make_float2(x.z, x.w)};
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                float ang;
+                float2 pv;
                 if (!mirrored)
-                    ang = (float)(ky * (fy + k)) / (float)TY + (float)(kx * fx) / (float)Tx;
-                else
-                    ang = -((float)(ky * ((TY - fy - k) & (TY - 1))) / (float)TY +
-                            (float)(kx * ((Tx - fx) & (Tx - 1))) / (float)Tx);
-                float2 v = cmul(xv[k], phase_pi(ang));
+                    pv = phase_tab(tw + TY, phx, fy + k, fx);
+                else {
+                    pv = phase_tab(tw + TY, phx, (TY - fy - k) & (TY - 1), (Tx - fx) & (Tx - 1));
+                    pv.y = -pv.y;
+                }
+                float2 v = cmul(xv[k], pv);
                 if (rot) v = mirrored ? make_float2(v.y, -v.x) : make_float2(-v.y, v.x);
                 xv[k] = v;
             }
@@ -1164,7 +1205,7 @@ template <int TY>
 __global__ void __launch_bounds__(fft_threads(TY), 2)
 k_inv_cols_msym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                 const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
-                int pair, int vfirst, int G, int rp_lo, int rp_hi, int ky, int kx,
+                int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
                 int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
                 float2* __restrict__ ym, int ystride, int np, int pcj, int tstride,
                 const TileDev* __restrict__ tiles, int py_valid) {
@@ -1216,8 +1257,7 @@ k_inv_cols_msym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
             float2 xv[2] = {make_float2(x.x, x.y), make_float2(x.z, x.w)};
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const float ang = (float)(ky * (fy + k)) / (float)TY + (float)(kx * fx) / (float)Tx;
-                float2 v = cmul(xv[k], phase_pi(ang));
+                float2 v = cmul(xv[k], phase_tab(tw + TY, phx, fy + k, fx));
                 if (rot) v = make_float2(-v.y, v.x);
                 xv[k] = v;
             }
@@ -1228,9 +1268,9 @@ k_inv_cols_msym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int f = (TY - fy - k) & (TY - 1);
-                const float ang = -((float)(ky * ((TY - f) & (TY - 1))) / (float)TY +
-                                    (float)(kx * ((Tx - fxt) & (Tx - 1))) / (float)Tx);
-                float2 v = cmul(xplane[(size_t)fxt * TY + f], phase_pi(ang));
+                float2 pv = phase_tab(tw + TY, phx, (TY - f) & (TY - 1), (Tx - fxt) & (Tx - 1));
+                pv.y = -pv.y;
+                float2 v = cmul(xplane[(size_t)fxt * TY + f], pv);
                 if (rot) v = make_float2(v.y, -v.x);
                 xm[u][k] = v;
             }
@@ -1848,18 +1888,25 @@ bool fft_size_supported(int T) {
     return T >= 64 && T <= 4096 && (T & (T - 1)) == 0;
 }
 
-static int upload_twiddles(sc_ctx* ctx, DevBuf& buf, int& have, int T) {
-    if (have == T) return SC_OK;
-    std::vector<float2> h(T);
+// Entries 0 .. T-1: the forward twiddles exp(-2 pi i k / T).  Entries T .. 2T-1: the phase
+// factor exp(i pi kph f / T) of the symmetric-template path along this axis (phase_tab).
+static int upload_twiddles(sc_ctx* ctx, DevBuf& buf, int& have, int T, int kph) {
+    const int key = T * 8 + (kph & 7);
+    if (have == key) return SC_OK;
+    std::vector<float2> h(2 * (size_t)T);
     for (int k = 0; k < T; ++k) {
         double a = -2.0 * M_PI * (double)k / (double)T;
         h[k] = make_float2((float)cos(a), (float)sin(a));
+        // kph * k mod 2T keeps the argument small (exact in integers)
+        long long m = ((long long)kph * k) % (2LL * T);
+        double b = M_PI * (double)m / (double)T;
+        h[T + k] = make_float2((float)cos(b), (float)sin(b));
     }
-    int rc = sc_ensure(ctx, buf, sizeof(float2) * T);
+    int rc = sc_ensure(ctx, buf, sizeof(float2) * h.size());
     if (rc) return rc;
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    SC_HIP(ctx, hipMemcpy(buf.p, h.data(), sizeof(float2) * T, hipMemcpyHostToDevice));
-    have = T;
+    SC_HIP(ctx, hipMemcpy(buf.p, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice));
+    have = key;
     return SC_OK;
 }
 
@@ -1870,8 +1917,8 @@ int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group, in
     if (!fft_size_supported(fg.Ty) || !fft_size_supported(fg.Tx))
         return sc_fail(ctx, SC_ERR_UNSUPPORTED, "FFT tile %dx%d not supported", fg.Ty, fg.Tx);
     int rc;
-    if ((rc = upload_twiddles(ctx, ctx->tw_y, ctx->tw_Ty, fg.Ty))) return rc;
-    if ((rc = upload_twiddles(ctx, ctx->tw_x, ctx->tw_Tx, fg.Tx))) return rc;
+    if ((rc = upload_twiddles(ctx, ctx->tw_y, ctx->tw_Ty, fg.Ty, 1 - ctx->g.oy))) return rc;
+    if ((rc = upload_twiddles(ctx, ctx->tw_x, ctx->tw_Tx, fg.Tx, 1 - ctx->g.ox))) return rc;
     const Geom& g = ctx->g;
     int np = npairs_of(fg);
     std::vector<TileDev> h(2 * np);
@@ -2038,7 +2085,7 @@ int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n, int 
         if (rc) return rc;                                                     \
         hipLaunchKernelGGL(k_fwd_cols_tsym<T>, gridc, dim3(fft_threads(T)), ldsc, ctx->stream, \
                            (const float2*)ctx->blk.p, fg.Tx, (const float2*)ctx->tw_y.p, \
-                           (const TemplDev*)ctx->templ.p + first, 1 - ctx->g.oy, 1 - ctx->g.ox, \
+                           (const TemplDev*)ctx->templ.p + first, (const float2*)ctx->tw_x.p + fg.Tx, \
                            parity, (float*)ctx->wh.p, (float*)ctx->mh.p);      \
     }
         switch (fg.Ty) {
@@ -2062,7 +2109,8 @@ int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n, int 
     sc_prof_begin(ctx, SC_K_FWD_COLS);
     if (fft_use_sym(ctx, fg, parity))
         hipLaunchKernelGGL(k_split_templ_sym, grid_s, dim3(256), 0, ctx->stream,
-                           (const float2*)ctx->vh.p, fg.Ty, fg.Tx, 1 - ctx->g.oy, 1 - ctx->g.ox,
+                           (const float2*)ctx->vh.p, fg.Ty, fg.Tx, (const float2*)ctx->tw_y.p + fg.Ty,
+                           (const float2*)ctx->tw_x.p + fg.Tx,
                            parity, (float*)ctx->wh.p, (float*)ctx->mh.p);
     else
         hipLaunchKernelGGL(k_split_templ, grid_s, dim3(256), 0, ctx->stream, (const float2*)ctx->vh.p,
@@ -2132,8 +2180,8 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         (const float2*)ctx->tw_y.p, ywp, ymp, group, np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py
 #define SYM_ARGS(CB0)                                                          \
     ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float*)ctx->wh.p, \
-        (const float*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, 1 - ctx->g.oy,     \
-        1 - ctx->g.ox, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group
+        (const float*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi,                    \
+        (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group
 #define SYM_ARGS_D(CB0) SYM_ARGS(CB0), ctx->dbg, np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py
 #define FN_SYM(T)                                                              \
     {                                                                          \
@@ -2168,7 +2216,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         hipLaunchKernelGGL((k_inv_cols_msym<T>), dim3(fg.Tx / 8, nb * pcc), dim3(fft_threads(T)), \
                            inv_cols_lds<T>(), ctx->stream, (const float2*)ctx->uc.p,      \
                            (const float2*)ctx->uc2.p, (const float*)ctx->wh.p, (const float*)ctx->mh.p, \
-                           fg.Tx, pair, g0, G, rp_lo, rp_hi, 1 - ctx->g.oy, 1 - ctx->g.ox, parity, \
+                           fg.Tx, pair, g0, G, rp_lo, rp_hi, (const float2*)ctx->tw_x.p + fg.Tx, parity, \
                            (const float2*)ctx->tw_y.p, ywp, ymp, group, np, pcc, n,       \
                            (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py);         \
     }
