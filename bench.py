@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--prof-stride", type=int, default=16)
+    ap.add_argument("--partition", default="tiles", choices=["tiles", "grid"],
+                    help="multi-rank cores: whole FFT tiles balanced over the ranks when that beats the "
+                         "even grid (scarplet_amd.dist.tile_cores), or always the even grid")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="run the R blocks of the R-rank tiled search sequentially on this GPU")
     ap.add_argument("--halo", default="rccl", choices=["rccl", "host", "gloo"],
@@ -299,7 +302,9 @@ def main():
         arr, bbox, area = m.describe(Template, scales[0], params, angles)
         halo = sd.halo_for_search(bbox, ny, nx)
         py, px = sd.grid_dims(R, ny, nx)
-        lay = sd.Layout(ny, nx, py, px, halo)
+        cores = sd.tile_cores(R, ny, nx, bbox) if a.partition == "tiles" else None
+        lay = sd.Layout(ny, nx, py, px, halo, cores=cores)
+        part_label = ("%d rectangles of whole FFT tiles" % R) if cores else "%dx%d even grid" % (py, px)
         blocks = [np.ascontiguousarray(sd.assemble_block_reference(g._griddata, lay, r)) for r in range(R)]
         halo_bytes = [8 * (blocks[r].size - (lay.core(r)[1] - lay.core(r)[0]) * (lay.core(r)[3] - lay.core(r)[2]))
                       for r in range(R)]
@@ -318,7 +323,7 @@ def main():
                 if len(plans) < R:
                     plans.append(plan)
         ctx = m.ctx
-        emu = (R, py, px, per_block, halo_bytes, plans)
+        emu = (R, part_label, [lay.core(r) for r in range(R)], per_block, halo_bytes, plans)
     elif world == 1:
         m = sl.Matcher(g, device=device)
         descs = []
@@ -336,9 +341,11 @@ def main():
     else:
         dm = sd.DistMatcher(rank, world, (ny, nx), float(g._georef_info.dx), float(g._georef_info.dy),
                             device=device, backend=a.halo, transport=transport)
-        c = dm.core()
-        z_core = np.ascontiguousarray(g._griddata[c[0]:c[1], c[2]:c[3]])
         arr, bbox, area = dm.m.describe(Template, scales[0], params, angles)
+        c = dm.partition_for(bbox) if a.partition == "tiles" else dm.core()
+        part_label = ("%d rectangles of whole FFT tiles" % world) if dm.cores else \
+            "%s even grid" % "x".join(map(str, sd.grid_dims(world, ny, nx)))
+        z_core = np.ascontiguousarray(g._griddata[c[0]:c[1], c[2]:c[3]])
         dm.load(z_core, bbox)                          # halo exchange over RCCL
         plan, sp = dm.m.plan_for(bbox, area, a.method, a.group or None, n_params=len(params))
 
@@ -395,7 +402,7 @@ def main():
             "config": {"workload": label, "method": a.method,
                        "tiles": ("%dx%d of %dx%d" % (plan.nty, plan.ntx, plan.Ty, plan.Tx)) if a.method == "fft" else "-",
                        "group": int(getattr(plan, "group", 0)),
-                       "ranks": "%d (%s tile grid)" % (world, "x".join(map(str, sd.grid_dims(world, ny, nx))))},
+                       "ranks": "%d (%s)" % (world, part_label if world > 1 else "whole DEM")},
             "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOLS.get(dom, dom) if a.method == "fft" else dom,
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -408,14 +415,14 @@ def main():
             "kernels_ms_per_step": {k: round(v[1] / a.steps, 2) for k, v in prof.items() if v[0]},
         }
         if emu:
-            R, py, px, per_block, halo_bytes, plans = emu
+            R, part_label, cores_, per_block, halo_bytes, plans = emu
             pb = per_block / a.steps
             out["emulated_ranks"] = {
-                "ranks": R, "grid": "%dx%d" % (py, px),
+                "ranks": R, "partition": part_label, "cores": [list(map(int, c)) for c in cores_],
                 "block_ms": [round(1e3 * v, 1) for v in pb],
                 "max_block_ms": round(1e3 * float(pb.max()), 1), "sum_block_ms": round(1e3 * float(pb.sum()), 1),
                 "halo_bytes_per_rank": int(max(halo_bytes)),
-                "tiles_per_block": "%dx%d of %dx%d" % (plans[0].nty, plans[0].ntx, plans[0].Ty, plans[0].Tx),
+                "tiles_per_block": ["%dx%d of %dx%d" % (p_.nty, p_.ntx, p_.Ty, p_.Tx) for p_ in plans],
                 "predicted_value_at_%d_gpus" % R: round(units / float(pb.max()) / 1e6, 1),
                 "note": "PREDICTED, not measured: every block (core + torus halo, upload and curvature planes "
                         "included) searched alone on one GPU; the slowest block bounds the %d-GPU step, the halo "

@@ -55,24 +55,115 @@ def cuts(n, parts):
     return np.array([(n * k) // parts for k in range(parts + 1)], dtype=int)
 
 
-class Layout(object):
-    """Tile grid of a ny x nx DEM over py x px ranks (rank = ry*px + rx)."""
+def grid_cores(ny, nx, py, px):
+    """Cores (y0, y1, x0, x1) of an even py x px grid, rank = ry*px + rx."""
+    cy, cx = cuts(ny, py), cuts(nx, px)
+    return [(int(cy[r // px]), int(cy[r // px + 1]), int(cx[r % px]), int(cx[r % px + 1]))
+            for r in range(py * px)]
 
-    def __init__(self, ny, nx, py, px, halo):
+
+def tile_partition(nranks, nty, ntx, budget=200000):
+    """Cut an nty x ntx grid of FFT tiles into ``nranks`` rectangles of as few tiles as possible
+    each (the cost of a rank's search is its tile count, not its area: an even 2x4 split of the
+    10000^2 benchmark DEM gives every rank 3x2 tiles of 2048^2 where 36 / 8 = 4.5 would do).
+    Among the partitions with the smallest maximum the one with the shortest total boundary
+    (least halo) found within ``budget`` search nodes is returned, as
+    [(ty0, ty1, tx0, tx1)] in tile units - or None when there are fewer tiles than ranks.
+
+    Exhaustive placement: the first free cell in row-major order is the top-left corner of
+    the next rectangle.  6x6 tiles over 8 ranks: four 1x5 strips around four 2x2 blocks."""
+    cells = nty * ntx
+    if nranks < 1 or cells < nranks:
+        return None
+    for cap in range(-(-cells // nranks), cells + 1):
+        shapes = sorted(((h, w) for h in range(1, nty + 1) for w in range(1, ntx + 1) if h * w <= cap),
+                        key=lambda hw: (-hw[0] * hw[1], abs(hw[0] - hw[1])))
+        used = np.zeros((nty, ntx), dtype=bool)
+        best = [None, None]
+        nodes = [0]
+        cur = []
+
+        def rec(k_left, free, perim):
+            if nodes[0] > budget:
+                return
+            nodes[0] += 1
+            if free == 0:
+                if k_left == 0 and (best[0] is None or perim < best[0]):
+                    best[0], best[1] = perim, list(cur)
+                return
+            if k_left == 0 or free > k_left * cap or free < k_left:
+                return
+            if best[0] is not None and perim >= best[0]:
+                return
+            i = int(np.argmin(used.ravel()))           # first free cell
+            y, x = divmod(i, ntx)
+            for (h, w) in shapes:
+                if y + h > nty or x + w > ntx or used[y:y + h, x:x + w].any():
+                    continue
+                used[y:y + h, x:x + w] = True
+                cur.append((y, y + h, x, x + w))
+                rec(k_left - 1, free - h * w, perim + h + w)
+                cur.pop()
+                used[y:y + h, x:x + w] = False
+
+        rec(nranks, cells, 0)
+        if best[1] is not None:
+            return best[1]
+    return None
+
+
+def tile_cores(nranks, ny, nx, bbox):
+    """Cores for ``nranks`` ranks aligned with the overlap-save tiles a template batch with
+    support box ``bbox`` gets (_plan.choose_tile), or None when that is no better than the
+    even grid of grid_dims (fewest tiles on the busiest rank decides)."""
+    pmin, pmax, qmin, qmax = bbox
+    try:
+        _, vy, nty, _ = _plan.choose_tile(ny, pmax - pmin, ny, False)
+        _, vx, ntx, _ = _plan.choose_tile(nx, qmax - qmin, nx, False)
+    except ValueError:
+        return None
+
+    def tiles_of(core):
+        return _plan.choose_tile(core[1] - core[0], pmax - pmin, ny, False)[2] * \
+            _plan.choose_tile(core[3] - core[2], qmax - qmin, nx, False)[2]
+
+    py, px = grid_dims(nranks, ny, nx)
+    even = max(tiles_of(c) for c in grid_cores(ny, nx, py, px))
+    part = tile_partition(nranks, nty, ntx)
+    if part is None or max((a1 - a0) * (b1 - b0) for (a0, a1, b0, b1) in part) >= even:
+        return None
+    return [(min(a0 * vy, ny), min(a1 * vy, ny), min(b0 * vx, nx), min(b1 * vx, nx))
+            for (a0, a1, b0, b1) in part]
+
+
+class Layout(object):
+    """Cores of a ny x nx DEM over the ranks - an even py x px grid (rank = ry*px + rx), or
+    any list ``cores`` of rectangles that tile the DEM (tile_cores) - and the halo around them."""
+
+    def __init__(self, ny, nx, py, px, halo, cores=None):
         self.ny, self.nx, self.py, self.px = ny, nx, py, px
-        self.cy, self.cx = cuts(ny, py), cuts(nx, px)
+        self.cores = [tuple(int(v) for v in c) for c in cores] if cores is not None \
+            else grid_cores(ny, nx, py, px)
+        area = 0
+        for k, (y0, y1, x0, x1) in enumerate(self.cores):
+            if not (0 <= y0 < y1 <= ny and 0 <= x0 < x1 <= nx):
+                raise ValueError("core outside the DEM")
+            area += (y1 - y0) * (x1 - x0)
+            for (v0, v1, u0, u1) in self.cores[:k]:
+                if y0 < v1 and v0 < y1 and x0 < u1 and u0 < x1:
+                    raise ValueError("cores overlap")
+        if area != ny * nx:
+            raise ValueError("cores must tile the DEM exactly")
         self.halo = tuple(int(h) for h in halo)       # (y_lo, y_hi, x_lo, x_hi)
         if max(self.halo[:2]) >= ny or max(self.halo[2:]) >= nx:
             raise ValueError("halo larger than the DEM")
 
     @property
     def nranks(self):
-        return self.py * self.px
+        return len(self.cores)
 
     def core(self, rank):
-        ry, rx = divmod(rank, self.px)
-        return (int(self.cy[ry]), int(self.cy[ry + 1]),
-                int(self.cx[rx]), int(self.cx[rx + 1]))
+        return self.cores[rank]
 
     def block_origin(self, rank):
         c = self.core(rank)
@@ -195,6 +286,7 @@ class DistMatcher(object):
         if backend == "host" and nranks > 1 and transport is None:
             raise ValueError("the host backend needs a transport (scarplet_amd/dist.py docstring)")
         self.py, self.px = grid_dims(nranks, self.ny, self.nx)
+        self.cores = None                     # None: the even py x px grid; else partition_for's
         self.m = Matcher(device=device)
         # describe() only needs the grid geometry
         self.m.ny, self.m.nx, self.m.de = self.ny, self.nx, dx
@@ -208,14 +300,32 @@ class DistMatcher(object):
             uid = broadcast_bytes(uid)
             self.m.ctx.comm_init(uid, rank, nranks)
 
+    def partition_for(self, bbox):
+        """Choose the ranks' cores for a template batch with support box ``bbox``: rectangles
+        of whole FFT tiles when that leaves the busiest rank fewer tiles than the even grid
+        (tile_cores), else the grid.  Every rank must call it with the same box, before
+        ``core()``; returns this rank's core."""
+        self.cores = tile_cores(self.nranks, self.ny, self.nx, bbox)
+        return self.core()
+
+    def prepare(self, Template, scale, params, angles, **kwargs):
+        """``partition_for`` the support box of a search (same arguments as ``search``)."""
+        params = np.atleast_1d(np.asarray(params, dtype=float))
+        angles = np.atleast_1d(np.asarray(angles, dtype=float))
+        _, bbox, _ = self.m.describe(Template, scale, params, angles, **kwargs)
+        return self.partition_for(bbox)
+
+    def _layout(self, halo):
+        return Layout(self.ny, self.nx, self.py, self.px, halo, cores=self.cores)
+
     def core(self):
-        return Layout(self.ny, self.nx, self.py, self.px, (0, 0, 0, 0)).core(self.rank)
+        return self._layout((0, 0, 0, 0)).core(self.rank)
 
     def load(self, z_core, bbox):
         """Exchange halos sized for a template batch and hand the block to
         the GPU."""
         halo = halo_for_search(bbox, self.ny, self.nx)
-        self.layout = Layout(self.ny, self.nx, self.py, self.px, halo)
+        self.layout = self._layout(halo)
         core = self.layout.core(self.rank)
         origin = self.layout.block_origin(self.rank)
         bshape = self.layout.block_shape(self.rank)
@@ -253,7 +363,7 @@ class DistMatcher(object):
         (sc_gather_result, device to root's host array) with the 'rccl' backend,
         through ``transport.gather`` with the host backend."""
         if self.backend == "rccl":
-            lay = Layout(self.ny, self.nx, self.py, self.px, (0, 0, 0, 0))
+            lay = self._layout((0, 0, 0, 0))
             cores = [lay.core(r) for r in range(self.nranks)]
             m = self.m
             out = m.ctx.gather_result(dst, cores, (self.ny, self.nx),

@@ -59,6 +59,68 @@ def test_transfer_list_fills_every_block():
                 assert sends == recvs
 
 
+def test_tile_partition_balances_tile_counts():
+    """36 tiles over 8 ranks: five per rank at most (four 1x5 strips around four 2x2 blocks),
+    where the even 2x4 grid gives every rank six."""
+    for (n, nty, ntx, want) in [(8, 6, 6, 5), (2, 6, 6, 18), (4, 6, 6, 9), (6, 6, 6, 6), (3, 2, 2, 2),
+                                (5, 1, 7, 2), (4, 2, 2, 1)]:
+        part = sd.tile_partition(n, nty, ntx)
+        assert len(part) == n
+        cover = np.zeros((nty, ntx), int)
+        for (a0, a1, b0, b1) in part:
+            cover[a0:a1, b0:b1] += 1
+        assert (cover == 1).all()
+        assert max((a1 - a0) * (b1 - b0) for (a0, a1, b0, b1) in part) == want
+    assert sd.tile_partition(5, 2, 2) is None
+    bbox = (-154, 153, -154, 153)
+    cores = sd.tile_cores(8, 10000, 10000, bbox)
+    assert cores is not None and len(cores) == 8
+    lay = sd.Layout(10000, 10000, 2, 4, sd.halo_for_search(bbox, 10000, 10000), cores=cores)
+    from scarplet_amd import _plan
+    padded = []                       # padded cells of each rank's own plan, in 2048^2 tiles
+    for r in range(8):
+        c = lay.core(r)
+        ty, _, nty, _ = _plan.choose_tile(c[1] - c[0], 307, 10000, False)
+        tx, _, ntx, _ = _plan.choose_tile(c[3] - c[2], 307, 10000, False)
+        padded.append(ty * nty * tx * ntx / 2048.0 ** 2)
+    assert max(padded) <= 5 and sum(padded) <= 36
+    # no gain over the even grid: keep the grid
+    assert sd.tile_cores(4, 10000, 10000, bbox) is None
+    assert sd.tile_cores(2, 10000, 10000, bbox) is None
+    with pytest.raises(ValueError):
+        sd.Layout(10, 10, 1, 2, (1, 1, 1, 1), cores=[(0, 10, 0, 6), (0, 10, 5, 10)])
+    with pytest.raises(ValueError):
+        sd.Layout(10, 10, 1, 2, (1, 1, 1, 1), cores=[(0, 10, 0, 5), (0, 9, 5, 10)])
+
+
+def _uneven_cores(ny, nx):
+    """A pinwheel of five rectangles (not a grid: no cut runs through the whole DEM)."""
+    a, b = ny // 3, nx // 3
+    return [(0, a, 0, nx - b), (0, ny - a, nx - b, nx), (ny - a, ny, b, nx), (a, ny, 0, b),
+            (a, ny - a, b, nx - b)]
+
+
+def test_transfer_list_fills_uneven_blocks():
+    rng = np.random.default_rng(6)
+    for (ny, nx, halo) in [(40, 37, (7, 6, 9, 8)), (33, 60, (10, 10, 12, 3))]:
+        z = rng.standard_normal((ny, nx))
+        cores = _uneven_cores(ny, nx)
+        lay = sd.Layout(ny, nx, 1, len(cores), halo, cores=cores)
+        n = lay.nranks
+        blocks = []
+        for r in range(n):
+            b = np.full(lay.block_shape(r), np.nan)
+            c = lay.core(r)
+            b[halo[0]:halo[0] + c[1] - c[0], halo[2]:halo[2] + c[3] - c[2]] = z[c[0]:c[1], c[2]:c[3]]
+            blocks.append(b)
+        for (src, dst, sy0, sx0, dy0, dx0, h, w) in lay.transfers():
+            piece = blocks[src][sy0:sy0 + h, sx0:sx0 + w]
+            assert not np.isnan(piece).any()
+            blocks[dst][dy0:dy0 + h, dx0:dx0 + w] = piece
+        for r in range(n):
+            assert np.array_equal(blocks[r], sd.assemble_block_reference(z, lay, r))
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -76,7 +138,7 @@ def _worker(rank, world, port, ny, nx, halo, q):
                                 rank=rank, world_size=world)
         z = np.random.default_rng(9).standard_normal((ny, nx))
         py, px = sd.grid_dims(world, ny, nx)
-        lay = sd.Layout(ny, nx, py, px, halo)
+        lay = sd.Layout(ny, nx, py, px, halo, cores=_uneven_cores(ny, nx) if world == 5 else None)
         c = lay.core(rank)
         blk = sd.exchange_host(z[c[0]:c[1], c[2]:c[3]], lay, rank, TorchTransport())
         ok = np.array_equal(blk, sd.assemble_block_reference(z, lay, rank))
@@ -87,7 +149,8 @@ def _worker(rank, world, port, ny, nx, halo, q):
         q.put((rank, repr(e)))
 
 
-@pytest.mark.parametrize("world,ny,nx,halo", [(2, 48, 50, (9, 8, 7, 10)), (4, 40, 60, (6, 6, 13, 5))])
+@pytest.mark.parametrize("world,ny,nx,halo", [(2, 48, 50, (9, 8, 7, 10)), (4, 40, 60, (6, 6, 13, 5)),
+                                              (5, 45, 39, (8, 7, 9, 6))])      # 5: uneven pinwheel cores
 def test_halo_exchange_over_gloo(world, ny, nx, halo):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -111,12 +111,15 @@ def test_gather_result_places_a_core_inside_the_dem():
         assert not out[k][mask].any()
 
 
-def test_c4_eight_rank_blocks_at_full_size():
-    """BASELINE config C4 on one GPU: the 10000 x 10000 DEM cut into the 2 x 4 rank grid, every
-    rank's block (5000 x 2500 core + torus halo, as sc_halo_exchange assembles it) searched on
-    its own with all 35 ages, the tiles stitched and compared with the whole-DEM search.  The
-    two runs tile differently (blocks: 3 x 4 tiles of 2048 x 1024, whole DEM: 6 x 6 of 2048^2),
-    so they differ by float32 rounding: winners must agree except inside the tie window."""
+@pytest.mark.parametrize("partition", ["grid", "tiles"])
+def test_c4_eight_rank_blocks_at_full_size(partition):
+    """BASELINE config C4 on one GPU: the 10000 x 10000 DEM cut into eight rank cores - the even
+    2 x 4 grid (5000 x 2500 cores), or dist.tile_cores' rectangles of whole FFT tiles (four
+    1 x 5 strips around four 2 x 2 blocks of 1741-cell tiles) - every rank's block (core + torus
+    halo, as sc_halo_exchange assembles it) searched on its own with all 35 ages, the cores
+    stitched and compared with the whole-DEM search.  The runs tile differently (grid blocks:
+    3 x 4 tiles of 2048 x 1024, whole DEM: 6 x 6 of 2048^2), so they differ by float32
+    rounding: winners must agree except inside the tie window."""
     n = 10000
     g = synthetic.synthetic_scarp(n)
     z = g._griddata
@@ -128,7 +131,9 @@ def test_c4_eight_rank_blocks_at_full_size():
     halo = sd.halo_for_search(bbox, n, n)
     py, px = sd.grid_dims(8, n, n)
     assert (py, px) in ((2, 4), (4, 2))
-    lay = sd.Layout(n, n, py, px, halo)
+    cores = sd.tile_cores(8, n, n, bbox) if partition == "tiles" else None
+    assert (cores is not None) == (partition == "tiles")
+    lay = sd.Layout(n, n, py, px, halo, cores=cores)
     tiled = np.zeros_like(whole)
     for r in range(8):
         c = lay.core(r)
@@ -140,7 +145,7 @@ def test_c4_eight_rank_blocks_at_full_size():
         tiled[:, c[0]:c[1], c[2]:c[3]] = m.ctx.get_result(np.repeat(ages, len(angles)), np.tile(angles, len(ages)))
     same = (whole[1] == tiled[1]) & (whole[2] == tiled[2])
     tie = orc.PARITY["tie_rtol"]
-    print("C4 blocks vs whole DEM: same (age, angle) %.6f of %d cells; the rest within the tie window: %s"
+    print("C4 blocks (" + partition + ") vs whole DEM: same (age, angle) %.6f of %d cells; the rest within the tie window: %s"
           % (same.mean(), same.size, bool(np.allclose(whole[3][~same], tiled[3][~same], rtol=tie))))
     assert same.mean() > 0.999, float(same.mean())
     assert np.allclose(whole[3][~same], tiled[3][~same], rtol=tie)

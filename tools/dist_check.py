@@ -25,7 +25,7 @@ g = synthetic.synthetic_scarp(a.n, ny=a.n - 60)
 z = g._griddata
 ages, angles = [3.0, 30.0, 300.0], _plan.angle_grid(-1.0, 1.0)[::10]
 dm = sd.DistMatcher(rank, world, z.shape, 1.0, 1.0, device=int(os.environ.get("LOCAL_RANK", 0)) % ndev, backend=a.halo, transport=TorchTransport())
-c = dm.core()
+c = dm.prepare(sl.Scarp, 30, ages, angles)      # cores of whole FFT tiles where that helps, else the grid
 dm.search(sl.Scarp, 30, ages, angles, np.ascontiguousarray(z[c[0]:c[1], c[2]:c[3]]), method="fft")
 full = dm.gather(0)
 if rank == 0:
