@@ -60,6 +60,11 @@ def parse():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--prof-stride", type=int, default=16)
+    ap.add_argument("--shard", default="auto", choices=["auto", "orientations", "tiles"],
+                    help="multi-rank sharding: 'orientations' = every rank the whole DEM and a chunk of the "
+                         "orientation grid, records folded over RCCL (scarplet_amd.dist.OrientationMatcher); "
+                         "'tiles' = BASELINE config C4, the DEM cut into rank cores with a halo exchange "
+                         "(DistMatcher); auto: orientations (the benchmark DEM fits one GPU)")
     ap.add_argument("--partition", default="tiles", choices=["tiles", "grid"],
                     help="multi-rank cores: whole FFT tiles balanced over the ranks when that beats the "
                          "even grid (scarplet_amd.dist.tile_cores), or always the even grid")
@@ -294,7 +299,31 @@ def main():
     units = float(ny) * nx * n_templates               # px.template per step
     emu = None
 
-    if world == 1 and a.emulate_ranks > 1:
+    shard = "orientations" if a.shard == "auto" else a.shard
+    if world == 1 and a.emulate_ranks > 1 and shard == "orientations":
+        # the R orientation chunks of the R-rank search, one after the other on this GPU
+        R = a.emulate_ranks
+        om = sd.OrientationMatcher(0, 1, g, device=device)
+        m = om.m
+        n_par = len(params)
+        arr, bbox, area = m.describe(Template, scales[0], params, angles, id_of=lambda ia, ib: ib * n_par + ia)
+        plan, sp = m.plan_for(bbox, area, a.method, a.group or None, n_params=n_par)
+        chunks = sd.orientation_chunks(len(angles), R)
+        subs = [(_lib.sc_template * ((b1 - b0) * n_par)).from_buffer(arr, b0 * n_par * _lib.C.sizeof(_lib.sc_template))
+                if b1 > b0 else None for (b0, b1) in chunks]
+        per_block = np.zeros(R)
+        part_label = "%d chunks of the orientation grid, whole DEM each" % R
+
+        def step():
+            for r in range(R):
+                t0 = time.perf_counter()
+                m.ctx.reset_best()
+                if subs[r] is not None:
+                    m.ctx.match(subs[r], sp, sync=True)
+                per_block[r] += time.perf_counter() - t0
+        ctx = m.ctx
+        emu = (R, part_label, chunks, per_block, [12 * ny * nx] * R, [plan] * R)
+    elif world == 1 and a.emulate_ranks > 1:
         # the R blocks of the R-rank search, one after the other on this GPU
         R = a.emulate_ranks
         m = sl.Matcher(device=device)
@@ -338,6 +367,15 @@ def main():
                 m.ctx.match(arr_, sp_, sync=True)
         ctx = m.ctx
         plan = descs[-1][2]
+    elif shard == "orientations":
+        om = sd.OrientationMatcher(rank, world, g, device=device, backend=a.halo, transport=transport)
+        mine, sp = om.describe(Template, scales[0], params, angles, a.method, a.group or None)
+        plan = om.m.plan
+        part_label = "orientation grid in %d chunks, whole DEM on every rank, records folded by two all-reduces" % world
+
+        def step():
+            om.run(mine, sp)                           # reset, this rank's orientations, fold over RCCL
+        ctx = om.m.ctx
     else:
         dm = sd.DistMatcher(rank, world, (ny, nx), float(g._georef_info.dx), float(g._georef_info.dy),
                             device=device, backend=a.halo, transport=transport)
@@ -421,12 +459,16 @@ def main():
                 "ranks": R, "partition": part_label, "cores": [list(map(int, c)) for c in cores_],
                 "block_ms": [round(1e3 * v, 1) for v in pb],
                 "max_block_ms": round(1e3 * float(pb.max()), 1), "sum_block_ms": round(1e3 * float(pb.sum()), 1),
-                "halo_bytes_per_rank": int(max(halo_bytes)),
+                "exchanged_bytes_per_rank": int(max(halo_bytes)),
                 "tiles_per_block": ["%dx%d of %dx%d" % (p_.nty, p_.ntx, p_.Ty, p_.Tx) for p_ in plans],
                 "predicted_value_at_%d_gpus" % R: round(units / float(pb.max()) / 1e6, 1),
-                "note": "PREDICTED, not measured: every block (core + torus halo, upload and curvature planes "
-                        "included) searched alone on one GPU; the slowest block bounds the %d-GPU step, the halo "
-                        "exchange (halo_bytes_per_rank over xGMI) comes on top" % R}
+                "note": ("PREDICTED, not measured: every rank's chunk of the orientation grid searched alone on "
+                         "one GPU (whole DEM); the slowest chunk bounds the %d-GPU step, the fold of the records "
+                         "(exchanged_bytes_per_rank all-reduced over xGMI: a 64-bit key and a float per cell) "
+                         "comes on top" % R) if shard == "orientations" else
+                        ("PREDICTED, not measured: every block (core + torus halo, upload and curvature planes "
+                         "included) searched alone on one GPU; the slowest block bounds the %d-GPU step, the halo "
+                         "exchange (exchanged_bytes_per_rank over xGMI) comes on top" % R)}
         if world == 1 and not emu:
             if not a.no_verify:
                 # the record the timed loop left behind (the last scale's, for C5)

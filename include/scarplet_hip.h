@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 2
+#define SC_ABI_VERSION 3
 
 #define SC_OK               0
 #define SC_ERR_INVALID     -1   /* bad argument                                */
@@ -298,6 +298,19 @@ int sc_halo_exchange(sc_ctx* ctx, const double* core, int core_h, int core_w,
 int sc_gather_result(sc_ctx* ctx, int root, const int32_t* cores, int ny, int nx,
                      const double* param_of_id, const double* angle_of_id, int n_ids,
                      double* out);
+/*
+ * Fold of an orientation-sharded search: every rank holds the WHOLE DEM and searched its share
+ * of the templates, numbered globally in fold order (the reference's own parallelism: a pool
+ * over orientations, core.py:180-183, folded by compare(), core.py:198-243).  On return every
+ * rank's running-best record is the fold of all ranks' records: per cell the greatest SNR
+ * wins, equal SNRs go to the smaller id (the earlier template of the fold order - what a
+ * single context folding all templates keeps), a NaN SNR beats every number (sc_match's
+ * sticky NaN).  Two all-reduces over RCCL/xGMI: ncclMax on the 64-bit key
+ * (SNR bits << 32 | ~id), ncclSum on the amplitude (zeroed on the ranks that lost the cell).
+ * Collective: all ranks of the communicator call it, with the same core.  No communicator:
+ * nothing to do.
+ */
+int sc_fold_ranks(sc_ctx* ctx);
 int sc_comm_destroy(sc_ctx* ctx);
 
 #ifdef __cplusplus

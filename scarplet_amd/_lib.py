@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCARPLET_HIP_LIB") or os.path.join(_HERE, "libscarplet_hip.so")
 
 SC_OK = 0
-ABI_VERSION = 2
+ABI_VERSION = 3
 ID_NONE = 0xFFFFFFFF
 COMM_ID_BYTES = 128
 
@@ -108,6 +108,7 @@ SIGNATURES = {
                                    _dp, _dp, C.c_int, _dp]),
     "sc_halo_exchange": (C.c_int, [_P, _dp] + [C.c_int] * 6
                          + [C.POINTER(sc_xfer), C.c_int, C.POINTER(_P)]),
+    "sc_fold_ranks": (C.c_int, [_P]),
     "sc_comm_destroy": (C.c_int, [_P]),
 }
 
@@ -338,6 +339,10 @@ class Context(object):
         buf = C.create_string_buffer(bytes(uid), COMM_ID_BYTES)
         self._check(self.lib.sc_comm_init(self._h, buf, rank, nranks),
                     "sc_comm_init")
+
+    def fold_ranks(self):
+        """Collective fold of the ranks' running-best records (orientation-sharded search)."""
+        self._check(self.lib.sc_fold_ranks(self._h), "sc_fold_ranks")
 
     def gather_result(self, root, cores, shape, param_of_id, angle_of_id, is_root):
         """Collective final gather over RCCL; returns (4, ny, nx) on root."""

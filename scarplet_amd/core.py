@@ -142,9 +142,10 @@ class Matcher(object):
         return np.stack([amp, zero, zero.copy(), snr])
 
     # -- templates --------------------------------------------------------------
-    def describe(self, Template, scale, params, angles, id_base=0, **kwargs):
+    def describe(self, Template, scale, params, angles, id_base=0, id_of=None, **kwargs):
         """Descriptors for the (param, angle) grid, orientation-major.
-        Template (param ia, angle ib) gets id ``id_base + ia * n_angles + ib``.
+        Template (param ia, angle ib) gets id ``id_base + ia * n_angles + ib``, or
+        ``id_of(ia, ib)`` (dist.OrientationMatcher numbers them in fold order).
         Returns (ctypes array, support bbox union, max taps)."""
         n_par, n_ang = len(params), len(angles)
         arr = (_lib.sc_template * (n_par * n_ang))()
@@ -167,7 +168,7 @@ class Matcher(object):
                 s.cc, s.sc2, s.ss = cc, sc2, ss
                 s.ilo, s.ihi, s.jlo, s.jhi = desc["limits"]
                 s.pmin, s.pmax, s.qmin, s.qmax = desc["bbox"]
-                s.id = id_base + ia * n_ang + ib
+                s.id = id_base + ia * n_ang + ib if id_of is None else int(id_of(ia, ib))
                 s.window = desc.get("window", -1)
                 if s.pmax < s.pmin or s.qmax < s.qmin:
                     # empty support: a 1-cell box of zeros keeps the kernels

@@ -181,3 +181,49 @@ extern "C" int sc_gather_result(sc_ctx* ctx, int root, const int32_t* cores, int
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SC_OK;
 }
+
+// ---- fold of the running-best records of orientation-sharded ranks ---------------------
+// key = SNR bits (order-preserving for the non-negative SNRs; a NaN sorts above every number,
+// as the sticky NaN of sc_fold does) << 32 | ~id: ncclMax picks the greatest SNR and, among
+// equal SNRs, the smallest id - what one context folding all templates in id order keeps.
+__global__ void __launch_bounds__(256)
+k_fold_pack(const float* __restrict__ snr, const uint32_t* __restrict__ id,
+            unsigned long long* __restrict__ key, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        key[i] = ((unsigned long long)__float_as_uint(snr[i]) << 32) | (unsigned long long)(0xFFFFFFFFu - id[i]);
+}
+// the winner's SNR and id to every rank; the amplitude stays only where this rank held the winner
+__global__ void __launch_bounds__(256)
+k_fold_unpack(const unsigned long long* __restrict__ key, float* __restrict__ snr,
+              float* __restrict__ amp, uint32_t* __restrict__ id, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long k = key[i];
+        const uint32_t w = 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull);
+        if (id[i] != w || w == 0xFFFFFFFFu) amp[i] = 0.f;
+        id[i] = w;
+        snr[i] = __uint_as_float((uint32_t)(k >> 32));
+    }
+}
+
+extern "C" int sc_fold_ranks(sc_ctx* ctx) {
+    if (!ctx) return SC_ERR_INVALID;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    if (!ctx->comm) return SC_OK;          // (a one-rank communicator runs the whole sequence: the tests' handle on it)
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
+    int rc = sc_ensure(ctx, ctx->halo_stage, sizeof(unsigned long long) * nc);
+    if (rc) return rc;
+    unsigned long long* key = (unsigned long long*)ctx->halo_stage.p;
+    const int blocks = (int)std::min<size_t>((nc + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_fold_pack, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)ctx->best_snr.p,
+                       (const uint32_t*)ctx->best_id.p, key, nc);
+    SC_HIP(ctx, hipGetLastError());
+    SC_NCCL(ctx, ncclAllReduce(key, key, nc, ncclUint64, ncclMax, (ncclComm_t)ctx->comm, ctx->stream));
+    hipLaunchKernelGGL(k_fold_unpack, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned long long*)key,
+                       (float*)ctx->best_snr.p, (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p, nc);
+    SC_HIP(ctx, hipGetLastError());
+    SC_NCCL(ctx, ncclAllReduce(ctx->best_amp.p, ctx->best_amp.p, nc, ncclFloat, ncclSum,
+                               (ncclComm_t)ctx->comm, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SC_OK;
+}

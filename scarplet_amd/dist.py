@@ -1,4 +1,11 @@
-"""Multi-GPU search: one process per GPU, the DEM cut into a grid of tiles.
+"""Multi-GPU search, one process per GPU.  Two ways to shard:
+
+* by ORIENTATION (``OrientationMatcher``, at the end of this module): every rank holds the whole
+  DEM, searches a chunk of the orientation grid and the running-best records are folded over
+  RCCL - the reference's own pool-over-orientations + compare() (core.py:180-195), bit-identical
+  to the single-GPU search.  The way to go whenever the DEM fits one GPU;
+* by SPACE (``DistMatcher``), for DEMs that do not: the DEM cut into rectangles, described next.
+
 
 The reference has no distributed path (its only parallelism is a process pool
 over orientations, core.py:180-183); its authors tiled large DEMs by hand on
@@ -381,3 +388,115 @@ class DistMatcher(object):
             for k in range(4):
                 out[k][core[0]:core[1], core[2]:core[3]] = res[k]
         return tuple(out)
+
+
+# ---- orientation sharding -------------------------------------------------------------------
+def orientation_chunks(n_angles, nranks):
+    """[b0, b1) of the orientation grid for every rank: contiguous, in grid order, as even as
+    possible (a rank may get none when there are more ranks than orientations)."""
+    c = cuts(n_angles, nranks)
+    return [(int(c[r]), int(c[r + 1])) for r in range(nranks)]
+
+
+def fold_host(results):
+    """compare() (core.py:198-243) over the ranks' (4, ny, nx) records in rank order, started
+    from the first: a later rank replaces a cell only with a strictly greater SNR, which is
+    the smaller-id rule of sc_fold_ranks for ranks holding increasing orientation chunks.
+    NaN SNRs stick, as in sc_match."""
+    best = np.array(results[0], dtype=np.float64, copy=True)
+    for r in results[1:]:
+        r = np.asarray(r)
+        with np.errstate(invalid="ignore"):
+            take = (r[3] > best[3]) | (np.isnan(r[3]) & ~np.isnan(best[3]))
+        best[:, take] = r[:, take]
+    return best
+
+
+class OrientationMatcher(object):
+    """Per-rank driver of an orientation-sharded search - the reference's own parallelism
+    (a pool over orientations, core.py:180-183, folded by compare()) across GPUs.
+
+    Every rank holds the WHOLE DEM and searches a contiguous chunk of the orientation grid
+    with all ages; the ranks' running-best records are then folded into one
+    (``sc_fold_ranks``: two all-reduces over RCCL/xGMI, or ``fold_host`` through the
+    transport with the host backend).  The templates carry global ids in fold order
+    (orientation-major) and every rank plans for the support box of the WHOLE grid, so the
+    folded record is, bit for bit, the one a single context searching all orientations holds.
+    Use it whenever the DEM fits one GPU: no tile quantisation, no replicated template
+    transforms - the spatial DistMatcher is for DEMs that do not fit.
+
+    ``data`` is a DEMGrid (or anything Matcher accepts)."""
+
+    def __init__(self, rank, nranks, data, device=0, backend="rccl", broadcast_bytes=None,
+                 transport=None):
+        from scarplet_amd.core import Matcher
+        self.rank, self.nranks = rank, nranks
+        self.backend = "host" if backend == "gloo" else backend
+        self.transport = transport
+        if self.backend not in ("rccl", "host"):
+            raise ValueError("backend must be 'rccl' or 'host'")
+        if self.backend == "host" and nranks > 1 and transport is None:
+            raise ValueError("the host backend needs a transport (scarplet_amd/dist.py docstring)")
+        self.m = Matcher(data, device=device)
+        if self.backend == "rccl" and nranks > 1:
+            if broadcast_bytes is None:
+                if transport is None:
+                    raise ValueError("RCCL with more than one rank needs broadcast_bytes= or "
+                                     "transport= to share the communicator id")
+                broadcast_bytes = transport.broadcast_bytes
+            uid = self.m.ctx.comm_unique_id() if rank == 0 else None
+            uid = broadcast_bytes(uid)
+            self.m.ctx.comm_init(uid, rank, nranks)
+
+    def describe(self, Template, scale, params, angles, method="auto", group=None, **kwargs):
+        """(descriptors of this rank's chunk, plan struct): the whole grid is described - ids
+        ib * n_params + ia, the fold order - and planned for; the chunk is a slice of it."""
+        m = self.m
+        params = np.atleast_1d(np.asarray(params, dtype=float))
+        angles = np.atleast_1d(np.asarray(angles, dtype=float))
+        n_par = len(params)
+        arr, bbox, area = m.describe(Template, scale, params, angles,
+                                     id_of=lambda ia, ib: ib * n_par + ia, **kwargs)
+        m.plan, sp = m.plan_for(bbox, area, method, group, n_params=n_par)
+        b0, b1 = orientation_chunks(len(angles), self.nranks)[self.rank]
+        n = (b1 - b0) * n_par
+        mine = (_lib.sc_template * n).from_buffer(arr, b0 * n_par * _lib.C.sizeof(_lib.sc_template)) \
+            if n else None
+        m._id_par, m._id_ang = np.tile(params, len(angles)), np.repeat(angles, n_par)
+        m.params, m.angles = params, angles
+        self._keep = arr                      # the slice borrows its memory
+        return mine, sp
+
+    def run(self, mine, sp):
+        """One search step: reset, this rank's templates, fold over the ranks."""
+        ctx = self.m.ctx
+        ctx.reset_best()
+        if mine is not None:
+            ctx.match(mine, sp)
+        self._folded = None
+        if self.backend == "rccl":
+            ctx.fold_ranks()
+        elif self.nranks > 1:
+            parts = self.transport.gather(self.m.result_array(), 0)
+            self._folded = fold_host(parts) if self.rank == 0 else None
+
+    def search(self, Template, scale, params, angles, method="auto", group=None, **kwargs):
+        if getattr(self.m, "nan_dem", False):      # the reference's all-NaN maps, on every rank
+            self.m.search(Template, scale, params, angles, method=method, **kwargs)
+            self._nan = True
+            return self
+        self._nan = False
+        mine, sp = self.describe(Template, scale, params, angles, method, group, **kwargs)
+        self.run(mine, sp)
+        return self
+
+    def result_array(self):
+        """(4, ny, nx): amp, age, angle, snr - on every rank with the 'rccl' backend (the fold is
+        an all-reduce), on rank 0 only (None elsewhere) with the host backend."""
+        if self.backend == "rccl" or self.nranks == 1 or getattr(self, "_nan", False):
+            return self.m.result_array()
+        return self._folded
+
+    def result(self):
+        out = self.result_array()
+        return None if out is None else tuple(out)

@@ -181,3 +181,31 @@ def test_halo_for_search_covers_the_reach():
     # output cell i reads curvature rows i - pmax + oy .. i - pmin + oy, +1 for the stencil
     assert sd.halo_for_search((-10, 9, -5, 6), 100, 101) == (10, 11, 6, 7)
     assert sd.halo_for_search((-10, 9, -5, 6), 101, 100) == (9, 12, 7, 6)
+
+
+def test_orientation_chunks_and_host_fold():
+    for (n, r) in [(181, 8), (35, 2), (3, 5), (91, 4)]:
+        ch = sd.orientation_chunks(n, r)
+        assert len(ch) == r and ch[0][0] == 0 and ch[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(ch, ch[1:]))
+        sizes = [b - a for a, b in ch]
+        assert max(sizes) - min(sizes) <= 1
+    # fold_host: greatest SNR wins, ties keep the earlier rank, NaN sticks
+    rng = np.random.default_rng(3)
+    parts = []
+    for r in range(4):
+        snr = rng.integers(0, 5, size=(6, 7)).astype(float)          # many exact ties
+        parts.append(np.stack([snr + 10 * (r + 1), np.full((6, 7), r + 1.0), np.full((6, 7), -r - 1.0), snr]))
+    parts[2][3, 1, 1] = np.nan
+    got = sd.fold_host(parts)
+    for i in range(6):
+        for j in range(7):
+            col = [p[3, i, j] for p in parts]
+            if (i, j) == (1, 1):
+                first_nan = 2
+                before = max(range(2), key=lambda r: (col[r], -r))
+                want = first_nan if not np.isnan(col[before]) else before
+                assert np.isnan(got[3, i, j]) and got[1, i, j] == want + 1
+                continue
+            want = max(range(4), key=lambda r: (col[r], -r))            # max SNR, then the earliest rank
+            assert got[3, i, j] == col[want] and got[1, i, j] == want + 1 and got[0, i, j] == col[want] + 10 * (want + 1)

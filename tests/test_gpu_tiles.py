@@ -7,7 +7,7 @@ import pytest
 
 import scarplet_oracle as orc
 import scarplet_amd as sl
-from scarplet_amd import _plan, dist as sd, synthetic
+from scarplet_amd import _lib, _plan, dist as sd, synthetic
 
 pytestmark = pytest.mark.gpu
 
@@ -151,3 +151,72 @@ def test_c4_eight_rank_blocks_at_full_size(partition):
     assert np.allclose(whole[3][~same], tiled[3][~same], rtol=tie)
     assert np.allclose(whole[0][same], tiled[0][same], rtol=2e-4, atol=2e-6 * np.abs(whole[0]).max())
     assert np.allclose(whole[3][same], tiled[3][same], rtol=2e-3, atol=2e-6 * whole[3].max())
+
+
+# ---- orientation sharding (dist.OrientationMatcher) ------------------------------------------
+def _fold_raw(parts):
+    """sc_fold_ranks on the host: per cell the greatest SNR, equal SNRs to the smaller id; the
+    amplitude follows the winner.  parts: [(amp, snr, id)] float32 / float32 / uint32."""
+    amp, snr, idx = [np.array(a, copy=True) for a in parts[0]]
+    for (a, s, i) in parts[1:]:
+        ks = (snr.view(np.uint32).astype(np.uint64) << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - idx.astype(np.uint64))
+        kt = (s.view(np.uint32).astype(np.uint64) << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - i.astype(np.uint64))
+        take = kt > ks
+        amp[take], snr[take], idx[take] = a[take], s[take], i[take]
+    return amp, snr, idx
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+@pytest.mark.parametrize("method", ["fft", "direct"])
+def test_orientation_chunks_fold_to_the_single_search_bit_for_bit(nranks, method):
+    """Every rank's chunk of the orientation grid searched on its own (whole DEM, ids in fold
+    order, the plan of the whole grid) and the records folded as sc_fold_ranks folds them:
+    amplitude, SNR and winner id equal the single search's in every bit - exact ties
+    included (a noise-free surface has many)."""
+    for (g, Template, scale) in [(synthetic.synthetic_scarp(230, seed=4, ny=200), sl.Scarp, 14),
+                                 (synthetic.synthetic_scarp(128, seed=2, sigma=0.0), sl.Scarp, 10)]:
+        params = [1.0, 4.0, 20.0, 100.0]
+        angles = _plan.angle_grid(-np.pi / 2, np.pi / 2)[::17]          # 11 orientations
+        om = sd.OrientationMatcher(0, 1, g)
+        ctx, n_par = om.m.ctx, len(params)
+        mine, sp = om.describe(Template, scale, params, angles, method=method)
+        assert len(mine) == n_par * len(angles)
+        om.run(mine, sp)
+        whole = ctx.get_best()
+        whole_arr = om.result_array()
+        parts, arrs = [], []
+        for (b0, b1) in sd.orientation_chunks(len(angles), nranks):
+            ctx.reset_best()
+            if b1 > b0:
+                sub = (type(mine[0]) * ((b1 - b0) * n_par)).from_buffer(om._keep, b0 * n_par * _lib.C.sizeof(type(mine[0])))
+                ctx.match(sub, sp)
+            parts.append(ctx.get_best())
+            arrs.append(om.m.result_array())
+        amp, snr, idx = _fold_raw(parts)
+        assert np.array_equal(idx, whole[2])
+        assert np.array_equal(snr.view(np.uint32), whole[1].view(np.uint32))
+        assert np.array_equal(amp.view(np.uint32), whole[0].view(np.uint32))
+        # and through the host fold of the decoded (amp, age, angle, snr) planes
+        assert np.array_equal(sd.fold_host(arrs), whole_arr)
+        # the ids decode in fold order: the single search through Matcher gives the same maps
+        ref = sl.Matcher(g).search(Template, scale, params, angles, method=method).result_array()
+        assert np.array_equal(ref, whole_arr)
+
+
+def test_fold_ranks_with_a_one_rank_communicator():
+    """sc_fold_ranks end to end on the hardware there is: pack, ncclAllReduce(max, uint64),
+    unpack, ncclAllReduce(sum, float) - with one rank the record must come back unchanged,
+    cells nobody won (id 0xFFFFFFFF, window-limit border) included."""
+    g = synthetic.synthetic_scarp(150, seed=8, ny=140)
+    om = sd.OrientationMatcher(0, 1, g)
+    ctx = om.m.ctx
+    ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+    mine, sp = om.describe(sl.Scarp, 12, [2.0, 30.0], _plan.angle_grid(-1.0, 1.0)[::20], method="fft")
+    ctx.reset_best()
+    ctx.match(mine, sp)
+    before = ctx.get_best()
+    assert (before[2] == 0xFFFFFFFF).any() and (before[2] != 0xFFFFFFFF).any()
+    ctx.fold_ranks()
+    after = ctx.get_best()
+    for a, b in zip(before, after):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

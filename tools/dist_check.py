@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Bring-up check of the N>1 code path: tiled search through DistMatcher under
-torch.distributed, gathered on rank 0 and compared with a single-context search.
-Usage (2 ranks sharing one GPU, host-side halo exchange):
+"""Bring-up check of the N>1 code paths under torch.distributed, compared on rank 0 with a
+single-context search: the orientation-sharded search (OrientationMatcher: must be identical
+in every bit) and the tiled search (DistMatcher: identical outside the tie window).
+Usage (2 ranks sharing one GPU, host-side exchange):
   python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 \
       tools/dist_check.py --halo gloo"""
 import argparse, os, sys
@@ -21,15 +22,25 @@ a = ap.parse_args()
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 ndev = max(1, _lib.load().sc_device_count())
+dev = int(os.environ.get("LOCAL_RANK", 0)) % ndev
 g = synthetic.synthetic_scarp(a.n, ny=a.n - 60)
 z = g._griddata
 ages, angles = [3.0, 30.0, 300.0], _plan.angle_grid(-1.0, 1.0)[::10]
-dm = sd.DistMatcher(rank, world, z.shape, 1.0, 1.0, device=int(os.environ.get("LOCAL_RANK", 0)) % ndev, backend=a.halo, transport=TorchTransport())
+ref = sl.Matcher(g, device=0).search(sl.Scarp, 30, ages, angles, method="fft").result_array() if rank == 0 else None
+
+om = sd.OrientationMatcher(rank, world, g, device=dev, backend=a.halo, transport=TorchTransport())
+full = om.search(sl.Scarp, 30, ages, angles, method="fft").result_array()
+if rank == 0:
+    print("ranks %d, orientation chunks %s: identical to the single search in every bit: %s" % (
+        world, sd.orientation_chunks(len(angles), world), bool(np.array_equal(full, ref))))
+    assert np.array_equal(full, ref)
+del om
+
+dm = sd.DistMatcher(rank, world, z.shape, 1.0, 1.0, device=dev, backend=a.halo, transport=TorchTransport())
 c = dm.prepare(sl.Scarp, 30, ages, angles)      # cores of whole FFT tiles where that helps, else the grid
 dm.search(sl.Scarp, 30, ages, angles, np.ascontiguousarray(z[c[0]:c[1], c[2]:c[3]]), method="fft")
 full = dm.gather(0)
 if rank == 0:
-    ref = sl.Matcher(g, device=0).search(sl.Scarp, 30, ages, angles, method="fft").result()
     same = (ref[1] == full[1]) & (ref[2] == full[2])
     print("ranks %d grid %s: same params %.5f, max |d snr| where same %.3g, max rel snr diff elsewhere %.3g" % (
         world, sd.grid_dims(world, *z.shape), same.mean(), np.abs(ref[3] - full[3])[same].max(),
