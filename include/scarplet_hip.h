@@ -143,9 +143,10 @@ int sc_clear_windows(sc_ctx* ctx);
  *   "kappa"    float32 resolution floor of the FFT epilogue in units of eps32
  *              (default 4; 0 switches the floor off; sc_internal.h sc_epi_floor)
  *   "variant"  alternative kernel paths kept for cross-checks in the tests:
- *              0 default, 5 no paired-template mode, 6 inverse column pass as two
- *              launches per tile pair (own columns, mirrors) instead of the merged
- *              kernel, 7 template spectra by the
+ *              0 default, 3 inverse column pass by the merged kernel (a column block
+ *              and its mirror in one workgroup), 5 no paired-template mode, 6 inverse
+ *              column pass as two launches per tile pair (own columns, mirrors) instead
+ *              of one launch with the two kinds paired per XCD, 7 template spectra by the
  *              separate column-transform and split kernels, 8 complex-spectrum I1 for
  *              symmetric templates, 9 generic row kernel at every tile size
  *   "batch"    1 (default): searches whose single orientation does not fill the

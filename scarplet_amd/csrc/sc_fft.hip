@@ -9,7 +9,10 @@
 //   S    k_split_templ_sym  Scarp / Ricker: FFT(W) = {i} a P, FFT(M) = b P with a, b
 //                           real (flip symmetry of the template): store a, b only
 //        k_split_templ      any other template: FFT(W), FFT(M) as complex half planes
-//   I1   k_inv_cols_sym     Y = a * (X P {i}) per column block, inverse column FFT;
+//   I1   k_inv_cols_symx    Y = a * (X P {i}) per column block, inverse column FFT; column
+//                           blocks and their mirrors in one launch, paired per XCD
+//        k_inv_cols_sym     the same as two launches (small tiles; cross-check variant 6)
+//        k_inv_cols_msym    a block and its mirror in one workgroup (cross-check variant 3)
 //        k_inv_cols         the same with complex spectra
 //   I2   k_inv_rows_fast    inverse row FFT -> xcorr(A) + i xcorr(B), T3 likewise;
 //        k_inv_rows         float32 amp/SNR epilogue, masks, running-best fold
@@ -1041,8 +1044,8 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
 // real part is template g's result and whose imaginary part is template g+1's
 // (X is the spectrum of ONE real tile).  Plane k of Y holds templates 2k, 2k+1.
 template <int TY, bool MIRROR, bool PT>
-__global__ void __launch_bounds__(fft_threads(TY), 2)
-k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
+__device__ __forceinline__ void
+inv_cols_sym_body(const int cbx, const float2* __restrict__ uc, const float2* __restrict__ uc2,
                const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
                int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
                int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
@@ -1059,7 +1062,7 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
     constexpr int NT = fft_threads(TY);
     constexpr int EP = 4 * TY / (2 * NT);     // 2-cell loads per thread per stream
     float4* xs = reinterpret_cast<float4*>(sm + 4 * fft_line(TY));   // parked spectrum, linear
-    const int cb = cb0 + blockIdx.x;
+    const int cb = cb0 + cbx;
     // several jobs per launch (grid.y), see k_inv_cols
     {
         const int ob = blockIdx.y / pcj, q = blockIdx.y - ob * pcj;
@@ -1181,6 +1184,46 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
             lds_barrier();
         }
     }
+}
+
+
+template <int TY, bool MIRROR, bool PT>
+__global__ void __launch_bounds__(fft_threads(TY), 2)
+k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
+               const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
+               int cb0, int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
+               int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
+               float2* __restrict__ ym, int ystride, int dbg, int np, int pcj, int tstride,
+               const TileDev* __restrict__ tiles, int py_valid) {
+    inv_cols_sym_body<TY, MIRROR, PT>((int)blockIdx.x, uc, uc2, wa, mb, Tx, cb0, pair, vfirst, G, rp_lo, rp_hi, phx,
+                                      parity, tw, yw, ym, ystride, dbg, np, pcj, tstride, tiles, py_valid);
+}
+
+// Both halves in ONE launch, a column block and the mirror block that streams (three of four
+// columns of) the same coefficients eight workgroup ids apart: the same XCD, started together,
+// so that the second read of a coefficient line hits that XCD's L2 instead of going to HBM
+// again (k_inv_rows_fast pairs its sibling rows the same way).  Workgroup j: group j / 16,
+// kind (j / 8) & 1, index i = 8 (j / 16) + j % 8; kind 0 is column block i, kind 1 the mirror
+// block Tx/4 - 1 - i, whose coefficient columns are 4i+1 .. 4i+4.  Measured on the sustained
+// C3 run: 728 us per tile pair against 745 (merged kernel) and 2 x 374 (two launches); C2,
+// paired templates: 985 against 2 x 557.  (Giving every XCD a CONTIGUOUS range of blocks, so
+// that the fourth column is shared too, is 13 % slower: each XCD then writes a 2-KB stripe of
+// every row and loads a few L2 channels only.)  profiles/r02_i1_xcd_paired.txt
+template <int TY, bool PT>
+__global__ void __launch_bounds__(fft_threads(TY), 2)
+k_inv_cols_symx(const float2* __restrict__ uc, const float2* __restrict__ uc2,
+                const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
+                int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
+                int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
+                float2* __restrict__ ym, int ystride, int dbg, int np, int pcj, int tstride,
+                const TileDev* __restrict__ tiles, int py_valid) {
+    const int j = blockIdx.x, i = ((j >> 4) << 3) | (j & 7);
+    if ((j >> 3) & 1)
+        inv_cols_sym_body<TY, true, PT>((Tx >> 2) - 1 - i, uc, uc2, wa, mb, Tx, 0, pair, vfirst, G, rp_lo, rp_hi, phx,
+                                        parity, tw, yw, ym, ystride, dbg, np, pcj, tstride, tiles, py_valid);
+    else
+        inv_cols_sym_body<TY, false, PT>(i, uc, uc2, wa, mb, Tx, 0, pair, vfirst, G, rp_lo, rp_hi, phx,
+                                         parity, tw, yw, ym, ystride, dbg, np, pcj, tstride, tiles, py_valid);
 }
 
 // ---- I1 for symmetric templates, a column block and its mirror in one workgroup ----
@@ -2148,7 +2191,9 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     //  registers - costs more than that of the two plain launches, which single-age searches
     //  notice: C1 1.03 -> 1.31 ms)
     const bool merged = sym && fast && (fg.Ty == 512 || fg.Ty == 1024 || fg.Ty == 2048) && n >= 8 &&
-                        ctx->variant != 6;
+                        ctx->variant == 3;
+    // block and mirror workgroups of the two-launch form in one launch, paired per XCD (k_inv_cols_symx)
+    const bool symx = sym && ctx->variant != 6 && ctx->variant != 3 && fg.Ty >= 512 && fg.Ty <= 2048 && (fg.Tx / 8) % 8 == 0;
     if (nb > 1 && (!fast || n > group || nb * n > SC_MAX_GROUP))
         return sc_fail(ctx, SC_ERR_INVALID, "orientation batching outside its conditions");
     // One chunk = pc tile pairs through I1 and I2, group by group.  PTV: the chunk is a
@@ -2173,7 +2218,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             const int pair = pair0 + pl0;
             float2* ywp = (float2*)ctx->yw.p + (size_t)pl0 * yblock;
             float2* ymp = (float2*)ctx->ym.p + (size_t)pl0 * yblock;
-            n_i1 += (merged && !PTV) ? 1 : 2;   // one merged launch, or own columns + mirrors
+            n_i1 += ((merged && !PTV) || symx) ? 1 : 2;   // one merged launch, or own columns + mirrors
 #define COL_ARGS(CB0)                                                          \
     ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float2*)ctx->wh.p, \
         (const float2*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, ctx->dbg,        \
@@ -2183,6 +2228,16 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         (const float*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi,                    \
         (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group
 #define SYM_ARGS_D(CB0) SYM_ARGS(CB0), ctx->dbg, np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py
+#define FN_SYMX(T)                                                             \
+    {                                                                          \
+        int rc = set_lds(ctx, k_inv_cols_symx<T, PTV>, inv_cols_lds<T>());     \
+        if (rc) return rc;                                                     \
+        hipLaunchKernelGGL((k_inv_cols_symx<T, PTV>), dim3(fg.Tx / 4, nb * pcc), dim3(fft_threads(T)), \
+                           inv_cols_lds<T>(), ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, \
+                           (const float*)ctx->wh.p, (const float*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo, rp_hi, \
+                           (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group, \
+                           ctx->dbg, np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py); \
+    }
 #define FN_SYM(T)                                                              \
     {                                                                          \
         int rc = set_lds(ctx, k_inv_cols_sym<T, false, PTV>, inv_cols_lds<T>());    \
@@ -2226,6 +2281,12 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                     case 1024: FN_MSYM(1024); break;
                     default: FN_MSYM(2048); break;
                 }
+            } else if (sym && symx) {
+                switch (fg.Ty) {
+                    case 512: FN_SYMX(512); break;
+                    case 1024: FN_SYMX(1024); break;
+                    default: FN_SYMX(2048); break;
+                }
             } else if (sym) {
                 switch (fg.Ty) {
                     case 64: FN_SYM(64); break;
@@ -2240,6 +2301,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             }
 #undef FN
 #undef FN_SYM
+#undef FN_SYMX
 #undef FN_MSYM
 #undef SYM_ARGS_D
 #undef SYM_ARGS

@@ -21,12 +21,18 @@ ap.add_argument("--angles", type=int, default=181)
 ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--warmup", type=int, default=1)
 ap.add_argument("--reset", default="variant=0", help="options restored before every set")
+ap.add_argument("--c2", action="store_true", help="BASELINE config C2 instead: 2048^2, 10 ages x 91 orientations")
 a = ap.parse_args()
+if a.c2:
+    a.n = 2048
 
 g = synthetic.synthetic_scarp(a.n)
 m = sl.Matcher(g)
 ages = _plan.age_grid()
 angs = _plan.angle_grid()[np.round(np.linspace(0, 180, a.angles)).astype(int)]
+if a.c2:
+    ages = ages[np.round(np.linspace(0, 34, 10)).astype(int)]
+    angs = _plan.angle_grid(-np.pi / 4, np.pi / 4)
 arr, bbox, area = m.describe(sl.Scarp, 100, ages, angs)
 plan, sp = m.plan_for(bbox, area, "fft", None, n_params=len(ages))
 units = a.n * a.n * len(ages) * len(angs) / 1e6
