@@ -1226,6 +1226,179 @@ k_inv_cols_symx(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                                          parity, tw, yw, ym, ystride, dbg, np, pcj, tstride, tiles, py_valid);
 }
 
+// ---- I1 for symmetric templates, one WAVE per column ----------------------------------
+// The kernels above transform four columns with 512 threads: every thread owns one 16-point
+// set per stage, and the eight waves meet at a workgroup barrier between reading and writing
+// every stage (seven barriers per template and plane) - LDS passes and butterflies of the
+// whole workgroup alternate instead of overlapping, and the transforms alone cost 4 us per
+// four columns where the LDS traffic is worth 1.8 (ISA count: 336 packed VALU and 90 LDS
+// instructions per wave and template).  A column's transform only needs the threads working
+// on that column to agree.  Here a workgroup takes EIGHT columns and each of its eight waves
+// owns one: two sets per lane and stage, ordered by the wave's own instruction stream (LDS
+// executes a wave's instructions in order) - no barrier inside a transform, the waves drift
+// apart and one wave's LDS pass runs under another's butterflies.
+//  * The lane's cells of its column are fy = lane + 64 k, k = 0 .. 31 - exactly the inputs of
+//    its two stage-1 sets (set tt reads tt + 128 j): the coefficient products go straight into
+//    the first butterflies, no fill pass through LDS.  The phase-multiplied curvature spectrum
+//    of those cells is parked in 64 registers (LDS holds the eight lines and nothing else).
+//  * Two workgroup barriers per template and plane remain: lines complete -> store pass
+//    (a wave stores whole 128-byte lines: 8 columns x 2 rows, the rows2 block I2 reads),
+//    and store pass done -> next stage-1 writes.
+//  * Same butterflies, twiddles and operand order as fft4_lines: Y is bit-identical.
+// Column blocks and mirror blocks are paired per XCD as in k_inv_cols_symx.
+template <int TY>
+__host__ __device__ constexpr int w8_line() { return TY + TY / 16 + 4; }   // lines 8 banks apart: the store pass reads 8 lines x 2 cells
+template <int TY>
+__host__ __device__ constexpr size_t w8_lds() {          // eight lines + the twiddle bases of stages 1 and 2
+    return ((size_t)8 * w8_line<TY>() + 4 * (TY / 16) + 4 * (TY / 256)) * sizeof(float2);
+}
+
+template <int TY, bool MIRROR>
+__device__ __forceinline__ void
+inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, const float2* __restrict__ uc2,
+                 const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
+                 int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
+                 int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
+                 float2* __restrict__ ym, int ystride, int np, int pcj, int tstride,
+                 const TileDev* __restrict__ tiles, int py_valid) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    constexpr int S = TY / 16;                 // 16-point sets per line
+    static_assert(S % 64 == 0 && S / 64 <= 2, "one wave per line: 64 or 128 sets");
+    constexpr int U = S / 64;                  // sets per lane and stage
+    constexpr int NK = 16 * U;                 // cells per lane
+    constexpr int LINE = w8_line<TY>();
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    float2* line = sm + w * LINE;
+    {
+        const int ob = jobx / pcj, q = jobx - ob * pcj;
+        if (py_valid >= 0) {
+            const int vy = max(tiles[2 * (pair + q)].vy, tiles[2 * (pair + q) + 1].vy);
+            rp_hi = min(rp_hi, (py_valid + vy - 1) >> 1);
+        }
+        pair += ob * np + q;
+        vfirst += ob * tstride;
+    }
+    const size_t plane = (size_t)TY * Tx, hplane = half_plane(TY, Tx);
+    yw += (size_t)jobx * ystride * plane;
+    ym += (size_t)jobx * ystride * plane;
+    const int ft = 8 * B + w;                  // this wave's column of Y
+    const int fs = MIRROR ? Tx - ft : ft;      // the coefficient column it pairs with
+    // twiddle bases of the sets (FftTw's, per set: stage 1 w^tt, stage 2 w^(16 (tt >> 4)), times
+    // 1, 2, 4, 8) in an LDS table behind the lines, [m][tt] and [m][tt >> 4]: 64 registers of
+    // parked spectrum leave no room for them
+    float2* t1 = sm + 8 * LINE;
+    float2* t2 = t1 + 4 * S;
+    for (int i = threadIdx.x; i < 4 * S; i += 512) t1[i] = tw[(i % S) << (i / S)];
+    for (int i = threadIdx.x; i < 4 * (S / 16); i += 512) t2[i] = tw[((i % (S / 16)) << 4) << (i / (S / 16))];
+    auto tw_of = [&](const float2* t, int n, int idx, float2 (&wq)[4]) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) wq[m] = t[m * n + idx];
+    };
+    float c[NK];
+    for (int pl = 0; pl < 2; ++pl) {
+        const float2* xcol = (pl ? uc2 : uc) + (size_t)pair * plane + (size_t)ft * TY;
+        const float* hsrc = (pl ? mb : wa) + (size_t)vfirst * hplane + (size_t)fs * TY;
+        const bool rot = pl == 0 && parity == 1;          // odd W: factor i (own columns) / -i (mirrors)
+        // ---- park X P {i} of the lane's cells (the arithmetic of k_inv_cols_sym, cell for cell)
+        float2 xp[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int fy = lane + 64 * k;
+            float2 pv;
+            if (!MIRROR) {
+                pv = phase_tab(tw + TY, phx, fy, ft);
+            } else {
+                pv = phase_tab(tw + TY, phx, (TY - fy) & (TY - 1), (Tx - ft) & (Tx - 1));
+                pv.y = -pv.y;
+            }
+            float2 v = cmul(xcol[fy], pv);
+            if (rot) v = MIRROR ? make_float2(v.y, -v.x) : make_float2(-v.y, v.x);
+            xp[k] = v;
+        }
+        // coefficient of cell fy: a[fs][fy], mirrors a[fs][-fy mod TY] = a[fs][TY - lane - 64 k] but for
+        // fy = 0 - one base per lane and compile-time offsets either way
+        const float* cbase = hsrc + (MIRROR ? TY - lane : lane);
+        const int c0off = (MIRROR && lane == 0) ? -TY : 0;
+        auto fetch = [&](int gi_) {
+            const float* p = cbase + (size_t)gi_ * hplane;
+            c[0] = p[c0off];
+#pragma unroll
+            for (int k = 1; k < NK; ++k) c[k] = p[MIRROR ? -64 * k : 64 * k];
+        };
+        fetch(0);
+        for (int gi_ = 0; gi_ < G; ++gi_) {
+            lds_barrier();                                   // the store pass of the previous transform is done with the lines
+            float2 wq[4];
+            // (LDS addresses rebuilt from the lane id in every transform, see the store pass)
+            int lt = lane;
+            asm volatile("" : "+v"(lt));
+            // stage 1 set by set, straight from the products: cell k = u + U j is input j of set u
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float2 a1[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int k = u + U * j;
+                    a1[j] = make_float2(c[k] * xp[k].x, c[k] * xp[k].y);
+                }
+                tw_of(t1, S, lt + 64 * u, wq);
+                set_compute_store<TY, 16, 0, true>(line, lt + 64 * u, a1, wq);
+            }
+            if (gi_ + 1 < G) fetch(gi_ + 1);
+            asm volatile("" ::: "memory");
+            float2 a[U][16];
+#pragma unroll
+            for (int u = 0; u < U; ++u) set_load<TY>(line, lt + 64 * u, a[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                tw_of(t2, S / 16, (lt + 64 * u) >> 4, wq);
+                set_compute_store<TY, 16, 4, true>(line, lt + 64 * u, a[u], wq);
+            }
+            asm volatile("" ::: "memory");
+            if constexpr (TY > 256) {
+                constexpr int R3 = TY / 256;
+#pragma unroll
+                for (int u = 0; u < U; ++u) set_load<TY>(line, lt + 64 * u, a[u]);
+#pragma unroll
+                for (int u = 0; u < U; ++u) set_compute_store<TY, R3, 8, true>(line, lt + 64 * u, a[u], wq);
+            }
+            lds_barrier();                                   // all eight lines are complete
+            // ---- store: lane (q, c) of wave w takes column c of row pair rp_lo + 8 w + 64 it + q:
+            // eight lanes write one 128-byte rows2 block
+            // (addresses rebuilt from the lane id every time: kept across the transform they would be
+            //  spilled, and a scratch reload here waits for the coefficient prefetch and the stores)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            float2* o = (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)B * 16 + 2 * (ln & 7);
+            const float2* lc = sm + (ln & 7) * LINE;
+#pragma unroll 2
+            for (int rp = rp_lo + 8 * w + (ln >> 3); rp <= rp_hi; rp += 64)
+                store_stream(o + (size_t)rp * (Tx >> 3) * 16, lc[ph(2 * rp)], lc[ph(2 * rp + 1)]);
+        }
+        lds_barrier();                                       // (the next plane's first barrier would do; kept simple)
+    }
+}
+
+// grid.x = Tx/8 workgroups j: index i = 8 (j / 16) + j % 8 in [0, Tx/16); (j / 8) & 1 = 0: column
+// block i (columns 8i .. 8i+7), 1: the mirror block Tx/8 - 1 - i, whose coefficient columns
+// are 8i+1 .. 8i+8 - the partner's but one, eight workgroup ids away on the same XCD.
+template <int TY>
+__global__ void __launch_bounds__(512, 2)
+k_inv_cols_w8(const float2* __restrict__ uc, const float2* __restrict__ uc2,
+              const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
+              int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
+              int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
+              float2* __restrict__ ym, int ystride, int np, int pcj, int tstride,
+              const TileDev* __restrict__ tiles, int py_valid) {
+    const int j = blockIdx.x, i = ((j >> 4) << 3) | (j & 7);
+    if ((j >> 3) & 1)
+        inv_cols_w8_body<TY, true>((Tx >> 3) - 1 - i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
+                                   rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid);
+    else
+        inv_cols_w8_body<TY, false>(i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
+                                    rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid);
+}
+
 // ---- I1 for symmetric templates, a column block and its mirror in one workgroup ----
 // k_inv_cols_sym runs twice per tile pair, once for the columns fx < Tx/2 and once for their
 // mirrors Tx - fx, and both launches stream the same real coefficients a[fx][fy]
@@ -2194,6 +2367,8 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                         ctx->variant == 3;
     // block and mirror workgroups of the two-launch form in one launch, paired per XCD (k_inv_cols_symx)
     const bool symx = sym && ctx->variant != 6 && ctx->variant != 3 && fg.Ty >= 512 && fg.Ty <= 2048 && (fg.Tx / 8) % 8 == 0;
+    // one wave per column (k_inv_cols_w8): tile pairs with both tiles, column length 1024 / 2048
+    const bool w8 = symx && ctx->variant != 2 && (fg.Ty == 2048 || fg.Ty == 1024) && (fg.Tx / 16) % 8 == 0;
     if (nb > 1 && (!fast || n > group || nb * n > SC_MAX_GROUP))
         return sc_fail(ctx, SC_ERR_INVALID, "orientation batching outside its conditions");
     // One chunk = pc tile pairs through I1 and I2, group by group.  PTV: the chunk is a
@@ -2238,6 +2413,16 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                            (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group, \
                            ctx->dbg, np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py); \
     }
+#define FN_W8(T)                                                               \
+    {                                                                          \
+        int rc = set_lds(ctx, k_inv_cols_w8<T>, w8_lds<T>());                  \
+        if (rc) return rc;                                                     \
+        hipLaunchKernelGGL((k_inv_cols_w8<T>), dim3(fg.Tx / 8, nb * pcc), dim3(512),       \
+                           w8_lds<T>(), ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, \
+                           (const float*)ctx->wh.p, (const float*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo, rp_hi, \
+                           (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group, \
+                           np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py); \
+    }
 #define FN_SYM(T)                                                              \
     {                                                                          \
         int rc = set_lds(ctx, k_inv_cols_sym<T, false, PTV>, inv_cols_lds<T>());    \
@@ -2281,6 +2466,8 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                     case 1024: FN_MSYM(1024); break;
                     default: FN_MSYM(2048); break;
                 }
+            } else if (w8 && !PTV) {
+                if (fg.Ty == 2048) FN_W8(2048) else FN_W8(1024)
             } else if (sym && symx) {
                 switch (fg.Ty) {
                     case 512: FN_SYMX(512); break;
@@ -2302,6 +2489,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
 #undef FN
 #undef FN_SYM
 #undef FN_SYMX
+#undef FN_W8
 #undef FN_MSYM
 #undef SYM_ARGS_D
 #undef SYM_ARGS
