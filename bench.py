@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_UNIT = 28.0        # bytes per px.template
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
 # profiling slot of the library -> kernel symbols as rocprofv3 lists them
-KERNEL_SYMBOLS = {"k_inv_cols": "k_inv_cols_symx<T,PT>", "k_inv_rows": "k_inv_rows_fast<T,false,false,false>"}
+KERNEL_SYMBOLS = {"k_inv_cols": "k_inv_cols_w8<T> (paired-template chunks: k_inv_cols_symx<T,true>)", "k_inv_rows": "k_inv_rows_fast<T,false,false,false>"}
 
 
 def parse():
@@ -448,10 +448,14 @@ def main():
                          "avg_launch_us": round(1e6 * avg_s, 2),
                          "pipeline_frac": round(value * 1e6 * ALGO_BYTES_PER_UNIT / (HBM_PEAK_GBS * 1e9 * world), 4),
                          "note": "frac follows the prescribed formula (28 B x the launch's px.templates / its "
-                                 "duration) and credits the dominant kernel with the whole path's bytes; "
-                                 "pipeline_frac is the whole search against 8 TB/s / 28 B"},
+                                 "duration): it credits the dominant kernel, which runs for about half of the "
+                                 "step, with the whole path's bytes and can therefore exceed 1; pipeline_frac is "
+                                 "the whole search against 8 TB/s / 28 B; kernel_hbm_frac (with traffic) is the "
+                                 "kernel's PMC-measured bytes per launch / its duration / 8 TB/s"},
             "kernels_ms_per_step": {k: round(v[1] / a.steps, 2) for k, v in prof.items() if v[0]},
         }
+        if out["roofline"]["traffic"] and avg_s > 0:
+            out["roofline"]["kernel_hbm_frac"] = round(out["roofline"]["traffic"] / avg_s / (HBM_PEAK_GBS * 1e9), 4)
         if emu:
             R, part_label, cores_, per_block, halo_bytes, plans = emu
             pb = per_block / a.steps

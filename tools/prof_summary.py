@@ -48,7 +48,7 @@ so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "
 h = hashlib.sha256(open(so, "rb").read()).hexdigest()
 out = {"so_sha256": h, "bytes_per_launch": {}, "detail": {},
        "_note": "bytes per kernel launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, bench.py "
-                "--angles 2), FETCH_SIZE doubled per MI355X_MICROARCH.md; k_inv_cols = mean k_inv_cols_symx launch "
+                "--angles 2), FETCH_SIZE doubled per MI355X_MICROARCH.md; k_inv_cols = mean k_inv_cols_w8 launch "
                 "(one tile pair, 35 templates, all columns), k_inv_rows = mean k_inv_rows_fast launch"}
 for key, pred in (("k_inv_cols", lambda n: "k_inv_cols" in n), ("k_inv_rows", lambda n: "k_inv_rows" in n)):
     f_, w_ = kib("pmc_fetch", "FETCH_SIZE", pred), kib("pmc_write", "WRITE_SIZE", pred)
