@@ -1253,7 +1253,7 @@ __host__ __device__ constexpr size_t w8_lds() {          // eight lines + the tw
     return ((size_t)8 * w8_line<TY>() + 4 * (TY / 16) + 4 * (TY / 256)) * sizeof(float2);
 }
 
-template <int TY, bool MIRROR>
+template <int TY, bool MIRROR, bool PT>
 __device__ __forceinline__ void
 inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, const float2* __restrict__ uc2,
                  const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
@@ -1294,7 +1294,8 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
 #pragma unroll
         for (int m = 0; m < 4; ++m) wq[m] = t[m * n + idx];
     };
-    float c[NK];
+    float c[NK], c2[PT ? NK : 1];
+    const int NG = PT ? (G + 1) / 2 : G;       // inverse transforms per plane (PT: templates 2k, 2k+1 in one)
     for (int pl = 0; pl < 2; ++pl) {
         const float2* xcol = (pl ? uc2 : uc) + (size_t)pair * plane + (size_t)ft * TY;
         const float* hsrc = (pl ? mb : wa) + (size_t)vfirst * hplane + (size_t)fs * TY;
@@ -1319,14 +1320,20 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
         // fy = 0 - one base per lane and compile-time offsets either way
         const float* cbase = hsrc + (MIRROR ? TY - lane : lane);
         const int c0off = (MIRROR && lane == 0) ? -TY : 0;
-        auto fetch = [&](int gi_) {
-            const float* p = cbase + (size_t)gi_ * hplane;
-            c[0] = p[c0off];
+        // the cells of the lane's set u (k = u mod U) of transform gi_; u < 0: of all its sets
+        auto fetch = [&](int gi_, int u) {
+            const float* p = cbase + (size_t)(PT ? 2 * gi_ : gi_) * hplane;
+            const bool has2 = PT && 2 * gi_ + 1 < G;
 #pragma unroll
-            for (int k = 1; k < NK; ++k) c[k] = p[MIRROR ? -64 * k : 64 * k];
+            for (int k = 0; k < NK; ++k) {
+                if (u >= 0 && k % U != u) continue;
+                const int off = k ? (MIRROR ? -64 * k : 64 * k) : c0off;
+                c[k] = p[off];
+                if constexpr (PT) c2[k] = has2 ? p[hplane + off] : 0.f;
+            }
         };
-        fetch(0);
-        for (int gi_ = 0; gi_ < G; ++gi_) {
+        fetch(0, -1);
+        for (int gi_ = 0; gi_ < NG; ++gi_) {
             lds_barrier();                                   // the store pass of the previous transform is done with the lines
             float2 wq[4];
             // (LDS addresses rebuilt from the lane id in every transform, see the store pass)
@@ -1339,12 +1346,17 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const int k = u + U * j;
-                    a1[j] = make_float2(c[k] * xp[k].x, c[k] * xp[k].y);
+                    // x * a (one template) or x * (a + i a2) (two templates, see k_inv_cols_sym)
+                    a1[j] = PT ? make_float2(xp[k].x * c[k] - xp[k].y * c2[k], xp[k].x * c2[k] + xp[k].y * c[k])
+                               : make_float2(c[k] * xp[k].x, c[k] * xp[k].y);
                 }
                 tw_of(t1, S, lt + 64 * u, wq);
                 set_compute_store<TY, 16, 0, true>(line, lt + 64 * u, a1, wq);
             }
-            if (gi_ + 1 < G) fetch(gi_ + 1);
+            // next coefficients: all of them now - or, two planes of them (PT) and two sets per lane,
+            // the second set's only once the transform's registers are free again
+            constexpr bool SPLIT = PT && U > 1;
+            if (gi_ + 1 < NG) fetch(gi_ + 1, SPLIT ? 0 : -1);
             asm volatile("" ::: "memory");
             float2 a[U][16];
 #pragma unroll
@@ -1363,6 +1375,7 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
                 for (int u = 0; u < U; ++u) set_compute_store<TY, R3, 8, true>(line, lt + 64 * u, a[u], wq);
             }
             lds_barrier();                                   // all eight lines are complete
+            if (SPLIT && gi_ + 1 < NG) fetch(gi_ + 1, 1);
             // ---- store: lane (q, c) of wave w takes column c of row pair rp_lo + 8 w + 64 it + q:
             // eight lanes write one 128-byte rows2 block
             // (addresses rebuilt from the lane id every time: kept across the transform they would be
@@ -1382,7 +1395,7 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
 // grid.x = Tx/8 workgroups j: index i = 8 (j / 16) + j % 8 in [0, Tx/16); (j / 8) & 1 = 0: column
 // block i (columns 8i .. 8i+7), 1: the mirror block Tx/8 - 1 - i, whose coefficient columns
 // are 8i+1 .. 8i+8 - the partner's but one, eight workgroup ids away on the same XCD.
-template <int TY>
+template <int TY, bool PT>
 __global__ void __launch_bounds__(512, 2)
 k_inv_cols_w8(const float2* __restrict__ uc, const float2* __restrict__ uc2,
               const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
@@ -1392,10 +1405,10 @@ k_inv_cols_w8(const float2* __restrict__ uc, const float2* __restrict__ uc2,
               const TileDev* __restrict__ tiles, int py_valid) {
     const int j = blockIdx.x, i = ((j >> 4) << 3) | (j & 7);
     if ((j >> 3) & 1)
-        inv_cols_w8_body<TY, true>((Tx >> 3) - 1 - i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
+        inv_cols_w8_body<TY, true, PT>((Tx >> 3) - 1 - i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
                                    rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid);
     else
-        inv_cols_w8_body<TY, false>(i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
+        inv_cols_w8_body<TY, false, PT>(i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
                                     rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid);
 }
 
@@ -2367,7 +2380,9 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                         ctx->variant == 3;
     // block and mirror workgroups of the two-launch form in one launch, paired per XCD (k_inv_cols_symx)
     const bool symx = sym && ctx->variant != 6 && ctx->variant != 3 && fg.Ty >= 512 && fg.Ty <= 2048 && (fg.Tx / 8) % 8 == 0;
-    // one wave per column (k_inv_cols_w8): tile pairs with both tiles, column length 1024 / 2048
+    // one wave per column (k_inv_cols_w8): column length 1024 / 2048; paired-template chunks at 1024
+    // only (at 2048 the second coefficient plane does not fit the registers: 32 spilled values
+    // reloaded per transform wait for the stores in flight - 1 455 us against k_inv_cols_symx's 1 000 at C2)
     const bool w8 = symx && ctx->variant != 2 && (fg.Ty == 2048 || fg.Ty == 1024) && (fg.Tx / 16) % 8 == 0;
     if (nb > 1 && (!fast || n > group || nb * n > SC_MAX_GROUP))
         return sc_fail(ctx, SC_ERR_INVALID, "orientation batching outside its conditions");
@@ -2415,9 +2430,9 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     }
 #define FN_W8(T)                                                               \
     {                                                                          \
-        int rc = set_lds(ctx, k_inv_cols_w8<T>, w8_lds<T>());                  \
+        int rc = set_lds(ctx, k_inv_cols_w8<T, PTV>, w8_lds<T>());             \
         if (rc) return rc;                                                     \
-        hipLaunchKernelGGL((k_inv_cols_w8<T>), dim3(fg.Tx / 8, nb * pcc), dim3(512),       \
+        hipLaunchKernelGGL((k_inv_cols_w8<T, PTV>), dim3(fg.Tx / 8, nb * pcc), dim3(512),  \
                            w8_lds<T>(), ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, \
                            (const float*)ctx->wh.p, (const float*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo, rp_hi, \
                            (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group, \
@@ -2466,7 +2481,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                     case 1024: FN_MSYM(1024); break;
                     default: FN_MSYM(2048); break;
                 }
-            } else if (w8 && !PTV) {
+            } else if (w8 && (!PTV || (fg.Ty == 1024 && ctx->variant != 1))) {
                 if (fg.Ty == 2048) FN_W8(2048) else FN_W8(1024)
             } else if (sym && symx) {
                 switch (fg.Ty) {

@@ -286,8 +286,9 @@ def test_fused_template_split_is_bit_identical():
 
 
 def test_column_pass_forms_are_bit_identical():
-    """The three forms of the inverse column pass: k_inv_cols_symx (default: block and mirror
-    workgroups in one launch, paired per XCD), k_inv_cols_msym (variant=3: a column block and
+    """The four forms of the inverse column pass: k_inv_cols_w8 (default at column lengths 1024 and
+    2048: one wave per column), k_inv_cols_symx (variant=2: four columns per workgroup, block and
+    mirror workgroups in one launch, paired per XCD), k_inv_cols_msym (variant=3: a column block and
     its mirror in one workgroup, permuted upper half of the hand-off) and the two-launch pass
     (variant=6) compute the same Y cell for cell, so the same record - at T = 2048 with several
     tile pairs and a partial last tile row, at T = 1024 / 512, on non-square tiles, with an odd
@@ -303,7 +304,7 @@ def test_column_pass_forms_are_bit_identical():
              (synthetic.synthetic_scarp(1024, seed=34), sl.Channel, 15, [0.05, 0.07, 0.1, 0.14, 0.2, 0.28, 0.4, 0.56], _plan.angle_grid()[::12])]
     for (g, cls, scale, params, angles) in cases:
         out = []
-        for variant in (0, 3, 6):
+        for variant in (0, 2, 3, 6):
             ctx = sl._lib.Context(0)
             ctx.set_option("variant", variant)
             m = sl.Matcher(g, ctx=ctx)
