@@ -521,10 +521,12 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
     for (const Chunk& c : chunks) {
         const int n_all = c.nb * c.n;
         if (c.nb > 1) {
+            float coef[32][3];
             for (int b = 0; b < c.nb; ++b) {
                 const sc_template& sb = t[c.first + b * c.n];
-                if ((rc = launch_curv_alpha(ctx, (float)sb.cc, (float)sb.sc2, (float)sb.ss, b))) return rc;
+                coef[b][0] = (float)sb.cc; coef[b][1] = (float)sb.sc2; coef[b][2] = (float)sb.ss;
             }
+            if ((rc = launch_curv_alpha_batch(ctx, coef, c.nb))) return rc;
             if ((rc = fft_forward_curv(ctx, fg, c.nb))) return rc;
             have_curv = false;                    // plane 0 no longer belongs to a single run
         } else {

@@ -136,6 +136,7 @@ void sc_prof_collect(sc_ctx* ctx);
 // ---- launchers implemented in sc_kernels.hip --------------------------------
 int launch_curv_planes(sc_ctx* ctx);
 int launch_curv_alpha(sc_ctx* ctx, float cc, float sc2, float ss, int plane = 0);
+int launch_curv_alpha_batch(sc_ctx* ctx, const float (*coef)[3], int nb);
 int launch_windows(sc_ctx* ctx, int first, int n, int wh_max, int ww_max);
 int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps);
 bool direct_window_fits(int ww);
