@@ -145,8 +145,7 @@ int sc_clear_windows(sc_ctx* ctx);
  *   "variant"  alternative kernel paths kept for cross-checks in the tests:
  *              0 default, 1 paired-template chunks by the four-column kernel at every
  *              tile size, 2 inverse column pass by the four-column kernels throughout
- *              (no wave-per-column kernel), 3 inverse column pass by the merged kernel (a column block
- *              and its mirror in one workgroup), 5 no paired-template mode, 6 inverse
+ *              (no wave-per-column kernel), 5 no paired-template mode, 6 inverse
  *              column pass as two launches per tile pair (own columns, mirrors) instead
  *              of one launch with the two kinds paired per XCD, 7 template spectra by the
  *              separate column-transform and split kernels, 8 complex-spectrum I1 for

@@ -12,7 +12,6 @@
 //   I1   k_inv_cols_symx    Y = a * (X P {i}) per column block, inverse column FFT; column
 //                           blocks and their mirrors in one launch, paired per XCD
 //        k_inv_cols_sym     the same as two launches (small tiles; cross-check variant 6)
-//        k_inv_cols_msym    a block and its mirror in one workgroup (cross-check variant 3)
 //        k_inv_cols         the same with complex spectra
 //   I2   k_inv_rows_fast    inverse row FFT -> xcorr(A) + i xcorr(B), T3 likewise;
 //        k_inv_rows         float32 amp/SNR epilogue, masks, running-best fold
@@ -1205,7 +1204,8 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
 // again (k_inv_rows_fast pairs its sibling rows the same way).  Workgroup j: group j / 16,
 // kind (j / 8) & 1, index i = 8 (j / 16) + j % 8; kind 0 is column block i, kind 1 the mirror
 // block Tx/4 - 1 - i, whose coefficient columns are 4i+1 .. 4i+4.  Measured on the sustained
-// C3 run: 728 us per tile pair against 745 (merged kernel) and 2 x 374 (two launches); C2,
+// C3 run: 728 us per tile pair against 745 (a kernel with block AND mirror in one workgroup,
+// since removed) and 2 x 374 (two launches); C2,
 // paired templates: 985 against 2 x 557.  (Giving every XCD a CONTIGUOUS range of blocks, so
 // that the fourth column is shared too, is 13 % slower: each XCD then writes a 2-KB stripe of
 // every row and loads a few L2 channels only.)  profiles/r02_i1_xcd_paired.txt
@@ -1412,159 +1412,6 @@ k_inv_cols_w8(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                                     rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid);
 }
 
-// ---- I1 for symmetric templates, a column block and its mirror in one workgroup ----
-// k_inv_cols_sym runs twice per tile pair, once for the columns fx < Tx/2 and once for their
-// mirrors Tx - fx, and both launches stream the same real coefficients a[fx][fy]
-// (FFT(W)[Tx-fx][Ty-fy] is the conjugate of FFT(W)[fx][fy]): 587 of the 1 662 MB a launch
-// moves, read twice.  Here ONE workgroup owns the columns 4cb .. 4cb+3 AND their mirrors:
-// every coefficient piece it fetches feeds two inverse transforms (the own columns, then the
-// mirrors, in the same LDS lines).  The phase-multiplied curvature spectrum of the own
-// columns is parked in LDS as before, that of the mirrors in registers (the 16 cells per
-// thread its coefficient loads pair with).
-//
-// The mirrors of an aligned block are not an aligned block (Tx - 4cb - 3 .. Tx - 4cb), so the
-// upper half of the rows2 hand-off is stored in PERMUTED column order ("perm" layout, read
-// back by k_inv_rows_fast with RowArgs.perm): the mirror of column 4cb + c goes to storage
-// column 4 (Tx/4 - cb) + c, i.e. logical column fx > Tx/2 lives at fx + 2 ((Tx - fx) & 3).
-// The block Tx/8 .. that leaves free holds the self-mirrored column Tx/2 (workgroup 0 computes
-// it in the line its column 0 - mirror of itself, already done - leaves idle; it fetches
-// that one coefficient column separately) and the mirrors of columns 1, 2, 3.
-// Cell for cell the arithmetic of k_inv_cols_sym: Y is bit-identical.
-template <int TY>
-__global__ void __launch_bounds__(fft_threads(TY), 2)
-k_inv_cols_msym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
-                const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
-                int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
-                int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
-                float2* __restrict__ ym, int ystride, int np, int pcj, int tstride,
-                const TileDev* __restrict__ tiles, int py_valid) {
-    extern __shared__ __attribute__((aligned(16))) float2 sm[];
-    static_assert(inv_cols_park<TY>(), "symmetric I1 parks the spectrum");
-    constexpr int NT = fft_threads(TY);
-    constexpr int EP = 4 * TY / (2 * NT);     // 2-cell loads per thread per stream
-    float4* xs = reinterpret_cast<float4*>(sm + 4 * fft_line(TY));   // parked spectrum of the own columns
-    FftTw<TY> twr;
-    twr.load(tw);
-    const int cb = blockIdx.x;                 // 0 .. Tx/8 - 1
-    {
-        const int ob = blockIdx.y / pcj, q = blockIdx.y - ob * pcj;
-        if (py_valid >= 0) {
-            const int vy = max(tiles[2 * (pair + q)].vy, tiles[2 * (pair + q) + 1].vy);
-            rp_hi = min(rp_hi, (py_valid + vy - 1) >> 1);
-        }
-        pair += ob * np + q;
-        vfirst += ob * tstride;
-    }
-    yw += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
-    ym += (size_t)blockIdx.y * ystride * ((size_t)TY * Tx);
-    const size_t plane = (size_t)TY * Tx;
-    const size_t col = (size_t)cb * 4 * TY;
-    const size_t hplane = half_plane(TY, Tx);
-    // storage block of the mirrors: Tx/4 - cb, or (cb = 0) the block at Tx/2
-    const int mblock = cb ? (Tx >> 2) - cb : (Tx >> 3);
-    const int e_lo = 4 * rp_lo, e_hi = 4 * (rp_hi + 1);
-    float2 hreg[EP];
-    for (int pl = 0; pl < 2; ++pl) {
-        const float2* xplane = (pl ? uc2 : uc) + (size_t)pair * plane;
-        const float* hsrc = (pl ? mb : wa) + (size_t)vfirst * hplane + col;
-        // coefficient column Tx/2 for line 0 of workgroup 0 (pieces with source column 0)
-        const float* hsrc_mid = (pl ? mb : wa) + (size_t)vfirst * hplane + (size_t)(Tx >> 1) * TY;
-        auto fetch = [&](int gi_) {
-            const float* p = hsrc + (size_t)gi_ * hplane;
-#pragma unroll
-            for (int u = 0; u < EP; ++u)
-                hreg[u] = *reinterpret_cast<const float2*>(p + 2 * (threadIdx.x + u * NT));
-        };
-        const bool rot = pl == 0 && parity == 1;          // odd W: factor i (own columns) / -i (mirrors)
-        // ---- park: own columns in LDS (k_inv_cols_sym, direct), mirrors in registers (mirrored)
-        float2 xm[EP][2];
-#pragma unroll
-        for (int u = 0; u < EP; ++u) {
-            const int e = 2 * (threadIdx.x + u * NT);
-            const int cc = e / TY, fy = e - cc * TY, fx = 4 * cb + cc;
-            float4 x = *reinterpret_cast<const float4*>(xplane + col + e);
-            float2 xv[2] = {make_float2(x.x, x.y), make_float2(x.z, x.w)};
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                float2 v = cmul(xv[k], phase_tab(tw + TY, phx, fy + k, fx));
-                if (rot) v = make_float2(-v.y, v.x);
-                xv[k] = v;
-            }
-            xs[threadIdx.x + u * NT] = make_float4(xv[0].x, xv[0].y, xv[1].x, xv[1].y);
-            // mirror target of coefficient cell (source column cc, row m = fy + k):
-            // column fxt = Tx - fx (workgroup 0, cc = 0: Tx/2), row f = -m mod TY
-            const int fxt = (cb == 0 && cc == 0) ? (Tx >> 1) : Tx - fx;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int f = (TY - fy - k) & (TY - 1);
-                float2 pv = phase_tab(tw + TY, phx, (TY - f) & (TY - 1), (Tx - fxt) & (Tx - 1));
-                pv.y = -pv.y;
-                float2 v = cmul(xplane[(size_t)fxt * TY + f], pv);
-                if (rot) v = make_float2(v.y, -v.x);
-                xm[u][k] = v;
-            }
-        }
-        fetch(0);
-        for (int gi_ = 0; gi_ < G; ++gi_) {
-            // (workgroup 0: the coefficients of column Tx/2, needed by the mirror fill below;
-            //  fetched here so that they land behind the first transform)
-            float2 hmid[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
-            if (cb == 0) {                                 // uniform
-                const float* p = hsrc_mid + (size_t)gi_ * hplane;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int e = 2 * (threadIdx.x + u * NT);
-                    if (e < TY) hmid[u] = *reinterpret_cast<const float2*>(p + e);
-                }
-            }
-            // half 0: own columns, 1: mirrors.  Written out twice on purpose: one shared copy of
-            // the transform with the fill / store addresses recomputed per half (and the twiddle
-            // bases in an LDS table to make room) was 13 % SLOWER on the sustained C3 run
-            // (416 vs 367 us per launch-equivalent; profiles/r02_i1_merged.txt).  The register
-            // spills the compiler reports for this kernel sit in the parking prologue, not in
-            // the template loop.
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int tid = threadIdx.x;
-                if (half == 0) {
-#pragma unroll
-                    for (int u = 0; u < EP; ++u) {
-                        const int e = 2 * (tid + u * NT);
-                        const int cc = e / TY, fy = e - cc * TY;
-                        const float4 x = xs[tid + u * NT];
-                        sm[lidx<TY>(cc, fy)] = make_float2(hreg[u].x * x.x, hreg[u].x * x.y);
-                        sm[lidx<TY>(cc, fy + 1)] = make_float2(hreg[u].y * x.z, hreg[u].y * x.w);
-                    }
-                } else {
-                    // line sc <- coefficient column sc (workgroup 0, line 0: column Tx/2), rows reversed
-#pragma unroll
-                    for (int u = 0; u < EP; ++u) {
-                        const int e = 2 * (tid + u * NT);
-                        const int sc = e / TY, m = e - sc * TY;
-                        const int f0 = (TY - m) & (TY - 1), f1 = (TY - m - 1) & (TY - 1);
-                        float2 h = hreg[u];
-                        if (u < 2 && cb == 0 && sc == 0) h = hmid[u < 2 ? u : 0];
-                        sm[lidx<TY>(sc, f0)] = make_float2(h.x * xm[u][0].x, h.x * xm[u][0].y);
-                        sm[lidx<TY>(sc, f1)] = make_float2(h.y * xm[u][1].x, h.y * xm[u][1].y);
-                    }
-                }
-                lds_barrier();
-                if (half == 1 && gi_ + 1 < G) fetch(gi_ + 1);
-                fft4_lines<TY, true>(sm, twr);
-                const int blk_ = half ? mblock : cb;
-                float2* o = (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)(blk_ >> 1) * 16 + (blk_ & 1) * 8;
-#pragma unroll 2
-                for (int e = e_lo + tid; e < e_hi; e += NT) {
-                    const int rp = e >> 2, k = e & 3;
-                    store_stream(o + (size_t)rp * (Tx >> 3) * 16 + 2 * k,
-                                 sm[lidx<TY>(k, 2 * rp)], sm[lidx<TY>(k, 2 * rp + 1)]);
-                }
-                lds_barrier();
-            }
-        }
-    }
-}
-
 // ---- I2: inverse row FFT -> epilogue -> fold ---------------------------------
 // grid = (valid row blocks): one workgroup per block of 4 tile rows.  The rows
 // are done as two sub-batches of 2 rows x {W plane, M plane} = 4 LDS lines, so
@@ -1587,7 +1434,6 @@ struct RowArgs {
     // (templates first + b*G + g, consecutive); the Y block of (orientation b, pair q of the
     // chunk) is job b*pcj + q, its tile norms are entry b*np + pair
     int nb, np, pcj;
-    int perm;                           // upper half of the Y columns in k_inv_cols_msym's permuted order
 };
 // One launch may serve several tile pairs (grid.y): pair = ra.pair + blockIdx.y,
 // its Y planes ystride planes further on.  More workgroups per launch fill the
@@ -1878,18 +1724,6 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     v2* line1 = sm + pl1 * LINE + 17 * tt1;
     const char* src1 = reinterpret_cast<const char*>((pl1 ? ym : yw) + (size_t)rp * 2 * TX);
     const uint32_t voff1 = (uint32_t)(((tt1 >> 3) * 16 + (tt1 & 7) * 2 + rh) * sizeof(float2));
-    // perm layout (k_inv_cols_msym): logical column fx > Tx/2 is stored at fx + 2 ((Tx - fx) & 3),
-    // the columns Tx-3 .. Tx-1 at Tx/2 + (Tx - fx).  fx = tt1 + j S: the shift is the thread's own
-    // for j >= 8 (S is a multiple of 8: one more base offset), and the last three threads take
-    // their j = 15 column from the block at Tx/2.
-    uint32_t voff1b = voff1, voff15 = voff1 + (uint32_t)(15 * 2 * S * sizeof(float2));
-    if (ra.perm) {
-        const int cperm = (-tt1) & 3, tb = tt1 + 2 * cperm;
-        voff1b = (uint32_t)(((tb >> 3) * 16 + (tb & 7) * 2 + rh) * sizeof(float2));
-        voff15 = voff1b + (uint32_t)(15 * 2 * S * sizeof(float2));
-        if (tt1 >= S - 3)        // fx = Tx - cperm (cperm = S - tt1): storage column Tx/2 + cperm
-            voff15 = (uint32_t)((cperm * 2 + rh) * sizeof(float2)) + (uint32_t)(8 * 2 * S * sizeof(float2));
-    }
     // stage-2 mapping (standard): line id / S, set tt2
     const int tt2 = id % S;
     v2* line2 = sm + (id / S) * LINE;
@@ -1957,9 +1791,8 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     int fk = 0;
     auto fetch = [&]() {
 #pragma unroll
-        for (int j = 0; j < 15; ++j)                             // column tt1 + j*S
-            a[j] = *reinterpret_cast<const v2*>(fp + (size_t)j * 2 * S * sizeof(float2) + (j < 8 ? voff1 : voff1b));
-        a[15] = *reinterpret_cast<const v2*>(fp + voff15);
+        for (int j = 0; j < 16; ++j)                             // column tt1 + j*S
+            a[j] = *reinterpret_cast<const v2*>(fp + (size_t)j * 2 * S * sizeof(float2) + voff1);
         fp += plane * sizeof(float2);
         if (++fk == NGO) { fk = 0; fp += ostep; }
     };
@@ -2371,15 +2204,8 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     const int pb = std::max(1, ctx->fft_pb);
     const size_t yblock = (size_t)fg.Ty * fg.Tx * group;          // cells per pair in yw / ym
     const bool fast = (fg.Tx == 512 || fg.Tx == 1024 || fg.Tx == 2048) && ctx->variant != 9;
-    // a column block and its mirror in one workgroup (k_inv_cols_msym): symmetric templates,
-    // the fast row kernel (it reads the permuted upper half) and a column length it is built for
-    // (and enough templates per launch: its parking prologue - the mirror cells gathered into
-    //  registers - costs more than that of the two plain launches, which single-age searches
-    //  notice: C1 1.03 -> 1.31 ms)
-    const bool merged = sym && fast && (fg.Ty == 512 || fg.Ty == 1024 || fg.Ty == 2048) && n >= 8 &&
-                        ctx->variant == 3;
     // block and mirror workgroups of the two-launch form in one launch, paired per XCD (k_inv_cols_symx)
-    const bool symx = sym && ctx->variant != 6 && ctx->variant != 3 && fg.Ty >= 512 && fg.Ty <= 2048 && (fg.Tx / 8) % 8 == 0;
+    const bool symx = sym && ctx->variant != 6 && fg.Ty >= 512 && fg.Ty <= 2048 && (fg.Tx / 8) % 8 == 0;
     // one wave per column (k_inv_cols_w8): column length 1024 / 2048; paired-template chunks at 1024
     // only (at 2048 the second coefficient plane does not fit the registers: 32 spilled values
     // reloaded per transform wait for the stores in flight - 1 455 us against k_inv_cols_symx's 1 000 at C2)
@@ -2408,7 +2234,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             const int pair = pair0 + pl0;
             float2* ywp = (float2*)ctx->yw.p + (size_t)pl0 * yblock;
             float2* ymp = (float2*)ctx->ym.p + (size_t)pl0 * yblock;
-            n_i1 += ((merged && !PTV) || symx) ? 1 : 2;   // one merged launch, or own columns + mirrors
+            n_i1 += symx ? 1 : 2;            // one paired launch, or own columns + mirrors
 #define COL_ARGS(CB0)                                                          \
     ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float2*)ctx->wh.p, \
         (const float2*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, ctx->dbg,        \
@@ -2464,24 +2290,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             hipLaunchKernelGGL((k_inv_cols<T, true>), dim3(nhi, nb * pcc), dim3(fft_threads(T)), \
                                inv_cols_lds<T>(), COL_ARGS(nlo));              \
     }
-#define FN_MSYM(T)                                                             \
-    {                                                                          \
-        int rc = set_lds(ctx, k_inv_cols_msym<T>, inv_cols_lds<T>());          \
-        if (rc) return rc;                                                     \
-        hipLaunchKernelGGL((k_inv_cols_msym<T>), dim3(fg.Tx / 8, nb * pcc), dim3(fft_threads(T)), \
-                           inv_cols_lds<T>(), ctx->stream, (const float2*)ctx->uc.p,      \
-                           (const float2*)ctx->uc2.p, (const float*)ctx->wh.p, (const float*)ctx->mh.p, \
-                           fg.Tx, pair, g0, G, rp_lo, rp_hi, (const float2*)ctx->tw_x.p + fg.Tx, parity, \
-                           (const float2*)ctx->tw_y.p, ywp, ymp, group, np, pcc, n,       \
-                           (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py);         \
-    }
-            if (merged && !PTV) {
-                switch (fg.Ty) {
-                    case 512: FN_MSYM(512); break;
-                    case 1024: FN_MSYM(1024); break;
-                    default: FN_MSYM(2048); break;
-                }
-            } else if (w8 && (!PTV || (fg.Ty == 1024 && ctx->variant != 1))) {
+            if (w8 && (!PTV || (fg.Ty == 1024 && ctx->variant != 1))) {
                 if (fg.Ty == 2048) FN_W8(2048) else FN_W8(1024)
             } else if (sym && symx) {
                 switch (fg.Ty) {
@@ -2505,7 +2314,6 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
 #undef FN_SYM
 #undef FN_SYMX
 #undef FN_W8
-#undef FN_MSYM
 #undef SYM_ARGS_D
 #undef SYM_ARGS
 #undef COL_ARGS
@@ -2514,7 +2322,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             const int pair = pair0;
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
                        ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg, group,
-                       nb, np, pc, (merged && !PTV) ? 1 : 0};
+                       nb, np, pc};
                         dim3 gridr(fast ? ((rp_n + 7) / 8) * 16 : (rp_n + 1) / 2, pc);
             sc_prof_begin(ctx, SC_K_INV_ROWS);
 #define ROW_ARGS lds_r, FAST_ARGS

@@ -286,14 +286,13 @@ def test_fused_template_split_is_bit_identical():
 
 
 def test_column_pass_forms_are_bit_identical():
-    """The four forms of the inverse column pass: k_inv_cols_w8 (default at column lengths 1024 and
+    """The three forms of the inverse column pass: k_inv_cols_w8 (default at column lengths 1024 and
     2048: one wave per column), k_inv_cols_symx (variant=2: four columns per workgroup, block and
-    mirror workgroups in one launch, paired per XCD), k_inv_cols_msym (variant=3: a column block and
-    its mirror in one workgroup, permuted upper half of the hand-off) and the two-launch pass
-    (variant=6) compute the same Y cell for cell, so the same record - at T = 2048 with several
+    mirror workgroups in one launch, paired per XCD) and the two-launch pass (variant=6)
+    compute the same Y cell for cell, so the same record - at T = 2048 with several
     tile pairs and a partial last tile row, at T = 1024 / 512, on non-square tiles, with an odd
     tile count (paired-template mode) and with batched orientations on a circular tile."""
-    a9 = _plan.age_grid()[::4]                          # 9 ages: the merged kernel needs >= 8 templates per launch
+    a9 = _plan.age_grid()[::4]                          # 9 ages
     cases = [(synthetic.synthetic_scarp(3900, ny=3700, seed=31), sl.Scarp, 100, a9, _plan.angle_grid()[3::45]),
              (synthetic.synthetic_scarp(1500, ny=1400, seed=32), sl.Scarp, 40, a9, _plan.angle_grid()[::30]),
              (synthetic.synthetic_scarp(700, seed=33), sl.Scarp, 12, list(10 ** np.linspace(0, 1.6, 8)), _plan.angle_grid()[::20]),
@@ -304,7 +303,7 @@ def test_column_pass_forms_are_bit_identical():
              (synthetic.synthetic_scarp(1024, seed=34), sl.Channel, 15, [0.05, 0.07, 0.1, 0.14, 0.2, 0.28, 0.4, 0.56], _plan.angle_grid()[::12])]
     for (g, cls, scale, params, angles) in cases:
         out = []
-        for variant in (0, 2, 3, 6):
+        for variant in (0, 2, 6):
             ctx = sl._lib.Context(0)
             ctx.set_option("variant", variant)
             m = sl.Matcher(g, ctx=ctx)
@@ -313,7 +312,7 @@ def test_column_pass_forms_are_bit_identical():
             plan = m.plan
             del m
             ctx.close()
-        print("paired-launch vs merged vs two-launch column pass:", plan)
+        print("wave-per-column vs paired-launch vs two-launch column pass:", plan)
         for other in out[1:]:
             for a, b, name in zip(out[0], other, ("amp", "snr", "id")):
                 assert np.array_equal(a, b), (str(plan), name, int((a != b).sum()))
