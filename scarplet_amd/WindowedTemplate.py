@@ -19,6 +19,8 @@ other subclass of ``WindowedTemplate`` is handled generically: its numpy
 Reference lines are cited as WT.py:<line> (= scarplet/WindowedTemplate.py).
 """
 
+import bisect
+
 import numpy as np
 from scipy.special import erfinv
 
@@ -38,6 +40,33 @@ EXP_UNDERFLOW = 745.1332191019412
 
 
 _AXIS_CACHE = {}
+_AXIS_LIST_CACHE = {}
+_TRIG_CACHE = {}
+_ERFINV_09 = erfinv(0.9)          # WT.py:156
+
+
+def _trig(alpha):
+    """(cos a, sin a, cos(a - pi/2), sin(a - pi/2)) evaluated with numpy as the
+    reference evaluates them (WT.py:55-56, 68-73), cached: a search builds 35
+    templates per orientation."""
+    t = _TRIG_CACHE.get(alpha)
+    if t is None:
+        t = (np.cos(alpha), np.sin(alpha), np.cos(alpha - np.pi / 2), np.sin(alpha - np.pi / 2))
+        if len(_TRIG_CACHE) > 4096:
+            _TRIG_CACHE.clear()
+        _TRIG_CACHE[alpha] = t
+    return t
+
+
+def _axis_list(n, de):
+    """centred_axis as a Python list (for bisect), None when it is not ascending."""
+    key = (int(n), float(de))
+    if key not in _AXIS_LIST_CACHE:
+        a = centred_axis(n, de)
+        if len(_AXIS_LIST_CACHE) > 64:
+            _AXIS_LIST_CACHE.clear()
+        _AXIS_LIST_CACHE[key] = a.tolist() if a[0] <= a[-1] else None
+    return _AXIS_LIST_CACHE[key]
 
 
 def centred_axis(n, de):
@@ -59,10 +88,12 @@ def centred_axis(n, de):
     return a
 
 
-def _interval_le(a, lo, hi):
+def _interval_le(a, lo, hi, alist=None):
     """Indices [i0, i1] of the cells of the monotonic axis ``a`` with
     lo <= a <= hi, found by bisection (same float compares as the elementwise
-    test, O(log n))."""
+    test, O(log n)).  ``alist``: the same axis as a Python list (_axis_list)."""
+    if alist is not None:
+        return bisect.bisect_left(alist, lo), bisect.bisect_right(alist, hi) - 1
     if a[0] <= a[-1]:
         i0 = int(np.searchsorted(a, lo, side="left"))
         i1 = int(np.searchsorted(a, hi, side="right")) - 1
@@ -103,13 +134,14 @@ class WindowedTemplate(object):
 
     def _limit_margins(self):
         """(an_x, an_y) of WT.py:68-73."""
-        a, d, c = self.alpha, self.d, self.c
-        x4 = d * np.cos(a - np.pi / 2)
-        y4 = d * np.sin(a - np.pi / 2)
-        x1 = d * np.cos(a)
-        y1 = d * np.sin(a)
-        an_y = abs((x4 - x1) + 2 * c * np.cos(a - np.pi / 2))
-        an_x = abs((y1 - y4) + 2 * c * np.sin(a - np.pi / 2))
+        d, c = self.d, self.c
+        ca, sa, cam, sam = _trig(self.alpha)
+        x4 = d * cam
+        y4 = d * sam
+        x1 = d * ca
+        y1 = d * sa
+        an_y = abs((x4 - x1) + 2 * c * cam)
+        an_x = abs((y1 - y4) + 2 * c * sam)
         return an_x, an_y
 
     def _limit_axes(self):
@@ -135,20 +167,23 @@ class WindowedTemplate(object):
         x > max(x) - an_x (WT.py:81-82)."""
         an_x, an_y = self._limit_margins()
         x, y = self._axes()
-        jlo, jhi = _interval_le(x, min(x[0], x[-1]) + an_x, max(x[0], x[-1]) - an_x)
-        ilo, ihi = _interval_le(y, min(y[0], y[-1]) + an_y, max(y[0], y[-1]) - an_y)
+        jlo, jhi = _interval_le(x, min(x[0], x[-1]) + an_x, max(x[0], x[-1]) - an_x,
+                                _axis_list(self.nx, self.de))
+        ilo, ihi = _interval_le(y, min(y[0], y[-1]) + an_y, max(y[0], y[-1]) - an_y,
+                                _axis_list(self.ny, self.de))
         return ilo, ihi, jlo, jhi
 
     def _support_bbox(self, c_eff=None):
         """Conservative bounding box of the support in centred offsets
         p = k - ny//2, q = l - nx//2 (clipped to the grid)."""
         c = self.c if c_eff is None else min(self.c, c_eff)
-        ca, sa = abs(np.cos(self.alpha)), abs(np.sin(self.alpha))
+        t = _trig(self.alpha)
+        ca, sa = abs(t[0]), abs(t[1])
         bx = (c * ca + self.d * sa) * (1 + 1e-12) + 1e-300
         by = (c * sa + self.d * ca) * (1 + 1e-12) + 1e-300
         x, y = self._axes()
-        l0, l1 = _interval_le(x, -bx, bx)
-        k0, k1 = _interval_le(y, -by, by)
+        l0, l1 = _interval_le(x, -bx, bx, _axis_list(self.nx, self.de))
+        k0, k1 = _interval_le(y, -by, by, _axis_list(self.ny, self.de))
         return (k0 - self.ny // 2, k1 - self.ny // 2,
                 l0 - self.nx // 2, l1 - self.nx // 2)
 
@@ -167,7 +202,7 @@ class Scarp(WindowedTemplate):
         self.nx = nx
         self.ny = ny
         self.de = de
-        self.c = abs(2 * np.sqrt(self.kt) * erfinv(0.9))   # WT.py:156-157
+        self.c = abs(2 * np.sqrt(self.kt) * _ERFINV_09)    # WT.py:156-157
 
     def _profile(self, xr):
         return (-xr / (2. * self.kt ** (3 / 2.) * np.sqrt(np.pi))) \
@@ -186,9 +221,9 @@ class Scarp(WindowedTemplate):
 
     def _device_descriptor(self):
         kt = self.kt
+        t = _trig(self.alpha)
         return dict(kind=self._kind, flags=self._flags,
-                    cos_a=float(np.cos(self.alpha)),
-                    sin_a=float(np.sin(self.alpha)),
+                    cos_a=float(t[0]), sin_a=float(t[1]),
                     c=float(self.c), d=float(self.d),
                     p0=float(2. * kt ** (3 / 2.) * np.sqrt(np.pi)),
                     p1=float(4. * kt),
@@ -299,9 +334,9 @@ class Ricker(WindowedTemplate):
     def _device_descriptor(self):
         pif = float(np.pi * self.f)
         c_eff = np.sqrt(EXP_UNDERFLOW) / abs(pif) if pif != 0 else np.inf
+        t = _trig(self.alpha)
         return dict(kind=self._kind, flags=self._flags,
-                    cos_a=float(np.cos(self.alpha)),
-                    sin_a=float(np.sin(self.alpha)),
+                    cos_a=float(t[0]), sin_a=float(t[1]),
                     c=float(self.c), d=float(self.d), p0=pif, p1=0.0,
                     limits=(0, self.ny - 1, 0, self.nx - 1),
                     bbox=self._support_bbox(c_eff=c_eff))
@@ -310,3 +345,66 @@ class Ricker(WindowedTemplate):
 class Channel(Ricker):
     """Ricker wavelet used for fluvial channels (WT.py:523-525)."""
     pass
+
+
+# ---- descriptors of a whole (angle, parameter) grid at once ------------------------------------
+def grid_descriptors(Template, scale, params, angles, nx, ny, de):
+    """``_device_descriptor()`` of ``Template(scale, p, a, nx, ny, de)`` for every angle a and
+    parameter p, as arrays of shape (n_angles, n_params) - or None when ``Template`` is not
+    exactly one of the built-in classes (a subclass may override anything) or the grid axes are
+    not ascending.  A search builds thousands of descriptors; one Python object and three dozen
+    numpy scalar calls each cost more than the device spends on a small search.
+
+    Bit-identical to the per-template path: every transcendental (cos, sin, sqrt, pow) is still
+    evaluated per scalar exactly as there; only the additions, multiplications and the bisection
+    are done on arrays (tests/test_templates.py compares the two exhaustively)."""
+    scarp_like = Template in (Scarp, RightFacingUpperBreakScarp, LeftFacingUpperBreakScarp)
+    ricker_like = Template in (Ricker, Channel)
+    if not (scarp_like or ricker_like):
+        return None
+    x, y = centred_axis(nx, de), centred_axis(ny, de)
+    if not (x[0] <= x[-1] and y[0] <= y[-1]):
+        return None
+    params = [p for p in params]
+    na, npar = len(angles), len(params)
+    trig = [_trig(-a) for a in angles]                 # alpha = -angle (WT.py:151, 489)
+    col = lambda k: np.array([t[k] for t in trig], dtype=np.float64)[:, np.newaxis]
+    ca, sa, cam, sam = col(0), col(1), col(2), col(3)
+    d = scale
+    if scarp_like:
+        c = np.array([abs(2 * np.sqrt(kt) * _ERFINV_09) for kt in params], dtype=np.float64)[np.newaxis, :]
+        p0 = np.array([float(2. * kt ** (3 / 2.) * np.sqrt(np.pi)) for kt in params])[np.newaxis, :]
+        p1 = np.array([float(4. * kt) for kt in params])[np.newaxis, :]
+        c_box = c
+        # window limits (WT.py:68-82)
+        x4, y4, x1, y1 = d * cam, d * sam, d * ca, d * sa
+        an_y = abs((x4 - x1) + 2 * c * cam)
+        an_x = abs((y1 - y4) + 2 * c * sam)
+        jlo = np.searchsorted(x, min(x[0], x[-1]) + an_x, side="left")
+        jhi = np.searchsorted(x, max(x[0], x[-1]) - an_x, side="right") - 1
+        ilo = np.searchsorted(y, min(y[0], y[-1]) + an_y, side="left")
+        ihi = np.searchsorted(y, max(y[0], y[-1]) - an_y, side="right") - 1
+    else:
+        pif = [float(np.pi * f) for f in params]
+        c = np.full((1, npar), float(nx))              # WT.py:492
+        c_eff = np.array([np.sqrt(EXP_UNDERFLOW) / abs(v) if v != 0 else np.inf for v in pif])[np.newaxis, :]
+        c_box = np.minimum(c, c_eff)
+        p0 = np.array(pif)[np.newaxis, :]
+        p1 = np.zeros((1, npar))
+        ilo = np.zeros((na, npar), dtype=np.int64)
+        ihi = np.full((na, npar), ny - 1, dtype=np.int64)
+        jlo = np.zeros((na, npar), dtype=np.int64)
+        jhi = np.full((na, npar), nx - 1, dtype=np.int64)
+    # support box (_support_bbox)
+    aca, asa = abs(ca), abs(sa)
+    bx = (c_box * aca + d * asa) * (1 + 1e-12) + 1e-300
+    by = (c_box * asa + d * aca) * (1 + 1e-12) + 1e-300
+    l0 = np.searchsorted(x, -bx, side="left")
+    l1 = np.searchsorted(x, bx, side="right") - 1
+    k0 = np.searchsorted(y, -by, side="left")
+    k1 = np.searchsorted(y, by, side="right") - 1
+    full = lambda v: np.broadcast_to(np.asarray(v, dtype=np.float64), (na, npar))
+    return dict(kind=Template._kind, flags=Template._flags, cos_a=full(ca), sin_a=full(sa),
+                c=full(c), d=full(float(d)), p0=full(p0), p1=full(p1),
+                ilo=ilo, ihi=ihi, jlo=jlo, jhi=jhi,
+                pmin=k0 - ny // 2, pmax=k1 - ny // 2, qmin=l0 - nx // 2, qmax=l1 - nx // 2)

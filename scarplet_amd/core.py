@@ -149,6 +149,10 @@ class Matcher(object):
         Returns (ctypes array, support bbox union, max taps)."""
         n_par, n_ang = len(params), len(angles)
         arr = (_lib.sc_template * (n_par * n_ang))()
+        fast = self._describe_grid(arr, Template, scale, params, angles, id_base, id_of) \
+            if not kwargs and n_par * n_ang > 0 else None
+        if fast is not None:
+            return (arr,) + fast
         boxes = []
         k = 0
         max_area = 0
@@ -179,6 +183,39 @@ class Matcher(object):
                                * (s.qmax - s.qmin + 1))
                 k += 1
         return arr, _plan.bbox_union(boxes), max_area
+
+    def _describe_grid(self, arr, Template, scale, params, angles, id_base, id_of):
+        """describe() for the built-in classes without a Python object per template
+        (WindowedTemplate.grid_descriptors): fills ``arr`` through a numpy view of the struct
+        array.  Returns (bbox union, max taps), or None when the class is not a built-in."""
+        from scarplet_amd.WindowedTemplate import grid_descriptors
+        g = grid_descriptors(Template, scale, params, angles, self.nx, self.ny, self.de)
+        if g is None:
+            return None
+        n_par, n_ang = len(params), len(angles)
+        T = _lib.sc_template
+        names = [f[0] for f in T._fields_]
+        dt = np.dtype({"names": names,
+                       "formats": [np.dtype(f[1]) for f in T._fields_],
+                       "offsets": [getattr(T, n).offset for n in names],
+                       "itemsize": _lib.C.sizeof(T)})
+        v = np.frombuffer(arr, dtype=dt).reshape(n_ang, n_par)
+        v["kind"], v["flags"], v["window"] = g["kind"], g["flags"], -1
+        for k in ("cos_a", "sin_a", "c", "d", "p0", "p1", "ilo", "ihi", "jlo", "jhi"):
+            v[k] = g[k]
+        cf = np.array([_plan.curvature_coefficients(a) for a in angles], dtype=np.float64)
+        v["cc"], v["sc2"], v["ss"] = cf[:, 0:1], cf[:, 1:2], cf[:, 2:3]
+        ia, ib = np.meshgrid(np.arange(n_par), np.arange(n_ang))
+        v["id"] = id_base + ia * n_ang + ib if id_of is None else id_of(ia, ib)
+        pmin, pmax, qmin, qmax = (np.array(g[k]) for k in ("pmin", "pmax", "qmin", "qmax"))
+        empty = (pmax < pmin) | (qmax < qmin)           # see the loop below
+        for a_ in (pmin, pmax, qmin, qmax):
+            a_[empty] = 0
+        v["pmin"], v["pmax"], v["qmin"], v["qmax"] = pmin, pmax, qmin, qmax
+        bbox = (min(0, int(pmin.min())), max(0, int(pmax.max())),
+                min(0, int(qmin.min())), max(0, int(qmax.max())))
+        area = int(((pmax - pmin + 1) * (qmax - qmin + 1)).max())
+        return bbox, area
 
     def _describe_generic(self, t):
         """Any WindowedTemplate-like plugin: evaluate its numpy methods on the

@@ -86,3 +86,52 @@ def test_shifted_templates_match_reference_captures():
         assert np.array_equal(W != 0, c["W"] != 0)
         assert np.array_equal(t.get_window_limits(), c["lim"])
         assert np.array_equal(t.get_err_mask(), c["err"])
+
+
+def test_grid_descriptors_equal_the_per_template_descriptors():
+    """WindowedTemplate.grid_descriptors (arrays for a whole (angle, parameter) grid) against
+    _device_descriptor() of every single template: every field equal, bit for bit."""
+    from scarplet_amd import _plan
+    angs = _plan.angle_grid()
+    cases = [(WT.Scarp, 100, _plan.age_grid()[::3], angs[::4], 1000, 901, 1.0),
+             (WT.Scarp, 30.5, _plan.age_grid()[::5], angs[::7], 333, 400, 2.0),
+             (WT.RightFacingUpperBreakScarp, 20, [3.0, 40.0], angs[::20], 128, 90, 0.5),
+             (WT.LeftFacingUpperBreakScarp, 12, [1.0, 7.5], angs[::25], 90, 128, 1.0),
+             (WT.Channel, 10, [0.05, 0.1, 0.3, 1.0], angs[::9], 512, 512, 1.0),
+             (WT.Ricker, 8, [0.0, 0.2], angs[::30], 63, 64, 1.5)]
+    for (cls, scale, params, angles, nx, ny, de) in cases:
+        g = WT.grid_descriptors(cls, scale, params, angles, nx, ny, de)
+        assert g is not None
+        for ib, a in enumerate(angles):
+            for ia, p in enumerate(params):
+                d = cls(scale, p, a, nx, ny, de)._device_descriptor()
+                one = dict(cos_a=d["cos_a"], sin_a=d["sin_a"], c=d["c"], d=d["d"], p0=d["p0"], p1=d["p1"],
+                           ilo=d["limits"][0], ihi=d["limits"][1], jlo=d["limits"][2], jhi=d["limits"][3],
+                           pmin=d["bbox"][0], pmax=d["bbox"][1], qmin=d["bbox"][2], qmax=d["bbox"][3])
+                for k, v in one.items():
+                    assert g[k][ib, ia] == v, (cls.__name__, k, ib, ia)
+                assert g["kind"] == d["kind"] and g["flags"] == d["flags"]
+
+    class Mine(WT.Scarp):               # a subclass may override anything: no shortcut
+        pass
+    assert WT.grid_descriptors(Mine, 10, [1.0], [0.1], 64, 64, 1.0) is None
+
+
+def test_describe_fast_path_fills_the_same_struct_array(monkeypatch):
+    """core.Matcher.describe through grid_descriptors and through one object per template:
+    the same bytes in the sc_template array, the same support box and tap count."""
+    import ctypes
+    import types
+    from scarplet_amd import _plan, core
+    fake = types.SimpleNamespace(nx=700, ny=520, de=2.0)
+    fake._describe_grid = lambda *a: core.Matcher._describe_grid(fake, *a)
+    params, angles = _plan.age_grid()[::6], _plan.angle_grid()[::11]
+    for cls, scale, pars in [(WT.Scarp, 60, params), (WT.LeftFacingUpperBreakScarp, 40, params[:3]),
+                             (WT.Channel, 25, [0.02, 0.05])]:
+        for id_of in (None, lambda ia, ib: ib * len(pars) + ia + 7):
+            fast = core.Matcher.describe(fake, cls, scale, np.asarray(pars, float), angles, id_base=3, id_of=id_of)
+            with monkeypatch.context() as m:
+                m.setattr(WT, "grid_descriptors", lambda *a, **k: None)
+                slow = core.Matcher.describe(fake, cls, scale, np.asarray(pars, float), angles, id_base=3, id_of=id_of)
+            assert fast[1:] == slow[1:], (fast[1:], slow[1:])
+            assert ctypes.string_at(fast[0], ctypes.sizeof(fast[0])) == ctypes.string_at(slow[0], ctypes.sizeof(slow[0]))
