@@ -173,9 +173,12 @@ def test_orientation_chunks_fold_to_the_single_search_bit_for_bit(nranks, method
     order, the plan of the whole grid) and the records folded as sc_fold_ranks folds them:
     amplitude, SNR and winner id equal the single search's in every bit - exact ties
     included (a noise-free surface has many)."""
-    for (g, Template, scale) in [(synthetic.synthetic_scarp(230, seed=4, ny=200), sl.Scarp, 14),
-                                 (synthetic.synthetic_scarp(128, seed=2, sigma=0.0), sl.Scarp, 10)]:
-        params = [1.0, 4.0, 20.0, 100.0]
+    from scarplet_amd import WindowedTemplate as WT
+    for (g, Template, scale, params) in [
+            (synthetic.synthetic_scarp(230, seed=4, ny=200), sl.Scarp, 14, [1.0, 4.0, 20.0, 100.0]),
+            (synthetic.synthetic_scarp(128, seed=2, sigma=0.0), sl.Scarp, 10, [1.0, 4.0, 20.0, 100.0]),
+            (synthetic.synthetic_scarp(150, seed=6, ny=140), WT.Channel, 8, [0.05, 0.1, 0.2]),
+            (synthetic.synthetic_scarp(150, seed=7, ny=160), WT.LeftFacingUpperBreakScarp, 12, [2.0, 30.0])]:
         angles = _plan.angle_grid(-np.pi / 2, np.pi / 2)[::17]          # 11 orientations
         om = sd.OrientationMatcher(0, 1, g)
         ctx, n_par = om.m.ctx, len(params)
