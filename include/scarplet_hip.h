@@ -143,8 +143,8 @@ int sc_clear_windows(sc_ctx* ctx);
  *   "kappa"    float32 resolution floor of the FFT epilogue in units of eps32
  *              (default 4; 0 switches the floor off; sc_internal.h sc_epi_floor)
  *   "variant"  alternative kernel paths kept for cross-checks in the tests:
- *              0 default, 1 paired-template chunks by the four-column kernel at every
- *              tile size, 2 inverse column pass by the four-column kernels throughout
+ *              0 default, 1 paired-template chunks by the four-column LDS-parked kernel at
+ *              every tile size, 2 inverse column pass by the four-column kernels throughout
  *              (no wave-per-column kernel), 5 no paired-template mode, 6 inverse
  *              column pass as two launches per tile pair (own columns, mirrors) instead
  *              of one launch with the two kinds paired per XCD, 7 template spectra by the

@@ -1253,7 +1253,7 @@ __host__ __device__ constexpr size_t w8_lds() {          // eight lines + the tw
     return ((size_t)8 * w8_line<TY>() + 4 * (TY / 16) + 4 * (TY / 256)) * sizeof(float2);
 }
 
-template <int TY, bool MIRROR, bool PT>
+template <int TY, bool MIRROR, bool PT, int NC>
 __device__ __forceinline__ void
 inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, const float2* __restrict__ uc2,
                  const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
@@ -1281,15 +1281,15 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
     const size_t plane = (size_t)TY * Tx, hplane = half_plane(TY, Tx);
     yw += (size_t)jobx * ystride * plane;
     ym += (size_t)jobx * ystride * plane;
-    const int ft = 8 * B + w;                  // this wave's column of Y
+    const int ft = NC * B + w;                 // this wave's column of Y (NC columns, NC waves per workgroup)
     const int fs = MIRROR ? Tx - ft : ft;      // the coefficient column it pairs with
     // twiddle bases of the sets (FftTw's, per set: stage 1 w^tt, stage 2 w^(16 (tt >> 4)), times
     // 1, 2, 4, 8) in an LDS table behind the lines, [m][tt] and [m][tt >> 4]: 64 registers of
     // parked spectrum leave no room for them
-    float2* t1 = sm + 8 * LINE;
+    float2* t1 = sm + NC * LINE;
     float2* t2 = t1 + 4 * S;
-    for (int i = threadIdx.x; i < 4 * S; i += 512) t1[i] = tw[(i % S) << (i / S)];
-    for (int i = threadIdx.x; i < 4 * (S / 16); i += 512) t2[i] = tw[((i % (S / 16)) << 4) << (i / (S / 16))];
+    for (int i = threadIdx.x; i < 4 * S; i += 64 * NC) t1[i] = tw[(i % S) << (i / S)];
+    for (int i = threadIdx.x; i < 4 * (S / 16); i += 64 * NC) t2[i] = tw[((i % (S / 16)) << 4) << (i / (S / 16))];
     auto tw_of = [&](const float2* t, int n, int idx, float2 (&wq)[4]) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) wq[m] = t[m * n + idx];
@@ -1355,7 +1355,7 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
             }
             // next coefficients: all of them now - or, two planes of them (PT) and two sets per lane,
             // the second set's only once the transform's registers are free again
-            constexpr bool SPLIT = PT && U > 1;
+            constexpr bool SPLIT = PT && U > 1 && NC == 8;   // (the four-wave form has the registers)
             if (gi_ + 1 < NG) fetch(gi_ + 1, SPLIT ? 0 : -1);
             asm volatile("" ::: "memory");
             float2 a[U][16];
@@ -1382,10 +1382,13 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
             //  spilled, and a scratch reload here waits for the coefficient prefetch and the stores)
             int ln = lane;
             asm volatile("" : "+v"(ln));
-            float2* o = (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)B * 16 + 2 * (ln & 7);
-            const float2* lc = sm + (ln & 7) * LINE;
+            // (NC = 4: the workgroup's four columns are half a rows2 block, 64 bytes, like the four-column kernels')
+            float2* o = (pl ? ym : yw) + (size_t)gi_ * plane +
+                        (NC == 8 ? (size_t)B * 16 : (size_t)(B >> 1) * 16 + (B & 1) * 8) + 2 * (ln & (NC - 1));
+            const float2* lc = sm + (ln & (NC - 1)) * LINE;
+            constexpr int RQ = 64 / NC;                      // row pairs per store instruction
 #pragma unroll 2
-            for (int rp = rp_lo + 8 * w + (ln >> 3); rp <= rp_hi; rp += 64)
+            for (int rp = rp_lo + RQ * w + ln / NC; rp <= rp_hi; rp += RQ * NC)
                 store_stream(o + (size_t)rp * (Tx >> 3) * 16, lc[ph(2 * rp)], lc[ph(2 * rp + 1)]);
         }
         lds_barrier();                                       // (the next plane's first barrier would do; kept simple)
@@ -1405,11 +1408,33 @@ k_inv_cols_w8(const float2* __restrict__ uc, const float2* __restrict__ uc2,
               const TileDev* __restrict__ tiles, int py_valid) {
     const int j = blockIdx.x, i = ((j >> 4) << 3) | (j & 7);
     if ((j >> 3) & 1)
-        inv_cols_w8_body<TY, true, PT>((Tx >> 3) - 1 - i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
+        inv_cols_w8_body<TY, true, PT, 8>((Tx >> 3) - 1 - i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
                                    rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid);
     else
-        inv_cols_w8_body<TY, false, PT>(i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
+        inv_cols_w8_body<TY, false, PT, 8>(i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
                                     rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid);
+}
+
+// The same with FOUR columns and four waves per workgroup, one wave per SIMD: a wave may then use
+// the whole register file (256 VGPRs + 256 AGPRs), which paired-template mode at column length
+// 2048 needs - the parked spectrum, two coefficient planes and two sets of data do not fit 256.
+// grid.x = Tx/4 workgroups, paired per XCD like the above (block i: columns 4i .. 4i+3; mirror
+// block Tx/4 - 1 - i, coefficient columns 4i+1 .. 4i+4).
+template <int TY, bool PT>
+__global__ void __launch_bounds__(256, 1)
+k_inv_cols_w4(const float2* __restrict__ uc, const float2* __restrict__ uc2,
+              const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
+              int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
+              int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
+              float2* __restrict__ ym, int ystride, int np, int pcj, int tstride,
+              const TileDev* __restrict__ tiles, int py_valid) {
+    const int j = blockIdx.x, i = ((j >> 4) << 3) | (j & 7);
+    if ((j >> 3) & 1)
+        inv_cols_w8_body<TY, true, PT, 4>((Tx >> 2) - 1 - i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
+                                          rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid);
+    else
+        inv_cols_w8_body<TY, false, PT, 4>(i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
+                                           rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid);
 }
 
 // ---- I2: inverse row FFT -> epilogue -> fold ---------------------------------
@@ -2206,9 +2231,10 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     const bool fast = (fg.Tx == 512 || fg.Tx == 1024 || fg.Tx == 2048) && ctx->variant != 9;
     // block and mirror workgroups of the two-launch form in one launch, paired per XCD (k_inv_cols_symx)
     const bool symx = sym && ctx->variant != 6 && fg.Ty >= 512 && fg.Ty <= 2048 && (fg.Tx / 8) % 8 == 0;
-    // one wave per column (k_inv_cols_w8): column length 1024 / 2048; paired-template chunks at 1024
-    // only (at 2048 the second coefficient plane does not fit the registers: 32 spilled values
-    // reloaded per transform wait for the stores in flight - 1 455 us against k_inv_cols_symx's 1 000 at C2)
+    // one wave per column (k_inv_cols_w8): column length 1024 / 2048.  Paired-template chunks at 2048 take
+    // the four-wave form k_inv_cols_w4 (one wave per SIMD, 512 registers): with eight waves the second
+    // coefficient plane does not fit - 32 spilled values reloaded per transform wait for the stores in
+    // flight, 1 455 us at C2 against k_inv_cols_symx's 1 000; k_inv_cols_w4: 915
     const bool w8 = symx && ctx->variant != 2 && (fg.Ty == 2048 || fg.Ty == 1024) && (fg.Tx / 16) % 8 == 0;
     if (nb > 1 && (!fast || n > group || nb * n > SC_MAX_GROUP))
         return sc_fail(ctx, SC_ERR_INVALID, "orientation batching outside its conditions");
@@ -2264,6 +2290,18 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                            (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group, \
                            np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py); \
     }
+#define FN_W4(T)                                                               \
+    {                                                                          \
+        /* (more LDS than it uses: one workgroup per CU, one wave per SIMD) */ \
+        const size_t lds4 = (size_t)88 * 1024;                                 \
+        int rc = set_lds(ctx, k_inv_cols_w4<T, PTV>, lds4);                    \
+        if (rc) return rc;                                                     \
+        hipLaunchKernelGGL((k_inv_cols_w4<T, PTV>), dim3(fg.Tx / 4, nb * pcc), dim3(256),  \
+                           lds4, ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, \
+                           (const float*)ctx->wh.p, (const float*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo, rp_hi, \
+                           (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group, \
+                           np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py); \
+    }
 #define FN_SYM(T)                                                              \
     {                                                                          \
         int rc = set_lds(ctx, k_inv_cols_sym<T, false, PTV>, inv_cols_lds<T>());    \
@@ -2292,6 +2330,8 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     }
             if (w8 && (!PTV || (fg.Ty == 1024 && ctx->variant != 1))) {
                 if (fg.Ty == 2048) FN_W8(2048) else FN_W8(1024)
+            } else if (w8 && PTV && fg.Ty == 2048 && ctx->variant != 1) {
+                FN_W4(2048)
             } else if (sym && symx) {
                 switch (fg.Ty) {
                     case 512: FN_SYMX(512); break;
@@ -2314,6 +2354,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
 #undef FN_SYM
 #undef FN_SYMX
 #undef FN_W8
+#undef FN_W4
 #undef SYM_ARGS_D
 #undef SYM_ARGS
 #undef COL_ARGS
