@@ -277,12 +277,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     transport = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("gloo")
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        from torch_transport import TorchTransport
-        transport = TorchTransport()
+    shard = "orientations" if a.shard == "auto" else a.shard
 
     import scarplet_amd as sl
     from scarplet_amd import _lib
@@ -293,13 +288,21 @@ def main():
     pool = None
     if rank == 0 and world == 1 and not a.emulate_ranks and not (a.no_verify and a.no_cpu_baseline):
         pool = make_pool(g, kind, scales[0])   # forked before the first HIP call below
+    if rank == 0 and world > 1 and shard == "orientations" and not a.no_verify:
+        pool = make_pool(g, kind, scales[0])   # (and before the process group's threads exist)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from torch_transport import TorchTransport
+        transport = TorchTransport()
     ndev = max(1, _lib.load().sc_device_count())
     device = local % ndev                      # one rank per GPU; wraps only in bring-up runs
     n_templates = len(params) * len(angles) * len(scales)
     units = float(ny) * nx * n_templates               # px.template per step
     emu = None
 
-    shard = "orientations" if a.shard == "auto" else a.shard
+    om = None
     if world == 1 and a.emulate_ranks > 1 and shard == "orientations":
         # the R orientation chunks of the R-rank search, one after the other on this GPU
         R = a.emulate_ranks
@@ -506,6 +509,13 @@ def main():
             if pool is not None:
                 pool.terminate()
                 pool.join()
+        elif world > 1 and om is not None and pool is not None:
+            # the folded record of the orientation-sharded search, checked like the single-GPU one
+            ver = verify_window(pool, om.result_array(), g, kind, scales[-1], params, angles, plan)
+            out["verified"] = ver["ok"]
+            out["verification"] = ver
+            pool.terminate()
+            pool.join()
         print(json.dumps(out, ensure_ascii=False))
     if dist is not None:
         dist.barrier()
