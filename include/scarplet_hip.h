@@ -315,6 +315,15 @@ int sc_gather_result(sc_ctx* ctx, int root, const int32_t* cores, int ny, int nx
 int sc_fold_ranks(sc_ctx* ctx);
 int sc_comm_destroy(sc_ctx* ctx);
 
+/* ---- host-side helper of the GeoTIFF reader (no GPU involved) ------------- */
+/*
+ * TIFF LZW (Compression = 5, TIFF 6.0 section 13) of one strip or tile - what
+ * GDAL's COMPRESS=LZW writes; the reference reads such rasters through GDAL
+ * (dem.py:291-348).  Returns the number of bytes written to dst, -1 for a
+ * malformed stream, -2 when dst (cap bytes) is too small.
+ */
+long long sc_tiff_lzw_decode(const unsigned char* src, size_t n, unsigned char* dst, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,6 +110,7 @@ SIGNATURES = {
                          + [C.POINTER(sc_xfer), C.c_int, C.POINTER(_P)]),
     "sc_fold_ranks": (C.c_int, [_P]),
     "sc_comm_destroy": (C.c_int, [_P]),
+    "sc_tiff_lzw_decode": (C.c_longlong, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]),
 }
 
 _lib = None
@@ -142,6 +143,20 @@ def load():
 
 def _as(arr, ptr_type):
     return arr.ctypes.data_as(ptr_type)
+
+
+def tiff_lzw_decode(raw, nbytes):
+    """One LZW strip / tile of a TIFF (Compression = 5) -> ``nbytes`` bytes (host code in the
+    library, no GPU needed)."""
+    out = np.empty(int(nbytes), dtype=np.uint8)
+    n = load().sc_tiff_lzw_decode(bytes(raw), len(raw), out.ctypes.data_as(C.c_void_p), out.size)
+    if n == -2 or n > nbytes:
+        raise ValueError("LZW strip decodes to more than the %d bytes its geometry allows" % nbytes)
+    if n < 0:
+        raise ValueError("malformed LZW stream")
+    if n < nbytes:
+        raise ValueError("LZW strip decodes to %d bytes, %d expected" % (n, nbytes))
+    return out.tobytes()
 
 
 class Context(object):

@@ -2,7 +2,7 @@
 
 Covers what single-band DEM rasters use in practice and what the reference's
 sample datasets need (scarplet/datasets/data/*.tif): classic (non-Big) TIFF,
-either byte order, strips or tiles, uncompressed or deflate, horizontal
+either byte order, strips or tiles, uncompressed, deflate or LZW, horizontal
 predictor, 8/16/32/64-bit integer or float samples, and the GeoTIFF tags
 that define the geotransform (ModelPixelScale + ModelTiepoint, or
 ModelTransformation) plus GDAL's nodata tag.  Replaces the read half of
@@ -90,6 +90,9 @@ def read_geotiff_full(path):
     def decode(raw, rows, cols):
         if comp in (8, 32946):
             raw = zlib.decompress(raw)
+        elif comp == 5:                             # LZW (GDAL COMPRESS=LZW)
+            from scarplet_amd import _lib
+            raw = _lib.tiff_lzw_decode(raw, rows * cols * dtype.itemsize)
         elif comp != 1:
             raise ValueError("%s: compression %d is not supported" % (path, comp))
         a = np.frombuffer(raw, dtype=dtype, count=rows * cols).reshape(rows, cols)

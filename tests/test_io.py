@@ -157,3 +157,27 @@ def test_plot_results_and_hillshade():
     assert len(fig.axes) == 8                       # four maps + four colour bars
     sl.Hillshade(g).plot()
     matplotlib.pyplot.close("all")
+
+
+def test_lzw_geotiffs_written_by_libtiff_decode_exactly():
+    """Compression = 5 (what GDAL's COMPRESS=LZW writes): fixtures encoded by libtiff through
+    Pillow (oracle/gen_lzw_fixtures.py) - one strip of float32, int16 with the horizontal
+    predictor, float32 in several strips - decode to the arrays they were written from
+    (sc_tiff_lzw_decode, host code in the library)."""
+    import os
+    import numpy as np
+    from scarplet_amd import tiff, _lib
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    e = np.load(os.path.join(G, "lzw_expected.npz"))
+    for name, key in (("lzw_f32_strips.tif", "f32"), ("lzw_i16_pred2.tif", "i16"),
+                      ("lzw_f32_multistrip.tif", "multistrip")):
+        a, gt, nodata, geokeys = tiff.read_geotiff_full(os.path.join(G, name))
+        want = e[key]
+        assert a.shape == want.shape and a.dtype.itemsize == want.dtype.itemsize
+        assert np.array_equal(a.view(want.dtype), want), name
+    # a truncated or corrupt stream is an error, not garbage
+    import pytest
+    with pytest.raises(ValueError):
+        _lib.tiff_lzw_decode(b"\x80\x00", 16)                  # ClearCode, then nothing
+    with pytest.raises(ValueError):
+        _lib.tiff_lzw_decode(b"\xff\xff\xff\xff", 16)          # a code far beyond the table
