@@ -19,6 +19,11 @@ Image.fromarray(i16.view(np.uint16)).save(os.path.join(G, "lzw_i16_pred2.tif"), 
                                        tiffinfo={317: 2})
 big = np.ascontiguousarray(z[:230, :250])                            # libtiff cuts it into 8-KB strips
 Image.fromarray(big).save(os.path.join(G, "lzw_f32_multistrip.tif"), compression="tiff_lzw")
-np.savez_compressed(os.path.join(G, "lzw_expected.npz"), f32=f32, i16=i16, multistrip=big)
-for n in ("lzw_f32_strips.tif", "lzw_i16_pred2.tif", "lzw_f32_multistrip.tif"):
+p3 = np.ascontiguousarray(z[150:230, 300:417])                       # floating-point predictor (GDAL PREDICTOR=3)
+Image.fromarray(p3).save(os.path.join(G, "deflate_f32_pred3.tif"), compression="tiff_adobe_deflate",
+                         tiffinfo={317: 3})
+Image.fromarray(p3).save(os.path.join(G, "lzw_f32_pred3.tif"), compression="tiff_lzw", tiffinfo={317: 3})
+np.savez_compressed(os.path.join(G, "lzw_expected.npz"), f32=f32, i16=i16, multistrip=big, p3=p3)
+for n in ("lzw_f32_strips.tif", "lzw_i16_pred2.tif", "lzw_f32_multistrip.tif", "deflate_f32_pred3.tif",
+          "lzw_f32_pred3.tif"):
     print(n, os.path.getsize(os.path.join(G, n)))

@@ -3,7 +3,7 @@
 Covers what single-band DEM rasters use in practice and what the reference's
 sample datasets need (scarplet/datasets/data/*.tif): classic (non-Big) TIFF,
 either byte order, strips or tiles, uncompressed, deflate or LZW, horizontal
-predictor, 8/16/32/64-bit integer or float samples, and the GeoTIFF tags
+and floating-point predictors, 8/16/32/64-bit integer or float samples, and the GeoTIFF tags
 that define the geotransform (ModelPixelScale + ModelTiepoint, or
 ModelTransformation) plus GDAL's nodata tag.  Replaces the read half of
 BaseSpatialGrid.load (dem.py:308-348); anything outside this subset raises.
@@ -95,6 +95,17 @@ def read_geotiff_full(path):
             raw = _lib.tiff_lzw_decode(raw, rows * cols * dtype.itemsize)
         elif comp != 1:
             raise ValueError("%s: compression %d is not supported" % (path, comp))
+        if pred == 3:
+            # floating-point predictor (TIFF Technical Note 3, GDAL PREDICTOR=3): every row is
+            # stored as its bytes regrouped into planes - most significant byte of every
+            # sample first - and then differenced byte by byte along the whole row
+            if kind != "f":
+                raise ValueError("%s: predictor 3 on non-float samples" % path)
+            nb = dtype.itemsize
+            r = np.frombuffer(raw, dtype=np.uint8, count=rows * cols * nb).reshape(rows, cols * nb)
+            r = np.cumsum(r, axis=1, dtype=np.uint8).reshape(rows, nb, cols)
+            be = np.ascontiguousarray(r.transpose(0, 2, 1))          # (rows, cols, nb), big-endian bytes
+            return be.view(np.dtype(">" + kind + str(nb))).reshape(rows, cols)
         a = np.frombuffer(raw, dtype=dtype, count=rows * cols).reshape(rows, cols)
         if pred == 2:
             # horizontal differencing is defined on the sample WORDS (libtiff

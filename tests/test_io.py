@@ -170,11 +170,12 @@ def test_lzw_geotiffs_written_by_libtiff_decode_exactly():
     G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     e = np.load(os.path.join(G, "lzw_expected.npz"))
     for name, key in (("lzw_f32_strips.tif", "f32"), ("lzw_i16_pred2.tif", "i16"),
-                      ("lzw_f32_multistrip.tif", "multistrip")):
+                      ("lzw_f32_multistrip.tif", "multistrip"),
+                      ("deflate_f32_pred3.tif", "p3"), ("lzw_f32_pred3.tif", "p3")):   # floating-point predictor
         a, gt, nodata, geokeys = tiff.read_geotiff_full(os.path.join(G, name))
         want = e[key]
         assert a.shape == want.shape and a.dtype.itemsize == want.dtype.itemsize
-        assert np.array_equal(a.view(want.dtype), want), name
+        assert np.array_equal(a.astype(want.dtype) if a.dtype.kind == "f" else a.view(want.dtype), want), name
     # a truncated or corrupt stream is an error, not garbage
     import pytest
     with pytest.raises(ValueError):
