@@ -23,7 +23,8 @@ p3 = np.ascontiguousarray(z[150:230, 300:417])                       # floating-
 Image.fromarray(p3).save(os.path.join(G, "deflate_f32_pred3.tif"), compression="tiff_adobe_deflate",
                          tiffinfo={317: 3})
 Image.fromarray(p3).save(os.path.join(G, "lzw_f32_pred3.tif"), compression="tiff_lzw", tiffinfo={317: 3})
+Image.fromarray(p3).save(os.path.join(G, "bigtiff_f32_lzw.tif"), big_tiff=True, compression="tiff_lzw")
 np.savez_compressed(os.path.join(G, "lzw_expected.npz"), f32=f32, i16=i16, multistrip=big, p3=p3)
 for n in ("lzw_f32_strips.tif", "lzw_i16_pred2.tif", "lzw_f32_multistrip.tif", "deflate_f32_pred3.tif",
-          "lzw_f32_pred3.tif"):
+          "lzw_f32_pred3.tif", "bigtiff_f32_lzw.tif"):
     print(n, os.path.getsize(os.path.join(G, n)))

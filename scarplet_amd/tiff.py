@@ -1,7 +1,7 @@
 """Minimal GeoTIFF reader and writer (no GDAL).
 
 Covers what single-band DEM rasters use in practice and what the reference's
-sample datasets need (scarplet/datasets/data/*.tif): classic (non-Big) TIFF,
+sample datasets need (scarplet/datasets/data/*.tif): classic TIFF and BigTIFF,
 either byte order, strips or tiles, uncompressed, deflate or LZW, horizontal
 and floating-point predictors, 8/16/32/64-bit integer or float samples, and the GeoTIFF tags
 that define the geotransform (ModelPixelScale + ModelTiepoint, or
@@ -19,22 +19,29 @@ import numpy as np
 
 _TYPES = {1: ("B", 1), 2: ("c", 1), 3: ("H", 2), 4: ("I", 4), 5: ("II", 8),
           6: ("b", 1), 7: ("B", 1), 8: ("h", 2), 9: ("i", 4), 10: ("ii", 8),
-          11: ("f", 4), 12: ("d", 8), 16: ("Q", 8)}
+          11: ("f", 4), 12: ("d", 8), 16: ("Q", 8), 17: ("q", 8), 18: ("Q", 8)}
 
 
-def _read_ifd(buf, off, bo):
-    (n,) = struct.unpack_from(bo + "H", buf, off)
+def _read_ifd(buf, off, bo, big=False):
+    """Tags of the image file directory at ``off``; ``big``: BigTIFF (64-bit counts and offsets,
+    20-byte entries)."""
+    if big:
+        (n,) = struct.unpack_from(bo + "Q", buf, off)
+        head, entry, efmt, inline, pfmt = 8, 20, "HHQ8s", 8, "Q"
+    else:
+        (n,) = struct.unpack_from(bo + "H", buf, off)
+        head, entry, efmt, inline, pfmt = 2, 12, "HHI4s", 4, "I"
     tags = {}
     for k in range(n):
-        tag, typ, cnt, val = struct.unpack_from(bo + "HHI4s", buf, off + 2 + 12 * k)
+        tag, typ, cnt, val = struct.unpack_from(bo + efmt, buf, off + head + entry * k)
         fmt, size = _TYPES.get(typ, (None, 0))
         if fmt is None:
             continue
         total = size * cnt
-        if total <= 4:
+        if total <= inline:
             data = val[:total]
         else:
-            (ptr,) = struct.unpack(bo + "I", val)
+            (ptr,) = struct.unpack(bo + pfmt, val)
             data = buf[ptr:ptr + total]
         if typ == 2:
             tags[tag] = data.split(b"\0")[0].decode("ascii", "replace")
@@ -68,10 +75,17 @@ def read_geotiff_full(path):
         bo = ">"
     else:
         raise ValueError("%s: not a TIFF file" % path)
-    magic, ifd = struct.unpack_from(bo + "HI", buf, 2)
-    if magic != 42:
-        raise ValueError("%s: BigTIFF / unknown TIFF variant is not supported" % path)
-    t = _read_ifd(buf, ifd, bo)
+    (magic,) = struct.unpack_from(bo + "H", buf, 2)
+    if magic == 42:
+        (ifd,) = struct.unpack_from(bo + "I", buf, 4)
+        t = _read_ifd(buf, ifd, bo)
+    elif magic == 43:                               # BigTIFF: offset size 8, then the first IFD's offset
+        osize, zero, ifd = struct.unpack_from(bo + "HHQ", buf, 4)
+        if osize != 8 or zero != 0:
+            raise ValueError("%s: malformed BigTIFF header" % path)
+        t = _read_ifd(buf, ifd, bo, big=True)
+    else:
+        raise ValueError("%s: unknown TIFF variant (magic %d)" % (path, magic))
     width, height = t[256][0], t[257][0]
     bits = t.get(258, (1,))[0]
     comp = t.get(259, (1,))[0]

@@ -171,7 +171,8 @@ def test_lzw_geotiffs_written_by_libtiff_decode_exactly():
     e = np.load(os.path.join(G, "lzw_expected.npz"))
     for name, key in (("lzw_f32_strips.tif", "f32"), ("lzw_i16_pred2.tif", "i16"),
                       ("lzw_f32_multistrip.tif", "multistrip"),
-                      ("deflate_f32_pred3.tif", "p3"), ("lzw_f32_pred3.tif", "p3")):   # floating-point predictor
+                      ("deflate_f32_pred3.tif", "p3"), ("lzw_f32_pred3.tif", "p3"),    # floating-point predictor
+                      ("bigtiff_f32_lzw.tif", "p3")):                                  # BigTIFF (64-bit offsets)
         a, gt, nodata, geokeys = tiff.read_geotiff_full(os.path.join(G, name))
         want = e[key]
         assert a.shape == want.shape and a.dtype.itemsize == want.dtype.itemsize
