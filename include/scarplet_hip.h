@@ -155,6 +155,11 @@ int sc_clear_windows(sc_ctx* ctx);
  *              orientation per launch sequence.  Results are bit-identical.
  *   "y_gb"     memory budget of the column -> row pass hand-off buffers in GB
  *              (0: a quarter of the free memory, at most 32)
+ *   "sib"      sibling rendezvous (bit 0: row pass): the two workgroups that read the two
+ *              halves of the same 128-byte hand-off lines keep within one template of each
+ *              other so that the second read hits the XCD's L2.  Default 0: it moves 10 % fewer
+ *              bytes and takes 3 % longer (profiles/r03_sibling_rendezvous.txt).  Results are
+ *              bit-identical either way.
  */
 int sc_set_option(sc_ctx* ctx, const char* name, double value);
 
@@ -233,6 +238,13 @@ int sc_compare_end(sc_ctx* ctx, double* amp, double* age, double* angle,
 
 /* Directional curvature of the block (dem.py:68-107), float32 ly x lx. */
 int sc_curvature(sc_ctx* ctx, double cc, double sc2, double ss, float* out);
+/* The same as the reference's data object returns it - float64, dem.py:103-104's expression in
+ * numpy's evaluation order: out = d2z_dx2 * cos2 - 2 * d2z_dxdy * sin_a * cos_a + d2z_dy2 * sin2,
+ * cos2 = cos(alpha)**2 and sin2 = sin(alpha)**2 evaluated by the caller.  Replaces
+ * CalculationMixin._calculate_directional_laplacian (dem.py:68-107) and _calculate_laplacian
+ * (dem.py:62-66) behind scarplet_amd.dem.DEMGrid's methods of those names. */
+int sc_curvature_f64(sc_ctx* ctx, double cos2, double sin_a, double cos_a, double sin2,
+                     double* out);
 
 /* Per-template scalars of the last sc_match / sc_match_template call:
  * n = count(W != 0) + eps (core.py:350) and sum(W**2) (core.py:356). */

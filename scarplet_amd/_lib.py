@@ -97,6 +97,7 @@ SIGNATURES = {
     "sc_fill_nodata": (C.c_int, [_P, _dp, C.c_int, C.c_int, C.c_double, C.c_int,
                                  C.POINTER(C.c_longlong)]),
     "sc_curvature": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, _fp]),
+    "sc_curvature_f64": (C.c_int, [_P] + [C.c_double] * 4 + [_dp]),
     "sc_get_template_sums": (C.c_int, [_P, C.c_int, _dp, _dp]),
     "sc_profile": (C.c_int, [_P, C.c_int]),
     "sc_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_longlong), _dp]),
@@ -252,6 +253,15 @@ class Context(object):
         out = np.empty(block_shape, dtype=np.float32)
         self._check(self.lib.sc_curvature(self._h, cc, sc2, ss, _as(out, _fp)),
                     "sc_curvature")
+        return out
+
+    def curvature_f64(self, alpha, block_shape):
+        """dem.py:68-107 in float64 (sc_curvature_f64); cos / sin / squares by numpy, as the
+        reference evaluates them."""
+        out = np.empty(block_shape, dtype=np.float64)
+        self._check(self.lib.sc_curvature_f64(self._h, float(np.cos(alpha) ** 2), float(np.sin(alpha)),
+                                              float(np.cos(alpha)), float(np.sin(alpha) ** 2),
+                                              _as(out, _dp)), "sc_curvature_f64")
         return out
 
     # -- generic plugin windows --------------------------------------------

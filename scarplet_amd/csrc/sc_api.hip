@@ -45,7 +45,7 @@ size_t sc_total_bytes(sc_ctx* c) {
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
-                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res};
+                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf};
     size_t s = 0;
     for (DevBuf* b : arr) s += b->cap;
     for (auto& w : c->windows) s += (size_t)w.h * w.wd * 5;
@@ -161,6 +161,8 @@ extern "C" int sc_set_option(sc_ctx* ctx, const char* name, double value) {
 #endif
     } else if (!strcmp(name, "batch")) {
         ctx->batch_off = value == 0.0;
+    } else if (!strcmp(name, "sib")) {
+        ctx->sib = (int)value;
     } else if (!strcmp(name, "y_gb")) {
         if (!(value >= 0.0)) return sc_fail(ctx, SC_ERR_INVALID, "y_gb must be >= 0");
         ctx->y_gb = value;
@@ -198,7 +200,7 @@ extern "C" void sc_destroy(sc_ctx* c) {
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
-                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res};
+                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf};
     for (DevBuf* b : arr) buf_free(*b);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp[k]);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp_in[k]);
@@ -293,6 +295,21 @@ extern "C" int sc_curvature(sc_ctx* ctx, double cc, double sc2, double ss, float
     if (rc) return rc;
     SC_HIP(ctx, hipMemcpyAsync(out, ctx->curv.p, sizeof(float) * (size_t)ctx->g.ly * ctx->g.lx,
                                hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SC_OK;
+}
+
+extern "C" int sc_curvature_f64(sc_ctx* ctx, double cos2, double sin_a, double cos_a, double sin2,
+                               double* out) {
+    if (!ctx || !out) return SC_ERR_INVALID;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = sizeof(double) * (size_t)ctx->g.ly * ctx->g.lx;
+    int rc = sc_ensure(ctx, ctx->res, bytes);        // (the result planes' buffer: nothing else is live here)
+    if (rc) return rc;
+    rc = launch_curv_f64(ctx, cos2, sin_a, cos_a, sin2, (double*)ctx->res.p);
+    if (rc) return rc;
+    SC_HIP(ctx, hipMemcpyAsync(out, ctx->res.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SC_OK;
 }

@@ -94,6 +94,41 @@ __device__ __forceinline__ void store_stream(float2* dst, float2 a, float2 b) {
     const f4 v = {a.x, a.y, b.x, b.y};
     __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dst));
 }
+// ---- sibling rendezvous (a speed hint, never needed for correctness) ---------------------------
+// Two workgroups that stream the SAME 128-byte lines - the two row workgroups of a rows2 pair in
+// I2, a column block and its mirror block in I1 - sit on one XCD (block ids 8 apart) so that the
+// second reader hits that XCD's L2.  It only does while the two stay within a fraction of a
+// template of each other: an XCD's 4 MB of L2 holds about ONE template step of its workgroups'
+// lines (tools/sectorbench.hip: co-timed readers of the two halves share perfectly, 6.1 - 6.3 TB/s
+// useful; the fabric moves whole lines, half-line reads cost the full line).  Left alone the
+// siblings drift and a third of the second reads go to memory again (I2: 1.17x its algorithmic
+// bytes).  So each workgroup publishes how many template fetches it has issued, and does not issue
+// fetch f before its sibling has issued fetch f - 1.  The wait is bounded: a sibling that is not
+// resident, or sits on another XCD and is therefore never seen, costs time, never the result.
+struct SibSync {
+    uint32_t* slots;       // one word per workgroup of the launch (nullptr: no rendezvous)
+    uint32_t base;         // launch epoch << 8: words of earlier launches compare below it
+};
+// The word travels through the XCD's L2: a plain store leaves it there, an sc1 load reads it from
+// there past the reader's L1 (sc1 on both sides goes to the memory side instead: 1 - 2 us per look,
+// measured as +3 % on the row pass).  Siblings on different XCDs would never see each other's word:
+// the first wait that runs out switches the waiting off for the rest of the workgroup's life.
+__device__ __forceinline__ void sib_publish(uint32_t* mine, uint32_t v) {
+    asm volatile("global_store_dword %0, %1, off" :: "v"(mine), "v"(v) : "memory");
+}
+__device__ __forceinline__ uint32_t sib_peek(const uint32_t* theirs) {
+    return __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// false: gave up (the caller stops waiting from here on)
+__device__ __forceinline__ bool sib_wait(const uint32_t* theirs, uint32_t target) {
+    for (int budget = 64; budget > 0; --budget) {
+        if ((int32_t)(sib_peek(theirs) - target) >= 0) return true;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return false;
+}
+constexpr uint32_t SIB_DONE = 0xFFu;
+
 #ifdef SC_ABLATE
 // store flavours for the ablation build (tools/ablate.sh): 0 non-temporal (production),
 // 1 plain, 2 sc1 (write-through, line dropped from L2), 3 sc0 sc1
@@ -1459,6 +1494,7 @@ struct RowArgs {
     // (templates first + b*G + g, consecutive); the Y block of (orientation b, pair q of the
     // chunk) is job b*pcj + q, its tile norms are entry b*np + pair
     int nb, np, pcj;
+    SibSync sib;                        // sibling rendezvous of the fast kernel (rows 2rp, 2rp+1)
 };
 // One launch may serve several tile pairs (grid.y): pair = ra.pair + blockIdx.y,
 // its Y planes ystride planes further on.  More workgroups per launch fill the
@@ -1697,7 +1733,13 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     const int id = threadIdx.x;
     // blocks b and b + 8 take the two rows of one pair (same XCD, same time)
     const int pi = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7), rh = (blockIdx.x >> 3) & 1;
-    if (pi >= ra.rp_n) return;
+    // sibling rendezvous (SibSync): this workgroup's word and the word of the other row of the pair
+    uint32_t* const sib_mine = ra.sib.slots ? ra.sib.slots + (size_t)blockIdx.y * gridDim.x + blockIdx.x : nullptr;
+    const uint32_t* const sib_theirs = ra.sib.slots ? ra.sib.slots + (size_t)blockIdx.y * gridDim.x + (blockIdx.x ^ 8) : nullptr;
+    if (pi >= ra.rp_n) {
+        if (sib_mine && id == 0) sib_publish(sib_mine, ra.sib.base + SIB_DONE);
+        return;
+    }
     const int rp = ra.rp_lo + pi;
     const size_t plane = (size_t)ra.Ty * TX;
     ra.pair += blockIdx.y;
@@ -1765,7 +1807,10 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     int ri = 2 * rp + rh - ra.Py;
     if (ra.circ_y) ri &= (ra.Ty - 1);
     const bool rowA = ri >= 0 && ri < tA.vy, rowB = ri >= 0 && ri < tB.vy;
-    if (!rowA && !rowB) return;                                  // whole workgroup
+    if (!rowA && !rowB) {                                        // whole workgroup
+        if (sib_mine && id == 0) sib_publish(sib_mine, ra.sib.base + SIB_DONE);
+        return;
+    }
     int cj0 = rem3 - ra.Qx;
     const int cmask = ra.circ_x ? TX - 1 : -1;
     auto col_of = [&](int c) { return (cj0 + (c / R3) * 2 * S + 256 * (c % R3)) & cmask; };
@@ -1822,12 +1867,16 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         if (++fk == NGO) { fk = 0; fp += ostep; }
     };
     fetch();
+    if (sib_mine && id == 0) sib_publish(sib_mine, ra.sib.base + 1);
     lds_barrier();                                               // tables and scalars are in place
     int ob = 0, ok_ = 0;                                         // orientation / transform within it of gi_
+    bool sib_on = sib_mine != nullptr;
+    uint32_t sib_seen = 0;
     for (int gi_ = 0; gi_ < NG; ++gi_) {
         // the columns are two instructions away from cj0: keep them out of the
         // loop-invariant registers (eight of them would not fit)
         asm volatile("" : "+v"(cj0));
+        if (sib_on && id == 0 && gi_ + 1 < NG) sib_seen = sib_peek(sib_theirs);
 
         // ---- stage 1 (radix 16, stride 1) from registers: outputs 16 tt1 + m
         {
@@ -1846,8 +1895,15 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 line1[k + 8] = pk::cmul(a[pk::B<16, true>::pos(k + 8)], pk::cmul(wk, w8));
             }
         }
+        // (the sibling must have issued fetch gi_ before this workgroup issues fetch gi_ + 1;
+        //  its word was looked at before stage 1, the load has had the stage to come back)
+        if (sib_on && id == 0 && gi_ + 1 < NG && (int32_t)(sib_seen - (ra.sib.base + gi_ + 1)) < 0)
+            sib_on = sib_wait(sib_theirs, ra.sib.base + gi_ + 1);
         lds_barrier();
-        if (FETCH_AT == 0 && gi_ + 1 < NG) fetch();              // in flight through stages 2-3
+        if (FETCH_AT == 0 && gi_ + 1 < NG) {
+            fetch();                                             // in flight through stages 2-3
+            if (sib_mine && id == 0) sib_publish(sib_mine, ra.sib.base + gi_ + 2);
+        }
         // ---- stage 2 (radix 16, stride 16): elements tt2 + j*S -> o + 16 m
         {
             v2 b[16];
@@ -1953,6 +2009,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         lds_barrier();
         if (++ok_ == NGO) { ok_ = 0; ++ob; }
     }
+    if (sib_mine && id == 0) sib_publish(sib_mine, ra.sib.base + SIB_DONE);
     if (!MAPS) {
 #pragma unroll
         for (int k = 0; k < NBEST; ++k) {
@@ -2071,6 +2128,22 @@ int fft_batch_orientations(const sc_ctx* ctx, const FftGeom& fg, int n_per, int 
     const int by_table = SC_MAX_GROUP / n_per;
     const int by_fill = 2048 / std::max(1, np * (fg.Tx / 8));
     return std::max(1, std::min(std::min(by_table, by_fill), 32));
+}
+
+// Rendezvous words for a launch of n workgroups (SibSync): one buffer per context, a new epoch per
+// launch - words left by earlier launches compare below the new base, so nothing is cleared
+// between launches; the buffer is zeroed when it grows and when the 24-bit epoch wraps.
+static int sib_slots(sc_ctx* ctx, size_t n, SibSync& out) {
+    const size_t bytes = n * sizeof(uint32_t);
+    if (bytes > ctx->sib_buf.cap || ctx->sib_epoch >= 0xFFFFFEu) {
+        int rc = sc_ensure(ctx, ctx->sib_buf, std::max(bytes, (size_t)1 << 20));
+        if (rc) return rc;
+        SC_HIP(ctx, hipMemsetAsync(ctx->sib_buf.p, 0, ctx->sib_buf.cap, ctx->stream));
+        ctx->sib_epoch = 0;
+    }
+    out.slots = (uint32_t*)ctx->sib_buf.p;
+    out.base = (++ctx->sib_epoch) << 8;
+    return SC_OK;
 }
 
 template <typename K>
@@ -2363,8 +2436,12 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             const int pair = pair0;
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
                        ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg, group,
-                       nb, np, pc};
-                        dim3 gridr(fast ? ((rp_n + 7) / 8) * 16 : (rp_n + 1) / 2, pc);
+                       nb, np, pc, SibSync{nullptr, 0}};
+            dim3 gridr(fast ? ((rp_n + 7) / 8) * 16 : (rp_n + 1) / 2, pc);
+            if (fast && (ctx->sib & 1)) {
+                int rc = sib_slots(ctx, (size_t)gridr.x * gridr.y, ra.sib);
+                if (rc) return rc;
+            }
             sc_prof_begin(ctx, SC_K_INV_ROWS);
 #define ROW_ARGS lds_r, FAST_ARGS
 #define FAST_ARGS                                                              \

@@ -90,6 +90,9 @@ struct sc_ctx {
     int variant = 0;           // sc_set_option "variant": alternative kernel paths kept for cross-checks
     int batch_off = 0;         // sc_set_option "batch" = 0: no orientation batching (cross-check in the tests)
     double y_gb = 0.0;         // sc_set_option "y_gb": memory budget of the I1 -> I2 hand-off (0: automatic)
+    int sib = 0;               // sc_set_option "sib": sibling rendezvous, bit 0 row pass, bit 1 column pass (sc_fft.hip SibSync)
+    DevBuf sib_buf;
+    uint32_t sib_epoch = 0;
     int dbg = 0;               // timing-only ablation bits; only an SC_ABLATE build reads them (tools/ablate.sh)
     // profiling
     int prof = 0;              // 0 off, k: time every k-th launch of a kernel
@@ -136,6 +139,7 @@ void sc_prof_collect(sc_ctx* ctx);
 // ---- launchers implemented in sc_kernels.hip --------------------------------
 int launch_curv_planes(sc_ctx* ctx);
 int launch_curv_alpha(sc_ctx* ctx, float cc, float sc2, float ss, int plane = 0);
+int launch_curv_f64(sc_ctx* ctx, double c2, double sn, double cs, double s2, double* out_dev);
 int launch_curv_alpha_batch(sc_ctx* ctx, const float (*coef)[3], int nb);
 int launch_windows(sc_ctx* ctx, int first, int n, int wh_max, int ww_max);
 int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps);

@@ -45,6 +45,54 @@ k_curv_planes(const double* __restrict__ z, Geom g, double dx, double dy,
     C[o] = (float)c;
 }
 
+// The reference's curvature as its data object returns it (dem.py:68-107), float64 out: the three
+// stencils of k_curv_planes and dem.py:103-104's combination
+//   d2z_dx2 * cos(a)**2 - 2 * d2z_dxdy * sin(a) * cos(a) + d2z_dy2 * sin(a)**2
+// in numpy's evaluation order (no contraction); c2 = cos(a)**2, s2 = sin(a)**2 come from the host.
+// Serves DEMGrid._calculate_directional_laplacian; the matcher keeps its float32 planes.
+__global__ void __launch_bounds__(256)
+k_curv_f64(const double* __restrict__ z, Geom g, double dx, double dy, double c2, double sn,
+           double cs, double s2, double* __restrict__ out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.y;
+    if (j >= g.lx) return;
+    int gi = wrap_index(g.gy0 + i, g.ny);
+    int gj = wrap_index(g.gx0 + j, g.nx);
+    int im = max(i - 1, 0), ip = min(i + 1, g.ly - 1);
+    int jm = max(j - 1, 0), jp = min(j + 1, g.lx - 1);
+    const double* r0 = z + (size_t)im * g.lx;
+    const double* r1 = z + (size_t)i * g.lx;
+    const double* r2 = z + (size_t)ip * g.lx;
+    double z11 = r1[j];
+    double a = 0.0, b = 0.0, c = 0.0;
+    if (gj >= 1 && gj <= g.nx - 2)
+        a = __ddiv_rn(__dsub_rn(__dsub_rn(r1[jp], z11), __dsub_rn(z11, r1[jm])),
+                      __dmul_rn(dx, dx));
+    if (gi >= 1 && gj >= 1) {
+        double d1 = __ddiv_rn(__dsub_rn(z11, r1[jm]), dx);
+        double d0 = __ddiv_rn(__dsub_rn(r0[j], r0[jm]), dx);
+        b = __ddiv_rn(__dsub_rn(d1, d0), dx);
+    }
+    if (gi >= 1 && gi <= g.ny - 2)
+        c = __ddiv_rn(__dsub_rn(__dsub_rn(r2[j], z11), __dsub_rn(z11, r0[j])),
+                      __dmul_rn(dy, dy));
+    const double t1 = __dmul_rn(a, c2);
+    const double t2 = __dmul_rn(__dmul_rn(__dmul_rn(2.0, b), sn), cs);
+    const double t3 = __dmul_rn(c, s2);
+    out[(size_t)i * g.lx + j] = __dadd_rn(__dsub_rn(t1, t2), t3);
+}
+
+int launch_curv_f64(sc_ctx* ctx, double c2, double sn, double cs, double s2, double* out_dev) {
+    const Geom& g = ctx->g;
+    dim3 grid((g.lx + 255) / 256, g.ly);
+    sc_prof_begin(ctx, SC_K_CURV);
+    hipLaunchKernelGGL(k_curv_f64, grid, dim3(256), 0, ctx->stream, ctx->z_dev, g, ctx->dx, ctx->dy,
+                       c2, sn, cs, s2, out_dev);
+    sc_prof_end(ctx);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
 // curv = cc*A - sc2*B + ss*C (dem.py:103-104), float4 per thread.
 __global__ void __launch_bounds__(256)
 k_curv_alpha(const float* __restrict__ A, const float* __restrict__ B,

@@ -120,6 +120,37 @@ class DEMGrid(object):
         proj = gi.projection if isinstance(gi.projection, dict) else None
         tiff.write_geotiff(filename, res, gi.geo_transform, geokeys=proj)
 
+    # -- curvature (the data-object half of the matcher's contract, core.py:341) ------------
+    def _calculate_laplacian(self, device=0):
+        """Curvature of the grid in the y direction (dem.py:62-66)."""
+        return self._calculate_directional_laplacian(0, device=device)
+
+    def _calculate_directional_laplacian(self, alpha, device=0):
+        """Curvature of the grid in direction ``alpha`` (dem.py:68-107), float64, computed on the
+        GPU (``sc_curvature_f64``: the reference's three finite-difference stencils with zero
+        borders, dx for the cross term, and dem.py:103-104's combination in numpy's evaluation
+        order).  NaN cells are zeroed before the stencils and come back as NaN in the result;
+        like the reference (dem.py:85-86 writes through ``self._griddata``) the grid itself
+        keeps the zeros."""
+        from scarplet_amd.core import _context
+        from scarplet_amd import WindowedTemplate as _WT
+        z = self._griddata
+        if z.dtype != np.float64 or not z.flags.c_contiguous:
+            z = self._griddata = np.ascontiguousarray(z, dtype=np.float64)
+        nan_idx = np.isnan(z)
+        z[nan_idx] = 0
+        gi = self._georef_info
+        dx = float(gi.dx)
+        dy = float(gi.dy if gi.dy is not None else gi.dx)
+        ny, nx = z.shape
+        ctx = _context(device)
+        ctx.set_dem(z, dx, dy, _WT.centred_axis(nx, dx), _WT.centred_axis(ny, dx))
+        del2z = ctx.curvature_f64(alpha, z.shape)
+        del2z[nan_idx] = np.nan
+        return del2z
+
+    _calculate_directional_laplacian_numexpr = _calculate_directional_laplacian   # dem.py:109-150
+
     def _fill_nodata(self, device=0, max_passes=64):
         """Fill nodata (NaN) cells by interpolation so that the matcher's NaN-free
         precondition holds (dem.py:388-414).  Like the reference: repeat

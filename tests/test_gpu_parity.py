@@ -61,6 +61,32 @@ def test_curvature_reference_goldens(gpu_ctx):
             assert np.allclose(c[sl_y, sl_x], gold[sl_y, sl_x], rtol=1e-5, atol=1e-6 * np.max(np.abs(gold)))
 
 
+def test_data_object_curvature_methods(gpu_ctx):
+    """DEMGrid._calculate_directional_laplacian / _calculate_laplacian (dem.py:62-107): the
+    methods the reference's own tests call (tests/test_dem.py:34,42), float64 out, against the
+    reference's golden crops cell for cell; NaN cells zeroed before the stencils and NaN in the
+    result (dem.py:85-86, 105), the grid keeping the zeros like the reference's."""
+    f = np.load(golden("ref_faultzone_curvature.npz"))
+    for name, sl_y, sl_x in (("tl", slice(None, -1), slice(None, -1)), ("br", slice(1, None), slice(1, None))):
+        g = grid(f["z_" + name], 2.0, 2.0)
+        for deg, ang in zip((0, -90, -45, 45, 90), (0.0, -np.pi / 2, -np.pi / 4, np.pi / 4, np.pi / 2)):
+            c = g._calculate_directional_laplacian(ang)
+            assert c.dtype == np.float64
+            gold = f["gold_%s_%d" % (name, deg)]
+            assert np.array_equal(c[sl_y, sl_x], gold[sl_y, sl_x]), (name, deg, np.abs(c - gold)[sl_y, sl_x].max())
+        assert np.array_equal(g._calculate_laplacian(), g._calculate_directional_laplacian(0))
+    rng = np.random.default_rng(5)
+    z = rng.standard_normal((37, 53)).cumsum(1)
+    z[4, 7] = z[20, 30:33] = np.nan
+    g = grid(z.copy(), 1.5, 2.5)
+    got = g._calculate_directional_laplacian(0.3)
+    z0 = np.where(np.isnan(z), 0.0, z)
+    want = orc.directional_curvature(z0, 1.5, 2.5, 0.3)
+    want[np.isnan(z)] = np.nan
+    assert np.array_equal(got, want, equal_nan=True)
+    assert not np.isnan(g._griddata).any() and np.array_equal(g._griddata, z0)
+
+
 # ------------------------------------------------------------------ K2..K4
 @pytest.mark.parametrize("method", ["direct", "fft"])
 def test_match_template_reference_outputs(gpu_ctx, method):

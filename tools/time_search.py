@@ -17,12 +17,16 @@ ap.add_argument("--scale", type=float, default=100.0)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--prof", type=int, default=8)
 ap.add_argument("--variant", type=int, default=0, help="sc_set_option variant (include/scarplet_hip.h)")
+ap.add_argument("--opt", default="", help="engine options name=value[,name=value...] (sc_set_option)")
 a = ap.parse_args()
 t0 = time.time()
 g = synthetic.synthetic_scarp(a.n)
 print("dem %dx%d built in %.1fs" % (a.n, a.n, time.time() - t0))
 m = sl.Matcher(g)
 m.ctx.set_option("variant", a.variant)
+for kv in a.opt.split(","):
+    if kv:
+        m.ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 ages = _plan.age_grid()[np.round(np.linspace(0, 34, a.ages)).astype(int)]
 angs = _plan.angle_grid()[np.round(np.linspace(0, 180, a.angles)).astype(int)]
 for rep in range(a.reps):
