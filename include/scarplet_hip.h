@@ -166,14 +166,18 @@ int sc_set_option(sc_ctx* ctx, const char* name, double value);
 /*
  * One pass of the nodata fill that precedes the matcher (DEMGrid._fill_nodata,
  * dem.py:388-414: rasterio.fill.fillnodata -> GDALFillNodata).  z: ny x nx
- * float64 host array, NaN = nodata, filled in place: every nodata cell takes the
- * inverse-distance mean of the nearest valid cells of its four quadrants within
- * max_search_distance (searching the columns x +- step, step <= floor(distance)),
- * then smoothing_iterations 3x3 means over the filled cells.  *remaining = cells
- * still nodata (no source within reach); the host repeats with a new distance as
- * the reference does.  Independent of the DEM held by the context.
- * GDAL itself is not available to check against: the algorithm is restated from
- * its published description (oracle/scarplet_oracle.py fill_nodata_pass).
+ * float64 host array, NaN = nodata, filled in place the way GDAL's second pass
+ * does it (alg/rasterfill.cpp as restated in oracle/scarplet_oracle.py
+ * fill_nodata_pass): float32 work values (valid cells come back rounded through
+ * float32 as well), per nodata cell the nearest valid cell of each quadrant over
+ * the columns x -+ step, step <= floor(max_search_distance) - left quadrants from
+ * step 0, right quadrants from step 1, columns clamped at the raster edge - and
+ * the mean weighted by 1 / distance over the quadrants within
+ * max_search_distance; then smoothing_iterations 3x3 means over the filled cells.
+ * *remaining = cells still nodata (no source within reach); the host repeats with
+ * a new distance as the reference does.  Independent of the DEM held by the
+ * context.  PARITY UNPINNED: GDAL is not available to check against and no
+ * GDAL-written fixture exists.
  */
 int sc_fill_nodata(sc_ctx* ctx, double* z, int ny, int nx, double max_search_distance,
                    int smoothing_iterations, long long* remaining);
@@ -327,14 +331,8 @@ int sc_gather_result(sc_ctx* ctx, int root, const int32_t* cores, int ny, int nx
 int sc_fold_ranks(sc_ctx* ctx);
 int sc_comm_destroy(sc_ctx* ctx);
 
-/* ---- host-side helper of the GeoTIFF reader (no GPU involved) ------------- */
-/*
- * TIFF LZW (Compression = 5, TIFF 6.0 section 13) of one strip or tile - what
- * GDAL's COMPRESS=LZW writes; the reference reads such rasters through GDAL
- * (dem.py:291-348).  Returns the number of bytes written to dst, -1 for a
- * malformed stream, -2 when dst (cap bytes) is too small.
- */
-long long sc_tiff_lzw_decode(const unsigned char* src, size_t n, unsigned char* dst, size_t cap);
+/* (The TIFF LZW decoder of the GeoTIFF reader moved to libscarplet_host.so in round 3:
+ * include/scarplet_host.h - reading a DEM must not need the HIP and RCCL runtimes.) */
 
 #ifdef __cplusplus
 }

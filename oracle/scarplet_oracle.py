@@ -274,30 +274,51 @@ def fill_nodata_pass(z, max_search_distance, smoothing_iterations=0):
     """One call of GDAL's GDALFillNodata as rasterio.fill.fillnodata reaches it
     (dem.py:408-410).  PARITY UNPINNED: GDAL is an un-vendored dependency
     (setup.py / requirements.txt: rasterio, unpinned) and neither it nor
-    rasterio is installed here, so this restates the algorithm GDAL publishes
-    (gdal/alg/rasterfill.cpp, "a four direction conic search ... using inverse
-    distance weighting ... then smoothing iterations of a 3x3 average filter on
-    interpolated pixels") and has not been checked against GDAL output:
+    rasterio is installed here; no GDAL-written fixture exists.  This restates
+    the second pass of GDALFillNodata as GDAL publishes it (alg/rasterfill.cpp,
+    GDAL 2.x / 3.x: the QUAD_CHECK macro and the pixel loop), statement by
+    statement as far as the published text is remembered here:
 
-      * for a nodata cell (x, y) and every column x' with |x' - x| <=
-        floor(max_search_distance), take the nearest valid cell of that column
-        at or above row y (top quadrants) and at or below it (bottom
-        quadrants); x' <= x feeds the left quadrant, x' >= x the right one
-        (the cell's own column feeds both);
-      * per quadrant keep the candidate of smallest Euclidean distance (first
-        found on a tie, scanning outwards from x);
-      * value = sum(v_q / d_q) / sum(1 / d_q) over the quadrants whose
-        distance is <= max_search_distance; none: the cell stays nodata;
-      * only original valid cells are sources (fills do not feed fills);
-      * smoothing: ``smoothing_iterations`` passes replacing each FILLED cell
-        by the mean of its 3x3 neighbourhood's non-nodata cells.
+      * work values are float32 scanlines: every source value is the float32 of
+        the input, a filled cell is float32(dfValueSum / dfWeightSum), and the
+        scanline is written back whole - a float64 grid comes back rounded
+        through float32 (a no-op for the reference's GDT_Float32 rasters);
+      * nMaxSearchDist = floor(dfMaxSearchDist); per nodata cell the four
+        quadrant distances start at dfMaxSearchDist + 1 and the steps run
+        iStep = 0 .. nThisMaxSearchDist over the columns
+        iLeftX = max(0, iX - iStep), iRightX = min(nXSize - 1, iX + iStep)
+        (clamped at the raster edge, not skipped);
+      * quadrant 0 = top left, 1 = bottom left, 2 = top right, 3 = bottom right.
+        The LEFT quadrants are checked at every step - "top left includes
+        current line": the nearest valid cell of the column at or above /
+        at or below row iY; the RIGHT quadrants only from iStep = 1 ("top right
+        and bottom right do no include center pixel"), so the cell's own column
+        counts once;
+      * QUAD_CHECK compares SQUARED distances, dfDistSq < quad_dist*quad_dist,
+        and stores quad_dist = sqrt(dfDistSq): a later candidate at the same
+        squared distance replaces the earlier one exactly when squaring the
+        stored root rounds up (2 < sqrt(2)**2);
+      * every four steps nThisMaxSearchDist = floor(max of the four distances)
+        - with all quadrants found the search stops at the farthest of them,
+        with one still missing it runs one step past nMaxSearchDist (such
+        candidates fail the final test);
+      * value = sum(v_q * w_q) / sum(w_q), w_q = 1 / dist_q, over the quadrants
+        with dist_q <= dfMaxSearchDist, accumulated in quadrant order in
+        float64; no such quadrant: the cell stays nodata;
+      * only original valid cells are sources (the last-value arrays of a line
+        are updated before its pixels are filled);
+      * smoothing (unused by the path: rasterio's default is 0 iterations):
+        ``smoothing_iterations`` passes replacing each FILLED cell by the mean
+        of its 3x3 neighbourhood's non-nodata cells - an approximation of
+        GDALMultiFilter's 3x3 average, not a restatement.
     Returns a new float64 array."""
-    z = np.array(z, dtype=float)
-    ny, nx = z.shape
-    valid = ~np.isnan(z)
+    zin = np.asarray(z, dtype=float)
+    ny, nx = zin.shape
+    valid = ~np.isnan(zin)
+    vals = zin.astype(np.float32)                   # the float32 scanlines
     big = 1 << 30
-    up = np.full((ny, nx), -big, dtype=np.int64)     # nearest valid row at or above
-    dn = np.full((ny, nx), big, dtype=np.int64)      # nearest valid row at or below
+    up = np.full((ny, nx), -big, dtype=np.int64)     # panTopDownY: nearest valid row at or above
+    dn = np.full((ny, nx), big, dtype=np.int64)      # panLastY:    nearest valid row at or below
     last = np.full(nx, -big, dtype=np.int64)
     for y in range(ny):
         last = np.where(valid[y], y, last)
@@ -306,29 +327,43 @@ def fill_nodata_pass(z, max_search_distance, smoothing_iterations=0):
     for y in range(ny - 1, -1, -1):
         last = np.where(valid[y], y, last)
         dn[y] = last
-    out = z.copy()
-    R = int(np.floor(max_search_distance))
+    out = vals.astype(np.float64)
+    msd = float(max_search_distance)
+    R = int(np.floor(msd))
     for (y, x) in np.argwhere(~valid):
-        qd = [np.inf] * 4          # TL, TR, BL, BR
-        qv = [0.0] * 4
-        for step in range(R + 1):
-            for side, xx in ((0, x - step), (1, x + step)):
-                if xx < 0 or xx >= nx:
-                    continue
-                for vert, yy in ((0, up[y, xx]), (2, dn[y, xx])):
-                    if yy < 0 or yy >= ny:
-                        continue
-                    d = np.sqrt(float((xx - x) ** 2 + (yy - y) ** 2))
-                    q = vert + side
-                    if d < qd[q]:
-                        qd[q], qv[q] = d, z[yy, xx]
+        qd = [msd + 1.0] * 4       # TL, BL, TR, BR
+        qv = [np.float32(0.0)] * 4
+
+        def check(q, tx, ty):
+            if ty < 0 or ty >= ny:
+                return
+            ddx, ddy = float(tx) - float(x), float(ty) - float(y)
+            dsq = ddx * ddx + ddy * ddy
+            if dsq < qd[q] * qd[q]:
+                qd[q] = float(np.sqrt(dsq))
+                qv[q] = vals[ty, tx]
+
+        this_max, step = R, 0
+        while step <= this_max:
+            lx, rx = max(0, x - step), min(nx - 1, x + step)
+            check(0, lx, up[y, lx])
+            check(1, lx, dn[y, lx])
+            if step > 0:
+                check(2, rx, up[y, rx])
+                check(3, rx, dn[y, rx])
+                if (step & 3) == 0:
+                    this_max = int(np.floor(max(qd)))
+            step += 1
         ws = vs = 0.0
+        have = False
         for q in range(4):
-            if qd[q] <= max_search_distance:
-                ws += 1.0 / qd[q]
-                vs += qv[q] / qd[q]
-        if ws > 0:
-            out[y, x] = vs / ws
+            if qd[q] <= msd:
+                w = 1.0 / qd[q]
+                have = True
+                ws += w
+                vs += float(qv[q]) * w
+        if have:
+            out[y, x] = float(np.float32(vs / ws))
     filled = ~valid & ~np.isnan(out)
     for _ in range(int(smoothing_iterations)):
         src = out.copy()
@@ -343,21 +378,38 @@ def fill_nodata_pass(z, max_search_distance, smoothing_iterations=0):
     return out
 
 
+def fill_search_distances(mask, stalled_at=None):
+    """dem.py:402-405: max_search_distance = max(most nodata cells in a row, in a column) / 2.
+    ``stalled_at``: the distance of a pass that filled nothing (an isolated nodata cell gives
+    1 / 2, and nothing lies within half a cell: the reference's loop never ends there,
+    dem.py:400) - the next pass searches at least one cell, then twice as far every time."""
+    dist = max(np.sum(mask, axis=1).max(), np.sum(mask, axis=0).max()) / 2
+    if stalled_at is not None:
+        dist = max(dist, 1.0, 2.0 * stalled_at)
+    return dist
+
+
 def fill_nodata(z, max_passes=64):
     """DEMGrid._fill_nodata, dem.py:388-414: repeat fillnodata with
     max_search_distance = max(most nodata cells in a row, in a column) / 2
-    until no nodata is left (bounded here: the reference loops forever when a
-    pass makes no progress)."""
+    until no nodata is left.  Where a pass makes no progress the reference
+    loops forever; here the search distance is widened (fill_search_distances)
+    until cells fill or the distance exceeds the grid (nothing valid at all)."""
     z = np.array(z, dtype=float)
+    stalled = None
     for _ in range(max_passes):
         mask = np.isnan(z)
         if not mask.any():
             break
-        dist = max(np.sum(mask, axis=1).max(), np.sum(mask, axis=0).max()) / 2
+        dist = fill_search_distances(mask, stalled)
         before = int(mask.sum())
         z = fill_nodata_pass(z, dist)
         if int(np.isnan(z).sum()) == before:
-            break
+            if dist > max(z.shape):
+                break
+            stalled = dist
+        else:
+            stalled = None
     return z
 
 

@@ -10,8 +10,10 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SCARPLET_HIP_LIB: developer hook of the tools/ scripts to load another build of the
-# same library (the -DSC_ABLATE timing build); the engine itself reads no environment
+# SCARPLET_HIP_LIB is the ONE environment variable this package reads: a developer hook of the
+# tools/ scripts to load another build of the same library (the -DSC_ABLATE timing build,
+# tools/ablate.sh).  The engine itself - libscarplet_hip.so - reads no environment at all; its
+# options go through sc_set_option.
 LIB_PATH = os.environ.get("SCARPLET_HIP_LIB") or os.path.join(_HERE, "libscarplet_hip.so")
 
 SC_OK = 0
@@ -111,7 +113,6 @@ SIGNATURES = {
                          + [C.POINTER(sc_xfer), C.c_int, C.POINTER(_P)]),
     "sc_fold_ranks": (C.c_int, [_P]),
     "sc_comm_destroy": (C.c_int, [_P]),
-    "sc_tiff_lzw_decode": (C.c_longlong, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]),
 }
 
 _lib = None
@@ -144,20 +145,6 @@ def load():
 
 def _as(arr, ptr_type):
     return arr.ctypes.data_as(ptr_type)
-
-
-def tiff_lzw_decode(raw, nbytes):
-    """One LZW strip / tile of a TIFF (Compression = 5) -> ``nbytes`` bytes (host code in the
-    library, no GPU needed)."""
-    out = np.empty(int(nbytes), dtype=np.uint8)
-    n = load().sc_tiff_lzw_decode(bytes(raw), len(raw), out.ctypes.data_as(C.c_void_p), out.size)
-    if n == -2 or n > nbytes:
-        raise ValueError("LZW strip decodes to more than the %d bytes its geometry allows" % nbytes)
-    if n < 0:
-        raise ValueError("malformed LZW stream")
-    if n < nbytes:
-        raise ValueError("LZW strip decodes to %d bytes, %d expected" % (n, nbytes))
-    return out.tobytes()
 
 
 class Context(object):

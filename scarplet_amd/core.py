@@ -131,6 +131,9 @@ class Matcher(object):
         """compare() over such maps (core.py:228-240): 0*NaN poisons amp and
         snr of every cell some template leaves unmasked; age and angle stay 0
         (0 * finite); fully masked cells keep the zero record."""
+        fast = self._nan_fold_builtin(Template, scale, params, angles) if not kwargs else None
+        if fast is not None:
+            return fast
         amp = np.zeros((self.ny, self.nx))
         snr = np.zeros((self.ny, self.nx))
         for ang in angles:
@@ -140,6 +143,44 @@ class Matcher(object):
                 snr[np.isnan(s)] = np.nan
         zero = np.zeros((self.ny, self.nx))
         return np.stack([amp, zero, zero.copy(), snr])
+
+    def _nan_fold_builtin(self, Template, scale, params, angles):
+        """_nan_fold for the built-in classes without a template object (and two full-grid
+        masks) per (age, orientation): a template leaves exactly its window-limit rectangle
+        unmasked (grid_descriptors' ilo..ihi x jlo..jhi), so the cells that turn NaN are the
+        union of those rectangles - one pass over a corner-count grid - and, for the UpperBreak
+        classes, the part of each orientation's union outside its error half-plane
+        (WT.py:257-267, 294-304).  None for any other class."""
+        from scarplet_amd.WindowedTemplate import grid_descriptors, centred_axis, _trig, \
+            FLAG_ERR_XR_LE0, FLAG_ERR_XR_GE0
+        g = grid_descriptors(Template, scale, params, angles, self.nx, self.ny, self.de)
+        if g is None:
+            return None
+        ny, nx = self.ny, self.nx
+
+        def union(ilo, ihi, jlo, jhi):
+            keep = (ihi >= ilo) & (jhi >= jlo)
+            cnt = np.zeros((ny + 1, nx + 1), dtype=np.int32)
+            for a, b, sgn in ((ilo, jlo, 1), (ilo, jhi + 1, -1), (ihi + 1, jlo, -1), (ihi + 1, jhi + 1, 1)):
+                np.add.at(cnt, (a[keep], b[keep]), sgn)
+            return cnt.cumsum(0).cumsum(1)[:ny, :nx] > 0
+
+        ilo, ihi, jlo, jhi = (np.asarray(g[k]) for k in ("ilo", "ihi", "jlo", "jhi"))
+        amp_nan = union(ilo.ravel(), ihi.ravel(), jlo.ravel(), jhi.ravel())
+        flags = int(g["flags"])
+        if flags & (FLAG_ERR_XR_LE0 | FLAG_ERR_XR_GE0):
+            x = centred_axis(nx, self.de)[np.newaxis, :]
+            y = centred_axis(ny, self.de)[:, np.newaxis]
+            snr_nan = np.zeros((ny, nx), dtype=bool)
+            for ib, ang in enumerate(angles):
+                ca, sa = _trig(-ang)[:2]
+                xr = x * ca + y * sa
+                err = (xr <= 0) if flags & FLAG_ERR_XR_LE0 else (xr >= 0)
+                snr_nan |= union(ilo[ib], ihi[ib], jlo[ib], jhi[ib]) & ~err
+        else:
+            snr_nan = amp_nan
+        zero = np.zeros((ny, nx))
+        return np.stack([np.where(amp_nan, np.nan, 0.0), zero, zero.copy(), np.where(snr_nan, np.nan, 0.0)])
 
     # -- templates --------------------------------------------------------------
     def describe(self, Template, scale, params, angles, id_base=0, id_of=None, **kwargs):

@@ -799,64 +799,3 @@ extern "C" const char* sc_kernel_name(int kernel) {
     return (kernel >= 0 && kernel < SC_K_COUNT) ? names[kernel] : "?";
 }
 
-// ---------------------------------------------------------------------------
-// Host-side helper of the GeoTIFF reader (scarplet_amd/tiff.py): TIFF LZW
-// (Compression = 5; TIFF 6.0 section 13: MSB-first codes of 9 .. 12 bits,
-// ClearCode 256, EndOfInformation 257, the code width grows one code early).
-// No GPU involved.  Returns the number of bytes written, -1 for a malformed
-// stream, -2 when dst is too small.
-// ---------------------------------------------------------------------------
-extern "C" long long sc_tiff_lzw_decode(const unsigned char* src, size_t n, unsigned char* dst, size_t cap) {
-    if (!src || !dst) return -1;
-    static thread_local unsigned short prefix[4096];
-    static thread_local unsigned char suffix[4096], first[4096];
-    static thread_local unsigned short length[4096];
-    for (int i = 0; i < 256; ++i) { prefix[i] = 0xFFFF; suffix[i] = first[i] = (unsigned char)i; length[i] = 1; }
-    size_t pos = 0, bitpos = 0;
-    const size_t nbits_total = n * 8;
-    int nbits = 9, next = 258, old = -1;
-    auto put = [&](int code) -> bool {                  // the string of `code` to dst
-        const size_t len = length[code];
-        if (pos + len > cap) return false;
-        size_t q = pos + len;
-        while (code != 0xFFFF && q > pos) { dst[--q] = suffix[code]; code = prefix[code]; }
-        pos += len;
-        return true;
-    };
-    while (bitpos + nbits <= nbits_total) {
-        // MSB-first: the next nbits bits starting at bitpos
-        const size_t byte = bitpos >> 3;
-        unsigned int w = (unsigned int)src[byte] << 16;
-        if (byte + 1 < n) w |= (unsigned int)src[byte + 1] << 8;
-        if (byte + 2 < n) w |= (unsigned int)src[byte + 2];
-        const int code = (int)((w >> (24 - nbits - (bitpos & 7))) & ((1u << nbits) - 1));
-        bitpos += nbits;
-        if (code == 257) break;                         // EndOfInformation
-        if (code == 256) { nbits = 9; next = 258; old = -1; continue; }
-        if (old < 0) {
-            if (code > 255) return -1;
-            if (!put(code)) return -2;
-            old = code;
-            continue;
-        }
-        if (code < next) {
-            if (code >= 258 && length[code] == 0) return -1;
-            if (!put(code)) return -2;
-            if (next < 4096) {
-                prefix[next] = (unsigned short)old; suffix[next] = first[code];
-                first[next] = first[old]; length[next] = (unsigned short)(length[old] + 1);
-                ++next;
-            }
-        } else if (code == next && next < 4096) {
-            prefix[next] = (unsigned short)old; suffix[next] = first[old];
-            first[next] = first[old]; length[next] = (unsigned short)(length[old] + 1);
-            ++next;
-            if (!put(code)) return -2;
-        } else {
-            return -1;
-        }
-        old = code;
-        if (next >= (1 << nbits) - 1 && nbits < 12) ++nbits;       // one code early
-    }
-    return (long long)pos;
-}

@@ -351,8 +351,9 @@ k_compare_fold(double* __restrict__ b_amp, double* __restrict__ b_age,
 // Nodata fill (DEMGrid._fill_nodata, dem.py:388-414 -> rasterio.fill.fillnodata ->
 // GDALFillNodata): four-quadrant inverse-distance interpolation from the nearest valid
 // cell of every column within the search distance, as restated in
-// the oracle's fill_nodata_pass (parity unpinned: GDAL is not in the image).
-// float64 throughout, the oracle's operation order.
+// the oracle's fill_nodata_pass (parity unpinned: GDAL is not in the image, no GDAL-written
+// fixture exists).  float32 work values like GDAL's scanlines, sums in float64, the oracle's
+// operation order.
 //   k_fill_scan : per column, the nearest valid row at or above / at or below every row
 //   k_fill_idw  : per nodata cell, the search over columns x +- step and the weighted mean
 //   k_fill_smooth: optional 3x3 means over filled cells
@@ -378,6 +379,12 @@ k_fill_scan(const double* __restrict__ z, int ny, int nx, int* __restrict__ up, 
     }
 }
 
+// One nodata cell of GDALFillNodata's second pass (alg/rasterfill.cpp as the oracle's
+// fill_nodata_pass restates it, statement by statement): float32 work values, quadrants TL, BL,
+// TR, BR, left quadrants at every step and right ones from step 1, columns clamped at the raster
+// edge, QUAD_CHECK on squared distances, the search limit refreshed every four steps, weights
+// 1 / distance accumulated in quadrant order.  Valid cells pass through float32 as well (GDAL
+// writes the whole float32 scanline back).
 __global__ void __launch_bounds__(256)
 k_fill_idw(const double* __restrict__ z, int ny, int nx, const int* __restrict__ up,
            const int* __restrict__ dn, double maxd, int R, double* __restrict__ out,
@@ -386,33 +393,41 @@ k_fill_idw(const double* __restrict__ z, int ny, int nx, const int* __restrict__
     if (x >= nx) return;
     const size_t o = (size_t)y * nx + x;
     const double v0 = z[o];
-    if (v0 == v0) { out[o] = v0; return; }
-    double qd[4] = {1e300, 1e300, 1e300, 1e300}, qv[4] = {0, 0, 0, 0};     // TL, TR, BL, BR
-    for (int step = 0; step <= R; ++step) {
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const int xx = side ? x + step : x - step;
-            if (xx < 0 || xx >= nx) continue;
-#pragma unroll
-            for (int vert = 0; vert < 2; ++vert) {
-                const int yy = vert ? dn[(size_t)y * nx + xx] : up[(size_t)y * nx + xx];
-                if (yy < 0 || yy >= ny) continue;
-                const double ddx = (double)(xx - x), ddy = (double)(yy - y);
-                const double d = __dsqrt_rn(__dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddy, ddy)));
-                const int q = 2 * vert + side;
-                if (d < qd[q]) { qd[q] = d; qv[q] = z[(size_t)yy * nx + xx]; }
-            }
+    if (v0 == v0) { out[o] = (double)(float)v0; return; }
+    const double far = __dadd_rn(maxd, 1.0);
+    double qd[4] = {far, far, far, far};
+    float qv[4] = {0.f, 0.f, 0.f, 0.f};
+    auto check = [&](int q, int tx, int ty) {
+        if (ty < 0 || ty >= ny) return;
+        const double ddx = (double)tx - (double)x, ddy = (double)ty - (double)y;
+        const double dsq = __dadd_rn(__dmul_rn(ddx, ddx), __dmul_rn(ddy, ddy));
+        if (dsq < __dmul_rn(qd[q], qd[q])) {
+            qd[q] = __dsqrt_rn(dsq);
+            qv[q] = (float)z[(size_t)ty * nx + tx];
         }
+    };
+    int this_max = R;
+    for (int step = 0; step <= this_max; ++step) {
+        const int lx = max(0, x - step), rx = min(nx - 1, x + step);
+        check(0, lx, up[(size_t)y * nx + lx]);
+        check(1, lx, dn[(size_t)y * nx + lx]);
+        if (step == 0) continue;
+        check(2, rx, up[(size_t)y * nx + rx]);
+        check(3, rx, dn[(size_t)y * nx + rx]);
+        if ((step & 3) == 0) this_max = (int)floor(fmax(fmax(qd[0], qd[1]), fmax(qd[2], qd[3])));
     }
     double ws = 0.0, vs = 0.0;
+    bool have = false;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         if (qd[q] <= maxd) {
-            ws = __dadd_rn(ws, __ddiv_rn(1.0, qd[q]));
-            vs = __dadd_rn(vs, __ddiv_rn(qv[q], qd[q]));
+            const double w = __ddiv_rn(1.0, qd[q]);
+            have = true;
+            ws = __dadd_rn(ws, w);
+            vs = __dadd_rn(vs, __dmul_rn((double)qv[q], w));
         }
-    if (ws > 0.0) {
-        out[o] = __ddiv_rn(vs, ws);
+    if (have) {
+        out[o] = (double)(float)__ddiv_rn(vs, ws);
     } else {
         out[o] = v0;                                  // stays nodata
         atomicAdd(remaining, 1ull);

@@ -156,9 +156,16 @@ class DEMGrid(object):
         precondition holds (dem.py:388-414).  Like the reference: repeat
         fillnodata with max_search_distance = max(most nodata cells in a row, in
         a column) / 2 until nothing is left.  One pass is ``sc_fill_nodata`` on
-        the GPU (four-quadrant inverse-distance fill; include/scarplet_hip.h).
-        GDAL / rasterio are not available to pin the pass against: it follows
-        GDAL's published algorithm, parity unpinned (oracle fill_nodata_pass).
+        the GPU (GDALFillNodata's four-quadrant inverse-distance search as GDAL
+        publishes it, float32 work values; include/scarplet_hip.h).  GDAL /
+        rasterio are not available to pin the pass against: PARITY UNPINNED
+        (oracle fill_nodata_pass).
+
+        Where a pass fills nothing - an isolated nodata cell gives a distance of
+        1 / 2 and nothing lies within half a cell - the reference's loop never
+        ends (dem.py:400); here the next pass searches at least one cell and
+        twice as far every time after that.  A grid without a single valid cell
+        cannot be filled: a warning, and ``is_interpolated`` stays False.
         A DEM without nodata cells does not touch the device."""
         z = np.ascontiguousarray(self._griddata, dtype=np.float64)
         mask = np.isnan(z)
@@ -166,12 +173,26 @@ class DEMGrid(object):
         if mask.any():
             from scarplet_amd.core import _context
             ctx = _context(device)
+            stalled = None
             for _ in range(max_passes):
                 dist = max(np.sum(mask, axis=1).max(), np.sum(mask, axis=0).max()) / 2
+                if stalled is not None:
+                    dist = max(dist, 1.0, 2.0 * stalled)
                 before = int(mask.sum())
                 left = ctx.fill_nodata(z, dist)
-                if left == 0 or left == before:   # done, or no source within reach of the rest
+                if left == 0:
                     break
+                if left == before:                # nothing within reach of any nodata cell
+                    if dist > max(z.shape):
+                        break
+                    stalled = dist
+                else:
+                    stalled = None
                 mask = np.isnan(z)
         self._griddata = z
+        if np.isnan(z).any():
+            import warnings
+            warnings.warn("_fill_nodata: %d nodata cells could not be filled (no valid cell to "
+                          "interpolate from)" % int(np.isnan(z).sum()))
+            return
         self.is_interpolated = True

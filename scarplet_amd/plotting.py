@@ -31,24 +31,39 @@ class Hillshade(object):
         return ax
 
 
+# One entry per plane of a search result, in the order ``match`` returns them.  The reference
+# draws the same four quantities (core.py:380-420); its orientation panel shows the plane as
+# returned (radians) under a degree label, which is kept so that figures compare.
+_PANELS = (
+    dict(plane=0, title="Amplitude [m]", cmap="Reds"),
+    dict(plane=1, title="Relative age [m$^2$]", cmap="viridis"),
+    dict(plane=2, title="Orientation [deg.]", cmap="RdBu_r"),
+    dict(plane=3, title="Signal-to-noise ratio", cmap="Reds"),
+)
+
+
+def _draw_panel(fig, axis, shade, values, title, cmap, opacity=0.5, ticks=3):
+    """One result plane, half transparent, over the grey relief, with a short horizontal
+    colour bar that carries the quantity's name."""
+    from matplotlib.ticker import MaxNLocator
+    axis.imshow(shade, cmap="gray", alpha=1)
+    mappable = axis.imshow(values, cmap=cmap, alpha=opacity)
+    bar = fig.colorbar(mappable, ax=axis, orientation="horizontal", shrink=0.5, label=title)
+    bar.locator = MaxNLocator(nbins=ticks)
+    bar.update_ticks()
+    return bar
+
+
 def plot_results(data, results, az=315, elev=45, figsize=(4, 16)):
-    """Maps of a search result over the hillshade (core.py:380-420): amplitude,
-    relative age, orientation (as returned, radians) and signal-to-noise ratio.
-    ``results``: the (4, ny, nx) array or 4-tuple ``match`` returns.  Returns the
-    figure."""
-    import matplotlib
+    """The four maps of a search result over the DEM's hillshade - the figure the reference's
+    ``plot_results`` makes (core.py:380-420).  ``results``: the (4, ny, nx) array or the
+    4-tuple ``match`` returns.  Returns the figure (2 x 2 panels, a colour bar each)."""
     import matplotlib.pyplot as plt
-    import matplotlib.ticker
-    fig, ax = plt.subplots(2, 2, figsize=figsize)
-    ax = ax.ravel()
+    planes = [np.asarray(p) for p in results]
+    if len(planes) != len(_PANELS):
+        raise ValueError("a search result has %d planes: amplitude, age, orientation, SNR" % len(_PANELS))
     shade = hillshade(data, az, elev)
-    labels = ['Amplitude [m]', 'Relative age [m$^2$]',
-              'Orientation [deg.]', 'Signal-to-noise ratio']
-    cmaps = ['Reds', 'viridis', 'RdBu_r', 'Reds']
-    for i, (axis, label, cmap) in enumerate(zip(ax, labels, cmaps)):
-        axis.imshow(shade, alpha=1, cmap='gray')
-        im = axis.imshow(np.asarray(results[i]), alpha=0.5, cmap=cmap)
-        cb = plt.colorbar(im, ax=axis, shrink=0.5, orientation='horizontal', label=label)
-        cb.locator = matplotlib.ticker.MaxNLocator(nbins=3)
-        cb.update_ticks()
+    fig = plt.figure(figsize=figsize)
+    for k, spec in enumerate(_PANELS):
+        _draw_panel(fig, fig.add_subplot(2, 2, k + 1), shade, planes[spec["plane"]], spec["title"], spec["cmap"])
     return fig

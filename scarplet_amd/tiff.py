@@ -105,8 +105,8 @@ def read_geotiff_full(path):
         if comp in (8, 32946):
             raw = zlib.decompress(raw)
         elif comp == 5:                             # LZW (GDAL COMPRESS=LZW)
-            from scarplet_amd import _lib
-            raw = _lib.tiff_lzw_decode(raw, rows * cols * dtype.itemsize)
+            from scarplet_amd import _hostlib
+            raw = _hostlib.tiff_lzw_decode(raw, rows * cols * dtype.itemsize)
         elif comp != 1:
             raise ValueError("%s: compression %d is not supported" % (path, comp))
         if pred == 3:

@@ -30,6 +30,19 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SIGNATURES) == names, "ctypes table out of sync with the header"
 
 
+def test_host_library_exports_every_declared_symbol():
+    """libscarplet_host.so (include/scarplet_host.h): plain C, linked against nothing of ROCm."""
+    from scarplet_amd import _hostlib
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "scarplet_host.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(sch_[a-z0-9_]+)\s*\(", src)))
+    lib = ctypes.CDLL(_hostlib.LIB_PATH)
+    assert names and sorted(_hostlib.SIGNATURES) == names
+    for n in names:
+        assert hasattr(lib, n), "missing export: " + n
+    needed = subprocess.check_output(["readelf", "-d", _hostlib.LIB_PATH]).decode()
+    assert "amdhip" not in needed and "rccl" not in needed
+
+
 def test_load_binds_and_reports_version():
     lib = _lib.load()
     assert lib.sc_abi_version() == _lib.ABI_VERSION

@@ -1,6 +1,7 @@
 """Host-side template plugins (scarplet_amd/WindowedTemplate.py) against the
 reference's classes (fixtures captured by oracle/gen_golden.py)."""
 import numpy as np
+import pytest
 
 from scarplet_amd import WindowedTemplate as WT
 from conftest import golden, load_cases
@@ -135,3 +136,29 @@ def test_describe_fast_path_fills_the_same_struct_array(monkeypatch):
                 slow = core.Matcher.describe(fake, cls, scale, np.asarray(pars, float), angles, id_base=3, id_of=id_of)
             assert fast[1:] == slow[1:], (fast[1:], slow[1:])
             assert ctypes.string_at(fast[0], ctypes.sizeof(fast[0])) == ctypes.string_at(slow[0], ctypes.sizeof(slow[0]))
+
+
+@pytest.mark.parametrize("cls", ["Scarp", "RightFacingUpperBreakScarp", "LeftFacingUpperBreakScarp", "Ricker"])
+def test_nan_dem_fold_without_template_objects(cls):
+    """A DEM with NaNs gets the reference's degenerate maps (core.py:228-240, 348-375).  For the
+    built-in classes they come from the window-limit rectangles and the error half-planes
+    directly (Matcher._nan_fold_builtin) - the same maps as folding every template's numpy
+    masks one by one, without 2 x (ny, nx) temporaries per (age, orientation)."""
+    import scarplet_amd as sl
+    from scarplet_amd.core import Matcher
+    m = object.__new__(Matcher)                     # no device: only the host-side fold is exercised
+    m.ny, m.nx, m.de = 61, 84, 2.0
+    T = getattr(sl, cls)
+    params = [0.05, 0.1] if cls == "Ricker" else [1.0, 10.0, 100.0]
+    angles = np.linspace(-np.pi / 2, np.pi / 2, 7)
+    fast = m._nan_fold_builtin(T, 12, params, angles)
+    assert fast is not None
+    amp = np.zeros((m.ny, m.nx))
+    snr = np.zeros((m.ny, m.nx))
+    for ang in angles:
+        for par in params:
+            a, s = m._nan_maps(T(12, par, ang, m.nx, m.ny, m.de))
+            amp[np.isnan(a)] = np.nan
+            snr[np.isnan(s)] = np.nan
+    assert np.array_equal(fast[0], amp, equal_nan=True) and np.array_equal(fast[3], snr, equal_nan=True)
+    assert not fast[1].any() and not fast[2].any()
