@@ -254,8 +254,8 @@ def so_sha256():
     return h.hexdigest()
 
 
-def measured_traffic(dom, default_workload):
-    """PMC bytes per launch of the dominant kernel from profiles/traffic.json -
+def measured_traffic(default_workload):
+    """PMC bytes per launch of every kernel slot from profiles/traffic.json ({slot: bytes}) -
     only if that file was measured (tools/prof_run.sh) on this very library."""
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if not (default_workload and os.path.exists(tf)):
@@ -264,12 +264,75 @@ def measured_traffic(dom, default_workload):
         t = json.load(open(tf))
         if t.get("so_sha256") != so_sha256():
             return None
-        return t.get("bytes_per_launch", {}).get(dom)
+        return t.get("bytes_per_launch", {})
     except Exception:
         return None
 
 
 # ----------------------------------------------------------------------------- main
+def timed_loop(step, ctx, a, dist, after_warmup=None):
+    """The contract's timing: W untimed steps, then EXACTLY K steps between a device sync + rank
+    barrier on both sides; the MAX over ranks.  Returns (seconds, per-kernel profile of this rank)."""
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+    for _ in range(a.warmup):
+        step()
+    if after_warmup:
+        after_warmup()
+    ctx.profile(a.prof_stride)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    prof = ctx.profile_get()
+    ctx.profile(0)
+    return dt, prof
+
+
+def roofline_block(value, world, prof, units, steps, method, default_workload):
+    """`frac` is the WHOLE path against the 28-B HBM roofline (value x 28 B / 8 TB/s per GPU): the
+    number that means something.  The prescribed per-kernel formula (28 B x the px.templates one
+    launch of the dominant kernel serves / its mean duration) is kept as formula_frac: it credits
+    one kernel with the whole path's bytes and exceeds 1 once that kernel is about half of the
+    step.  traffic = PMC bytes per launch of that kernel, traffic_ratio = PMC bytes of ALL
+    kernels per step / (28 B x units) - both only when profiles/traffic.json was measured on
+    this very library (tools/prof_run.sh)."""
+    dom = max(prof, key=lambda k: prof[k][1])
+    launches, total_ms = prof[dom]
+    per_launch_units = units * steps / max(launches, 1) / (world if world > 1 else 1)
+    avg_s = total_ms / 1e3 / max(launches, 1)
+    formula = ALGO_BYTES_PER_UNIT * per_launch_units / avg_s / 1e9 if avg_s > 0 else 0.0
+    achieved = value * 1e6 * ALGO_BYTES_PER_UNIT / 1e9 / world
+    r = {"bound": "hbm", "kernel": KERNEL_SYMBOLS.get(dom, dom) if method == "fft" else dom,
+         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4),
+         "traffic": None, "launches": int(launches), "avg_launch_us": round(1e6 * avg_s, 2),
+         "formula_achieved": round(formula, 1), "formula_frac": round(formula / HBM_PEAK_GBS, 4),
+         "note": "achieved / frac: the whole search, value x 28 B per px.template per GPU, against 8 TB/s. "
+                 "formula_*: the prescribed per-kernel form (28 B x the px.templates of one launch of the "
+                 "dominant kernel / its mean duration, HIP events on the context's stream) - it credits one "
+                 "kernel with the whole path's bytes. kernel_hbm_frac: that kernel's PMC-measured bytes per "
+                 "launch / its duration / 8 TB/s; traffic_ratio: PMC bytes of all kernels per step / (28 B x units)"}
+    t = measured_traffic(default_workload)
+    if t and t.get(dom) and avg_s > 0:
+        r["traffic"] = t[dom]
+        r["kernel_hbm_frac"] = round(t[dom] / avg_s / (HBM_PEAK_GBS * 1e9), 4)
+        per_step = sum(t.get(k, 0) * prof[k][0] / steps for k in prof if prof[k][0])
+        if all(k in t for k in prof if prof[k][0]):
+            r["traffic_ratio"] = round(per_step / (ALGO_BYTES_PER_UNIT * units), 4)
+            r["traffic_bytes_per_step"] = int(per_step)
+    return r
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -277,7 +340,6 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     transport = None
-    shard = "orientations" if a.shard == "auto" else a.shard
 
     import scarplet_amd as sl
     from scarplet_amd import _lib
@@ -286,10 +348,9 @@ def main():
     g, Template, scales, params, angles, label, kind = workload(a)     # same seed on every rank
     ny, nx = g._griddata.shape
     pool = None
-    if rank == 0 and world == 1 and not a.emulate_ranks and not (a.no_verify and a.no_cpu_baseline):
-        pool = make_pool(g, kind, scales[0])   # forked before the first HIP call below
-    if rank == 0 and world > 1 and shard == "orientations" and not a.no_verify:
-        pool = make_pool(g, kind, scales[0])   # (and before the process group's threads exist)
+    if rank == 0 and not a.emulate_ranks and not (a.no_verify and (a.no_cpu_baseline or world > 1)):
+        pool = make_pool(g, kind, scales[0])   # forked before the first HIP call below (and before
+                                               # the process group's threads exist)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo")
@@ -300,10 +361,114 @@ def main():
     device = local % ndev                      # one rank per GPU; wraps only in bring-up runs
     n_templates = len(params) * len(angles) * len(scales)
     units = float(ny) * nx * n_templates               # px.template per step
-    emu = None
+    default_workload = (world == 1 and not a.emulate_ranks and a.config == "C3" and label.startswith("C3:")
+                        and a.method == "fft")
 
-    om = None
-    if world == 1 and a.emulate_ranks > 1 and shard == "orientations":
+    def base_line(value, ms, plan, ranks_label, prof, n_gpus):
+        return {
+            "metric": "Mpixel·template/s (DEM pixels × ages × orientations / s)",
+            "value": round(value, 1), "unit": "Mpx·template/s", "n_gpus": n_gpus,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic" if a.config in ("C2", "C3") else "reference sample DEM (tests/golden)",
+            "config": {"workload": label, "method": a.method,
+                       "tiles": ("%dx%d of %dx%d" % (plan.nty, plan.ntx, plan.Ty, plan.Tx)) if a.method == "fft" else "-",
+                       "group": int(getattr(plan, "group", 0)), "ranks": ranks_label},
+            "roofline": roofline_block(value, n_gpus, prof, units, a.steps, a.method, default_workload),
+            "kernels_ms_per_step": {k: round(v[1] / a.steps, 2) for k, v in prof.items() if v[0]},
+        }
+
+    # ------------------------------------------------------------------ N > 1: both shardings
+    if world > 1:
+        shards = ["orientations", "tiles"] if a.shard == "auto" else [a.shard]
+        runs = {}
+        for sh in shards:
+          try:
+              if sh == "orientations":
+                  om = sd.OrientationMatcher(rank, world, g, device=device, backend=a.halo, transport=transport)
+                  mine, sp = om.describe(Template, scales[0], params, angles, a.method, a.group or None)
+                  plan, ctx = om.m.plan, om.m.ctx
+                  part = "orientation grid in %d chunks, whole DEM on every rank, records folded by two all-reduces" % world
+
+                  def step():
+                      om.run(mine, sp)                   # reset, this rank's orientations, fold over RCCL
+
+                  def after_warmup():
+                      om.fold_seconds = 0.0
+              else:
+                  dm = sd.DistMatcher(rank, world, (ny, nx), float(g._georef_info.dx), float(g._georef_info.dy),
+                                      device=device, backend=a.halo, transport=transport)
+                  arr, bbox, area = dm.m.describe(Template, scales[0], params, angles)
+                  c = dm.partition_for(bbox) if a.partition == "tiles" else dm.core()
+                  part = ("BASELINE config C4: %d rectangles of whole FFT tiles, halo exchange" % world) if dm.cores else \
+                      "BASELINE config C4: %s even grid, halo exchange" % "x".join(map(str, sd.grid_dims(world, ny, nx)))
+                  z_core = np.ascontiguousarray(g._griddata[c[0]:c[1], c[2]:c[3]])
+                  dm.load(z_core, bbox)                  # halo exchange over RCCL
+                  plan, sp = dm.m.plan_for(bbox, area, a.method, a.group or None, n_params=len(params))
+                  dm.m.params, dm.m.angles = np.asarray(params, float), np.asarray(angles, float)
+                  ctx = dm.m.ctx
+                  halo_s = [0.0]
+
+                  def step():
+                      t_ = time.perf_counter()
+                      dm.load(z_core, bbox)              # the exchange is part of a search
+                      halo_s[0] += time.perf_counter() - t_
+                      dm.m.ctx.reset_best()
+                      dm.m.ctx.match(arr, sp, sync=True)
+
+                  def after_warmup():
+                      halo_s[0] = 0.0
+              dt, prof = timed_loop(step, ctx, a, dist, after_warmup)
+              # what RCCL itself says about the communicator this sharding ran on, from every rank
+              infos = transport.gather(ctx.comm_info(), 0)
+              extra = transport.gather(om.fold_seconds / a.steps if sh == "orientations" else halo_s[0] / a.steps, 0)
+              full = None
+              if sh == "tiles":
+                  full = dm.gather(0)                    # collective; the assembled maps on rank 0
+              if rank == 0:
+                  ms = 1e3 * dt / a.steps
+                  line = base_line(units / (dt / a.steps) / 1e6, ms, plan, "%d (%s)" % (world, part), prof, world)
+                  line["rccl"] = {"nranks": int(infos[0]["nranks"]),
+                                  "devices": [{"rank": i_["rank"], "device": i_["device"], "bus_id": i_["bus_id"]} for i_ in infos],
+                                  "note": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice of every rank's communicator "
+                                          "(sc_comm_info); nranks 0 = no RCCL communicator (--halo host)"}
+                  key = "fold_ms" if sh == "orientations" else "halo_exchange_ms"
+                  line[key] = {"min_over_ranks": round(1e3 * min(extra), 3), "max_over_ranks": round(1e3 * max(extra), 3),
+                               "note": "wall time per step inside the collective on a rank; the minimum is the rank that "
+                                       "arrived last, i.e. the collective itself" if sh == "orientations" else
+                                       "upload of the rank's core, pack, grouped ncclSend/ncclRecv, unpack, per step"}
+                  if pool is not None:
+                      res = om.result_array() if sh == "orientations" else np.stack(full)
+                      ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan)
+                      line["verified"], line["verification"] = ver["ok"], ver
+                  runs[sh] = line
+              dist.barrier()
+          except Exception as e:                     # a sharding that fails on this node must not cost the other its line
+            import traceback
+            traceback.print_exc()
+            if rank == 0:
+                runs[sh] = {"error": "%s: %s" % (type(e).__name__, e), "ms_per_step": None}
+        if rank == 0:
+            first = min(runs, key=lambda k: runs[k]["ms_per_step"] if runs[k]["ms_per_step"] is not None else float("inf"))
+            out = runs[first]
+            if "error" in out:
+                raise SystemExit("every sharding failed: %r" % runs)
+            out["sharding"] = first
+            for k, v in runs.items():
+                if k != first:
+                    out["c4_tiles" if k == "tiles" else "orientations"] = v
+            if pool is not None:
+                pool.terminate()
+                pool.join()
+            print(json.dumps(out, ensure_ascii=False))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    # ------------------------------------------------------------------ N = 1
+    emu = None
+    shard = "orientations" if a.shard == "auto" else a.shard
+    if a.emulate_ranks > 1 and shard == "orientations":
         # the R orientation chunks of the R-rank search, one after the other on this GPU
         R = a.emulate_ranks
         om = sd.OrientationMatcher(0, 1, g, device=device)
@@ -326,7 +491,7 @@ def main():
                 per_block[r] += time.perf_counter() - t0
         ctx = m.ctx
         emu = (R, part_label, chunks, per_block, [12 * ny * nx] * R, [plan] * R)
-    elif world == 1 and a.emulate_ranks > 1:
+    elif a.emulate_ranks > 1:
         # the R blocks of the R-rank search, one after the other on this GPU
         R = a.emulate_ranks
         m = sl.Matcher(device=device)
@@ -356,7 +521,7 @@ def main():
                     plans.append(plan)
         ctx = m.ctx
         emu = (R, part_label, [lay.core(r) for r in range(R)], per_block, halo_bytes, plans)
-    elif world == 1:
+    else:
         m = sl.Matcher(g, device=device)
         descs = []
         for sc in scales:
@@ -370,156 +535,68 @@ def main():
                 m.ctx.match(arr_, sp_, sync=True)
         ctx = m.ctx
         plan = descs[-1][2]
-    elif shard == "orientations":
-        om = sd.OrientationMatcher(rank, world, g, device=device, backend=a.halo, transport=transport)
-        mine, sp = om.describe(Template, scales[0], params, angles, a.method, a.group or None)
-        plan = om.m.plan
-        part_label = "orientation grid in %d chunks, whole DEM on every rank, records folded by two all-reduces" % world
 
-        def step():
-            om.run(mine, sp)                           # reset, this rank's orientations, fold over RCCL
-        ctx = om.m.ctx
-    else:
-        dm = sd.DistMatcher(rank, world, (ny, nx), float(g._georef_info.dx), float(g._georef_info.dy),
-                            device=device, backend=a.halo, transport=transport)
-        arr, bbox, area = dm.m.describe(Template, scales[0], params, angles)
-        c = dm.partition_for(bbox) if a.partition == "tiles" else dm.core()
-        part_label = ("%d rectangles of whole FFT tiles" % world) if dm.cores else \
-            "%s even grid" % "x".join(map(str, sd.grid_dims(world, ny, nx)))
-        z_core = np.ascontiguousarray(g._griddata[c[0]:c[1], c[2]:c[3]])
-        dm.load(z_core, bbox)                          # halo exchange over RCCL
-        plan, sp = dm.m.plan_for(bbox, area, a.method, a.group or None, n_params=len(params))
+    def after_warmup():
+        if emu:
+            emu[3][:] = 0.0
+    dt, prof = timed_loop(step, ctx, a, None, after_warmup)
 
-        def step():
-            dm.load(z_core, bbox)                      # the exchange is part of a search
-            dm.m.ctx.reset_best()
-            dm.m.ctx.match(arr, sp, sync=True)
-        ctx = dm.m.ctx
-
-    def barrier():
-        ctx.sync()
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(a.warmup):
-        step()
+    ms = 1e3 * dt / a.steps
+    value = units / (dt / a.steps) / 1e6
     if emu:
-        emu[3][:] = 0.0
-    ctx.profile(a.prof_stride)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-    prof = ctx.profile_get()
-    ctx.profile(0)
-
-    if rank == 0:
-        ms = 1e3 * dt / a.steps
-        value = units / (dt / a.steps) / 1e6
-        # dominant kernel by total device time; its algorithmic bytes per launch
-        # = 28 B x the px.templates one launch serves (DESIGN.md "Roofline")
-        dom = max(prof, key=lambda k: prof[k][1])
-        launches, total_ms = prof[dom]
-        per_launch_units = units * a.steps / max(launches, 1) / (world if world > 1 else 1)
-        avg_s = total_ms / 1e3 / max(launches, 1)
-        achieved = ALGO_BYTES_PER_UNIT * per_launch_units / avg_s / 1e9 if avg_s > 0 else 0.0
-        default_workload = (world == 1 and not emu and a.config == "C3" and label.startswith("C3:")
-                            and a.method == "fft")
-        if emu:
-            plan = emu[5][0]
-        out = {
-            "metric": "Mpixel·template/s (DEM pixels × ages × orientations / s)",
-            "value": round(value, 1), "unit": "Mpx·template/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic" if a.config in ("C2", "C3") else "reference sample DEM (tests/golden)",
-            "config": {"workload": label, "method": a.method,
-                       "tiles": ("%dx%d of %dx%d" % (plan.nty, plan.ntx, plan.Ty, plan.Tx)) if a.method == "fft" else "-",
-                       "group": int(getattr(plan, "group", 0)),
-                       "ranks": "%d (%s)" % (world, part_label if world > 1 else "whole DEM")},
-            "roofline": {"bound": "hbm", "kernel": KERNEL_SYMBOLS.get(dom, dom) if a.method == "fft" else dom,
-                         "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic(dom, default_workload), "launches": int(launches),
-                         "avg_launch_us": round(1e6 * avg_s, 2),
-                         "pipeline_frac": round(value * 1e6 * ALGO_BYTES_PER_UNIT / (HBM_PEAK_GBS * 1e9 * world), 4),
-                         "note": "frac follows the prescribed formula (28 B x the launch's px.templates / its "
-                                 "duration): it credits the dominant kernel, which runs for about half of the "
-                                 "step, with the whole path's bytes and can therefore exceed 1; pipeline_frac is "
-                                 "the whole search against 8 TB/s / 28 B; kernel_hbm_frac (with traffic) is the "
-                                 "kernel's PMC-measured bytes per launch / its duration / 8 TB/s"},
-            "kernels_ms_per_step": {k: round(v[1] / a.steps, 2) for k, v in prof.items() if v[0]},
-        }
-        if out["roofline"]["traffic"] and avg_s > 0:
-            out["roofline"]["kernel_hbm_frac"] = round(out["roofline"]["traffic"] / avg_s / (HBM_PEAK_GBS * 1e9), 4)
-        if emu:
-            R, part_label, cores_, per_block, halo_bytes, plans = emu
-            pb = per_block / a.steps
-            out["emulated_ranks"] = {
-                "ranks": R, "partition": part_label, "cores": [list(map(int, c)) for c in cores_],
-                "block_ms": [round(1e3 * v, 1) for v in pb],
-                "max_block_ms": round(1e3 * float(pb.max()), 1), "sum_block_ms": round(1e3 * float(pb.sum()), 1),
-                "exchanged_bytes_per_rank": int(max(halo_bytes)),
-                "tiles_per_block": ["%dx%d of %dx%d" % (p_.nty, p_.ntx, p_.Ty, p_.Tx) for p_ in plans],
-                "predicted_value_at_%d_gpus" % R: round(units / float(pb.max()) / 1e6, 1),
-                "note": ("PREDICTED, not measured: every rank's chunk of the orientation grid searched alone on "
-                         "one GPU (whole DEM); the slowest chunk bounds the %d-GPU step, the fold of the records "
-                         "(exchanged_bytes_per_rank all-reduced over xGMI: a 64-bit key and a float per cell) "
-                         "comes on top" % R) if shard == "orientations" else
-                        ("PREDICTED, not measured: every block (core + torus halo, upload and curvature planes "
-                         "included) searched alone on one GPU; the slowest block bounds the %d-GPU step, the halo "
-                         "exchange (exchanged_bytes_per_rank over xGMI) comes on top" % R)}
-        if world == 1 and not emu:
-            if not a.no_verify:
-                # the record the timed loop left behind (the last scale's, for C5)
-                res = ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
-                ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan)
-                del res
-                out["verified"] = ver["ok"]
-                out["verification"] = ver
-            if not a.no_e2e and len(scales) == 1:
-                # the whole call a user makes: upload of z, curvature planes, descriptors, search,
-                # float64 result planes, D2H
-                ctx.sync()
-                t1 = time.perf_counter()
-                if default_workload:
-                    sl.match(g, Template, scale=scales[0], device=device, method=a.method)
-                elif len(params) == 1:
-                    sl.match(g, Template, scale=scales[0], age=float(params[0]), ang_min=float(angles[0]),
-                             ang_max=float(angles[-1]), device=device, method=a.method)
-                else:
-                    sl.Matcher(g, device=device).search(Template, scales[0], params, angles, method=a.method,
-                                                        group=a.group or None).result()
-                e2e = time.perf_counter() - t1
-                out["end_to_end"] = {"value": round(units / e2e / 1e6, 1), "unit": "Mpx·template/s",
-                                     "seconds": round(e2e, 3),
-                                     "call": "sl.match(data, Template, scale=...)" if (default_workload or len(params) == 1)
-                                             else "Matcher(data).search(...).result()",
-                                     "includes": "H2D of the float64 DEM, curvature planes, template descriptors, "
-                                                 "search, float64 (4,ny,nx) result conversion and D2H"}
-            if not a.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(pool, g, params, angles)
-            if pool is not None:
-                pool.terminate()
-                pool.join()
-        elif world > 1 and om is not None and pool is not None:
-            # the folded record of the orientation-sharded search, checked like the single-GPU one
-            ver = verify_window(pool, om.result_array(), g, kind, scales[-1], params, angles, plan)
+        plan = emu[5][0]
+    out = base_line(value, ms, plan, "1 (whole DEM)", prof, 1)
+    if emu:
+        R, part_label, cores_, per_block, halo_bytes, plans = emu
+        pb = per_block / a.steps
+        out["emulated_ranks"] = {
+            "ranks": R, "partition": part_label, "cores": [list(map(int, c)) for c in cores_],
+            "block_ms": [round(1e3 * v, 1) for v in pb],
+            "max_block_ms": round(1e3 * float(pb.max()), 1), "sum_block_ms": round(1e3 * float(pb.sum()), 1),
+            "exchanged_bytes_per_rank": int(max(halo_bytes)),
+            "tiles_per_block": ["%dx%d of %dx%d" % (p_.nty, p_.ntx, p_.Ty, p_.Tx) for p_ in plans],
+            "predicted_value_at_%d_gpus" % R: round(units / float(pb.max()) / 1e6, 1),
+            "note": ("PREDICTED, not measured: every rank's chunk of the orientation grid searched alone on "
+                     "one GPU (whole DEM); the slowest chunk bounds the %d-GPU step, the fold of the records "
+                     "(exchanged_bytes_per_rank all-reduced over xGMI: a 64-bit key and a float per cell) "
+                     "comes on top" % R) if shard == "orientations" else
+                    ("PREDICTED, not measured: every block (core + torus halo, upload and curvature planes "
+                     "included) searched alone on one GPU; the slowest block bounds the %d-GPU step, the halo "
+                     "exchange (exchanged_bytes_per_rank over xGMI) comes on top" % R)}
+    else:
+        if not a.no_verify:
+            # the record the timed loop left behind (the last scale's, for C5)
+            res = ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
+            ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan)
+            del res
             out["verified"] = ver["ok"]
             out["verification"] = ver
-            pool.terminate()
-            pool.join()
-        print(json.dumps(out, ensure_ascii=False))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        if not a.no_e2e and len(scales) == 1:
+            # the whole call a user makes: upload of z, curvature planes, descriptors, search,
+            # float64 result planes, D2H
+            ctx.sync()
+            t1 = time.perf_counter()
+            if default_workload:
+                sl.match(g, Template, scale=scales[0], device=device, method=a.method)
+            elif len(params) == 1:
+                sl.match(g, Template, scale=scales[0], age=float(params[0]), ang_min=float(angles[0]),
+                         ang_max=float(angles[-1]), device=device, method=a.method)
+            else:
+                sl.Matcher(g, device=device).search(Template, scales[0], params, angles, method=a.method,
+                                                    group=a.group or None).result()
+            e2e = time.perf_counter() - t1
+            out["end_to_end"] = {"value": round(units / e2e / 1e6, 1), "unit": "Mpx·template/s",
+                                 "seconds": round(e2e, 3),
+                                 "call": "sl.match(data, Template, scale=...)" if (default_workload or len(params) == 1)
+                                         else "Matcher(data).search(...).result()",
+                                 "includes": "H2D of the float64 DEM, curvature planes, template descriptors, "
+                                             "search, float64 (4,ny,nx) result conversion and D2H"}
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pool, g, params, angles)
+    if pool is not None:
+        pool.terminate()
+        pool.join()
+    print(json.dumps(out, ensure_ascii=False))
 
 
 if __name__ == "__main__":

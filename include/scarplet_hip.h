@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 3
+#define SC_ABI_VERSION 4
 
 #define SC_OK               0
 #define SC_ERR_INVALID     -1   /* bad argument                                */
@@ -329,6 +329,10 @@ int sc_gather_result(sc_ctx* ctx, int root, const int32_t* cores, int ny, int nx
  * nothing to do.
  */
 int sc_fold_ranks(sc_ctx* ctx);
+/* What RCCL reports for this context's communicator: ncclCommCount, ncclCommUserRank,
+ * ncclCommCuDevice, and the PCI bus id of the context's device (bus_id: at least 16 bytes, may
+ * be NULL).  Without a communicator *nranks = 0, *rank = -1. */
+int sc_comm_info(sc_ctx* ctx, int* nranks, int* rank, int* device, char* bus_id, int bus_id_len);
 int sc_comm_destroy(sc_ctx* ctx);
 
 /* (The TIFF LZW decoder of the GeoTIFF reader moved to libscarplet_host.so in round 3:

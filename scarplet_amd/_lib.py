@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCARPLET_HIP_LIB") or os.path.join(_HERE, "libscarplet_hip.so")
 
 SC_OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 ID_NONE = 0xFFFFFFFF
 COMM_ID_BYTES = 128
 
@@ -113,6 +113,8 @@ SIGNATURES = {
                          + [C.POINTER(sc_xfer), C.c_int, C.POINTER(_P)]),
     "sc_fold_ranks": (C.c_int, [_P]),
     "sc_comm_destroy": (C.c_int, [_P]),
+    "sc_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                               C.c_char_p, C.c_int]),
 }
 
 _lib = None
@@ -351,6 +353,14 @@ class Context(object):
         buf = C.create_string_buffer(bytes(uid), COMM_ID_BYTES)
         self._check(self.lib.sc_comm_init(self._h, buf, rank, nranks),
                     "sc_comm_init")
+
+    def comm_info(self):
+        """What RCCL reports for this context's communicator (sc_comm_info): a dict with
+        nranks (0: no communicator), rank, device and the device's PCI bus id."""
+        n, r, d = C.c_int(0), C.c_int(-1), C.c_int(-1)
+        bus = C.create_string_buffer(32)
+        self._check(self.lib.sc_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d), bus, 32), "sc_comm_info")
+        return {"nranks": n.value, "rank": r.value, "device": d.value, "bus_id": bus.value.decode()}
 
     def fold_ranks(self):
         """Collective fold of the ranks' running-best records (orientation-sharded search)."""

@@ -38,6 +38,22 @@ extern "C" int sc_comm_init(sc_ctx* ctx, const void* id, int rank, int nranks) {
     return SC_OK;
 }
 
+// What RCCL itself reports about this rank's communicator (bench.py prints it with every
+// multi-GPU line: "did RCCL see N ranks, and which devices").
+extern "C" int sc_comm_info(sc_ctx* ctx, int* nranks, int* rank, int* device, char* bus_id, int bus_id_len) {
+    if (!ctx || !nranks || !rank || !device) return SC_ERR_INVALID;
+    *nranks = 0; *rank = -1; *device = ctx->device;
+    if (bus_id && bus_id_len > 0) {
+        bus_id[0] = 0;
+        (void)hipDeviceGetPCIBusId(bus_id, bus_id_len, ctx->device);
+    }
+    if (!ctx->comm) return SC_OK;                       // no communicator: nranks = 0
+    SC_NCCL(ctx, ncclCommCount((ncclComm_t)ctx->comm, nranks));
+    SC_NCCL(ctx, ncclCommUserRank((ncclComm_t)ctx->comm, rank));
+    SC_NCCL(ctx, ncclCommCuDevice((ncclComm_t)ctx->comm, device));
+    return SC_OK;
+}
+
 extern "C" int sc_comm_destroy(sc_ctx* ctx) {
     if (!ctx) return SC_ERR_INVALID;
     if (ctx->comm) {
@@ -190,7 +206,14 @@ __global__ void __launch_bounds__(256)
 k_fold_pack(const float* __restrict__ snr, const uint32_t* __restrict__ id,
             unsigned long long* __restrict__ key, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        key[i] = ((unsigned long long)__float_as_uint(snr[i]) << 32) | (unsigned long long)(0xFFFFFFFFu - id[i]);
+    {
+        // the bit order is the numeric order only for non-negative numbers: a record SNR is |..| >= 0
+        // by construction (sc_epilogue), but a -0.0 or a negative value would sort above every
+        // positive one - anything that is not > 0 and not a NaN packs as 0
+        const float s = snr[i];
+        const uint32_t bits = (s > 0.f || s != s) ? __float_as_uint(s) : 0u;
+        key[i] = ((unsigned long long)bits << 32) | (unsigned long long)(0xFFFFFFFFu - id[i]);
+    }
 }
 // the winner's SNR and id to every rank; the amplitude stays only where this rank held the winner
 __global__ void __launch_bounds__(256)

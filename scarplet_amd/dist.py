@@ -469,16 +469,20 @@ class OrientationMatcher(object):
 
     def run(self, mine, sp):
         """One search step: reset, this rank's templates, fold over the ranks."""
+        import time
         ctx = self.m.ctx
         ctx.reset_best()
         if mine is not None:
             ctx.match(mine, sp)
         self._folded = None
+        t0 = time.perf_counter()
         if self.backend == "rccl":
             ctx.fold_ranks()
         elif self.nranks > 1:
             parts = self.transport.gather(self.m.result_array(), 0)
             self._folded = fold_host(parts) if self.rank == 0 else None
+        # wall time of the fold on this rank, the wait for slower ranks included (bench.py: fold_ms)
+        self.fold_seconds = getattr(self, "fold_seconds", 0.0) + (time.perf_counter() - t0)
 
     def search(self, Template, scale, params, angles, method="auto", group=None, **kwargs):
         if getattr(self.m, "nan_dem", False):      # the reference's all-NaN maps, on every rank

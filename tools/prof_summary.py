@@ -46,11 +46,17 @@ def kib(tag, counter, pred):
     return tot / n if n else None
 so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scarplet_amd", "libscarplet_hip.so")
 h = hashlib.sha256(open(so, "rb").read()).hexdigest()
+# every profiling slot of the library (sc_kernel_name) <- the kernels rocprofv3 lists under it
+SLOTS = (("k_curv", ("k_curv",)), ("k_windows", ("k_windows",)), ("k_direct", ("k_direct",)),
+         ("k_fwd_rows", ("k_fwd_rows",)), ("k_fwd_cols", ("k_fwd_cols", "k_split_templ")),
+         ("k_inv_cols", ("k_inv_cols",)), ("k_inv_rows", ("k_inv_rows",)))
 out = {"so_sha256": h, "bytes_per_launch": {}, "detail": {},
-       "_note": "bytes per kernel launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, bench.py "
-                "--angles 2), FETCH_SIZE doubled per MI355X_MICROARCH.md; k_inv_cols = mean k_inv_cols_w8 launch "
-                "(one tile pair, 35 templates, all columns), k_inv_rows = mean k_inv_rows_fast launch"}
-for key, pred in (("k_inv_cols", lambda n: "k_inv_cols" in n), ("k_inv_rows", lambda n: "k_inv_rows" in n)):
+       "_note": "bytes per kernel launch, per profiling slot of the library, from rocprofv3 --pmc FETCH_SIZE / "
+                "WRITE_SIZE (separate passes, bench.py --angles 2), FETCH_SIZE doubled per MI355X_MICROARCH.md; "
+                "k_inv_cols = mean k_inv_cols_w8 launch (one tile pair, 35 templates, all columns), k_inv_rows = "
+                "mean k_inv_rows_fast launch; the forward slots average their curvature and template launches"}
+for key, pats in SLOTS:
+    pred = lambda n, pats=pats: any(p_ in n for p_ in pats)
     f_, w_ = kib("pmc_fetch", "FETCH_SIZE", pred), kib("pmc_write", "WRITE_SIZE", pred)
     if f_ is not None and w_ is not None:
         out["bytes_per_launch"][key] = int(2 * 1024 * f_ + 1024 * w_)
