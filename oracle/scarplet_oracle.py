@@ -544,13 +544,26 @@ def snr_stack_window(z, dx, dy, kind, scale, ages, angles, win, margin,
 # oracle (DESIGN.md "Parity"); shared by tests/, smoke() and bench.py's check:
 #   amp : |d| <= rtol*|amp| + atol*max|amp|      snr likewise
 #   tie : a device winner other than the oracle's argmax is accepted only if its
-#         oracle SNR is within tie_rtol of the maximum.  The window follows the
-#         measured device error (check_fold's snr_err, profiles/r02_gputest_log.txt):
-#         at most 4.3e-5 on the benchmark workload (Scarp, 10000^2: 7x inside the
-#         window) and 2.2e-4 in the worst case of the suite (Ricker on the int16
-#         Grand Canyon DEM through the FFT path); two candidates each off by the
-#         error can swap when they are closer than twice that
-PARITY = dict(amp=(2e-4, 2e-6), snr=(2e-3, 2e-6), tie_rtol=3e-4)
+#         oracle SNR is within the tie window of the maximum.  The window is
+#         TWICE the largest SNR error measured on the device path that ran (two
+#         candidates, each off by that error, can swap when they are closer than
+#         twice it), per path, and every fold test asserts it the other way
+#         round: snr_err <= window / 2 (tests/test_gpu_*.py, report()).
+#         Measured (check_fold's snr_err, profiles/r03_gputest_log.txt):
+#           FFT tiles   <= 4.3e-5 on the benchmark workload (Scarp, 10000^2), 3.2e-4 in the
+#                       worst case of the suite (Ricker, scale 5, on the int16 Grand Canyon
+#                       DEM: a float32 FFT convolution is only as accurate as its tile's
+#                       energy allows)                               -> window 7e-4
+#           real space  <= 4.0e-5 in every test on a DEM with a noise floor -> window 1e-4
+#         Surfaces WITHOUT a noise floor (synthetic erf scarps stored as float32) sit
+#         outside this policy: resolution_floor() states their tolerance per cell.
+PARITY = dict(amp=(2e-4, 2e-6), snr=(2e-3, 2e-6), tie_rtol=7e-4, tie_rtol_direct=1e-4)
+
+
+def tie_window(method):
+    """The tie window of the device path ``method`` ('fft' / 'direct'; anything else - 'auto',
+    a mixed search - gets the wider one)."""
+    return PARITY["tie_rtol_direct"] if method == "direct" else PARITY["tie_rtol"]
 
 
 def xcorr_direct(curv, W):

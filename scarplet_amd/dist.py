@@ -428,7 +428,7 @@ class OrientationMatcher(object):
     ``data`` is a DEMGrid (or anything Matcher accepts)."""
 
     def __init__(self, rank, nranks, data, device=0, backend="rccl", broadcast_bytes=None,
-                 transport=None):
+                 transport=None, matcher=None):
         from scarplet_amd.core import Matcher
         self.rank, self.nranks = rank, nranks
         self.backend = "host" if backend == "gloo" else backend
@@ -437,7 +437,9 @@ class OrientationMatcher(object):
             raise ValueError("backend must be 'rccl' or 'host'")
         if self.backend == "host" and nranks > 1 and transport is None:
             raise ValueError("the host backend needs a transport (scarplet_amd/dist.py docstring)")
-        self.m = Matcher(data, device=device)
+        # (matcher=: a ready Matcher-like object instead of Matcher(data) - the CPU tests of the
+        #  multi-rank logic hand in one whose context answers from the oracle)
+        self.m = matcher if matcher is not None else Matcher(data, device=device)
         if self.backend == "rccl" and nranks > 1:
             if broadcast_bytes is None:
                 if transport is None:

@@ -164,6 +164,90 @@ def test_halo_exchange_over_gloo(world, ny, nx, halo):
     assert sorted(res) == [(r, True) for r in range(world)], res
 
 
+class _OracleContext(object):
+    """Stands in for the GPU context in the CPU test of OrientationMatcher: `match` folds the
+    oracle's maps of the templates it is handed (ties keep the incumbent, like sc_match)."""
+
+    def __init__(self, m, z, kind, scale):
+        self.m, self.z, self.kind, self.scale = m, z, kind, scale
+
+    def reset_best(self):
+        ny, nx = self.z.shape
+        self.rec = np.zeros((4, ny, nx))
+
+    def match(self, templates, plan, sync=True):
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import scarplet_oracle as orc
+        for t in templates:
+            age, ang = float(self.m._id_par[t.id]), float(self.m._id_ang[t.id])
+            amp, _, _, snr = orc.match_template(self.z, 1.0, 1.0, self.kind, self.scale, age, ang)
+            take = snr > self.rec[3]
+            for k, v in enumerate((amp, age, ang, snr)):
+                self.rec[k] = np.where(take, v, self.rec[k])
+
+
+def _orientation_worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from torch_transport import TorchTransport
+        import scarplet_oracle as orc
+        import scarplet_amd as sl
+        from scarplet_amd.core import Matcher
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+        rng = np.random.default_rng(17)                      # the same DEM on every rank
+        z = (np.cumsum(rng.standard_normal((40, 36)), 1) * 0.05 + rng.standard_normal((40, 36)) * 0.03)
+        z[:, 18:] = z[:, :18][:, ::-1]                       # mirror symmetry: exact SNR ties between orientations
+        ages, angles = [1.0, 4.0, 16.0], np.linspace(-1.2, 1.2, 5)
+        m = object.__new__(Matcher)                          # host side only: descriptors and plans need no device
+        m.ny, m.nx, m.de, m.core, m.whole = 40, 36, 1.0, (0, 40, 0, 36), True
+        m.ctx = _OracleContext(m, z, orc.SCARP, 6)
+        m.result_array = lambda: m.ctx.rec
+        om = sd.OrientationMatcher(rank, world, None, backend="host", transport=TorchTransport(), matcher=m)
+        om.search(sl.Scarp, 6, ages, angles, method="fft")
+        ok = True
+        if rank == 0:
+            # one context folding every template in id order (orientation-major), ties to the incumbent
+            want = np.zeros((4, 40, 36))
+            for ang in angles:
+                for age in ages:
+                    amp, _, _, snr = orc.match_template(z, 1.0, 1.0, orc.SCARP, 6, age, float(ang))
+                    take = snr > want[3]
+                    for k, v in enumerate((amp, age, float(ang), snr)):
+                        want[k] = np.where(take, v, want[k])
+            ok = bool(np.array_equal(om.result_array(), want))
+            # every rank got its contiguous chunk of the orientation grid, all ages each
+            ch = sd.orientation_chunks(len(angles), world)
+            ok = ok and sum(b - a for a, b in ch) == len(angles)
+        else:
+            ok = om.result_array() is None
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, ok))
+    except Exception as e:                       # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_orientation_sharded_search_folds_over_gloo(world):
+    """OrientationMatcher end to end on CPU ranks (host backend): every rank describes the whole
+    grid, searches its chunk of the orientations (the oracle answers for the GPU), the records are
+    gathered through the transport and folded in rank order - bit for bit the record of ONE context
+    folding all templates in id order, exact SNR ties included."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_orientation_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)], res
+
+
 def test_package_imports_no_process_group_library():
     """north_star: host code is Python over ctypes, no PyTorch in the product."""
     import subprocess

@@ -6,10 +6,12 @@ Stated tolerances (float32 device arithmetic vs the float64 reference):
   amp : |d| <= AMP_RTOL * |amp| + AMP_ATOL * max|amp|
   snr : |d| <= SNR_RTOL * snr  + SNR_ATOL * max(snr)
   argmax (age, angle): exact, except where the oracle's best and the chosen
-  template's SNR differ by less than TIE_RTOL = 3e-4 - twice the largest SNR
-  error measured on the device (near-tie policy, see oracle.check_fold and
+  template's SNR differ by less than the tie window of the device path that
+  ran (oracle.tie_window: 7e-4 FFT tiles, 1e-4 real space) - twice the largest
+  SNR error measured on that path (near-tie policy, see oracle.check_fold and
   DESIGN.md "Parity").  Every fold test prints and asserts the fraction of
-  cells that carry exactly the oracle's argmax (EXACT_MIN).
+  cells that carry exactly the oracle's argmax (EXACT_MIN) and that its own
+  measured SNR error is at most HALF the window (report()).
 """
 import numpy as np
 import pytest
@@ -28,11 +30,15 @@ TIE_RTOL = orc.PARITY["tie_rtol"]      # twice the measured SNR error (oracle.PA
 EXACT_MIN = 0.99                       # cells that must carry the oracle's own argmax
 
 
-def report(name, chk):
-    """One line per fold check in the test log (pytest -s / GPUTEST output)."""
-    print("fold %-44s bad=%d exact=%.4f strict=%d tie=%d of %d snr_err=%.2e amp_err=%.2e"
+def report(name, chk, method="fft", window=None):
+    """One line per fold check in the test log (pytest -s / GPUTEST output), and the policy
+    behind the tie window: the SNR error this check measured is at most half the window of the
+    device path that ran ('auto' searches are judged by the wider FFT window)."""
+    window = orc.tie_window(method) if window is None else window
+    print("fold %-44s bad=%d exact=%.4f strict=%d tie=%d of %d snr_err=%.2e amp_err=%.2e (window %.0e)"
           % (name, chk["n_bad"], chk["exact_frac"], chk["n_strict"], chk["n_tie"], chk["n"],
-             chk["snr_err"], chk["amp_err"]))
+             chk["snr_err"], chk["amp_err"], window))
+    assert chk["snr_err"] <= 0.5 * window, (name, chk["snr_err"], window)
 
 CLS = {"scarp": WT.Scarp, "ricker": WT.Ricker,
        "right_upper_break": WT.RightFacingUpperBreakScarp,
@@ -139,14 +145,14 @@ def test_fft_tiling_is_invisible(gpu_ctx):
 
 
 # ------------------------------------------------------------------ K5 + drivers
-def fold_check(res, z, dx, dy, kind, scale, params, angles):
+def fold_check(res, z, dx, dy, kind, scale, params, angles, method="fft"):
     a_st, s_st = orc.snr_stack(z, dx, dy, kind, scale, params, angles)
     T = len(params) * len(angles)
     ny, nx = z.shape
     ages = np.repeat(np.asarray(params, float), len(angles))
     angs = np.tile(np.asarray(angles, float), len(params))
     return orc.check_fold(res, a_st.reshape(T, ny, nx), s_st.reshape(T, ny, nx), ages, angs,
-                          tie_rtol=TIE_RTOL, amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
+                          tie_rtol=orc.tie_window(method), amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
                           snr_tol=(SNR_RTOL, SNR_ATOL * np.max(s_st)))
 
 
@@ -159,8 +165,8 @@ def test_fold_against_oracle_stack(gpu_ctx, method):
     angles = _plan.angle_grid(-0.6, 0.6)
     m = sl.Matcher(grid(z, 1.0), ctx=gpu_ctx)
     res = m.search(WT.Scarp, 10, params, angles, method=method).result()
-    chk = fold_check(res, z, 1.0, 1.0, orc.SCARP, 10, params, angles)
-    report("oracle stack 96x90 %s" % method, chk)
+    chk = fold_check(res, z, 1.0, 1.0, orc.SCARP, 10, params, angles, method)
+    report("oracle stack 96x90 %s" % method, chk, method)
     assert chk["n_bad"] == 0, chk
     assert chk["exact_frac"] >= EXACT_MIN, chk
 
@@ -175,8 +181,8 @@ def test_fold_channel_even_template(gpu_ctx, method):
     angles = _plan.angle_grid()[::6]
     m = sl.Matcher(grid(z, 1.0, -1.0), ctx=gpu_ctx)
     res = m.search(WT.Channel, 6, params, angles, method=method).result()
-    chk = fold_check(res, z, 1.0, -1.0, orc.RICKER, 6, params, angles)
-    report("channel (even template: -90/+90 tie) %s" % method, chk)
+    chk = fold_check(res, z, 1.0, -1.0, orc.RICKER, 6, params, angles, method)
+    report("channel (even template: -90/+90 tie) %s" % method, chk, method)
     assert chk["n_bad"] == 0, chk
     # (-pi/2 and +pi/2 are the same template: check_fold counts either as the argmax)
     assert chk["exact_frac"] >= EXACT_MIN, chk
@@ -284,11 +290,15 @@ def test_noise_free_surfaces_resolution_floor(gpu_ctx):
         res = m.ctx.get_result(ages_t, angs_t)
         chk = orc.check_fold(res, A, S, ages_t, angs_t, slack=K, **tol)
         name = "noise-free %s %dx%d de=%g tiles %dx%d" % (kind, ny, nx, dx, p.nty, p.ntx)
-        report(name + " fft", chk)
+        report(name + " fft", chk, window=float("inf"))       # outside the window policy: the slack states it per cell
         print("     (template, cell) pairs with slack > 1e-3: %.3f; cells accepted through the slack: %d, below the "
               "absolute tolerance: %d" % ((K > 1e-3).mean(), chk["n_slack"], chk["n_below"]))
-        if chk["n_bad"]:
-            failures.append((name, "fft", chk["n_bad"]))
+        # what the FFT path delivers on such a surface: every cell inside its stated resolution
+        # (n_bad == 0) and at least nine cells in ten still on the oracle's own argmax
+        # (measured 0.918 / 0.947 / 0.994); method="auto" does not take this path here
+        # (test_auto_takes_the_exact_path_without_a_noise_floor)
+        if chk["n_bad"] or chk["exact_frac"] < 0.90:
+            failures.append((name, "fft", chk["n_bad"], chk["exact_frac"]))
             for (i, j) in np.argwhere(~chk["ok"])[:6]:
                 t_dev = np.nonzero((ages_t == res[1][i, j]) & (angs_t == res[2][i, j]))[0]
                 t_max = int(np.argmax(S[:, i, j]))
@@ -299,7 +309,7 @@ def test_noise_free_surfaces_resolution_floor(gpu_ctx):
         # the real-space path sums locally: no resolution limit, plain check
         res_d = m.search(cls, scale, params, angles, method="direct").result()
         chk_d = orc.check_fold(res_d, A, S, ages_t, angs_t, **tol)
-        report(name + " direct", chk_d)
+        report(name + " direct", chk_d, window=TIE_RTOL)
         if chk_d["n_bad"] or chk_d["exact_frac"] < EXACT_MIN:
             failures.append((name, "direct", chk_d["n_bad"], chk_d["exact_frac"]))
     assert not failures, failures
@@ -427,7 +437,7 @@ def test_second_search_with_another_grid_keeps_its_winners(gpu_ctx):
     angs = np.concatenate([np.tile(a1, len(p1)), np.tile(a2, len(p2))])
     chk = orc.check_fold(res, A, S, ages, angs, tie_rtol=TIE_RTOL,
                          amp_tol=(AMP_RTOL, AMP_ATOL * np.abs(A).max()), snr_tol=(SNR_RTOL, SNR_ATOL * S.max()))
-    report("two searches, two grids, one record", chk)
+    report("two searches, two grids, one record", chk, "auto")
     assert chk["n_bad"] == 0 and chk["exact_frac"] >= EXACT_MIN, chk
     assert np.isin(res[1][res[3] > 0], ages).all()
     assert (np.isin(res[1], p1) & (res[3] > 0)).any() and (np.isin(res[1], p2) & (res[3] > 0)).any()
