@@ -164,29 +164,32 @@ class Plan(object):
                    self.circ_y, self.circ_x, (self.bbox,)))
 
 
-# real-space kernel (k_direct): a 64-cell wide patch plus the template window must
-# fit 16 rows of its 36 K-float LDS slab (sc_kernels.hip direct_window_fits)
-DIRECT_MAX_WINDOW = 2304 - 64
+# real-space kernel (k_direct2): a 256-cell wide patch plus the template window, padded to groups
+# of four taps, must fit 16 rows of its 39.5 K-float LDS slab - and the box kernel kept for
+# cross-checks its own slab (sc_kernels.hip direct_window_fits)
+DIRECT_MAX_WINDOW = 2208
 
 
 def direct_window_fits(ww):
-    return ((64 + ww - 1) | 1) * 16 <= 36 * 1024
+    return (256 + ((ww + 3) & ~3)) * 16 <= 39 * 1024 + 512 and ((64 + ww - 1) | 1) * 16 <= 36 * 1024
 
 
 def direct_cost(n_taps):
-    """Time per output cell and template of the real-space path, picoseconds
-    (tools/crossover.py at 4096^2, profiles/r02_crossover.txt: 1.04 ms at 46
-    taps, 7.75 ms at 466, 46.7 ms at 1474)."""
-    return 60.0 + 1.9 * n_taps
+    """Time per output cell and template of the real-space path, picoseconds.  Round 3, k_direct2
+    (device time at 4096^2, profiles/r03_crossover.txt): 0.27 ms at 46 taps, 1.5 ms at 930, 6.3 ms
+    at 4652, 37 ms at 29 424 - 16 ps + 0.075 ps per tap for windows wider than a few cells, up to
+    0.12 ps per tap for the thinnest (a 5-cell run is padded to two groups of four); 0.09 here.
+    (Round 2's box kernel: 60 + 1.9 ps per BOX cell, 72.8 ms at 928 taps.)"""
+    return 16.0 + 0.09 * n_taps
 
 
-def fft_cost(plan, n_cells):
-    """The same for the FFT path: ~28 ps per PADDED cell for single-template
-    searches (0.60 - 0.78 ms per template at 4096^2 whatever the support; with
-    many ages per orientation it falls to 4.4), times the tile-size penalty of
-    tiles below 512.  Since orientation batching the FFT path wins at every
-    support size measured; the real-space path is for templates no tile holds
-    and for surfaces without a noise floor (it is exact per
-    cell)."""
-    return 28.0 * math.sqrt(TILE_PENALTY.get(plan.Ty, 1.0) * TILE_PENALTY.get(plan.Tx, 1.0)) \
+def fft_cost(plan, n_cells, n_params=1):
+    """The same for the FFT path: per PADDED cell ~24 ps of work that an orientation does once
+    (curvature transforms, launches) plus ~4.4 ps per template (0.56 - 0.64 ms per template at
+    4096^2 with one age per orientation whatever the support; 5.7 ps per cell and template at
+    10000^2 with 35 ages), times the tile-size penalty of tiles below 512.  The real-space path
+    wins for single-age searches below ~250 taps, for templates no tile holds, and it is the
+    exact one on surfaces without a noise floor."""
+    per_template = 4.4 + 24.0 / max(1, n_params)
+    return per_template * math.sqrt(TILE_PENALTY.get(plan.Ty, 1.0) * TILE_PENALTY.get(plan.Tx, 1.0)) \
         * plan.padded_cells() / float(n_cells)

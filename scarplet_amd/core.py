@@ -187,7 +187,9 @@ class Matcher(object):
         """Descriptors for the (param, angle) grid, orientation-major.
         Template (param ia, angle ib) gets id ``id_base + ia * n_angles + ib``, or
         ``id_of(ia, ib)`` (dist.OrientationMatcher numbers them in fold order).
-        Returns (ctypes array, support bbox union, max taps)."""
+        Returns (ctypes array, support bbox union, largest tap count): the taps of a built-in
+        window are estimated as the lattice points of its c x d rectangle (at most its box),
+        a generic window's are counted."""
         n_par, n_ang = len(params), len(angles)
         arr = (_lib.sc_template * (n_par * n_ang))()
         fast = self._describe_grid(arr, Template, scale, params, angles, id_base, id_of) \
@@ -220,8 +222,14 @@ class Matcher(object):
                     # uniform (W == 0 everywhere -> amp = nan/0 like numpy)
                     s.pmin = s.pmax = s.qmin = s.qmax = 0
                 boxes.append((s.pmin, s.pmax, s.qmin, s.qmax))
-                max_area = max(max_area, (s.pmax - s.pmin + 1)
-                               * (s.qmax - s.qmin + 1))
+                box = (s.pmax - s.pmin + 1) * (s.qmax - s.qmin + 1)
+                if s.kind == _WT.KIND_WINDOW:
+                    taps = int(s.p0)
+                else:
+                    c_eff = min(float(s.c), np.sqrt(_WT.EXP_UNDERFLOW) / abs(s.p0)) \
+                        if (s.kind == _WT.KIND_RICKER and s.p0 != 0) else float(s.c)
+                    taps = int((2 * c_eff / self.de + 1) * (2 * float(s.d) / self.de + 1))
+                max_area = max(max_area, min(box, taps))
                 k += 1
         return arr, _plan.bbox_union(boxes), max_area
 
@@ -255,7 +263,13 @@ class Matcher(object):
         v["pmin"], v["pmax"], v["qmin"], v["qmax"] = pmin, pmax, qmin, qmax
         bbox = (min(0, int(pmin.min())), max(0, int(pmax.max())),
                 min(0, int(qmin.min())), max(0, int(qmax.max())))
-        area = int(((pmax - pmin + 1) * (qmax - qmin + 1)).max())
+        box = (pmax - pmin + 1) * (qmax - qmin + 1)
+        c_eff = np.asarray(g["c"], dtype=np.float64)
+        if int(g["kind"]) == _WT.KIND_RICKER:
+            with np.errstate(divide="ignore"):
+                c_eff = np.minimum(c_eff, np.sqrt(_WT.EXP_UNDERFLOW) / np.abs(np.asarray(g["p0"])))
+        taps = (2 * c_eff / self.de + 1) * (2 * np.asarray(g["d"]) / self.de + 1)
+        area = int(np.minimum(box, taps).max())
         return bbox, area
 
     def _describe_generic(self, t):
@@ -314,7 +328,7 @@ class Matcher(object):
                 fft = None
             n_cells = (self.core[1] - self.core[0]) * (self.core[3] - self.core[2])
             method = "direct" if fft is None or (
-                direct_ok and _plan.direct_cost(max_area) < _plan.fft_cost(fft, n_cells)) else "fft"
+                direct_ok and _plan.direct_cost(max_area) < _plan.fft_cost(fft, n_cells, n_params)) else "fft"
         m = _plan.METHOD_DIRECT if method == "direct" else _plan.METHOD_FFT
         p = _plan.Plan(self.ny, self.nx, self.core, bbox, whole=self.whole,
                        method=m)

@@ -45,7 +45,7 @@ size_t sc_total_bytes(sc_ctx* c) {
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
-                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf};
+                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans};
     size_t s = 0;
     for (DevBuf* b : arr) s += b->cap;
     for (auto& w : c->windows) s += (size_t)w.h * w.wd * 5;
@@ -200,7 +200,7 @@ extern "C" void sc_destroy(sc_ctx* c) {
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
-                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf};
+                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans};
     for (DevBuf* b : arr) buf_free(*b);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp[k]);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp_in[k]);
@@ -492,7 +492,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
     // and mask kind sent through every launch together (sc_fft.hip, "Orientation batching")
     struct Chunk { int first, n, nb, wh, ww, parity; bool full; size_t cells; };
     std::vector<Chunk> chunks;
-    size_t max_cells = 0;
+    size_t max_cells = 0, max_dcells = 0, max_spans = 0;
     int nb_max = 1;
     for (size_t r = 0; r < runs.size();) {
         int nb = 1;
@@ -502,15 +502,23 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
                    runs[r + nb].parity == runs[r].parity && runs[r + nb].full == runs[r].full)
                 ++nb;
         }
-        size_t off = 0;
-        int wh = 0, ww = 0;
+        size_t off = 0, doff = 0;
+        int wh = 0, ww = 0, soff = 0;
         for (int j = runs[r].first; j < runs[r].first + nb * runs[r].n; ++j) {
             h[j].win_off = (long long)off;
             off += (size_t)h[j].wh * h[j].ww;
             off = (off + 3) & ~(size_t)3;
             wh = std::max(wh, h[j].wh);
             ww = std::max(ww, h[j].ww);
+            // real-space path: rows reversed and padded to groups of four taps (k_direct_prep)
+            h[j].dpitch = (h[j].ww + 3) & ~3;
+            h[j].dwin_off = (long long)doff;
+            h[j].span_off = soff;
+            doff += (size_t)h[j].wh * h[j].dpitch;
+            soff += h[j].wh;
         }
+        max_dcells = std::max(max_dcells, doff);
+        max_spans = std::max(max_spans, (size_t)soff);
         chunks.push_back({runs[r].first, runs[r].n, nb, wh, ww, runs[r].parity, runs[r].full, off});
         max_cells = std::max(max_cells, off);
         nb_max = std::max(nb_max, nb);
@@ -524,6 +532,10 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
     if ((rc = sc_ensure(ctx, ctx->wl1, sizeof(double) * n))) return rc;
     if ((rc = sc_ensure(ctx, ctx->win_w, sizeof(float) * max_cells))) return rc;
     if ((rc = sc_ensure(ctx, ctx->win_m, max_cells))) return rc;
+    if (plan->method == SC_METHOD_DIRECT) {
+        if ((rc = sc_ensure(ctx, ctx->dwin, sizeof(float2) * std::max<size_t>(max_dcells, 4)))) return rc;
+        if ((rc = sc_ensure(ctx, ctx->spans, sizeof(int2) * std::max<size_t>(max_spans, 1)))) return rc;
+    }
     SC_HIP(ctx, hipMemcpyAsync(ctx->templ.p, h.data(), sizeof(TemplDev) * n,
                                hipMemcpyHostToDevice, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(ctx->sums.p, sums.data(), sizeof(double) * 2 * n,
@@ -566,7 +578,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
         }
         if ((rc = launch_windows(ctx, c.first, n_all, c.wh, c.ww))) return rc;
         if (plan->method == SC_METHOD_DIRECT) {
-            if ((rc = launch_direct(ctx, c.first, c.n, to_maps))) return rc;
+            if ((rc = launch_direct(ctx, c.first, c.n, to_maps, c.nb, c.wh))) return rc;
         } else {
             if ((rc = fft_forward_templates(ctx, fg, c.first, n_all, c.parity))) return rc;
             if ((rc = fft_inverse_fold(ctx, fg, c.first, c.n, group, to_maps, c.full, c.parity, c.nb))) return rc;

@@ -29,6 +29,8 @@ struct TemplDev {
     uint32_t id;
     int32_t wh, ww;            // window (bbox) height / width
     long long win_off;         // element offset of the window in win_w / win_m
+    long long dwin_off;        // real-space path: element offset of the reversed, padded (w, m) rows in dwin
+    int32_t dpitch, span_off;  //   their pitch (a multiple of 4) and the first entry of the row-span table
     const uint8_t* mask_lim;   // optional explicit masks (generic plugins)
     const uint8_t* mask_err;
 };
@@ -79,6 +81,7 @@ struct sc_ctx {
     DevBuf map_amp, map_snr;
     DevBuf cmp[4], cmp_in[4];   // sc_compare_*: amp, age, angle, snr (float64); inputs amp, snr, age, angle
     size_t cmp_n = 0;
+    DevBuf dwin, spans;         // real-space path: k_direct_prep's rows and row spans
     DevBuf templ, sums, wl1, norms, win_w, win_m;   // wl1: sum|W| per template; norms: per tile pair
     DevBuf tw_y, tw_x;
     int tw_Ty = 0, tw_Tx = 0;
@@ -142,7 +145,7 @@ int launch_curv_alpha(sc_ctx* ctx, float cc, float sc2, float ss, int plane = 0)
 int launch_curv_f64(sc_ctx* ctx, double c2, double sn, double cs, double s2, double* out_dev);
 int launch_curv_alpha_batch(sc_ctx* ctx, const float (*coef)[3], int nb);
 int launch_windows(sc_ctx* ctx, int first, int n, int wh_max, int ww_max);
-int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps);
+int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_max);
 bool direct_window_fits(int ww);
 int launch_fill_nodata(sc_ctx* ctx, double* zdev, double* tmp, int* up, int* dn, int ny, int nx,
                        double maxd, int smoothing, unsigned long long* remaining_dev);     // template window width the real-space kernel can stage in LDS

@@ -324,6 +324,255 @@ k_direct(const float* __restrict__ curv, Geom g,
 }
 
 // ---------------------------------------------------------------------------
+// K3, round 3: the real-space path rebuilt around TAPS instead of the support box.
+//
+// The kernel above walks the whole bounding box of a template - an LDS read and a register
+// shift per box cell, the FMAs only where the window is non-zero; a rotated Scarp window fills
+// 2 - 5 % of its box, and the path ran at 1 - 3 % of the chip's FP32 rate.  Here
+//
+//  * k_direct_prep turns every window into rows REVERSED in x (xcorr[x] = sum_b' R[b'] *
+//    slab[x + b'] is a plain correlation), padded to groups of four taps, as float2
+//    (w, m = W != 0) - and records per window row the span of groups that hold a non-zero:
+//    the work of a template is its taps (rounded up to four per row end), not its box;
+//  * a lane owns NB blocks of FOUR adjacent outputs (columns 4 lane + 256 n) on RW rows.
+//    A group of four taps needs the eight slab cells x .. x + 7 of the row: four carried from
+//    the previous group, four new ones from ONE ds_read_b128 (64 lanes read 1 KB of one slab
+//    row: conflict-free) - 32 FMAs for xcorr and 32 for T3 per LDS read instruction;
+//  * the four (w, m) pairs of a group are wave-uniform: one s_load_dwordx8, the FMAs take them
+//    as scalar operands; T3 accumulates m * curv^2 from the squares formed once per cell read;
+//  * eight waves per workgroup (two per SIMD: one wave alone issues a VALU instruction every
+//    four cycles, two share the SIMD at two), the patch is 8 RW rows x 256 NB columns, slabs of
+//    as many template rows as the 158 KB of LDS hold;
+//  * per-cell float32 sums as before: exact per cell, no resolution floor.
+// ---------------------------------------------------------------------------
+#define DR2_LDS_FLOATS (39 * 1024 + 512)        // 158 KB
+#define DR2_WAVES 8
+
+// grid = (ceil(wh_max / 4), n_templates), block = 256: one wave per window row
+__global__ void __launch_bounds__(256)
+k_direct_prep(const TemplDev* __restrict__ templ, int first, const float* __restrict__ win_w,
+              const uint8_t* __restrict__ win_m, float2* __restrict__ dwin, int2* __restrict__ spans) {
+    const TemplDev t = templ[first + blockIdx.y];
+    const int a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (a >= t.wh) return;
+    const float* wrow = win_w + t.win_off + (size_t)a * t.ww;
+    const uint8_t* mrow = win_m + t.win_off + (size_t)a * t.ww;
+    float2* out = dwin + t.dwin_off + (size_t)a * t.dpitch;
+    int lo = INT_MAX, hi = -1;
+    for (int bp = lane; bp < t.dpitch; bp += 64) {
+        float2 v = make_float2(0.f, 0.f);
+        if (bp < t.ww) {
+            const int b = t.ww - 1 - bp;
+            const bool m = mrow[b] != 0;
+            v = make_float2(m ? wrow[b] : 0.f, m ? 1.f : 0.f);
+            if (m) { lo = min(lo, bp); hi = max(hi, bp); }
+        }
+        out[bp] = v;
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        lo = min(lo, __shfl_xor(lo, sft, 64));
+        hi = max(hi, __shfl_xor(hi, sft, 64));
+    }
+    if (lane == 0) spans[t.span_off + a] = hi >= 0 ? make_int2(lo >> 2, (hi >> 2) - (lo >> 2) + 1) : make_int2(0, 0);
+}
+
+template <int NB, int RW, bool PIPE>
+__global__ void __launch_bounds__(64 * DR2_WAVES, 2)
+k_direct2(const float* __restrict__ curv, size_t curv_stride, Geom g,
+          const TemplDev* __restrict__ templ, int first, int n_templ,
+          const float2* __restrict__ dwin, const int2* __restrict__ spans,
+          const double* __restrict__ sums, const double* __restrict__ xaxis,
+          const double* __restrict__ yaxis, float* __restrict__ best_snr,
+          float* __restrict__ best_amp, uint32_t* __restrict__ best_id,
+          float* __restrict__ map_amp, float* __restrict__ map_snr) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TXW = 256 * NB, TY = DR2_WAVES * RW;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // blockIdx.z: the orientation of a batched launch (its curvature plane and its n_templ
+    // templates lie curv_stride floats / n_templ descriptors further on)
+    curv += (size_t)blockIdx.z * curv_stride;
+    first += blockIdx.z * n_templ;
+    const int i0 = g.cy0 + blockIdx.y * TY, j0 = g.cx0 + blockIdx.x * TXW;
+    const int cw = g.cx1 - g.cx0;
+
+    // running best of the lane's cells: row w RW + rr, columns j0 + 256 n + 4 lane + u
+    float b_snr[RW][NB][4], b_amp[RW][NB][4];
+    uint32_t b_id[RW][NB][4];
+    unsigned dirty = 0;
+    auto cell = [&](int rr, int n, int u, int& gi, int& gj) {
+        gi = i0 + w * RW + rr;
+        gj = j0 + 256 * n + 4 * lane + u;
+        return gi < g.cy1 && gj < g.cx1;
+    };
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int gi, gj;
+                const bool in = cell(rr, n, u, gi, gj);
+                b_snr[rr][n][u] = (in && !map_amp) ? best_snr[(size_t)(gi - g.cy0) * cw + (gj - g.cx0)] : 0.f;
+                b_amp[rr][n][u] = 0.f;
+                b_id[rr][n][u] = SC_ID_NONE;
+            }
+
+    for (int it = 0; it < n_templ; ++it) {
+        const TemplDev* tp = templ + first + it;
+        const int wh = tp->wh, P = tp->dpitch, pmin = tp->pmin, qmax = tp->qmax, span_off = tp->span_off;
+        const float2* dw = dwin + tp->dwin_off;
+        float xc[RW][NB][4], t3[RW][NB][4];
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xc[rr][n][u] = t3[rr][n][u] = 0.f;
+        // slab: curvature columns gj_left .. gj_left + lwp - 1 (output column x, tap b' reads
+        // slab column x + b'), rows for template rows [a0, a0 + na): output row r, template
+        // row a reads slab row r + (na - 1 - a)
+        const int lwp = TXW + P;                                  // a multiple of 4
+        int na_max = DR2_LDS_FLOATS / lwp - (TY - 1);
+        na_max = max(1, min(na_max, wh));
+        const int gj_left = j0 - qmax + g.ox;
+        for (int a0 = 0; a0 < wh; a0 += na_max) {
+            const int na = min(na_max, wh - a0);
+            const int rows = TY + na - 1;
+            const int gi_top = i0 - (pmin + a0 + na - 1) + g.oy;
+            __syncthreads();
+            for (int r = w; r < rows; r += DR2_WAVES) {            // a wave per slab row, 64 cells at a time
+                const int gi = gi_top + r;
+                int li;
+                bool row_ok = true;
+                if (g.wrap) li = wrap_index(gi, g.ny);
+                else { li = gi - g.gy0; row_ok = li >= 0 && li < g.ly; }
+                const float* src = curv + (size_t)(row_ok ? li : 0) * g.lx;
+                float* dst = lds + r * lwp;
+                for (int c = lane; c < lwp; c += 64) {
+                    const int gj = gj_left + c;
+                    int lj;
+                    bool ok = row_ok;
+                    if (g.wrap) lj = wrap_index(gj, g.nx);
+                    else { lj = gj - g.gx0; ok = ok && lj >= 0 && lj < g.lx; }
+                    dst[c] = ok ? src[ok ? lj : 0] : 0.f;
+                }
+            }
+            __syncthreads();
+            for (int a = 0; a < na; ++a) {
+                const int2 sp = spans[span_off + a0 + a];         // (first group, groups): wave-uniform
+                if (sp.y == 0) continue;
+                const float2* wrow = dw + (size_t)(a0 + a) * P + 4 * sp.x;
+                // the lane's slab cells of its rows: row (w RW + rr) + (na - 1 - a), column 4 lane + 4 g (+ 256 n)
+                const float* lrow = lds + (w * RW + (na - 1 - a)) * lwp + 4 * lane + 4 * sp.x;
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                f4 va[RW][NB], sa[RW][NB];                        // carried cells and their squares
+#pragma unroll
+                for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) {
+                        va[rr][n] = *reinterpret_cast<const f4*>(lrow + rr * lwp + 256 * n);
+                        sa[rr][n] = va[rr][n] * va[rr][n];
+                    }
+                // software pipeline: the four (w, m) pairs and the new cells of group gq + 1 are requested
+                // before group gq is computed (a scalar load and an LDS read waited for right after
+                // their issue cost more than the group's 128 FMAs)
+                float2 wm[4];
+                f4 vn[RW][NB];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wm[k] = wrow[k];
+#pragma unroll
+                for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) vn[rr][n] = *reinterpret_cast<const f4*>(lrow + rr * lwp + 256 * n + 4);
+                for (int gq = 0; gq < sp.y; ++gq) {
+                    float2 wc[4];
+                    f4 vc[RW][NB];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) wc[k] = wm[k];
+#pragma unroll
+                    for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                        for (int n = 0; n < NB; ++n) vc[rr][n] = vn[rr][n];
+                    if (!PIPE) {                                   // (variant 11: each group's operands when it starts)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) wc[k] = wrow[4 * gq + k];
+#pragma unroll
+                        for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                            for (int n = 0; n < NB; ++n)
+                                vc[rr][n] = *reinterpret_cast<const f4*>(lrow + rr * lwp + 256 * n + 4 * (gq + 1));
+                    } else if (gq + 1 < sp.y) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) wm[k] = wrow[4 * (gq + 1) + k];
+#pragma unroll
+                        for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                            for (int n = 0; n < NB; ++n)
+                                vn[rr][n] = *reinterpret_cast<const f4*>(lrow + rr * lwp + 256 * n + 4 * (gq + 2));
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                        for (int n = 0; n < NB; ++n) {
+                            const f4 vb = vc[rr][n];
+                            const f4 sb = vb * vb;
+                            const float v[8] = {va[rr][n].x, va[rr][n].y, va[rr][n].z, va[rr][n].w, vb.x, vb.y, vb.z, vb.w};
+                            const float q[8] = {sa[rr][n].x, sa[rr][n].y, sa[rr][n].z, sa[rr][n].w, sb.x, sb.y, sb.z, sb.w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    xc[rr][n][u] = fmaf(wc[k].x, v[u + k], xc[rr][n][u]);
+                                    t3[rr][n][u] = fmaf(wc[k].y, q[u + k], t3[rr][n][u]);
+                                }
+                            va[rr][n] = vb;
+                            sa[rr][n] = sb;
+                        }
+                }
+            }
+        }
+        const EpiScal es = sc_epi_scalars(sums, first + it);
+        const TemplDev t = *tp;
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int gi, gj;
+                    if (!cell(rr, n, u, gi, gj)) continue;
+                    float amp, snr;
+                    sc_epilogue(xc[rr][n][u], t3[rr][n][u], es, amp, snr);
+                    sc_apply_masks(t, g, xaxis, yaxis, gi, gj, amp, snr);
+                    if (map_amp) {
+                        const size_t o = (size_t)(gi - g.cy0) * cw + (gj - g.cx0);
+                        map_amp[o] = amp;
+                        map_snr[o] = snr;
+                    } else if (sc_fold(b_snr[rr][n][u], b_amp[rr][n][u], b_id[rr][n][u], snr, amp, t.id)) {
+                        dirty |= 1u << ((rr * NB + n) * 4 + u);
+                    }
+                }
+    }
+    if (!map_amp && dirty) {
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (!((dirty >> ((rr * NB + n) * 4 + u)) & 1u)) continue;
+                    int gi, gj;
+                    cell(rr, n, u, gi, gj);
+                    const size_t o = (size_t)(gi - g.cy0) * cw + (gj - g.cx0);
+                    best_snr[o] = b_snr[rr][n][u];
+                    best_amp[o] = b_amp[rr][n][u];
+                    best_id[o] = b_id[rr][n][u];
+                }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // compare() on host-provided float64 results (core.py:230-240), written the
 // way numexpr evaluates it: boolean * value + boolean * value, snr last.
 // ---------------------------------------------------------------------------
@@ -595,13 +844,15 @@ int launch_windows(sc_ctx* ctx, int first, int n, int wh_max, int ww_max) {
     return SC_OK;
 }
 
-// widest template window the real-space kernel can stage: a slab holds at least
-// DR_TY rows of DR_TX + ww - 1 cells (odd pitch) in its DR_LDS_FLOATS floats
+// widest template window the real-space kernels can stage: the slab must hold at least one
+// template row for every output row of the patch (k_direct2: 256 + the padded window width
+// cells, 16 rows; the box kernel, variant 10: DR_TX + ww - 1 cells, odd pitch, DR_TY rows)
 bool direct_window_fits(int ww) {
-    return (long long)(((DR_TX + ww - 1) | 1)) * DR_TY <= DR_LDS_FLOATS;
+    const long long p2 = 256 + ((ww + 3) & ~3);
+    return p2 * 16 <= DR2_LDS_FLOATS && (long long)(((DR_TX + ww - 1) | 1)) * DR_TY <= DR_LDS_FLOATS;
 }
 
-int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps) {
+static int launch_direct_box(sc_ctx* ctx, int first, int n, bool to_maps) {
     const Geom& g = ctx->g;
     int ch = g.cy1 - g.cy0, cw = g.cx1 - g.cx0;
     dim3 grid((cw + DR_TX - 1) / DR_TX, (ch + DR_TY - 1) / DR_TY);
@@ -619,6 +870,50 @@ int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps) {
                        to_maps ? (float*)ctx->map_amp.p : nullptr,
                        to_maps ? (float*)ctx->map_snr.p : nullptr);
     sc_prof_end(ctx);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+// templates [first, first + nb * n): nb orientations of n templates, orientation b on curvature
+// plane b (nb = 1 unless the launch sequence batches orientations); wh_max: tallest window
+int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_max) {
+    if (ctx->variant == 10) {
+        if (nb != 1) return sc_fail(ctx, SC_ERR_INVALID, "the box kernel takes one orientation per launch");
+        return launch_direct_box(ctx, first, n, to_maps);
+    }
+    const Geom& g = ctx->g;
+    const int ch = g.cy1 - g.cy0, cw = g.cx1 - g.cx0;
+    sc_prof_begin(ctx, SC_K_WINDOWS);
+    hipLaunchKernelGGL(k_direct_prep, dim3((wh_max + 3) / 4, nb * n), dim3(256), 0, ctx->stream,
+                       (const TemplDev*)ctx->templ.p, first, (const float*)ctx->win_w.p,
+                       (const uint8_t*)ctx->win_m.p, (float2*)ctx->dwin.p, (int2*)ctx->spans.p);
+    sc_prof_end(ctx);
+    SC_HIP(ctx, hipGetLastError());
+    // patch: 512 x 16 cells where that still gives every CU a workgroup, else 256 x 16, else 256 x 8
+    const size_t lds = (size_t)DR2_LDS_FLOATS * sizeof(float);
+    const size_t plane = (size_t)g.ly * g.lx;
+    auto wgs = [&](int txw, int ty) { return (long long)((cw + txw - 1) / txw) * ((ch + ty - 1) / ty) * nb; };
+#define DR2_LAUNCH(NBV, RWV, PIPEV)                                                                     \
+    {                                                                                              \
+        int rc = sc_lds_attr(ctx, (const void*)k_direct2<NBV, RWV, PIPEV>, lds);                   \
+        if (rc) return rc;                                                                         \
+        dim3 grid((cw + 256 * NBV - 1) / (256 * NBV), (ch + 8 * RWV - 1) / (8 * RWV), nb);        \
+        sc_prof_begin(ctx, SC_K_DIRECT);                                                           \
+        hipLaunchKernelGGL((k_direct2<NBV, RWV, PIPEV>), grid, dim3(64 * DR2_WAVES), lds, ctx->stream, \
+                           (const float*)ctx->curv.p, plane, g, (const TemplDev*)ctx->templ.p, first, n, \
+                           (const float2*)ctx->dwin.p, (const int2*)ctx->spans.p,                  \
+                           (const double*)ctx->sums.p, (const double*)ctx->xaxis.p,                \
+                           (const double*)ctx->yaxis.p, (float*)ctx->best_snr.p,                   \
+                           (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p,                     \
+                           to_maps ? (float*)ctx->map_amp.p : nullptr,                             \
+                           to_maps ? (float*)ctx->map_snr.p : nullptr);                            \
+        sc_prof_end(ctx);                                                                          \
+    }
+    const bool pipe = ctx->variant != 11;
+    if (wgs(512, 16) >= 512) { if (pipe) DR2_LAUNCH(2, 2, true) else DR2_LAUNCH(2, 2, false) }
+    else if (wgs(256, 16) >= 256) { if (pipe) DR2_LAUNCH(1, 2, true) else DR2_LAUNCH(1, 2, false) }
+    else { if (pipe) DR2_LAUNCH(1, 1, true) else DR2_LAUNCH(1, 1, false) }
+#undef DR2_LAUNCH
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
 }
