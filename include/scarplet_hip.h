@@ -250,6 +250,15 @@ int sc_curvature(sc_ctx* ctx, double cc, double sc2, double ss, float* out);
 int sc_curvature_f64(sc_ctx* ctx, double cos2, double sin_a, double cos_a, double sin2,
                      double* out);
 
+/* Float32 resolution of the FFT path on THIS surface, measured by the searches since the last
+ * sc_reset_best: *wins = cells a template of the FFT path won, *near_floor = those whose residual
+ * T3 - T1 (what the SNR divides by, core.py:362-366) lies within 256 x the transforms' float32
+ * resolution floor (sc_internal.h sc_epi_floor) - their SNR is off by more than the stated
+ * tolerance and their argmax is rounding noise.  ~0 on DEMs with a noise floor of their own
+ * (lidar, the benchmark DEM), tens of per cent on synthetic surfaces stored without one; the
+ * real-space path has no such limit.  scarplet_amd.match(method="auto") reads it to fall back. */
+int sc_get_resolution_stats(sc_ctx* ctx, long long* wins, long long* near_floor);
+
 /* Per-template scalars of the last sc_match / sc_match_template call:
  * n = count(W != 0) + eps (core.py:350) and sum(W**2) (core.py:356). */
 int sc_get_template_sums(sc_ctx* ctx, int n, double* n_out, double* ts_out);

@@ -100,6 +100,7 @@ SIGNATURES = {
                                  C.POINTER(C.c_longlong)]),
     "sc_curvature": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, _fp]),
     "sc_curvature_f64": (C.c_int, [_P] + [C.c_double] * 4 + [_dp]),
+    "sc_get_resolution_stats": (C.c_int, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "sc_get_template_sums": (C.c_int, [_P, C.c_int, _dp, _dp]),
     "sc_profile": (C.c_int, [_P, C.c_int]),
     "sc_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_longlong), _dp]),
@@ -353,6 +354,13 @@ class Context(object):
         buf = C.create_string_buffer(bytes(uid), COMM_ID_BYTES)
         self._check(self.lib.sc_comm_init(self._h, buf, rank, nranks),
                     "sc_comm_init")
+
+    def resolution_stats(self):
+        """(wins, wins near the float32 resolution floor) of the FFT searches since the last
+        reset_best (sc_get_resolution_stats)."""
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        self._check(self.lib.sc_get_resolution_stats(self._h, C.byref(a), C.byref(b)), "sc_get_resolution_stats")
+        return a.value, b.value
 
     def comm_info(self):
         """What RCCL reports for this context's communicator (sc_comm_info): a dict with

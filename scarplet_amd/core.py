@@ -365,11 +365,46 @@ class Matcher(object):
         if reset:
             self.ctx.reset_best()
         self.ctx.match(arr, sp, sync=sync)
+        self.method_used = "direct" if sp.method == _plan.METHOD_DIRECT else "fft"
+        if method == "auto" and reset and sync and self.method_used == "fft":
+            self._exact_path_if_unresolved(arr, bbox, max_area, group, len(params))
         self.params, self.angles = params, angles
         self.n_templates = len(arr)
         self._id_par = np.concatenate([self._id_par, np.repeat(params, len(angles))])
         self._id_ang = np.concatenate([self._id_ang, np.tile(angles, len(params))])
         return self
+
+    # share of the cells an FFT search won whose residual lies near the transforms' float32
+    # resolution floor (sc_get_resolution_stats) above which method="auto" takes the exact path
+    UNRESOLVED_MAX = 0.01
+
+    def _exact_path_if_unresolved(self, arr, bbox, max_area, group, n_params):
+        """method="auto" on a surface WITHOUT a noise floor (synthetic scarps stored as float32:
+        quantisation noise only away from the feature): a float32 FFT convolution resolves an
+        output only to a fraction of its tile's energy, and where the residual T3 - T1 the SNR
+        divides by sinks to that resolution the argmax over templates is rounding noise (8 % of
+        the cells of such a surface, tests/test_gpu_parity.py).  The device counts those cells
+        while it folds; when more than UNRESOLVED_MAX of the wins are such, the search is run
+        again on the real-space path, which sums locally and has no such limit - unless that
+        would take beyond a hundred times longer, then a warning says so."""
+        wins, near = self.ctx.resolution_stats()
+        self.unresolved_frac = near / wins if wins else 0.0
+        if self.unresolved_frac <= self.UNRESOLVED_MAX:
+            return
+        import warnings
+        note = ("the FFT path cannot resolve %.1f %% of this surface's cells in float32 (no noise floor "
+                "of its own)" % (100 * self.unresolved_frac))
+        ww = bbox[3] - bbox[2] + 1
+        n_cells = (self.core[1] - self.core[0]) * (self.core[3] - self.core[2])
+        if not _plan.direct_window_fits(ww) or \
+                _plan.direct_cost(max_area) > 100 * _plan.fft_cost(self.plan, n_cells, n_params):
+            warnings.warn(note + "; method='direct' is exact but much slower here - not taken automatically")
+            return
+        warnings.warn(note + ": searched again on the exact real-space path")
+        self.plan, sp = self.plan_for(bbox, max_area, "direct", group, n_params=n_params)
+        self.ctx.reset_best()
+        self.ctx.match(arr, sp, sync=True)
+        self.method_used = "direct"
 
     def result(self):
         """(amp, age, angle, snr) float64 maps of the core region."""

@@ -45,7 +45,7 @@ size_t sc_total_bytes(sc_ctx* c) {
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
-                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans};
+                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats};
     size_t s = 0;
     for (DevBuf* b : arr) s += b->cap;
     for (auto& w : c->windows) s += (size_t)w.h * w.wd * 5;
@@ -200,7 +200,7 @@ extern "C" void sc_destroy(sc_ctx* c) {
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
-                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans};
+                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats};
     for (DevBuf* b : arr) buf_free(*b);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp[k]);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp_in[k]);
@@ -375,6 +375,22 @@ extern "C" int sc_reset_best(sc_ctx* ctx) {
     SC_HIP(ctx, hipMemsetAsync(ctx->best_snr.p, 0, sizeof(float) * nc, ctx->stream));
     SC_HIP(ctx, hipMemsetAsync(ctx->best_amp.p, 0, sizeof(float) * nc, ctx->stream));
     SC_HIP(ctx, hipMemsetAsync(ctx->best_id.p, 0xFF, sizeof(uint32_t) * nc, ctx->stream));
+    int rc = sc_ensure(ctx, ctx->res_stats, 2 * sizeof(unsigned long long));
+    if (rc) return rc;
+    SC_HIP(ctx, hipMemsetAsync(ctx->res_stats.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    return SC_OK;
+}
+
+extern "C" int sc_get_resolution_stats(sc_ctx* ctx, long long* wins, long long* near_floor) {
+    if (!ctx || !wins || !near_floor) return SC_ERR_INVALID;
+    *wins = *near_floor = 0;
+    if (!ctx->res_stats.p) return SC_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long h[2] = {0, 0};
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SC_HIP(ctx, hipMemcpy(h, ctx->res_stats.p, sizeof(h), hipMemcpyDeviceToHost));
+    *wins = (long long)h[0];
+    *near_floor = (long long)h[1];
     return SC_OK;
 }
 

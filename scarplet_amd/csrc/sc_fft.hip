@@ -1495,6 +1495,7 @@ struct RowArgs {
     // chunk) is job b*pcj + q, its tile norms are entry b*np + pair
     int nb, np, pcj;
     SibSync sib;                        // sibling rendezvous of the fast kernel (rows 2rp, 2rp+1)
+    unsigned long long* stats;          // {wins, wins near the resolution floor} of the search (sc_get_resolution_stats)
 };
 // One launch may serve several tile pairs (grid.y): pair = ra.pair + blockIdx.y,
 // its Y planes ystride planes further on.  More workgroups per launch fill the
@@ -1651,6 +1652,13 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
                                 best_snr[o] = t_snr[c];
                                 best_amp[o] = nan ? 0.f : t_amp[c];
                                 best_id[o] = nan ? SC_ID_NONE : tid_;
+                                if (ra.stats) {       // a win; near the resolution floor? (see k_inv_rows_fast)
+                                    const float xr_ = t_amp[c] / es.inv_ts, T1 = xr_ * t_amp[c];
+                                    const float fl = es.d3 + fabsf(xr_) * es.dx2 + es.dxx;
+                                    const float d = (T1 / t_snr[c] - (float)SC_EPS) / es.inv_n;
+                                    atomicAdd(ra.stats, 1ull);
+                                    if (fl > 0.f && d < 256.f * fl) atomicAdd(ra.stats + 1, 1ull);
+                                }
                             }
                         }
                     }
@@ -2011,15 +2019,36 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     }
     if (sib_mine && id == 0) sib_publish(sib_mine, ra.sib.base + SIB_DONE);
     if (!MAPS) {
+        // resolution statistic (sc_get_resolution_stats): of the cells this launch's templates won, how
+        // many hold a residual T3 - T1 within 256 floors of the float32 resolution floor (sc_epi_floor) -
+        // there the SNR is off by more than the stated tolerance (error ~ floor / residual) and the
+        // argmax is the transform's rounding noise.  Recovered from the record at the write-back
+        // (d = (T1 / snr - eps) n), not in the template loop.
+        int n_won = 0, n_near = 0;
 #pragma unroll
         for (int k = 0; k < NBEST; ++k) {
             const uint32_t ix = (b_ix[k >> 2] >> (8 * (k & 3))) & 0xFFu;
             if (ix != 0xFFu) {
                 const int c = PT ? k : k >> 1, part = PT ? 0 : (k & 1);
                 const uint32_t o = 4u * (uint32_t)col_of(c);
+                const float* e = epi + EPI_FLOATS * ix;
                 at_bytes(best_snr + off_of(part), o) = b_snr[k];
-                at_bytes(best_amp + off_of(part), o) = b_xr[k] * epi[EPI_FLOATS * ix];
+                at_bytes(best_amp + off_of(part), o) = b_xr[k] * e[0];
                 at_bytes(best_id + off_of(part), o) = templ[ra.first + ix].id;
+                const float T1 = b_xr[k] * b_xr[k] * e[1], fl = fmaf(fabsf(b_xr[k]), e[2], e[3]);
+                const float d = (T1 / b_snr[k] - (float)SC_EPS) / e[4];
+                ++n_won;
+                n_near += (fl > 0.f && d < 256.f * fl) ? 1 : 0;
+            }
+        }
+        if (ra.stats) {
+            for (int sft = 32; sft > 0; sft >>= 1) {
+                n_won += __shfl_down(n_won, sft, 64);
+                n_near += __shfl_down(n_near, sft, 64);
+            }
+            if ((id & 63) == 0 && n_won) {
+                atomicAdd(ra.stats, (unsigned long long)n_won);
+                atomicAdd(ra.stats + 1, (unsigned long long)n_near);
             }
         }
     }
@@ -2436,7 +2465,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             const int pair = pair0;
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
                        ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg, group,
-                       nb, np, pc, SibSync{nullptr, 0}};
+                       nb, np, pc, SibSync{nullptr, 0}, (unsigned long long*)ctx->res_stats.p};
             dim3 gridr(fast ? ((rp_n + 7) / 8) * 16 : (rp_n + 1) / 2, pc);
             if (fast && (ctx->sib & 1)) {
                 int rc = sib_slots(ctx, (size_t)gridr.x * gridr.y, ra.sib);

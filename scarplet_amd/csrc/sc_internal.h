@@ -81,6 +81,7 @@ struct sc_ctx {
     DevBuf map_amp, map_snr;
     DevBuf cmp[4], cmp_in[4];   // sc_compare_*: amp, age, angle, snr (float64); inputs amp, snr, age, angle
     size_t cmp_n = 0;
+    DevBuf res_stats;           // two counters: wins of the FFT path, wins near its float32 resolution floor
     DevBuf dwin, spans;         // real-space path: k_direct_prep's rows and row spans
     DevBuf templ, sums, wl1, norms, win_w, win_m;   // wl1: sum|W| per template; norms: per tile pair
     DevBuf tw_y, tw_x;

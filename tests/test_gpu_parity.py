@@ -315,6 +315,32 @@ def test_noise_free_surfaces_resolution_floor(gpu_ctx):
     assert not failures, failures
 
 
+def test_auto_takes_the_exact_path_without_a_noise_floor(gpu_ctx):
+    """method="auto": on a synthetic surface without a noise floor the device's own resolution
+    statistic (sc_get_resolution_stats: wins whose residual lies near the float32 floor of the
+    transforms) sends the search to the real-space path - the result carries the oracle's argmax
+    like the explicit direct search; on a DEM with a noise floor the statistic is ~0 and the
+    FFT result stands."""
+    from scipy.special import erf
+    y, x = np.mgrid[-300:300, -330:330].astype(float)
+    z = (-erf((-x * np.sin(1.1) + y * np.cos(1.1)) / (2 * np.sqrt(10.0))) + 0.01 * x).astype(np.float32)
+    params, angles = [3.0, 10.0, 30.0], _plan.angle_grid()[5::30]
+    m = sl.Matcher(grid(z, 1.0), ctx=gpu_ctx)
+    with pytest.warns(UserWarning, match="exact real-space path"):
+        res = m.search(WT.Scarp, 40, params, angles, method="auto").result()
+    assert m.method_used == "direct" and m.unresolved_frac > m.UNRESOLVED_MAX
+    chk = fold_check(res, z, 1.0, 1.0, orc.SCARP, 40, params, angles, "fft")
+    report("auto on a noise-free scarp 600x660 (unresolved %.3f -> direct)" % m.unresolved_frac, chk, window=TIE_RTOL)
+    assert chk["n_bad"] == 0 and chk["exact_frac"] >= EXACT_MIN, chk
+    # a DEM with a noise floor: nothing to fall back from
+    g = synthetic.synthetic_scarp(600, seed=4)
+    m = sl.Matcher(g, ctx=gpu_ctx)
+    m.search(WT.Scarp, 20, params, angles, method="fft")
+    wins, near = m.ctx.resolution_stats()
+    print("     noisy 600x600: %d wins, %d near the floor" % (wins, near))
+    assert wins > 0 and near <= 1e-4 * wins
+
+
 # ------------------------------------------------------------------ plugin API
 def test_generic_plugin_goes_through_the_window_path(gpu_ctx):
     """A user subclass with its own template() (docs/source/new_template.rst
