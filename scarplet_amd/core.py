@@ -495,6 +495,20 @@ def calculate_best_fit_parameters_serial(dem, Template, scale,
         m.ctx.clear_windows()
 
 
+def _reference_fold_one_age(m, Template, scale, age, ang_min, ang_max, method):
+    """calculate_best_fit_parameters' fold as the reference writes it (core.py:180-195): every
+    orientation's match_template maps through compare() - two strict compares, a tie zeroes the
+    record (core.py:230-240) - in float64 on the device (sc_compare_*)."""
+    from scarplet_amd import _fold
+    ny, nx = m.ny, m.nx
+
+    def maps():
+        for angle in _plan.angle_grid(ang_min, ang_max):
+            amp, snr = m.match_template(Template, scale, age, angle, method=method)
+            yield amp, age, angle, snr
+    return np.stack(_fold.compare(maps(), ny, nx))
+
+
 def match(data, Template, **kwargs):
     """Match a template family to a DEM (core.py:266-294).
 
@@ -502,7 +516,37 @@ def match(data, Template, **kwargs):
     grid 10**arange(0, 3.5, 0.1), returns the 4-tuple (amp, age, angle, snr).
     Keyword arguments: ``scale``, ``age``, ``ang_max``, ``ang_min`` as in the
     reference, plus ``device=`` (GPU ordinal), ``method=`` ('auto', 'fft',
-    'direct') and ``ages=`` (override the age grid)."""
+    'direct'), ``ages=`` (override the age grid) and ``fold=``:
+
+    ``fold="fused"`` (default): ONE device search, the running best folded in
+    the kernels - ties keep the incumbent, orientation-major order.
+    ``fold="reference"``: the reference's literal fold - one match_template per
+    (age, orientation), orientations folded per age by compare() and the ages'
+    results folded by compare() again (core.py:180-195, 288-292), a tie zeroing
+    the record (core.py:230-240) - on float32 maps, so where the float64
+    reference saw no tie this may see one.  One device pass and two 8-byte-per-
+    cell transfers per template: for small DEMs and for inspecting ties."""
+    fold = kwargs.pop("fold", "fused")
+    if fold not in ("fused", "reference"):
+        raise ValueError("fold must be 'fused' or 'reference'")
+    if fold == "reference":
+        device = kwargs.pop("device", 0)
+        method = kwargs.pop("method", "auto")
+        ages = kwargs.pop("ages", None)
+        scale = kwargs.pop("scale")
+        ang_max = kwargs.pop("ang_max", np.pi / 2)
+        ang_min = kwargs.pop("ang_min", -np.pi / 2)
+        m = Matcher(data, device=device)
+        try:
+            if 'age' in kwargs:
+                return _reference_fold_one_age(m, Template, scale, kwargs['age'], ang_min, ang_max, method)
+            from scarplet_amd import _fold
+            # (a list, not a generator: the context holds ONE compare session at a time)
+            per_age = [_reference_fold_one_age(m, Template, scale, age, ang_min, ang_max, method)
+                       for age in (_plan.age_grid() if ages is None else ages)]
+            return _fold.compare(per_age, m.ny, m.nx)
+        finally:
+            m.ctx.clear_windows()
     if 'age' in kwargs:
         return calculate_best_fit_parameters(data, Template, **kwargs)
     device = kwargs.pop("device", 0)

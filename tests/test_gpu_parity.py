@@ -315,6 +315,34 @@ def test_noise_free_surfaces_resolution_floor(gpu_ctx):
     assert not failures, failures
 
 
+def test_match_with_the_reference_fold(gpu_ctx):
+    """sl.match(..., fold="reference"): the literal two-level fold (core.py:180-195, 288-292)
+    with tie -> zero (core.py:230-240) over per-template device maps, against the oracle's
+    literal fold (oracle.match)."""
+    rng = np.random.default_rng(33)
+    z = (np.cumsum(rng.standard_normal((72, 64)), 1) * 0.05 + rng.standard_normal((72, 64)) * 0.04).astype(np.float32)
+    g = grid(z, 1.0)
+    ages = [2.0, 8.0, 32.0]
+    want = orc.match(z, 1.0, 1.0, orc.SCARP, ages=ages, scale=8, ang_min=-0.3, ang_max=0.3)
+    got = sl.match(g, sl.Scarp, scale=8, ages=ages, ang_min=-0.3, ang_max=0.3, fold="reference")
+    assert isinstance(got, tuple) and len(got) == 4 and got[0].shape == z.shape
+    same = (got[1] == want[1]) & (got[2] == want[2])
+    print("     reference fold, 3 ages x 35 orientations: same (age, angle) as the oracle's literal fold %.4f" % same.mean())
+    assert same.mean() >= 0.99
+    ok, err = close_maps(got[0][same], got[3][same], want[0][same], want[3][same])
+    assert ok, err
+    one = sl.match(g, sl.Scarp, scale=8, age=8.0, ang_min=-0.3, ang_max=0.3, fold="reference")
+    ref1 = orc.match(z, 1.0, 1.0, orc.SCARP, scale=8, age=8.0, ang_min=-0.3, ang_max=0.3)
+    assert one.shape == (4,) + z.shape and ((one[2] == ref1[2]).mean() >= 0.99)
+    # the literal rule on an exact tie: Ricker is even in xr, -pi/2 and +pi/2 are ONE template -
+    # bit-identical float32 maps, the record of a cell they share the maximum of is zeroed
+    zc = (np.cumsum(rng.standard_normal((64, 64)), 0) * 0.04).astype(np.float32)
+    r = sl.match(grid(zc, 1.0, -1.0), sl.Channel, scale=6., age=0.2, fold="reference")
+    f = sl.match(grid(zc, 1.0, -1.0), sl.Channel, scale=6., age=0.2)
+    tied = np.abs(f[2]) == np.pi / 2                     # the fused fold keeps the incumbent there
+    assert tied.any() and (r[3][tied] == 0).all() and (r[0][tied] == 0).all()
+
+
 def test_auto_takes_the_exact_path_without_a_noise_floor(gpu_ctx):
     """method="auto": on a synthetic surface without a noise floor the device's own resolution
     statistic (sc_get_resolution_stats: wins whose residual lies near the float32 floor of the
