@@ -512,8 +512,13 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
     int nb_max = 1;
     for (size_t r = 0; r < runs.size();) {
         int nb = 1;
-        if (plan->method == SC_METHOD_FFT && !to_maps) {
-            const int want = fft_batch_orientations(ctx, fg, runs[r].n, group);
+        if ((plan->method == SC_METHOD_FFT || (!ctx->batch_off && ctx->variant != 10)) && !to_maps) {
+            // (real space: small DEMs fold up to 32 orientations per launch, in order, inside the
+            //  workgroup that owns a patch - a 512 x 512 search is 905 launches of a few microseconds
+            //  otherwise; DEMs of a thousand workgroups per orientation gain nothing)
+            const long long wg1 = (long long)((g.cx1 - g.cx0 + 255) / 256) * ((g.cy1 - g.cy0 + 7) / 8);
+            const int want = plan->method == SC_METHOD_FFT ? fft_batch_orientations(ctx, fg, runs[r].n, group)
+                                                           : (wg1 <= 1024 ? 32 : 1);
             while (nb < want && r + nb < runs.size() && runs[r + nb].n == runs[r].n &&
                    runs[r + nb].parity == runs[r].parity && runs[r + nb].full == runs[r].full)
                 ++nb;
@@ -549,8 +554,9 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
     if ((rc = sc_ensure(ctx, ctx->win_w, sizeof(float) * max_cells))) return rc;
     if ((rc = sc_ensure(ctx, ctx->win_m, max_cells))) return rc;
     if (plan->method == SC_METHOD_DIRECT) {
+        if ((rc = sc_ensure(ctx, ctx->curv, sizeof(float) * (size_t)g.ly * g.lx * nb_max))) return rc;
         if ((rc = sc_ensure(ctx, ctx->dwin, sizeof(float2) * std::max<size_t>(max_dcells, 4)))) return rc;
-        if ((rc = sc_ensure(ctx, ctx->spans, sizeof(int2) * std::max<size_t>(max_spans, 1)))) return rc;
+        if ((rc = sc_ensure(ctx, ctx->spans, sizeof(int4) * std::max<size_t>(max_spans, 1)))) return rc;
     }
     SC_HIP(ctx, hipMemcpyAsync(ctx->templ.p, h.data(), sizeof(TemplDev) * n,
                                hipMemcpyHostToDevice, ctx->stream));
@@ -572,7 +578,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
                 coef[b][0] = (float)sb.cc; coef[b][1] = (float)sb.sc2; coef[b][2] = (float)sb.ss;
             }
             if ((rc = launch_curv_alpha_batch(ctx, coef, c.nb))) return rc;
-            if ((rc = fft_forward_curv(ctx, fg, c.nb))) return rc;
+            if (plan->method == SC_METHOD_FFT && (rc = fft_forward_curv(ctx, fg, c.nb))) return rc;
             have_curv = false;                    // plane 0 no longer belongs to a single run
         } else {
             const sc_template& s0 = t[c.first];

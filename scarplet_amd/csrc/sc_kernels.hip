@@ -339,7 +339,10 @@ k_direct(const float* __restrict__ curv, Geom g,
 //    the previous group, four new ones from ONE ds_read_b128 (64 lanes read 1 KB of one slab
 //    row: conflict-free) - 32 FMAs for xcorr and 32 for T3 per LDS read instruction;
 //  * the four (w, m) pairs of a group are wave-uniform: one s_load_dwordx8, the FMAs take them
-//    as scalar operands; T3 accumulates m * curv^2 from the squares formed once per cell read;
+//    as scalar operands; T3 accumulates m * curv^2 from the squares formed once per cell read
+//    (sharing the sum over the cells common to a lane's four adjacent outputs - 4 FMAs per chunk
+//    instead of 16 - was built and measured 25 % SLOWER: the per-cell masks of the run ends
+//    became 28 v_cndmask per chunk; profiles/r03_crossover.txt);
 //  * eight waves per workgroup (two per SIMD: one wave alone issues a VALU instruction every
 //    four cycles, two share the SIMD at two), the patch is 8 RW rows x 256 NB columns, slabs of
 //    as many template rows as the 158 KB of LDS hold;
@@ -348,39 +351,49 @@ k_direct(const float* __restrict__ curv, Geom g,
 #define DR2_LDS_FLOATS (39 * 1024 + 512)        // 158 KB
 #define DR2_WAVES 8
 
-// grid = (ceil(wh_max / 4), n_templates), block = 256: one wave per window row
+// grid = (ceil(wh_max / 4), n_templates), block = 256: one wave per window row.
+// spans[row] = (first group, groups, s, e): taps s .. e of the span (counted from its first group's
+// first tap) are the row's support when that is ONE run without holes, e = -1 otherwise.
 __global__ void __launch_bounds__(256)
 k_direct_prep(const TemplDev* __restrict__ templ, int first, const float* __restrict__ win_w,
-              const uint8_t* __restrict__ win_m, float2* __restrict__ dwin, int2* __restrict__ spans) {
+              const uint8_t* __restrict__ win_m, float2* __restrict__ dwin, int4* __restrict__ spans) {
     const TemplDev t = templ[first + blockIdx.y];
     const int a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (a >= t.wh) return;
     const float* wrow = win_w + t.win_off + (size_t)a * t.ww;
     const uint8_t* mrow = win_m + t.win_off + (size_t)a * t.ww;
     float2* out = dwin + t.dwin_off + (size_t)a * t.dpitch;
-    int lo = INT_MAX, hi = -1;
+    int lo = INT_MAX, hi = -1, cnt = 0;
     for (int bp = lane; bp < t.dpitch; bp += 64) {
         float2 v = make_float2(0.f, 0.f);
         if (bp < t.ww) {
             const int b = t.ww - 1 - bp;
             const bool m = mrow[b] != 0;
             v = make_float2(m ? wrow[b] : 0.f, m ? 1.f : 0.f);
-            if (m) { lo = min(lo, bp); hi = max(hi, bp); }
+            if (m) { lo = min(lo, bp); hi = max(hi, bp); ++cnt; }
         }
         out[bp] = v;
     }
     for (int sft = 32; sft > 0; sft >>= 1) {
         lo = min(lo, __shfl_xor(lo, sft, 64));
         hi = max(hi, __shfl_xor(hi, sft, 64));
+        cnt += __shfl_xor(cnt, sft, 64);
     }
-    if (lane == 0) spans[t.span_off + a] = hi >= 0 ? make_int2(lo >> 2, (hi >> 2) - (lo >> 2) + 1) : make_int2(0, 0);
+    if (lane == 0) {
+        int4 r = make_int4(0, 0, 0, -1);
+        if (hi >= 0) {
+            const int g0 = lo >> 2;
+            r = make_int4(g0, (hi >> 2) - g0 + 1, lo - 4 * g0, cnt == hi - lo + 1 ? hi - 4 * g0 : -1);
+        }
+        spans[t.span_off + a] = r;
+    }
 }
 
-template <int NB, int RW, bool PIPE>
+template <int NB, int RW>
 __global__ void __launch_bounds__(64 * DR2_WAVES, 2)
-k_direct2(const float* __restrict__ curv, size_t curv_stride, Geom g,
-          const TemplDev* __restrict__ templ, int first, int n_templ,
-          const float2* __restrict__ dwin, const int2* __restrict__ spans,
+k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
+          const TemplDev* __restrict__ templ, int first, int n_per, int nb,
+          const float2* __restrict__ dwin, const int4* __restrict__ spans,
           const double* __restrict__ sums, const double* __restrict__ xaxis,
           const double* __restrict__ yaxis, float* __restrict__ best_snr,
           float* __restrict__ best_amp, uint32_t* __restrict__ best_id,
@@ -389,10 +402,9 @@ k_direct2(const float* __restrict__ curv, size_t curv_stride, Geom g,
     constexpr int TXW = 256 * NB, TY = DR2_WAVES * RW;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // blockIdx.z: the orientation of a batched launch (its curvature plane and its n_templ
-    // templates lie curv_stride floats / n_templ descriptors further on)
-    curv += (size_t)blockIdx.z * curv_stride;
-    first += blockIdx.z * n_templ;
+    // nb orientations per launch (small DEMs: fewer, longer launches), folded IN ORDER by the one
+    // workgroup that owns the patch: orientation b's curvature plane lies b * curv_stride floats
+    // further on, its n_per templates follow those of orientation b - 1
     const int i0 = g.cy0 + blockIdx.y * TY, j0 = g.cx0 + blockIdx.x * TXW;
     const int cw = g.cx1 - g.cx0;
 
@@ -418,8 +430,10 @@ k_direct2(const float* __restrict__ curv, size_t curv_stride, Geom g,
                 b_id[rr][n][u] = SC_ID_NONE;
             }
 
+    const int n_templ = n_per * nb;
     for (int it = 0; it < n_templ; ++it) {
         const TemplDev* tp = templ + first + it;
+        const float* curv = curv0 + (size_t)(it / n_per) * curv_stride;
         const int wh = tp->wh, P = tp->dpitch, pmin = tp->pmin, qmax = tp->qmax, span_off = tp->span_off;
         const float2* dw = dwin + tp->dwin_off;
         float xc[RW][NB][4], t3[RW][NB][4];
@@ -460,75 +474,56 @@ k_direct2(const float* __restrict__ curv, size_t curv_stride, Geom g,
             }
             __syncthreads();
             for (int a = 0; a < na; ++a) {
-                const int2 sp = spans[span_off + a0 + a];         // (first group, groups): wave-uniform
-                if (sp.y == 0) continue;
+                const int4 sp = spans[span_off + a0 + a];         // (first group, groups, s, e): wave-uniform
+                const int ng = sp.y;
+                if (ng == 0) continue;
                 const float2* wrow = dw + (size_t)(a0 + a) * P + 4 * sp.x;
                 // the lane's slab cells of its rows: row (w RW + rr) + (na - 1 - a), column 4 lane + 4 g (+ 256 n)
                 const float* lrow = lds + (w * RW + (na - 1 - a)) * lwp + 4 * lane + 4 * sp.x;
                 typedef float f4 __attribute__((ext_vector_type(4)));
-                f4 va[RW][NB], sa[RW][NB];                        // carried cells and their squares
-#pragma unroll
-                for (int rr = 0; rr < RW; ++rr)
-#pragma unroll
-                    for (int n = 0; n < NB; ++n) {
-                        va[rr][n] = *reinterpret_cast<const f4*>(lrow + rr * lwp + 256 * n);
-                        sa[rr][n] = va[rr][n] * va[rr][n];
-                    }
-                // software pipeline: the four (w, m) pairs and the new cells of group gq + 1 are requested
-                // before group gq is computed (a scalar load and an LDS read waited for right after
-                // their issue cost more than the group's 128 FMAs)
-                float2 wm[4];
-                f4 vn[RW][NB];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) wm[k] = wrow[k];
-#pragma unroll
-                for (int rr = 0; rr < RW; ++rr)
-#pragma unroll
-                    for (int n = 0; n < NB; ++n) vn[rr][n] = *reinterpret_cast<const f4*>(lrow + rr * lwp + 256 * n + 4);
-                for (int gq = 0; gq < sp.y; ++gq) {
-                    float2 wc[4];
-                    f4 vc[RW][NB];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) wc[k] = wm[k];
-#pragma unroll
-                    for (int rr = 0; rr < RW; ++rr)
-#pragma unroll
-                        for (int n = 0; n < NB; ++n) vc[rr][n] = vn[rr][n];
-                    if (!PIPE) {                                   // (variant 11: each group's operands when it starts)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) wc[k] = wrow[4 * gq + k];
-#pragma unroll
-                        for (int rr = 0; rr < RW; ++rr)
-#pragma unroll
-                            for (int n = 0; n < NB; ++n)
-                                vc[rr][n] = *reinterpret_cast<const f4*>(lrow + rr * lwp + 256 * n + 4 * (gq + 1));
-                    } else if (gq + 1 < sp.y) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) wm[k] = wrow[4 * (gq + 1) + k];
-#pragma unroll
-                        for (int rr = 0; rr < RW; ++rr)
-#pragma unroll
-                            for (int n = 0; n < NB; ++n)
-                                vn[rr][n] = *reinterpret_cast<const f4*>(lrow + rr * lwp + 256 * n + 4 * (gq + 2));
-                    }
+                f4 ca[RW][NB], cb[RW][NB], qa[RW][NB], qb[RW][NB];   // two chunks of four cells and their squares
+                auto chunk = [&](int j, f4 (&v)[RW][NB], f4 (&q)[RW][NB]) {
 #pragma unroll
                     for (int rr = 0; rr < RW; ++rr)
 #pragma unroll
                         for (int n = 0; n < NB; ++n) {
-                            const f4 vb = vc[rr][n];
-                            const f4 sb = vb * vb;
-                            const float v[8] = {va[rr][n].x, va[rr][n].y, va[rr][n].z, va[rr][n].w, vb.x, vb.y, vb.z, vb.w};
-                            const float q[8] = {sa[rr][n].x, sa[rr][n].y, sa[rr][n].z, sa[rr][n].w, sb.x, sb.y, sb.z, sb.w};
+                            v[rr][n] = *reinterpret_cast<const f4*>(lrow + rr * lwp + 256 * n + 4 * j);
+                            q[rr][n] = v[rr][n] * v[rr][n];
+                        }
+                };
+                // the four taps of group gq on the carried cells v0 (the first four) and the new cells v1
+                auto group = [&](int gq, const f4 (&v0)[RW][NB], const f4 (&v1)[RW][NB], const f4 (&q0)[RW][NB],
+                                 const f4 (&q1)[RW][NB]) {
+                    float2 wm[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) wm[k] = wrow[4 * gq + k];
+#pragma unroll
+                    for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                        for (int n = 0; n < NB; ++n) {
+                            const float v[8] = {v0[rr][n].x, v0[rr][n].y, v0[rr][n].z, v0[rr][n].w,
+                                                v1[rr][n].x, v1[rr][n].y, v1[rr][n].z, v1[rr][n].w};
+                            const float q[8] = {q0[rr][n].x, q0[rr][n].y, q0[rr][n].z, q0[rr][n].w,
+                                                q1[rr][n].x, q1[rr][n].y, q1[rr][n].z, q1[rr][n].w};
 #pragma unroll
                             for (int k = 0; k < 4; ++k)
 #pragma unroll
                                 for (int u = 0; u < 4; ++u) {
-                                    xc[rr][n][u] = fmaf(wc[k].x, v[u + k], xc[rr][n][u]);
-                                    t3[rr][n][u] = fmaf(wc[k].y, q[u + k], t3[rr][n][u]);
+                                    xc[rr][n][u] = fmaf(wm[k].x, v[u + k], xc[rr][n][u]);
+                                    t3[rr][n][u] = fmaf(wm[k].y, q[u + k], t3[rr][n][u]);
                                 }
-                            va[rr][n] = vb;
-                            sa[rr][n] = sb;
                         }
+                };
+                chunk(0, ca, qa);
+                // two groups per trip: the chunks swap roles (carried / new) instead of being copied
+                // (the copies were 16 v_mov_b64 per 128 FMAs: +9 % on large supports)
+                for (int gq = 0; gq < ng; gq += 2) {
+                    chunk(gq + 1, cb, qb);
+                    group(gq, ca, cb, qa, qb);
+                    if (gq + 1 < ng) {
+                        chunk(gq + 2, ca, qa);
+                        group(gq + 1, cb, ca, qb, qa);
+                    }
                 }
             }
         }
@@ -886,22 +881,22 @@ int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_ma
     sc_prof_begin(ctx, SC_K_WINDOWS);
     hipLaunchKernelGGL(k_direct_prep, dim3((wh_max + 3) / 4, nb * n), dim3(256), 0, ctx->stream,
                        (const TemplDev*)ctx->templ.p, first, (const float*)ctx->win_w.p,
-                       (const uint8_t*)ctx->win_m.p, (float2*)ctx->dwin.p, (int2*)ctx->spans.p);
+                       (const uint8_t*)ctx->win_m.p, (float2*)ctx->dwin.p, (int4*)ctx->spans.p);
     sc_prof_end(ctx);
     SC_HIP(ctx, hipGetLastError());
     // patch: 512 x 16 cells where that still gives every CU a workgroup, else 256 x 16, else 256 x 8
     const size_t lds = (size_t)DR2_LDS_FLOATS * sizeof(float);
     const size_t plane = (size_t)g.ly * g.lx;
-    auto wgs = [&](int txw, int ty) { return (long long)((cw + txw - 1) / txw) * ((ch + ty - 1) / ty) * nb; };
-#define DR2_LAUNCH(NBV, RWV, PIPEV)                                                                     \
+    auto wgs = [&](int txw, int ty) { return (long long)((cw + txw - 1) / txw) * ((ch + ty - 1) / ty); };
+#define DR2_LAUNCH(NBV, RWV)                                                                            \
     {                                                                                              \
-        int rc = sc_lds_attr(ctx, (const void*)k_direct2<NBV, RWV, PIPEV>, lds);                   \
+        int rc = sc_lds_attr(ctx, (const void*)k_direct2<NBV, RWV>, lds);                   \
         if (rc) return rc;                                                                         \
-        dim3 grid((cw + 256 * NBV - 1) / (256 * NBV), (ch + 8 * RWV - 1) / (8 * RWV), nb);        \
+        dim3 grid((cw + 256 * NBV - 1) / (256 * NBV), (ch + 8 * RWV - 1) / (8 * RWV));            \
         sc_prof_begin(ctx, SC_K_DIRECT);                                                           \
-        hipLaunchKernelGGL((k_direct2<NBV, RWV, PIPEV>), grid, dim3(64 * DR2_WAVES), lds, ctx->stream, \
-                           (const float*)ctx->curv.p, plane, g, (const TemplDev*)ctx->templ.p, first, n, \
-                           (const float2*)ctx->dwin.p, (const int2*)ctx->spans.p,                  \
+        hipLaunchKernelGGL((k_direct2<NBV, RWV>), grid, dim3(64 * DR2_WAVES), lds, ctx->stream, \
+                           (const float*)ctx->curv.p, plane, g, (const TemplDev*)ctx->templ.p, first, n, nb, \
+                           (const float2*)ctx->dwin.p, (const int4*)ctx->spans.p,                  \
                            (const double*)ctx->sums.p, (const double*)ctx->xaxis.p,                \
                            (const double*)ctx->yaxis.p, (float*)ctx->best_snr.p,                   \
                            (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p,                     \
@@ -909,10 +904,9 @@ int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_ma
                            to_maps ? (float*)ctx->map_snr.p : nullptr);                            \
         sc_prof_end(ctx);                                                                          \
     }
-    const bool pipe = ctx->variant != 11;
-    if (wgs(512, 16) >= 512) { if (pipe) DR2_LAUNCH(2, 2, true) else DR2_LAUNCH(2, 2, false) }
-    else if (wgs(256, 16) >= 256) { if (pipe) DR2_LAUNCH(1, 2, true) else DR2_LAUNCH(1, 2, false) }
-    else { if (pipe) DR2_LAUNCH(1, 1, true) else DR2_LAUNCH(1, 1, false) }
+    if (wgs(512, 16) >= 512) DR2_LAUNCH(2, 2)
+    else if (wgs(256, 16) >= 256) DR2_LAUNCH(1, 2)
+    else DR2_LAUNCH(1, 1)
 #undef DR2_LAUNCH
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
