@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256) k(const f4* __restrict__ big, size_t nbig
     constexpr int U = 8;
     f4 acc = {0, 0, 0, 0};
     const bool sweeper = MODE == 1 || (MODE == 2 && (blockIdx.x & 1));
-    const size_t nb = MODE == 2 ? gridDim.x / 2 : gridDim.x, b = MODE == 2 ? blockIdx.x / 2 : blockIdx.x;
+    const size_t nb = gridDim.x, b = blockIdx.x;
     const size_t chunk = (size_t)256 * U;
     // every block reads nbig / nb elements in all
     const size_t per_block = nbig / nb / chunk;
@@ -55,7 +55,7 @@ int main() {
         printf("-- small buffer %zu MiB\n", mb);
         run<0>("all blocks stream 3 GiB (HBM)", big, nbig, sm, nsmall, sink, 16.0 * nbig);
         run<1>("all blocks sweep the small buffer (Infinity Cache)", big, nbig, sm, nsmall, sink, 16.0 * nbig);
-        run<2>("half stream, half sweep (each half reads 1.5 GiB)", big, nbig / 1, sm, nsmall, sink, 16.0 * nbig);
+        run<2>("half of the blocks stream, half sweep (1.5 GiB each)", big, nbig, sm, nsmall, sink, 16.0 * nbig);
     }
     return 0;
 }
