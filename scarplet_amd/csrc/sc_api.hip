@@ -464,7 +464,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
     // plane (at most CHUNK of them per run).
     std::vector<TemplDev> h(n);
     std::vector<double> sums(2 * (size_t)n, 0.0), wl1(n, 0.0);
-    struct Run { int first, n, parity; bool full; };
+    struct Run { int first, n, parity; bool full, long_runs; };
     std::vector<Run> runs;
     for (int i = 0; i < n;) {
         int j = i;
@@ -501,12 +501,22 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
                     d.mask_lim != nullptr || d.mask_err != nullptr;
             ++j;
         }
-        runs.push_back({i, j - i, parity < 0 ? 0 : parity, full});
+        // real-space path: does some template of the run have window rows of 16 taps or more along x
+        // (about min(2c / |cos a|, 2d / |sin a|) cells for the built-in rectangles; a window uploaded
+        // by the host: unknown, taken as long)?  Decides the kernel form of the run's launch
+        // (launch_direct) - per RUN, so that a template's sums do not depend on what it is batched with
+        bool long_runs = false;
+        for (int k = i; k < j && !long_runs; ++k) {
+            if (t[k].kind == SC_KIND_WINDOW) { long_runs = true; break; }
+            const double ca = fabs(t[k].cos_a) + 1e-9, sa = fabs(t[k].sin_a) + 1e-9;
+            long_runs = std::min(2.0 * t[k].c / ca, 2.0 * t[k].d / sa) / fabs(ctx->dx) >= 16.0;
+        }
+        runs.push_back({i, j - i, parity < 0 ? 0 : parity, full, long_runs});
         i = j;
     }
     // Chunks: one run, or - small FFT searches - nb consecutive runs of equal length, parity
     // and mask kind sent through every launch together (sc_fft.hip, "Orientation batching")
-    struct Chunk { int first, n, nb, wh, ww, parity; bool full; size_t cells; };
+    struct Chunk { int first, n, nb, wh, ww, parity; bool full, long_runs; size_t cells; };
     std::vector<Chunk> chunks;
     size_t max_cells = 0, max_dcells = 0, max_spans = 0;
     int nb_max = 1;
@@ -520,7 +530,8 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
             const int want = plan->method == SC_METHOD_FFT ? fft_batch_orientations(ctx, fg, runs[r].n, group)
                                                            : (wg1 <= 1024 ? 32 : 1);
             while (nb < want && r + nb < runs.size() && runs[r + nb].n == runs[r].n &&
-                   runs[r + nb].parity == runs[r].parity && runs[r + nb].full == runs[r].full)
+                   runs[r + nb].parity == runs[r].parity && runs[r + nb].full == runs[r].full &&
+                   (plan->method == SC_METHOD_FFT || runs[r + nb].long_runs == runs[r].long_runs))
                 ++nb;
         }
         size_t off = 0, doff = 0;
@@ -540,7 +551,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
         }
         max_dcells = std::max(max_dcells, doff);
         max_spans = std::max(max_spans, (size_t)soff);
-        chunks.push_back({runs[r].first, runs[r].n, nb, wh, ww, runs[r].parity, runs[r].full, off});
+        chunks.push_back({runs[r].first, runs[r].n, nb, wh, ww, runs[r].parity, runs[r].full, runs[r].long_runs, off});
         max_cells = std::max(max_cells, off);
         nb_max = std::max(nb_max, nb);
         r += nb;
@@ -600,7 +611,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
         }
         if ((rc = launch_windows(ctx, c.first, n_all, c.wh, c.ww))) return rc;
         if (plan->method == SC_METHOD_DIRECT) {
-            if ((rc = launch_direct(ctx, c.first, c.n, to_maps, c.nb, c.wh))) return rc;
+            if ((rc = launch_direct(ctx, c.first, c.n, to_maps, c.nb, c.wh, c.long_runs))) return rc;
         } else {
             if ((rc = fft_forward_templates(ctx, fg, c.first, n_all, c.parity))) return rc;
             if ((rc = fft_inverse_fold(ctx, fg, c.first, c.n, group, to_maps, c.full, c.parity, c.nb))) return rc;

@@ -339,10 +339,15 @@ k_direct(const float* __restrict__ curv, Geom g,
 //    the previous group, four new ones from ONE ds_read_b128 (64 lanes read 1 KB of one slab
 //    row: conflict-free) - 32 FMAs for xcorr and 32 for T3 per LDS read instruction;
 //  * the four (w, m) pairs of a group are wave-uniform: one s_load_dwordx8, the FMAs take them
-//    as scalar operands; T3 accumulates m * curv^2 from the squares formed once per cell read
-//    (sharing the sum over the cells common to a lane's four adjacent outputs - 4 FMAs per chunk
-//    instead of 16 - was built and measured 25 % SLOWER: the per-cell masks of the run ends
-//    became 28 v_cndmask per chunk; profiles/r03_crossover.txt);
+//    as scalar operands;
+//  * T3 over a run without holes is SHARED by a lane's four adjacent outputs: the cells common to
+//    the four (all but three at either end) are summed once per block, whole chunks at a time
+//    (3 adds + 1 per chunk instead of 16 weighted FMAs), the end cells are read again after the
+//    groups - the same addends.  +25 - 35 % on supports of thousands of taps.  (A first form with a
+//    0/1 mask per cell was 25 % SLOWER than no sharing: the masks became 28 v_cndmask per chunk.)
+//    Rows with holes and runs below 16 taps accumulate m * curv^2 tap by tap; runs whose every
+//    template is thin take a kernel without the shared form (fewer registers: 10 % faster there)
+//    - decided per orientation run, so that a template's sums never depend on its batch;
 //  * eight waves per workgroup (two per SIMD: one wave alone issues a VALU instruction every
 //    four cycles, two share the SIMD at two), the patch is 8 RW rows x 256 NB columns, slabs of
 //    as many template rows as the 158 KB of LDS hold;
@@ -389,7 +394,7 @@ k_direct_prep(const TemplDev* __restrict__ templ, int first, const float* __rest
     }
 }
 
-template <int NB, int RW>
+template <int NB, int RW, bool SHARE>
 __global__ void __launch_bounds__(64 * DR2_WAVES, 2)
 k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
           const TemplDev* __restrict__ templ, int first, int n_per, int nb,
@@ -514,16 +519,113 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                                 }
                         }
                 };
-                chunk(0, ca, qa);
-                // two groups per trip: the chunks swap roles (carried / new) instead of being copied
-                // (the copies were 16 v_mov_b64 per 128 FMAs: +9 % on large supports)
-                for (int gq = 0; gq < ng; gq += 2) {
-                    chunk(gq + 1, cb, qb);
-                    group(gq, ca, cb, qa, qb);
-                    if (gq + 1 < ng) {
-                        chunk(gq + 2, ca, qa);
-                        group(gq + 1, cb, ca, qb, qa);
+                // T3 of a lane's four adjacent outputs over a run WITHOUT holes, taps s .. e: output u sums
+                // curv^2 over the cells s + u .. e + u.  The cells s + 3 .. e are common to the four: whole
+                // chunks of them go into ONE sum per block (3 adds for the chunk's four squares + 1,
+                // instead of 16 weighted FMAs), the 3 - 6 cells at either end are read again after the
+                // groups and added to the outputs they belong to - the same addends, no per-cell masks.
+                // Rows with holes (Scarp's xr = 0 column at -pi/2, 0, pi/2; generic windows) and runs
+                // shorter than 16 taps keep the weighted form.
+                const bool shared = SHARE && sp.w >= 0 && sp.w - sp.z >= 15;
+                if (!shared) {
+                    chunk(0, ca, qa);
+                    // two groups per trip: the chunks swap roles (carried / new) instead of being copied
+                    // (the copies were 16 v_mov_b64 per 128 FMAs: +9 % on large supports)
+                    for (int gq = 0; gq < ng; gq += 2) {
+                        chunk(gq + 1, cb, qb);
+                        group(gq, ca, cb, qa, qb);
+                        if (gq + 1 < ng) {
+                            chunk(gq + 2, ca, qa);
+                            group(gq + 1, cb, ca, qb, qa);
+                        }
                     }
+                } else {
+                    const int jlo = (sp.z + 6) >> 2;              // first chunk inside s + 3 .. e
+                    const int jhi = ((sp.w + 1) >> 2) - 1;        // last chunk inside it
+                    float csum[RW][NB];
+#pragma unroll
+                    for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                        for (int n = 0; n < NB; ++n) csum[rr][n] = 0.f;
+                    auto chunk_s = [&](int j, f4 (&v)[RW][NB]) {
+#pragma unroll
+                        for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                            for (int n = 0; n < NB; ++n) v[rr][n] = *reinterpret_cast<const f4*>(lrow + rr * lwp + 256 * n + 4 * j);
+                        if (j >= jlo && j <= jhi) {
+#pragma unroll
+                            for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                                for (int n = 0; n < NB; ++n) {
+                                    const f4 q = v[rr][n] * v[rr][n];
+                                    csum[rr][n] += (q.x + q.y) + (q.z + q.w);
+                                }
+                        }
+                    };
+                    auto group_x = [&](int gq, const f4 (&v0)[RW][NB], const f4 (&v1)[RW][NB]) {
+                        float2 wm[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) wm[k] = wrow[4 * gq + k];
+#pragma unroll
+                        for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                            for (int n = 0; n < NB; ++n) {
+                                const float v[8] = {v0[rr][n].x, v0[rr][n].y, v0[rr][n].z, v0[rr][n].w,
+                                                    v1[rr][n].x, v1[rr][n].y, v1[rr][n].z, v1[rr][n].w};
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) xc[rr][n][u] = fmaf(wm[k].x, v[u + k], xc[rr][n][u]);
+                            }
+                    };
+                    chunk_s(0, ca);
+                    for (int gq = 0; gq < ng; gq += 2) {
+                        chunk_s(gq + 1, cb);
+                        group_x(gq, ca, cb);
+                        if (gq + 1 < ng) {
+                            chunk_s(gq + 2, ca);
+                            group_x(gq + 1, cb, ca);
+                        }
+                    }
+                    // the end cells: cell s + i (below the first whole chunk) belongs to the outputs u <= i,
+                    // cell c above the last whole chunk (c <= e + 3) to the outputs u >= c - e
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        const int c = sp.z + i;
+                        if (c >= 4 * jlo) break;
+#pragma unroll
+                        for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                            for (int n = 0; n < NB; ++n) {
+                                const float v = lrow[rr * lwp + 256 * n + c], q = v * v;
+#pragma unroll
+                                for (int u = 0; u < 4; ++u)
+                                    if (u <= i) t3[rr][n][u] += q;
+                            }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        const int c = 4 * (jhi + 1) + i;
+                        if (c > sp.w + 3) break;
+                        const int umin = c - sp.w;
+                        float mu[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) mu[u] = u >= umin ? 1.f : 0.f;
+#pragma unroll
+                        for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                            for (int n = 0; n < NB; ++n) {
+                                const float v = lrow[rr * lwp + 256 * n + c], q = v * v;
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) t3[rr][n][u] = fmaf(mu[u], q, t3[rr][n][u]);
+                            }
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                        for (int n = 0; n < NB; ++n)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) t3[rr][n][u] += csum[rr][n];
                 }
             }
         }
@@ -871,7 +973,7 @@ static int launch_direct_box(sc_ctx* ctx, int first, int n, bool to_maps) {
 
 // templates [first, first + nb * n): nb orientations of n templates, orientation b on curvature
 // plane b (nb = 1 unless the launch sequence batches orientations); wh_max: tallest window
-int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_max) {
+int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_max, bool long_runs) {
     if (ctx->variant == 10) {
         if (nb != 1) return sc_fail(ctx, SC_ERR_INVALID, "the box kernel takes one orientation per launch");
         return launch_direct_box(ctx, first, n, to_maps);
@@ -888,13 +990,13 @@ int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_ma
     const size_t lds = (size_t)DR2_LDS_FLOATS * sizeof(float);
     const size_t plane = (size_t)g.ly * g.lx;
     auto wgs = [&](int txw, int ty) { return (long long)((cw + txw - 1) / txw) * ((ch + ty - 1) / ty); };
-#define DR2_LAUNCH(NBV, RWV)                                                                            \
+#define DR2_LAUNCH(NBV, RWV, SHV)                                                                       \
     {                                                                                              \
-        int rc = sc_lds_attr(ctx, (const void*)k_direct2<NBV, RWV>, lds);                   \
+        int rc = sc_lds_attr(ctx, (const void*)k_direct2<NBV, RWV, SHV>, lds);                   \
         if (rc) return rc;                                                                         \
         dim3 grid((cw + 256 * NBV - 1) / (256 * NBV), (ch + 8 * RWV - 1) / (8 * RWV));            \
         sc_prof_begin(ctx, SC_K_DIRECT);                                                           \
-        hipLaunchKernelGGL((k_direct2<NBV, RWV>), grid, dim3(64 * DR2_WAVES), lds, ctx->stream, \
+        hipLaunchKernelGGL((k_direct2<NBV, RWV, SHV>), grid, dim3(64 * DR2_WAVES), lds, ctx->stream, \
                            (const float*)ctx->curv.p, plane, g, (const TemplDev*)ctx->templ.p, first, n, nb, \
                            (const float2*)ctx->dwin.p, (const int4*)ctx->spans.p,                  \
                            (const double*)ctx->sums.p, (const double*)ctx->xaxis.p,                \
@@ -904,9 +1006,13 @@ int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_ma
                            to_maps ? (float*)ctx->map_snr.p : nullptr);                            \
         sc_prof_end(ctx);                                                                          \
     }
-    if (wgs(512, 16) >= 512) DR2_LAUNCH(2, 2)
-    else if (wgs(256, 16) >= 256) DR2_LAUNCH(1, 2)
-    else DR2_LAUNCH(1, 1)
+    // (variant 11: T3 in the weighted form on every row; long_runs: some template of the launch has
+    //  rows of 16 taps or more - the shared form's kernel carries more registers, thin windows are
+    //  10 % faster on the plain one)
+    const bool share = ctx->variant != 11 && long_runs;
+    if (wgs(512, 16) >= 512) { if (share) DR2_LAUNCH(2, 2, true) else DR2_LAUNCH(2, 2, false) }
+    else if (wgs(256, 16) >= 256) { if (share) DR2_LAUNCH(1, 2, true) else DR2_LAUNCH(1, 2, false) }
+    else { if (share) DR2_LAUNCH(1, 1, true) else DR2_LAUNCH(1, 1, false) }
 #undef DR2_LAUNCH
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
