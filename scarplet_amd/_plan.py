@@ -176,11 +176,12 @@ def direct_window_fits(ww):
 
 def direct_cost(n_taps):
     """Time per output cell and template of the real-space path, picoseconds.  Round 3, k_direct2
-    (device time at 4096^2, profiles/r03_crossover.txt): 0.27 ms at 46 taps, 1.5 ms at 930, 6.3 ms
-    at 4652, 37 ms at 29 424 - 16 ps + 0.075 ps per tap for windows wider than a few cells, up to
-    0.12 ps per tap for the thinnest (a 5-cell run is padded to two groups of four); 0.09 here.
+    (device time at 4096^2, profiles/r03_crossover.txt): 0.27 ms at 46 taps, 1.34 ms at 930, 4.7 ms
+    at 4652, 9.0 ms at 9304, 25.7 ms at 29 424 - 16 ps + 0.055 ps per tap for windows whose rows
+    run 16 taps or more (T3 shared between adjacent outputs), up to 0.12 ps per tap for the
+    thinnest (a 5-cell run is padded to two groups of four); 0.07 here.
     (Round 2's box kernel: 60 + 1.9 ps per BOX cell, 72.8 ms at 928 taps.)"""
-    return 16.0 + 0.09 * n_taps
+    return 16.0 + 0.07 * n_taps
 
 
 def fft_cost(plan, n_cells, n_params=1):
