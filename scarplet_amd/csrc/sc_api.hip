@@ -611,7 +611,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
         }
         if ((rc = launch_windows(ctx, c.first, n_all, c.wh, c.ww))) return rc;
         if (plan->method == SC_METHOD_DIRECT) {
-            if ((rc = launch_direct(ctx, c.first, c.n, to_maps, c.nb, c.wh, c.long_runs))) return rc;
+            if ((rc = launch_direct(ctx, c.first, c.n, to_maps, c.nb, c.wh, c.ww, c.long_runs))) return rc;
         } else {
             if ((rc = fft_forward_templates(ctx, fg, c.first, n_all, c.parity))) return rc;
             if ((rc = fft_inverse_fold(ctx, fg, c.first, c.n, group, to_maps, c.full, c.parity, c.nb))) return rc;

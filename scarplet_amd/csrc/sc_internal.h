@@ -146,7 +146,7 @@ int launch_curv_alpha(sc_ctx* ctx, float cc, float sc2, float ss, int plane = 0)
 int launch_curv_f64(sc_ctx* ctx, double c2, double sn, double cs, double s2, double* out_dev);
 int launch_curv_alpha_batch(sc_ctx* ctx, const float (*coef)[3], int nb);
 int launch_windows(sc_ctx* ctx, int first, int n, int wh_max, int ww_max);
-int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_max, bool long_runs);
+int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_max, int ww_max, bool long_runs);
 bool direct_window_fits(int ww);
 int launch_fill_nodata(sc_ctx* ctx, double* zdev, double* tmp, int* up, int* dn, int ny, int nx,
                        double maxd, int smoothing, unsigned long long* remaining_dev);     // template window width the real-space kernel can stage in LDS

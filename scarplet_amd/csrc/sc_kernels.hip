@@ -973,7 +973,7 @@ static int launch_direct_box(sc_ctx* ctx, int first, int n, bool to_maps) {
 
 // templates [first, first + nb * n): nb orientations of n templates, orientation b on curvature
 // plane b (nb = 1 unless the launch sequence batches orientations); wh_max: tallest window
-int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_max, bool long_runs) {
+int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_max, int ww_max, bool long_runs) {
     if (ctx->variant == 10) {
         if (nb != 1) return sc_fail(ctx, SC_ERR_INVALID, "the box kernel takes one orientation per launch");
         return launch_direct_box(ctx, first, n, to_maps);
@@ -1010,7 +1010,9 @@ int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_ma
     //  rows of 16 taps or more - the shared form's kernel carries more registers, thin windows are
     //  10 % faster on the plain one)
     const bool share = ctx->variant != 11 && long_runs;
-    if (wgs(512, 16) >= 512) { if (share) DR2_LAUNCH(2, 2, true) else DR2_LAUNCH(2, 2, false) }
+    // (the 512-wide patch needs a slab of 512 + the padded window width cells x 16 rows)
+    const bool fits512 = (long long)(512 + ((ww_max + 3) & ~3)) * 16 <= DR2_LDS_FLOATS;
+    if (fits512 && wgs(512, 16) >= 512) { if (share) DR2_LAUNCH(2, 2, true) else DR2_LAUNCH(2, 2, false) }
     else if (wgs(256, 16) >= 256) { if (share) DR2_LAUNCH(1, 2, true) else DR2_LAUNCH(1, 2, false) }
     else { if (share) DR2_LAUNCH(1, 1, true) else DR2_LAUNCH(1, 1, false) }
 #undef DR2_LAUNCH

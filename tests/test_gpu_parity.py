@@ -521,6 +521,34 @@ def test_direct_path_rejects_windows_wider_than_its_lds_slab(gpu_ctx):
         m.ctx.clear_windows()
 
 
+def test_direct_path_widest_window_on_a_large_dem(gpu_ctx):
+    """A window close to the widest the real-space kernel stages (2 100 cells: the 512-cell patch
+    would overflow its LDS slab, the 256-cell patch holds it) on a DEM large enough to be offered
+    the 512-cell patch: the result equals the FFT path's."""
+    rng = np.random.default_rng(8)
+    z = (rng.standard_normal((400, 4600)) * 0.1).astype(np.float32)
+    m = sl.Matcher(grid(z, 1.0), ctx=gpu_ctx)
+
+    class Wide(WT.Scarp):
+        def _device_descriptor(self):
+            return None
+
+        def template(self):
+            W = np.zeros((self.ny, self.nx))
+            W[self.ny // 2 - 1:self.ny // 2 + 2, self.nx // 2 - 1050:self.nx // 2 + 1050] = \
+                np.sin(np.arange(2100) * 0.01)[np.newaxis, :] + 0.5
+            return W
+    try:
+        a_d, s_d = m.match_template(Wide, 10, 1.0, 0.0, method="direct")
+        a_f, s_f = m.match_template(Wide, 10, 1.0, 0.0, method="fft")
+        # (two float32 paths against each other, on white noise: to the maps' own scale)
+        assert np.abs(a_d - a_f).max() <= AMP_RTOL * np.abs(a_f).max()
+        assert np.abs(s_d - s_f).max() <= SNR_RTOL * s_f.max()
+        assert s_f.max() > 0 and np.isfinite(a_d).all()
+    finally:
+        m.ctx.clear_windows()
+
+
 def test_nan_dem_gives_the_reference_nan_maps(gpu_ctx):
     """dem.py:85-86,105 + core.py:349-375: one NaN cell turns every output cell NaN
     (the FFT spreads it), masks then zero their cells; compare() keeps age/angle 0."""
