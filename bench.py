@@ -353,7 +353,9 @@ def main():
                                                # the process group's threads exist)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("gloo")
+        import datetime
+        # (a rank that dies must not leave the others in a collective for gloo's default half hour)
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from torch_transport import TorchTransport
         transport = TorchTransport()
