@@ -149,7 +149,10 @@ int sc_clear_windows(sc_ctx* ctx);
  *              column pass as two launches per tile pair (own columns, mirrors) instead
  *              of one launch with the two kinds paired per XCD, 7 template spectra by the
  *              separate column-transform and split kernels, 8 complex-spectrum I1 for
- *              symmetric templates, 9 generic row kernel at every tile size
+ *              symmetric templates, 9 generic row kernel at every tile size, 10 the round-2
+ *              real-space kernel (walks the support box; one orientation per launch), 11 the
+ *              real-space kernel with T3 accumulated tap by tap on every row (no sum shared
+ *              between a lane's adjacent outputs)
  *   "batch"    1 (default): searches whose single orientation does not fill the
  *              chip send several orientations through every launch; 0: one
  *              orientation per launch sequence.  Results are bit-identical.

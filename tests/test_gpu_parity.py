@@ -521,6 +521,27 @@ def test_direct_path_rejects_windows_wider_than_its_lds_slab(gpu_ctx):
         m.ctx.clear_windows()
 
 
+def test_real_space_kernel_forms_agree(gpu_ctx):
+    """The real-space path in its three forms - k_direct2 with T3 shared between a lane's adjacent
+    outputs (default), with T3 accumulated tap by tap (variant 11), and the round-2 box kernel
+    (variant 10) - sums the same products in different orders: the maps agree to float32 rounding,
+    on thin and on wide windows, with and without the hole a Scarp window has at xr = 0."""
+    g = synthetic.synthetic_scarp(700, ny=610, seed=12)
+    m = sl.Matcher(g, ctx=gpu_ctx)
+    try:
+        for scale, age, ang in ((60, 1.0, 0.0), (60, 300.0, 0.0), (40, 100.0, 0.7), (25, 30.0, -np.pi / 2), (80, 1000.0, 1.2)):
+            out = {}
+            for v in (0, 11, 10):
+                m.ctx.set_option("variant", v)
+                out[v] = m.match_template(WT.Scarp, scale, age, ang, method="direct")
+            for v in (11, 10):
+                for k in (0, 1):
+                    d = np.abs(out[v][k] - out[0][k]).max()
+                    assert d <= 2e-5 * np.abs(out[0][k]).max(), (scale, age, ang, v, k, d)
+    finally:
+        m.ctx.set_option("variant", 0)
+
+
 def test_direct_path_widest_window_on_a_large_dem(gpu_ctx):
     """A window close to the widest the real-space kernel stages (2 100 cells: the 512-cell patch
     would overflow its LDS slab, the 256-cell patch holds it) on a DEM large enough to be offered
