@@ -335,6 +335,18 @@ def roofline_block(value, world, prof, units, steps, method, default_workload):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE line, the JSON: whatever libraries print on the way (gloo announces
+    # its ranks on stdout, RCCL its version) goes to stderr - file descriptor 1 points at stderr until
+    # emit() restores it
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(obj, ensure_ascii=False), flush=True)
+        os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -462,7 +474,7 @@ def main():
             if pool is not None:
                 pool.terminate()
                 pool.join()
-            print(json.dumps(out, ensure_ascii=False))
+            emit(out)
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -598,7 +610,7 @@ def main():
     if pool is not None:
         pool.terminate()
         pool.join()
-    print(json.dumps(out, ensure_ascii=False))
+    emit(out)
 
 
 if __name__ == "__main__":
