@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""BASELINE config C3 at full size against the oracle, beyond bench.py's one window: the 10000 x 10000 search
+(35 ages x 181 orientations, the benchmark's plan) checked on a spread of windows - tile interiors, the seams
+and corners of the 6 x 6 tiles, both wrap edges, the partial last tiles - against ALL 6335 templates
+(oracle.snr_stack_window + check_fold, tolerances oracle.PARITY), and repeated to see that the record is the
+same in every bit from run to run.       python tools/full_size_check.py [windows]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import multiprocessing as mp
+import scarplet_oracle as orc
+from scarplet_amd import _plan, synthetic
+
+n = 10000
+g = synthetic.synthetic_scarp(n)
+ages, angles = _plan.age_grid(), _plan.angle_grid()
+pool = mp.get_context("fork").Pool(min(64, len(os.sched_getaffinity(0))))      # before the first HIP call
+import scarplet_amd as sl
+
+m = sl.Matcher(g)
+t0 = time.time()
+m.search(sl.Scarp, 100, ages, angles, method="fft")
+res = m.result()
+best0 = m.ctx.get_best()
+p = m.plan
+print("search: %.2f s, plan %s" % (time.time() - t0, p), flush=True)
+V, w = p.Vy, 48
+wins = {"tile interior": (800, 900), "corner of tiles (1,1)": (V - 24, V - 24), "corner of tiles (3,2)": (3 * V - 24, 2 * V - 24),
+        "row seam 2|3": (3 * V - 24, 4000), "column seam 4|5": (6100, 5 * V - 24), "wrap corner": (0, n - w),
+        "top wrap edge": (0, 5000), "left wrap edge": (4321, 0), "right wrap edge": (7000, n - w),
+        "bottom wrap edge": (n - w, 2500), "partial last tiles": (n - 400, n - 420), "last tile row, interior": (9500, 3300),
+        "window-limit border (top)": (150, 6000), "centre of the scarp": (5000 - 24, 5000 - 24)}
+k = int(sys.argv[1]) if len(sys.argv) > 1 else len(wins)
+T = len(ages) * len(angles)
+P = orc.PARITY
+worst, exact_min, cells = 0.0, 1.0, 0
+for name, (i0, j0) in list(wins.items())[:k]:
+    win = (i0, i0 + w, j0, j0 + w)
+    t1 = time.time()
+    a_st, s_st = orc.snr_stack_window(g._griddata, 1.0, 1.0, orc.SCARP, 100, ages, angles, win, 160, pool=pool)
+    sub = tuple(np.asarray(r)[win[0]:win[1], win[2]:win[3]] for r in res)
+    chk = orc.check_fold(sub, a_st.reshape(T, w, w), s_st.reshape(T, w, w), np.repeat(ages, len(angles)),
+                         np.tile(angles, len(ages)), tie_rtol=orc.tie_window("fft"),
+                         amp_tol=(P["amp"][0], P["amp"][1] * np.max(np.abs(a_st))), snr_tol=(P["snr"][0], P["snr"][1] * np.max(s_st)))
+    print("window %-28s (%5d, %5d)  bad=%d exact=%.4f strict=%d tie=%d of %d  snr_err=%.2e amp_err=%.2e  (oracle %.0f s)"
+          % (name, i0, j0, chk["n_bad"], chk["exact_frac"], chk["n_strict"], chk["n_tie"], chk["n"], chk["snr_err"], chk["amp_err"],
+             time.time() - t1), flush=True)
+    assert chk["n_bad"] == 0, name
+    worst, exact_min, cells = max(worst, chk["snr_err"]), min(exact_min, chk["exact_frac"]), cells + chk["n"]
+print("%d cells x %d templates: exact argmax >= %.4f, largest SNR error %.2e (window of the FFT path %.0e)" % (cells, T, exact_min, worst, orc.tie_window("fft")))
+assert worst <= 0.5 * orc.tie_window("fft")
+pool.terminate()
+for rep in range(3):
+    m.search(sl.Scarp, 100, ages, angles, method="fft")
+    b = m.ctx.get_best()
+    same = [bool(np.array_equal(x.view(np.uint32), y.view(np.uint32))) for x, y in zip(b, best0)]
+    print("repeat %d: record identical in every bit to the first search: amp %s snr %s id %s" % ((rep + 1,) + tuple(same)), flush=True)
+    assert all(same)
