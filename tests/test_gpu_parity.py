@@ -393,6 +393,45 @@ def test_generic_plugin_goes_through_the_window_path(gpu_ctx):
         assert close_maps(amp, snr, o_amp, o_snr)[0]
 
 
+def test_generic_windows_with_holes_and_long_runs(gpu_ctx):
+    """Uploaded windows exercise every row form of the real-space kernel: rows with holes
+    (every other column zeroed: taps accumulate one by one), long rows without holes (the T3 sum
+    shared between adjacent outputs, run ends at every offset within a group of four) and rows
+    that start and end anywhere - against the oracle, both device paths."""
+    class Holes(WT.Scarp):
+        def _device_descriptor(self):
+            return None
+
+        def template(self):
+            W = super().template()
+            W[:, ::2] = 0.0
+            return W
+
+    class Ragged(WT.Scarp):                       # a wide window whose rows start / end at every offset
+        def _device_descriptor(self):
+            return None
+
+        def template(self):
+            W = np.zeros((self.ny, self.nx))
+            cy, cx = self.ny // 2, self.nx // 2
+            for r in range(-9, 10):
+                lo, hi = cx - 20 - (r % 7), cx + 18 + (r * r) % 11
+                W[cy + r, lo:hi] = np.cos(np.arange(hi - lo) * 0.3 + r) + 0.2
+            return W
+
+    rng = np.random.default_rng(15)
+    z = (rng.standard_normal((90, 140)).cumsum(1) * 0.05 + rng.standard_normal((90, 140)) * 0.02).astype(np.float32)
+    g = grid(z, 1.0)
+    for cls in (Holes, Ragged):
+        t = cls(12, 30.0, 0.4, 140, 90, 1.0)
+        curv = orc.directional_curvature(z, 1.0, 1.0, 0.4)
+        o_amp, o_snr = orc.match_arrays(curv, t.template(), t.get_window_limits())
+        for method in ("direct", "fft"):
+            amp, _, _, snr = sl.match_template(g, cls, 12, 30.0, 0.4, method=method)
+            ok, err = close_maps(amp, snr, o_amp, o_snr)
+            assert ok, (cls.__name__, method, err)
+
+
 def test_upper_break_err_masks(gpu_ctx):
     rng = np.random.default_rng(6)
     z = rng.standard_normal((70, 66)).cumsum(0).astype(np.float32) * 0.05
