@@ -468,11 +468,16 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                 else { li = gi - g.gy0; row_ok = li >= 0 && li < g.ly; }
                 const float* src = curv + (size_t)(row_ok ? li : 0) * g.lx;
                 float* dst = lds + r * lwp;
+                // (periodic DEM at least as wide as the slab: the left edge is reduced once, a cell
+                //  wraps at most once - no division per cell)
+                const bool once = g.wrap && g.nx >= lwp;
+                const int jl = once ? wrap_index(gj_left, g.nx) : 0;
                 for (int c = lane; c < lwp; c += 64) {
                     const int gj = gj_left + c;
                     int lj;
                     bool ok = row_ok;
-                    if (g.wrap) lj = wrap_index(gj, g.nx);
+                    if (once) { lj = jl + c; lj = lj >= g.nx ? lj - g.nx : lj; }
+                    else if (g.wrap) lj = wrap_index(gj, g.nx);
                     else { lj = gj - g.gx0; ok = ok && lj >= 0 && lj < g.lx; }
                     dst[c] = ok ? src[ok ? lj : 0] : 0.f;
                 }
