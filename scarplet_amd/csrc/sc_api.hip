@@ -43,7 +43,7 @@ static void buf_free(DevBuf& b) {
 size_t sc_total_bytes(sc_ctx* c) {
     DevBuf* arr[] = {&c->z, &c->xaxis, &c->yaxis, &c->A, &c->B, &c->C, &c->curv,
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
-                     &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->win_w, &c->win_m,
+                     &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->norm_part, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
                      &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats};
     size_t s = 0;
@@ -198,7 +198,7 @@ extern "C" void sc_destroy(sc_ctx* c) {
     sc_clear_windows(c);
     DevBuf* arr[] = {&c->z, &c->xaxis, &c->yaxis, &c->A, &c->B, &c->C, &c->curv,
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
-                     &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->win_w, &c->win_m,
+                     &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->norm_part, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
                      &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats};
     for (DevBuf* b : arr) buf_free(*b);

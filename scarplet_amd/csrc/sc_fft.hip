@@ -470,15 +470,23 @@ __device__ __forceinline__ void set_compute_store(float2* line_, int tt, float2 
 
 // one Stockham stage of radix R at stride 2^LST over the 4 lines in LDS,
 // standard mapping: set id -> line id / S, tt = id % S
-template <int T, int R, int LST, bool INV, typename TW>
+template <int T, int R, int LST, bool INV, bool REBUILD, typename TW>
 __device__ __forceinline__ void fft_stage(float2* s, const TW& twr) {
     constexpr int S = T / 16;                  // 16-point sets per line
     constexpr int NT = fft_threads(T);
     constexpr int U = (4 * S + NT - 1) / NT;   // sets per thread
     float2 a[U][16];
+    // REBUILD: the thread id as a value the compiler cannot trace, so that the stage's LDS
+    // addresses are rebuilt from it (a few integer operations) where they are used.  Traced,
+    // the addresses of all stages are hoisted to the top of the kernel and out of its loops:
+    // right where a loop runs over many templates, a loss where it runs twice (the forward
+    // kernels: the hoisted values were spilled to scratch there).
+    int tid = threadIdx.x;
+    if constexpr (REBUILD) asm volatile("" : "+v"(tid));
+    __builtin_assume(tid >= 0 && tid < NT);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        int id = threadIdx.x + u * NT;
+        int id = tid + u * NT;
         if (id < 4 * S) set_load<T>(s + (id / S) * fft_line(T), id % S, a[u]);
     }
     // the last stage works in place: butterfly bt reads the elements bt + k*T/R and
@@ -487,7 +495,7 @@ __device__ __forceinline__ void fft_stage(float2* s, const TW& twr) {
     if constexpr ((R << LST) != T) lds_barrier();
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        int id = threadIdx.x + u * NT;
+        int id = tid + u * NT;
         if (id < 4 * S)
             set_compute_store<T, R, LST, INV>(s + (id / S) * fft_line(T), id % S, a[u],
                                               twr.get((LST / 4) < TW::NTW ? LST / 4 : 0, u, wl[u]));
@@ -495,30 +503,31 @@ __device__ __forceinline__ void fft_stage(float2* s, const TW& twr) {
     lds_barrier();
 }
 
-template <int T, int LST, bool INV, typename TW>
+template <int T, int LST, bool INV, bool REBUILD, typename TW>
 __device__ __forceinline__ void fft_stages(float2* s, const TW& twr) {
     if constexpr ((1 << LST) < T) {
         constexpr int REM = T >> LST;
         constexpr int R = REM >= 16 ? 16 : REM;
-        fft_stage<T, R, LST, INV>(s, twr);
-        fft_stages<T, LST + __builtin_ctz(R), INV>(s, twr);
+        fft_stage<T, R, LST, INV, REBUILD>(s, twr);
+        fft_stages<T, LST + __builtin_ctz(R), INV, REBUILD>(s, twr);
     }
 }
 
 // Transform the 4 lines at s (padded layout, see lidx).  Ends with a barrier.
-template <int T, bool INV, typename TW>
+template <int T, bool INV, bool REBUILD = false, typename TW>
 __device__ __forceinline__ void fft4_lines(float2* s, const TW& twr) {
-    fft_stages<T, 0, INV>(s, twr);
+    fft_stages<T, 0, INV, REBUILD>(s, twr);
 }
 
 // ---- F1c: curvature of a tile pair -> row FFT -> blocked ---------------------
-// grid = (Ty/4, npairs); out plane index = pair*2 + {0: curv, 1: curv^2}
+// grid = (Ty/4/FWD_ROWS_RBW, npairs); out plane index = pair*2 + {0: curv, 1: curv^2}
+constexpr int FWD_ROWS_RBW = 2;            // row blocks (of 4 tile rows) per workgroup
 template <int TX>
 __global__ void __launch_bounds__(fft_threads(TX), 4)
 k_fwd_rows_curv(const float* __restrict__ curv, Geom g,
                 const TileDev* __restrict__ tiles, int Ty,
                 const float2* __restrict__ tw, float2* __restrict__ blk,
-                double* __restrict__ norms, int dbg, int np, size_t curv_stride) {
+                double* __restrict__ norm_part, int dbg, int np, size_t curv_stride) {
     // blockIdx.y = b * np + p: tile pair p of the b-th orientation of the launch (its
     // curvature plane lies curv_stride floats further on); small searches batch several
     // orientations per launch (sc_api.hip, "orientation batching")
@@ -526,106 +535,157 @@ k_fwd_rows_curv(const float* __restrict__ curv, Geom g,
     FftTw<TX> twr;
     twr.load(tw);
     constexpr int NT = fft_threads(TX);
-    const int rb = blockIdx.x, pair = blockIdx.y;
+    constexpr int RBW = FWD_ROWS_RBW;
+    const int rb0 = blockIdx.x * RBW, pair = blockIdx.y;
     const int ob = pair / np, ptile = pair - ob * np;
     curv += (size_t)ob * curv_stride;
     const TileDev ta = tiles[2 * ptile], tb = tiles[2 * ptile + 1];
     const size_t plane = (size_t)Ty * TX;
     constexpr int E = 4 * TX / NT;
     static_assert(TX % NT == 0, "a thread's cell u lies in row (u*NT)/TX, column (u*NT)%TX + tid");
-    // Local row of each of the 4 tile rows (the same for the whole workgroup) and
-    // the local column of this thread's cells, without a division per cell: on
-    // the periodic DEM the tile origin is reduced once and a cell wraps at most
-    // once when the DEM is at least as wide as the tile.
-    auto load_tile = [&](const TileDev& t, float (&v)[E]) {
+    // A thread's cells lie in CPR columns (tid + k*NT) of each of the 4 rows: the CPR column
+    // offsets are worked out once per tile (on the periodic DEM one division per thread, then
+    // a step of NT mod nx with one conditional subtraction), the row bases are uniform.
+    constexpr int CPR = TX / NT;
+    auto load_tile = [&](const TileDev& t, float (&v)[E], int tid, int rb) {
         if (t.vy <= 0) {
 #pragma unroll
             for (int u = 0; u < E; ++u) v[u] = 0.f;
             return;
         }
-        const int j0 = g.wrap ? wrap_index(t.gj0, g.nx) : t.gj0 - g.gx0;
-        const bool once = g.nx >= TX;
+        // every load is issued unconditionally, from an address made valid beforehand, and
+        // masked afterwards with an AND: written as "inside ? load : 0" the loads end up in
+        // branches, two at a time with a wait for each pair
+        unsigned col[CPR], cmask[CPR];
+        if (g.wrap) {
+            unsigned c = (unsigned)wrap_index(t.gj0 + tid, g.nx);
+            const unsigned step = (unsigned)NT % (unsigned)g.nx;
+#pragma unroll
+            for (int k = 0; k < CPR; ++k) {
+                col[k] = c;
+                cmask[k] = ~0u;
+                c += step;
+                c = min(c, c - (unsigned)g.nx);     // (c - nx wraps past c while c < nx)
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < CPR; ++k) {
+                const int lj = t.gj0 - g.gx0 + k * NT + tid;
+                const bool ok = lj >= 0 && lj < g.lx;
+                cmask[k] = ok ? ~0u : 0u;
+                col[k] = ok ? lj : 0;
+            }
+        }
+        const unsigned* cu = reinterpret_cast<const unsigned*>(curv);
+        unsigned x[E];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int gi = t.gi0 + 4 * rb + rr;
             const int li = g.wrap ? wrap_index(gi, g.ny) : gi - g.gy0;
             const bool row_ok = g.wrap || (li >= 0 && li < g.ly);
-            const float* row = curv + (size_t)(row_ok ? li : 0) * g.lx;
+            const unsigned* row = cu + (size_t)(row_ok ? li : 0) * g.lx;
+            const unsigned rmask = row_ok ? ~0u : 0u;
 #pragma unroll
-            for (int u = 0; u < E; ++u) {
-                if ((u * NT) / TX != rr) continue;
-                int lj = j0 + (u * NT) % TX + (int)threadIdx.x;
-                bool ok = row_ok;
-                if (g.wrap) {
-                    if (once) lj = lj >= g.nx ? lj - g.nx : lj;
-                    else lj %= g.nx;
-                } else {
-                    ok = ok && lj >= 0 && lj < g.lx;
-                }
-                v[u] = ok ? row[ok ? lj : 0] : 0.f;
-            }
+            for (int k = 0; k < CPR; ++k) x[rr * CPR + k] = row[col[k]] & (rmask & cmask[k]);
         }
+#pragma unroll
+        for (int u = 0; u < E; ++u) v[u] = __uint_as_float(x[u]);
     };
-    // The two planes (curv, curv^2) are transformed one after the other; the
-    // values are fetched again for the second (they come from L2) rather than
-    // held in 32 registers across the first transform, which keeps the kernel at
-    // two workgroups per CU.
-    for (int pl = 0; pl < 2; ++pl) {
-        float va[E], vb[E];
-        if (!SC_DBGBIT(dbg, 8)) { load_tile(ta, va); load_tile(tb, vb); }
+    // A workgroup takes RBW row blocks and the two planes (curv, curv^2) of each, one after
+    // the other.  The values of the next step are fetched (for the second plane: fetched
+    // again, they come from L2, rather than held in 32 more registers across the transform)
+    // as soon as the transform's registers are free, so that they arrive under the stores
+    // of this one: left where they are needed, every load was waited for with nothing else
+    // to do (12 of a plane's 21 us at T = 2048).
+    float va[E], vb[E];
+    auto fetch = [&](int rbk) {
+        int tid = threadIdx.x;                  // (opaque: addresses are rebuilt per step, see fft_stage)
+        asm volatile("" : "+v"(tid));
+        if (!SC_DBGBIT(dbg, 8)) { load_tile(ta, va, tid, rbk); load_tile(tb, vb, tid, rbk); }
         else {
 #pragma unroll
             for (int u = 0; u < E; ++u) va[u] = vb[u] = 1.f + u;
         }
+    };
+    fetch(rb0);
+    for (int step = 0; step < 2 * RBW; ++step) {
+        const int rb = rb0 + (step >> 1), pl = step & 1;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        __builtin_assume(tid >= 0 && tid < NT);
         if (pl == 0 && !SC_DBGBIT(dbg, 1)) {  // |curv|_2^2 and |curv^2|_2^2 of the tile pair (resolution floor, sc_epi_floor)
-            double s2 = 0.0, s4 = 0.0;
+            // a thread's 2E cells in float32 (the norms only scale the resolution floor, a
+            // 1e-7 relative error there moves nothing), float64 from the wave upwards
+            float f2 = 0.f, f4 = 0.f;
 #pragma unroll
             for (int u = 0; u < E; ++u) {
-                double a2 = (double)va[u] * va[u], b2 = (double)vb[u] * vb[u];
-                s2 += a2 + b2;
-                s4 += a2 * a2 + b2 * b2;
+                float a2 = va[u] * va[u], b2 = vb[u] * vb[u];
+                f2 += a2 + b2;
+                f4 = fmaf(a2, a2, fmaf(b2, b2, f4));
             }
+            double s2 = f2, s4 = f4;
             for (int sft = 32; sft > 0; sft >>= 1) {
                 s2 += __shfl_down(s2, sft, 64);
                 s4 += __shfl_down(s4, sft, 64);
             }
-            // one atomic pair per workgroup: 512 workgroups add into the same two
-            // doubles, and same-address float64 atomics serialise (one per wave cost
-            // 670 us of this kernel's 1 200 at C3)
+            // one pair of partial sums per row block, added up by k_tile_norms: same-address
+            // float64 atomics serialise (one pair per workgroup was 20 us of this kernel at
+            // T = 512 and at T = 2048 alike) and leave the sum's last bits to the arrival order
             __shared__ double red[2 * (NT / 64)];
-            if ((threadIdx.x & 63) == 0) {
-                red[2 * (threadIdx.x >> 6)] = s2;
-                red[2 * (threadIdx.x >> 6) + 1] = s4;
+            if ((tid & 63) == 0) {
+                red[2 * (tid >> 6)] = s2;
+                red[2 * (tid >> 6) + 1] = s4;
             }
             lds_barrier();
-            if (threadIdx.x == 0) {
+            if (tid == 0) {
                 double t2 = 0.0, t4 = 0.0;
 #pragma unroll
                 for (int w = 0; w < NT / 64; ++w) {
                     t2 += red[2 * w];
                     t4 += red[2 * w + 1];
                 }
-                atomicAdd(&norms[2 * pair], t2);
-                atomicAdd(&norms[2 * pair + 1], t4);
+                reinterpret_cast<double2*>(norm_part)[(size_t)pair * (Ty >> 2) + rb] = make_double2(t2, t4);
             }
         }
 #pragma unroll
         for (int u = 0; u < E; ++u) {
-            int e = threadIdx.x + u * NT;
+            int e = tid + u * NT;
             sm[lidx<TX>(e / TX, e % TX)] = pl ? make_float2(va[u] * va[u], vb[u] * vb[u])
                                               : make_float2(va[u], vb[u]);
         }
         lds_barrier();
-        if (!SC_DBGBIT(dbg, 2)) fft4_lines<TX, false>(sm, twr);
+        if (!SC_DBGBIT(dbg, 2)) fft4_lines<TX, false, true>(sm, twr);
+        if (step + 1 < 2 * RBW) fetch(rb0 + ((step + 1) >> 1));
         float2* out = blk + (size_t)(pair * 2 + pl) * plane + (size_t)rb * 4 * TX;
         if (!SC_DBGBIT(dbg, 4))
 #pragma unroll 4
-        for (int e = 2 * threadIdx.x; e < 4 * TX; e += 2 * NT) {
+        for (int e = 2 * tid; e < 4 * TX; e += 2 * NT) {
             int cb = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
             float2 x0 = sm[lidx<TX>(rr, 4 * cb + cc)], x1 = sm[lidx<TX>(rr, 4 * cb + cc + 1)];
             *reinterpret_cast<float4*>(out + e) = make_float4(x0.x, x0.y, x1.x, x1.y);
         }
         lds_barrier();
+    }
+}
+
+// |curv|_2^2 and |curv^2|_2^2 of every tile pair from k_fwd_rows_curv's partial sums (nrb per
+// pair), in a fixed order: one wave per pair.
+__global__ void __launch_bounds__(64)
+k_tile_norms(const double* __restrict__ part, int nrb, double* __restrict__ norms) {
+    const double2* p = reinterpret_cast<const double2*>(part) + (size_t)blockIdx.x * nrb;
+    double s2 = 0.0, s4 = 0.0;
+    for (int i = threadIdx.x; i < nrb; i += 64) {
+        const double2 v = p[i];
+        s2 += v.x;
+        s4 += v.y;
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        s2 += __shfl_down(s2, sft, 64);
+        s4 += __shfl_down(s4, sft, 64);
+    }
+    if (threadIdx.x == 0) {
+        norms[2 * blockIdx.x] = s2;
+        norms[2 * blockIdx.x + 1] = s4;
     }
 }
 
@@ -2115,6 +2175,7 @@ int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group, in
     size_t nblk = std::max((size_t)2 * np * nb, (size_t)n_templ_chunk);
     if ((rc = sc_ensure(ctx, ctx->blk, plane * nblk))) return rc;
     if ((rc = sc_ensure(ctx, ctx->norms, sizeof(double) * 2 * np * nb))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->norm_part, sizeof(double) * 2 * np * nb * (fg.Ty / 4)))) return rc;
     if ((rc = sc_ensure(ctx, ctx->uc, plane * np * nb))) return rc;
     if ((rc = sc_ensure(ctx, ctx->uc2, plane * np * nb))) return rc;
     if ((rc = sc_ensure(ctx, ctx->curv, sizeof(float) * (size_t)ctx->g.ly * ctx->g.lx * nb))) return rc;
@@ -2216,9 +2277,8 @@ static int launch_fwd_cols(sc_ctx* ctx, const FftGeom& fg, int nplanes,
 
 int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg, int nb) {
     int np = npairs_of(fg);
-    SC_HIP(ctx, hipMemsetAsync(ctx->norms.p, 0, sizeof(double) * 2 * np * nb, ctx->stream));
     size_t lds = fft_lds_bytes(fg.Tx);
-    dim3 grid(fg.Ty / 4, np * nb);
+    dim3 grid(fg.Ty / 4 / FWD_ROWS_RBW, np * nb);
     sc_prof_begin(ctx, SC_K_FWD_ROWS);
 #define FN(T)                                                                  \
     {                                                                          \
@@ -2228,11 +2288,13 @@ int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg, int nb) {
                            lds, ctx->stream, (const float*)ctx->curv.p,        \
                            ctx->g, (const TileDev*)ctx->tiles.p, fg.Ty,        \
                            (const float2*)ctx->tw_x.p, (float2*)ctx->blk.p,    \
-                           (double*)ctx->norms.p, ctx->dbg, np,                \
+                           (double*)ctx->norm_part.p, ctx->dbg, np,            \
                            (size_t)ctx->g.ly * ctx->g.lx);                     \
     }
     DISPATCH_T(fg.Tx, FN)
 #undef FN
+    hipLaunchKernelGGL(k_tile_norms, dim3(np * nb), dim3(64), 0, ctx->stream,
+                       (const double*)ctx->norm_part.p, fg.Ty / 4, (double*)ctx->norms.p);
     sc_prof_end(ctx);
     SC_HIP(ctx, hipGetLastError());
     return launch_fwd_cols(ctx, fg, 2 * np * nb, (float2*)ctx->uc.p, (float2*)ctx->uc2.p, 1);

@@ -84,6 +84,7 @@ struct sc_ctx {
     DevBuf res_stats;           // two counters: wins of the FFT path, wins near its float32 resolution floor
     DevBuf dwin, spans;         // real-space path: k_direct_prep's rows and row spans
     DevBuf templ, sums, wl1, norms, win_w, win_m;   // wl1: sum|W| per template; norms: per tile pair
+    DevBuf norm_part;                               // k_fwd_rows_curv's partial sums of the norms
     DevBuf tw_y, tw_x;
     int tw_Ty = 0, tw_Tx = 0;
     int fft_pb = 1;            // tile pairs per inverse launch (fft_prepare)
