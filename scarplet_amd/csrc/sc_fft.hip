@@ -919,7 +919,9 @@ k_fwd_cols_tsym(const float2* __restrict__ blk, int Tx, const float2* __restrict
     const TemplDev t = templ[q];
     // ---- mirror columns: line c holds column (Tx - (4cb + c)) mod Tx
     // (all loads of a fill are issued before its first LDS store: a load per loop trip, waited
-    //  for before the next, made this kernel a chain of sixteen memory latencies)
+    //  for before the next, made this kernel a chain of sixteen memory latencies; and the
+    //  own columns' loads are issued before the mirror columns' transform, which hides them)
+    float4 x[EP];
     {
         constexpr int NM = 4 * TY / NT;
         float2 v[NM];
@@ -938,9 +940,17 @@ k_fwd_cols_tsym(const float2* __restrict__ blk, int Tx, const float2* __restrict
             const int c = e / TY, r = e - c * TY;
             sm[lidx<TY>(c, r)] = v[u];
         }
+        // own columns 4cb .. 4cb+3 (k_fwd_cols' fill), 2 cells = 16 B per lane
+#pragma unroll
+        for (int u = 0; u < EP; ++u) {
+            const int e = 2 * (threadIdx.x + u * NT);
+            x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < 4 * TY && templ_rowblock_used(t, e >> 4, TY))
+                x[u] = *reinterpret_cast<const float4*>(in + ((size_t)(e >> 4) * nbx + cb) * 16 + (e & 15));
+        }
     }
     lds_barrier();
-    fft4_lines<TY, false>(sm, twr);
+    fft4_lines<TY, false, true>(sm, twr);
     float2 vm0[EP], vm1[EP];
 #pragma unroll
     for (int u = 0; u < EP; ++u) {
@@ -952,27 +962,16 @@ k_fwd_cols_tsym(const float2* __restrict__ blk, int Tx, const float2* __restrict
         }
     }
     lds_barrier();
-    // ---- own columns 4cb .. 4cb+3 (k_fwd_cols' fill)
-    {
-        float4 x[EP];
 #pragma unroll
-        for (int u = 0; u < EP; ++u) {                                // 2 cells = 16 B per lane
-            const int e = 2 * (threadIdx.x + u * NT);
-            x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < 4 * TY && templ_rowblock_used(t, e >> 4, TY))
-                x[u] = *reinterpret_cast<const float4*>(in + ((size_t)(e >> 4) * nbx + cb) * 16 + (e & 15));
-        }
-#pragma unroll
-        for (int u = 0; u < EP; ++u) {
-            const int e = 2 * (threadIdx.x + u * NT);
-            if (e >= 4 * TY) continue;
-            const int rbk = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
-            sm[lidx<TY>(cc, 4 * rbk + rr)] = make_float2(x[u].x, x[u].y);
-            sm[lidx<TY>(cc + 1, 4 * rbk + rr)] = make_float2(x[u].z, x[u].w);
-        }
+    for (int u = 0; u < EP; ++u) {
+        const int e = 2 * (threadIdx.x + u * NT);
+        if (e >= 4 * TY) continue;
+        const int rbk = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
+        sm[lidx<TY>(cc, 4 * rbk + rr)] = make_float2(x[u].x, x[u].y);
+        sm[lidx<TY>(cc + 1, 4 * rbk + rr)] = make_float2(x[u].z, x[u].w);
     }
     lds_barrier();
-    fft4_lines<TY, false>(sm, twr);
+    fft4_lines<TY, false, true>(sm, twr);
     // ---- split (k_split_templ_sym, cell for cell) and store
 #pragma unroll
     for (int u = 0; u < EP; ++u) {
