@@ -277,6 +277,13 @@ def timed_loop(step, ctx, a, dist, after_warmup=None):
         ctx.sync()
         if dist is not None:
             dist.barrier()
+    inner = step
+
+    def step():
+        # every step pays for its own curvature spectra: what an earlier step kept (option
+        # "spectra_mb": the scales of ONE multi-scale job share them) is dropped first
+        ctx.forget_spectra()
+        inner()
     for _ in range(a.warmup):
         step()
     if after_warmup:

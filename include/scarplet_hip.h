@@ -163,6 +163,14 @@ int sc_clear_windows(sc_ctx* ctx);
  *              other so that the second read hits the XCD's L2.  Default 0: it moves 10 % fewer
  *              bytes and takes 3 % longer (profiles/r03_sibling_rendezvous.txt).  Results are
  *              bit-identical either way.
+ *   "spectra_mb"  > 0: a search whose orientations' curvature spectra fit this many MiB keeps
+ *              them (one slot per orientation instead of one per batched orientation), and a
+ *              later sc_match on the same DEM with the same tile plan and the same orientations
+ *              - the next scale of a multi-scale job, the reference's one sl.match per scale
+ *              (docs/source/examples/channels.ipynb) - skips the curvature passes.  The spectra
+ *              are the same bits either way, so are the results.  Setting the option (to any
+ *              value) and loading a DEM drop what was kept.  Default 0 in the library; the
+ *              Python host sets 8192.
  */
 int sc_set_option(sc_ctx* ctx, const char* name, double value);
 

@@ -150,6 +150,9 @@ def _as(arr, ptr_type):
     return arr.ctypes.data_as(ptr_type)
 
 
+SPECTRA_MB = 8192.0
+
+
 class Context(object):
     """One GPU's matcher state (an ``sc_ctx``)."""
 
@@ -167,6 +170,12 @@ class Context(object):
                                    % (device, rc))
         self.device = int(device)
         self.core = None
+        self.dem_key = None        # Matcher.set_data: fingerprint of the DEM resident in this context
+        self.spectra_mb = 0.0
+        # searches small enough for it keep their curvature spectra (sc_set_option "spectra_mb"): the
+        # next search of the same DEM with the same tiles and orientations - the next scale of a
+        # multi-scale job - starts from them
+        self.set_option("spectra_mb", SPECTRA_MB)
 
     # -- plumbing ----------------------------------------------------------
     def _check(self, rc, what):
@@ -188,9 +197,16 @@ class Context(object):
 
     def set_option(self, name, value):
         """Engine options (include/scarplet_hip.h sc_set_option): 'kappa',
-        'variant', 'y_gb'."""
+        'variant', 'y_gb', 'spectra_mb'."""
         self._check(self.lib.sc_set_option(self._h, name.encode(), float(value)),
                     "sc_set_option(%s)" % name)
+        if name == "spectra_mb":
+            self.spectra_mb = float(value)
+
+    def forget_spectra(self):
+        """Drop the curvature spectra kept from earlier searches (option
+        'spectra_mb'): the next search computes its own again."""
+        self.set_option("spectra_mb", self.spectra_mb)
 
     def fill_nodata(self, z, max_search_distance, smoothing_iterations=0):
         """One GDALFillNodata-style pass over ``z`` (float64, NaN = nodata), in
@@ -222,6 +238,7 @@ class Context(object):
         ya = np.ascontiguousarray(yaxis, dtype=np.float64)
         assert xa.size == shape[1] and ya.size == shape[0]
         args = self._dem_args(ly, lx, origin, shape, core, wrap)
+        self.dem_key = None
         self._check(self.lib.sc_set_dem(
             self._h, _as(z, _dp), *args, float(dx), float(dy), int(bool(wrap)),
             _as(xa, _dp), _as(ya, _dp)), "sc_set_dem")
@@ -231,6 +248,7 @@ class Context(object):
         xa = np.ascontiguousarray(xaxis, dtype=np.float64)
         ya = np.ascontiguousarray(yaxis, dtype=np.float64)
         args = self._dem_args(ly, lx, origin, shape, core, False)
+        self.dem_key = None
         self._check(self.lib.sc_set_dem_device(
             self._h, z_dev, *args, float(dx), float(dy), 0, _as(xa, _dp),
             _as(ya, _dp)), "sc_set_dem_device")

@@ -135,6 +135,14 @@ class Plan(object):
                 cy1 - cy0, pmax - pmin, ny, whole and (cy1 - cy0) == ny, t_max)
             self.Tx, self.Vx, self.ntx, self.circ_x = choose_tile(
                 cx1 - cx0, qmax - qmin, nx, whole and (cx1 - cx0) == nx, t_max)
+            # a circular axis has no halo to place: any origin with pmax <= P <= T + pmin serves.
+            # T/2 serves every template that fits the grid, so that the tile - and with it the
+            # curvature spectra a search keeps (sc_set_option "spectra_mb") - is the same for
+            # every scale of a multi-scale job
+            if self.circ_y:
+                self.Py = self.Ty // 2
+            if self.circ_x:
+                self.Qx = self.Tx // 2
         else:
             self.Ty = self.Tx = self.Vy = self.Vx = 0
             self.nty = self.ntx = 0

@@ -48,6 +48,18 @@ def _context(device):
     return ctx
 
 
+def _dem_fingerprint(z, dx, dy):
+    """Shape, cell size and a 128-bit hash of the values."""
+    zc = np.ascontiguousarray(z)
+    try:
+        import xxhash
+        h = xxhash.xxh3_128_hexdigest(zc.view(np.uint8).reshape(-1))
+    except ImportError:
+        import hashlib
+        h = hashlib.blake2b(zc.view(np.uint8).reshape(-1), digest_size=16).hexdigest()
+    return (zc.shape, str(zc.dtype), float(dx), float(dy), h)
+
+
 def _grid_of(data):
     z = np.asarray(data._griddata)
     if z.ndim != 2:
@@ -93,8 +105,14 @@ class Matcher(object):
         self.dx, self.dy = dx, dy
         self.core = (0, self.ny, 0, self.nx)
         self.whole = True
+        # the same DEM as the one already in the context (one sl.match per scale on the same
+        # data): nothing to upload, and the curvature spectra of the last search stay usable
+        key = _dem_fingerprint(z, dx, dy)
+        if self.ctx.dem_key is not None and self.ctx.dem_key == key:
+            return
         self.ctx.set_dem(z, dx, dy, _WT.centred_axis(self.nx, dx),
                          _WT.centred_axis(self.ny, dx))
+        self.ctx.dem_key = key
 
     def set_block(self, z_dev_or_host, origin, shape, core, dx, dy,
                   block_shape=None):

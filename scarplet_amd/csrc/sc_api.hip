@@ -163,6 +163,10 @@ extern "C" int sc_set_option(sc_ctx* ctx, const char* name, double value) {
         ctx->batch_off = value == 0.0;
     } else if (!strcmp(name, "sib")) {
         ctx->sib = (int)value;
+    } else if (!strcmp(name, "spectra_mb")) {
+        if (!(value >= 0.0)) return sc_fail(ctx, SC_ERR_INVALID, "spectra_mb must be >= 0");
+        ctx->spec_mb = value;
+        fft_spectra_forget(ctx);
     } else if (!strcmp(name, "y_gb")) {
         if (!(value >= 0.0)) return sc_fail(ctx, SC_ERR_INVALID, "y_gb must be >= 0");
         ctx->y_gb = value;
@@ -253,6 +257,7 @@ static int set_dem_common(sc_ctx* ctx, int ly, int lx, int gy0, int gx0, int ny,
     SC_HIP(ctx, hipMemcpyAsync(ctx->yaxis.p, yaxis, sizeof(double) * ny,
                                hipMemcpyHostToDevice, ctx->stream));
     if ((rc = launch_curv_planes(ctx))) return rc;
+    fft_spectra_forget(ctx);
     ctx->have_dem = true;
     if ((rc = sc_reset_best(ctx))) return rc;
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -516,7 +521,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
     }
     // Chunks: one run, or - small FFT searches - nb consecutive runs of equal length, parity
     // and mask kind sent through every launch together (sc_fft.hip, "Orientation batching")
-    struct Chunk { int first, n, nb, wh, ww, parity; bool full, long_runs; size_t cells; };
+    struct Chunk { int first, n, nb, wh, ww, parity; bool full, long_runs; size_t cells; int run0; };
     std::vector<Chunk> chunks;
     size_t max_cells = 0, max_dcells = 0, max_spans = 0;
     int nb_max = 1;
@@ -551,14 +556,30 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
         }
         max_dcells = std::max(max_dcells, doff);
         max_spans = std::max(max_spans, (size_t)soff);
-        chunks.push_back({runs[r].first, runs[r].n, nb, wh, ww, runs[r].parity, runs[r].full, runs[r].long_runs, off});
+        chunks.push_back({runs[r].first, runs[r].n, nb, wh, ww, runs[r].parity, runs[r].full, runs[r].long_runs, off, (int)r});
         max_cells = std::max(max_cells, off);
         nb_max = std::max(nb_max, nb);
         r += nb;
     }
+    // Spectra kept across searches (option "spectra_mb"): slot of run r = its orientation's index among the
+    // search's distinct consecutive orientations; a batch must sit in consecutive slots
+    std::vector<int> slot_of(runs.size(), 0);
+    int n_slots = 0;
+    if (plan->method == SC_METHOD_FFT && !to_maps && ctx->spec_mb > 0.0) {
+        for (size_t r = 0; r < runs.size(); ++r) {
+            const sc_template &a = t[runs[r].first];
+            const bool same = r > 0 && a.cc == t[runs[r - 1].first].cc && a.sc2 == t[runs[r - 1].first].sc2 &&
+                              a.ss == t[runs[r - 1].first].ss;
+            slot_of[r] = same ? slot_of[r - 1] : n_slots++;
+        }
+        for (const Chunk& c : chunks)
+            for (int b = 1; b < c.nb; ++b)
+                if (slot_of[c.run0 + b] != slot_of[c.run0] + b) n_slots = 0;     // (an orientation twice in a batch)
+    }
     if (plan->method == SC_METHOD_FFT &&
-        (rc = fft_prepare(ctx, fg, std::min(n, CHUNK), group, nb_max)))
+        (rc = fft_prepare(ctx, fg, std::min(n, CHUNK), group, nb_max, n_slots)))
         return rc;
+    const bool keep = plan->method == SC_METHOD_FFT && ctx->spec_slots > 0;
     if ((rc = sc_ensure(ctx, ctx->templ, sizeof(TemplDev) * n))) return rc;
     if ((rc = sc_ensure(ctx, ctx->sums, sizeof(double) * 2 * n))) return rc;
     if ((rc = sc_ensure(ctx, ctx->wl1, sizeof(double) * n))) return rc;
@@ -582,7 +603,22 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
     bool have_curv = false;
     for (const Chunk& c : chunks) {
         const int n_all = c.nb * c.n;
-        if (c.nb > 1) {
+        // kept spectra: this chunk's slots, and whether they already hold its orientations
+        bool hit = false;
+        if (keep) {
+            const int s0 = slot_of[c.run0];
+            ctx->uc_off = (size_t)s0 * ctx->spec_uc_stride;
+            ctx->norms_off = (size_t)s0 * ctx->spec_norm_stride;
+            hit = true;
+            for (int b = 0; b < c.nb; ++b) {
+                const sc_template& sb = t[c.first + b * c.n];
+                const double* k = &ctx->spec_key[3 * (size_t)(s0 + b)];
+                hit = hit && k[0] == sb.cc && k[1] == sb.sc2 && k[2] == sb.ss;
+            }
+        }
+        if (hit) {
+            have_curv = false;                    // (the curvature plane itself was not rebuilt)
+        } else if (c.nb > 1) {
             float coef[32][3];
             for (int b = 0; b < c.nb; ++b) {
                 const sc_template& sb = t[c.first + b * c.n];
@@ -600,6 +636,12 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
                 have_curv = true;
             }
         }
+        if (keep && !hit)
+            for (int b = 0; b < c.nb; ++b) {
+                const sc_template& sb = t[c.first + b * c.n];
+                double* k = &ctx->spec_key[3 * (size_t)(slot_of[c.run0] + b)];
+                k[0] = sb.cc; k[1] = sb.sc2; k[2] = sb.ss;
+            }
         for (int j = c.first; j < c.first + n_all; ++j) {
             if (t[j].kind != SC_KIND_WINDOW) continue;
             const WindowSlot& w = ctx->windows[t[j].window];

@@ -40,6 +40,7 @@
 #include "sc_internal.h"
 #include <math.h>
 #include <type_traits>
+#include <string.h>
 
 struct TileDev {
     int i0, j0, vy, vx, gi0, gj0;
@@ -2144,7 +2145,12 @@ static int upload_twiddles(sc_ctx* ctx, DevBuf& buf, int& have, int T, int kph) 
 
 static int npairs_of(const FftGeom& fg) { return (fg.ntiles + 1) / 2; }
 
-int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group, int nb) {
+void fft_spectra_forget(sc_ctx* ctx) {
+    std::fill(ctx->spec_key.begin(), ctx->spec_key.end(), NAN);
+}
+
+// n_slots: orientations of the search whose curvature spectra would be kept (0: none asked for)
+int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group, int nb, int n_slots) {
     // nb: orientations batched per launch (fft_batch_orientations); 1 for the large searches
     if (!fft_size_supported(fg.Ty) || !fft_size_supported(fg.Tx))
         return sc_fail(ctx, SC_ERR_UNSUPPORTED, "FFT tile %dx%d not supported", fg.Ty, fg.Tx);
@@ -2173,10 +2179,30 @@ int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group, in
     size_t plane = (size_t)fg.Ty * fg.Tx * sizeof(float2);
     size_t nblk = std::max((size_t)2 * np * nb, (size_t)n_templ_chunk);
     if ((rc = sc_ensure(ctx, ctx->blk, plane * nblk))) return rc;
-    if ((rc = sc_ensure(ctx, ctx->norms, sizeof(double) * 2 * np * nb))) return rc;
+    // spectra kept across searches: a slot per orientation, if the option's budget holds them
+    {
+        const Geom& gg = ctx->g;
+        const long long sig[24] = {fg.Ty, fg.Tx, fg.Vy, fg.Vx, fg.nty, fg.ntx, fg.circ_y, fg.circ_x, fg.Py, fg.Qx,
+                                   gg.ly, gg.lx, gg.gy0, gg.gx0, gg.ny, gg.nx, gg.cy0, gg.cy1, gg.cx0, gg.cx1,
+                                   gg.wrap, n_slots, 0, 0};
+        const bool keep = n_slots > 0 && 2.0 * (double)plane * np * n_slots <= ctx->spec_mb * 1048576.0;
+        const int slots = keep ? n_slots : 0;
+        const void *p0 = ctx->uc.p, *p1 = ctx->uc2.p, *p2 = ctx->norms.p;
+        const size_t have = std::max(nb, slots);
+        if ((rc = sc_ensure(ctx, ctx->norms, sizeof(double) * 2 * np * have))) return rc;
+        if ((rc = sc_ensure(ctx, ctx->uc, plane * np * have))) return rc;
+        if ((rc = sc_ensure(ctx, ctx->uc2, plane * np * have))) return rc;
+        if (!keep || slots != ctx->spec_slots || memcmp(sig, ctx->spec_sig, sizeof(sig)) != 0 ||
+            p0 != ctx->uc.p || p1 != ctx->uc2.p || p2 != ctx->norms.p) {
+            ctx->spec_key.assign((size_t)3 * slots, NAN);
+            memcpy(ctx->spec_sig, sig, sizeof(sig));
+        }
+        ctx->spec_slots = slots;
+        ctx->spec_uc_stride = (size_t)np * fg.Ty * fg.Tx;
+        ctx->spec_norm_stride = (size_t)2 * np;
+        ctx->uc_off = ctx->norms_off = 0;
+    }
     if ((rc = sc_ensure(ctx, ctx->norm_part, sizeof(double) * 2 * np * nb * (fg.Ty / 4)))) return rc;
-    if ((rc = sc_ensure(ctx, ctx->uc, plane * np * nb))) return rc;
-    if ((rc = sc_ensure(ctx, ctx->uc2, plane * np * nb))) return rc;
     if ((rc = sc_ensure(ctx, ctx->curv, sizeof(float) * (size_t)ctx->g.ly * ctx->g.lx * nb))) return rc;
     if ((rc = sc_ensure(ctx, ctx->vh, plane * n_templ_chunk))) return rc;
     size_t hplane = half_plane(fg.Ty, fg.Tx) * sizeof(float2);
@@ -2293,10 +2319,10 @@ int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg, int nb) {
     DISPATCH_T(fg.Tx, FN)
 #undef FN
     hipLaunchKernelGGL(k_tile_norms, dim3(np * nb), dim3(64), 0, ctx->stream,
-                       (const double*)ctx->norm_part.p, fg.Ty / 4, (double*)ctx->norms.p);
+                       (const double*)ctx->norm_part.p, fg.Ty / 4, (double*)ctx->norms.p + ctx->norms_off);
     sc_prof_end(ctx);
     SC_HIP(ctx, hipGetLastError());
-    return launch_fwd_cols(ctx, fg, 2 * np * nb, (float2*)ctx->uc.p, (float2*)ctx->uc2.p, 1);
+    return launch_fwd_cols(ctx, fg, 2 * np * nb, (float2*)ctx->uc.p + ctx->uc_off, (float2*)ctx->uc2.p + ctx->uc_off, 1);
 }
 
 // Symmetric fast path (k_split_templ_sym / k_inv_cols_sym): all templates of the
@@ -2425,11 +2451,11 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             float2* ymp = (float2*)ctx->ym.p + (size_t)pl0 * yblock;
             n_i1 += symx ? 1 : 2;            // one paired launch, or own columns + mirrors
 #define COL_ARGS(CB0)                                                          \
-    ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float2*)ctx->wh.p, \
+    ctx->stream, (const float2*)ctx->uc.p + ctx->uc_off, (const float2*)ctx->uc2.p + ctx->uc_off, (const float2*)ctx->wh.p, \
         (const float2*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi, ctx->dbg,        \
         (const float2*)ctx->tw_y.p, ywp, ymp, group, np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py
 #define SYM_ARGS(CB0)                                                          \
-    ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, (const float*)ctx->wh.p, \
+    ctx->stream, (const float2*)ctx->uc.p + ctx->uc_off, (const float2*)ctx->uc2.p + ctx->uc_off, (const float*)ctx->wh.p, \
         (const float*)ctx->mh.p, fg.Tx, CB0, pair, g0, G, rp_lo, rp_hi,                    \
         (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group
 #define SYM_ARGS_D(CB0) SYM_ARGS(CB0), ctx->dbg, np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py
@@ -2438,7 +2464,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         int rc = set_lds(ctx, k_inv_cols_symx<T, PTV>, inv_cols_lds<T>());     \
         if (rc) return rc;                                                     \
         hipLaunchKernelGGL((k_inv_cols_symx<T, PTV>), dim3(fg.Tx / 4, nb * pcc), dim3(fft_threads(T)), \
-                           inv_cols_lds<T>(), ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, \
+                           inv_cols_lds<T>(), ctx->stream, (const float2*)ctx->uc.p + ctx->uc_off, (const float2*)ctx->uc2.p + ctx->uc_off, \
                            (const float*)ctx->wh.p, (const float*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo, rp_hi, \
                            (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group, \
                            ctx->dbg, np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py); \
@@ -2448,7 +2474,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         int rc = set_lds(ctx, k_inv_cols_w8<T, PTV>, w8_lds<T>());             \
         if (rc) return rc;                                                     \
         hipLaunchKernelGGL((k_inv_cols_w8<T, PTV>), dim3(fg.Tx / 8, nb * pcc), dim3(512),  \
-                           w8_lds<T>(), ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, \
+                           w8_lds<T>(), ctx->stream, (const float2*)ctx->uc.p + ctx->uc_off, (const float2*)ctx->uc2.p + ctx->uc_off, \
                            (const float*)ctx->wh.p, (const float*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo, rp_hi, \
                            (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group, \
                            np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py); \
@@ -2460,7 +2486,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         int rc = set_lds(ctx, k_inv_cols_w4<T, PTV>, lds4);                    \
         if (rc) return rc;                                                     \
         hipLaunchKernelGGL((k_inv_cols_w4<T, PTV>), dim3(fg.Tx / 4, nb * pcc), dim3(256),  \
-                           lds4, ctx->stream, (const float2*)ctx->uc.p, (const float2*)ctx->uc2.p, \
+                           lds4, ctx->stream, (const float2*)ctx->uc.p + ctx->uc_off, (const float2*)ctx->uc2.p + ctx->uc_off, \
                            (const float*)ctx->wh.p, (const float*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo, rp_hi, \
                            (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group, \
                            np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py); \
@@ -2537,7 +2563,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
 #define FAST_ARGS                                                              \
     ctx->stream, (const float2*)ctx->yw.p, (const float2*)ctx->ym.p, ra, ctx->g,     \
         (const TileDev*)ctx->tiles.p, (const TemplDev*)ctx->templ.p, (const double*)ctx->sums.p, \
-        (const double*)ctx->wl1.p, (const double*)ctx->norms.p, ctx->kappa,                 \
+        (const double*)ctx->wl1.p, (const double*)ctx->norms.p + ctx->norms_off, ctx->kappa,                 \
         (const double*)ctx->xaxis.p, (const double*)ctx->yaxis.p, (const float2*)ctx->tw_x.p, \
         (float*)ctx->best_snr.p, (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p,        \
         to_maps ? (float*)ctx->map_amp.p : nullptr, to_maps ? (float*)ctx->map_snr.p : nullptr

@@ -85,6 +85,17 @@ struct sc_ctx {
     DevBuf dwin, spans;         // real-space path: k_direct_prep's rows and row spans
     DevBuf templ, sums, wl1, norms, win_w, win_m;   // wl1: sum|W| per template; norms: per tile pair
     DevBuf norm_part;                               // k_fwd_rows_curv's partial sums of the norms
+    // Curvature spectra kept across searches (sc_set_option "spectra_mb" > 0): uc / uc2 / norms hold one
+    // slot per orientation of the search instead of one per batched orientation, and a later search on
+    // the same DEM with the same plan and orientations - a multi-scale job is one search per scale -
+    // finds them there and skips the curvature passes (k_curv_alpha, F1c, F2).
+    double spec_mb = 0.0;
+    int spec_slots = 0;                 // slots the buffers hold (0: not keeping)
+    size_t spec_uc_stride = 0;          // float2 elements of uc / uc2 per slot; norms: 2 * npairs doubles
+    size_t spec_norm_stride = 0;
+    size_t uc_off = 0, norms_off = 0;   // the current chunk's first slot, in elements of uc / uc2 and of norms
+    std::vector<double> spec_key;       // (cc, sc2, ss) per slot, NaN while empty
+    long long spec_sig[24] = {0};       // tile plan and block geometry the slots were computed for
     DevBuf tw_y, tw_x;
     int tw_Ty = 0, tw_Tx = 0;
     int fft_pb = 1;            // tile pairs per inverse launch (fft_prepare)
@@ -154,7 +165,8 @@ int launch_fill_nodata(sc_ctx* ctx, double* zdev, double* tmp, int* up, int* dn,
 int launch_compare_fold(sc_ctx* ctx, double age, double angle, bool planes);
 
 // ---- launchers implemented in sc_fft.hip ------------------------------------
-int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group, int nb);
+int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group, int nb, int n_slots);
+void fft_spectra_forget(sc_ctx* ctx);
 int fft_batch_orientations(const sc_ctx* ctx, const FftGeom& fg, int n_per, int group);
 int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg, int nb);
 int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n, int parity);

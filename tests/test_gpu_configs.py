@@ -346,3 +346,70 @@ def test_column_pass_forms_are_bit_identical():
             for a, b, name in zip(out[0], other, ("amp", "snr", "id")):
                 assert np.array_equal(a, b), (str(plan), name, int((a != b).sum()))
         assert (out[0][1] > 0).any()
+
+
+def _fwd_rows_launches(ctx, fn):
+    """launches of the curvature/template forward row kernels while fn() runs"""
+    ctx.profile(1)
+    fn()
+    n = ctx.profile_get()["k_fwd_rows"][0]
+    ctx.profile(0)
+    return n
+
+
+@pytest.mark.gpu
+def test_kept_curvature_spectra_are_reused_and_change_nothing():
+    """A search keeps the curvature spectra of its orientations (option "spectra_mb"); the next
+    search on the same DEM with the same tiles and orientations - the next scale of a multi-scale
+    job, C5 - starts from them.  The record must equal, bit for bit, the one a context without
+    kept spectra produces; fewer forward launches show that the spectra were in fact reused; a
+    different orientation grid, a different DEM or forget_spectra() recompute them."""
+    gc = dem_fixture("dem_grandcanyon.npz")
+    g = grid(gc[0], gc[1], gc[2])
+    rng = np.random.default_rng(5)
+    g2 = grid((gc[0] + 0.05 * rng.standard_normal(gc[0].shape)).astype(gc[0].dtype), gc[1], gc[2])
+    angles = _plan.angle_grid()[::4]
+
+    def fresh(gr, scale, ang):
+        ctx = sl._lib.Context(0)
+        ctx.set_option("spectra_mb", 0)
+        m = sl.Matcher(gr, ctx=ctx)
+        m.search(WT.Channel, scale, [0.1], ang, method="fft")
+        out = m.ctx.get_best()
+        ctx.close()
+        return out
+
+    ctx = sl._lib.Context(0)
+    assert ctx.spectra_mb > 0                       # on by default
+    m = sl.Matcher(g, ctx=ctx)
+    n_first = _fwd_rows_launches(ctx, lambda: m.search(WT.Channel, 5., [0.1], angles, method="fft"))
+    for a, b in zip(m.ctx.get_best(), fresh(g, 5., angles)):
+        assert np.array_equal(a, b)
+    # the next scale: same orientations -> only the template rows are transformed
+    n_second = _fwd_rows_launches(ctx, lambda: m.search(WT.Channel, 20., [0.1], angles, method="fft"))
+    assert 0 < n_second < n_first, (n_first, n_second)
+    for a, b in zip(m.ctx.get_best(), fresh(g, 20., angles)):
+        assert np.array_equal(a, b)
+    # the same data through a new Matcher on the same context (one sl.match per scale): not uploaded again
+    key = ctx.dem_key
+    m2 = sl.Matcher(g, ctx=ctx)
+    assert ctx.dem_key == key
+    n_third = _fwd_rows_launches(ctx, lambda: m2.search(WT.Channel, 40., [0.1], angles, method="fft"))
+    assert n_third == n_second
+    for a, b in zip(m2.ctx.get_best(), fresh(g, 40., angles)):
+        assert np.array_equal(a, b)
+    # other orientations: recomputed
+    other = _plan.angle_grid()[1::4]
+    n_other = _fwd_rows_launches(ctx, lambda: m2.search(WT.Channel, 40., [0.1], other, method="fft"))
+    assert n_other > n_second
+    for a, b in zip(m2.ctx.get_best(), fresh(g, 40., other)):
+        assert np.array_equal(a, b)
+    # forgotten on request, and with another DEM in the context
+    ctx.forget_spectra()
+    assert _fwd_rows_launches(ctx, lambda: m2.search(WT.Channel, 40., [0.1], other, method="fft")) == n_other
+    m3 = sl.Matcher(g2, ctx=ctx)
+    assert ctx.dem_key != key
+    assert _fwd_rows_launches(ctx, lambda: m3.search(WT.Channel, 40., [0.1], other, method="fft")) == n_other
+    for a, b in zip(m3.ctx.get_best(), fresh(g2, 40., other)):
+        assert np.array_equal(a, b)
+    ctx.close()
