@@ -789,17 +789,27 @@ k_fwd_cols(const float2* __restrict__ blk, int Tx, const float2* __restrict__ tw
     // blocks outside the template's support were not written - they are zero
     TemplDev t{};
     if (templ) t = templ[q];
-#pragma unroll 4
-    for (int e = 2 * threadIdx.x; e < 4 * TY; e += 2 * NT) {      // 2 cells = 16 B per lane
-        int rbk = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!templ || templ_rowblock_used(t, rbk, TY))
-            x = *reinterpret_cast<const float4*>(in + ((size_t)rbk * nbx + cb) * 16 + (e & 15));
-        sm[lidx<TY>(cc, 4 * rbk + rr)] = make_float2(x.x, x.y);
-        sm[lidx<TY>(cc + 1, 4 * rbk + rr)] = make_float2(x.z, x.w);
+    // (all loads of the fill first, then the LDS stores: in one loop the second half of the loads
+    //  was issued only once the first half had arrived and been stored)
+    constexpr int EP = (4 * TY + 2 * NT - 1) / (2 * NT);
+    float4 x[EP];
+#pragma unroll
+    for (int u = 0; u < EP; ++u) {                                // 2 cells = 16 B per lane
+        const int e = 2 * ((int)threadIdx.x + u * NT);
+        x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < 4 * TY && (!templ || templ_rowblock_used(t, e >> 4, TY)))
+            x[u] = *reinterpret_cast<const float4*>(in + ((size_t)(e >> 4) * nbx + cb) * 16 + (e & 15));
+    }
+#pragma unroll
+    for (int u = 0; u < EP; ++u) {
+        const int e = 2 * ((int)threadIdx.x + u * NT);
+        if (e >= 4 * TY) continue;
+        const int rbk = e >> 4, rr = (e >> 2) & 3, cc = e & 3;
+        sm[lidx<TY>(cc, 4 * rbk + rr)] = make_float2(x[u].x, x[u].y);
+        sm[lidx<TY>(cc + 1, 4 * rbk + rr)] = make_float2(x[u].z, x[u].w);
     }
     lds_barrier();
-    fft4_lines<TY, false>(sm, twr);
+    fft4_lines<TY, false, true>(sm, twr);
     float2* out = split2 ? ((q & 1) ? out1 : out0) + (size_t)(q >> 1) * plane
                          : out0 + (size_t)q * plane;
     out += (size_t)cb * 4 * TY;                 // columns 4cb..4cb+3 are contiguous
