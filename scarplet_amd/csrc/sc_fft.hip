@@ -450,14 +450,14 @@ __device__ __forceinline__ void set_compute_store(float2* line_, int tt, float2 
         const int bt = tt + b * S;             // butterfly index in [0, T/R)
         const int p = bt >> LST, q = bt & (ST - 1);
         const int o = q + (p << (LST + LR));
-        // output m goes to element o + m*ST
-        v2* wb;
-        int wstep;                             // padded distance of ST elements
-        if (LST >= 4) { wb = line + ph(o); wstep = ST + ST / 16; }
-        else if (LST == 0 && R == 16) { wb = line + 17 * bt; wstep = 1; }
-        else { wb = nullptr; wstep = 0; }
+        // output m goes to element o + m*ST: one base per butterfly and compile-time offsets where
+        // the padding allows it.  (The choice is made at compile time: a null base as the "no base"
+        // flag was not folded - LDS address 0 is a valid one - and cost two selects per output.)
+        constexpr bool STRIDED = LST >= 4, UNIT = LST == 0 && R == 16;
+        v2* const wb = STRIDED ? line + ph(o) : (UNIT ? line + 17 * bt : line);
+        constexpr int wstep = STRIDED ? ST + ST / 16 : 1;      // padded distance of ST elements
         auto put = [&](int m, v2 val) {
-            if (wb) wb[m * wstep] = val;
+            if constexpr (STRIDED || UNIT) wb[m * wstep] = val;
             else line[ph(o + (m << LST))] = val;
         };
         if constexpr (LAST) {
