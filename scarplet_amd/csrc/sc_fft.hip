@@ -1197,11 +1197,17 @@ inv_cols_sym_body(const int cbx, const float2* __restrict__ uc, const float2* __
             for (int u = 0; u < EP; ++u)
                 hreg[u] = *reinterpret_cast<const float2*>(p + 2 * (threadIdx.x + u * NT));
             if constexpr (PT) {
+                // (an odd template count: the last transform's second plane is zero.  Loaded
+                //  unconditionally - from the first plane again - and masked: "has2 ? load : 0"
+                //  put the loads in a branch and a wait for them right behind it, i.e. no prefetch)
                 const bool has2 = 2 * gi_ + 1 < G;
+                const uint2* p2 = reinterpret_cast<const uint2*>(has2 ? p + hplane : p);
+                const unsigned keep = has2 ? ~0u : 0u;
 #pragma unroll
-                for (int u = 0; u < EP; ++u)
-                    hreg2[u] = has2 ? *reinterpret_cast<const float2*>(p + hplane + 2 * (threadIdx.x + u * NT))
-                                    : make_float2(0.f, 0.f);
+                for (int u = 0; u < EP; ++u) {
+                    const uint2 r = p2[threadIdx.x + u * NT];
+                    hreg2[u] = make_float2(__uint_as_float(r.x & keep), __uint_as_float(r.y & keep));
+                }
             }
         };
         // cell value: x * a (one template) or x * (a + i a2) (two templates)
@@ -1209,11 +1215,17 @@ inv_cols_sym_body(const int cbx, const float2* __restrict__ uc, const float2* __
             return PT ? make_float2(x.x * a - x.y * a2, x.x * a2 + x.y * a) : make_float2(a * x.x, a * x.y);
         };
         const bool rot = pl == 0 && parity == 1;          // odd W: factor i (direct) / -i (mirrored)
+        // (the spectrum's loads all first: fetched where they are used, one instantiation of this
+        //  loop waited for each of them in turn - eight latencies per plane, a quarter of a
+        //  fifteen-template launch at T = 512)
+        float4 xall[EP];
+#pragma unroll
+        for (int u = 0; u < EP; ++u) xall[u] = uu[threadIdx.x + u * NT];
 #pragma unroll
         for (int u = 0; u < EP; ++u) {
             const int e = 2 * (threadIdx.x + u * NT);
             const int cc = e / TY, fy = e - cc * TY, fx = 4 * cb + cc;
-            float4 x = uu[threadIdx.x + u * NT];
+            const float4 x = xall[u];
             float2 xv[2] = {make_float2(x.x, x.y), make_float2(x.z, x.w)};
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -1429,12 +1441,14 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
         auto fetch = [&](int gi_, int u) {
             const float* p = cbase + (size_t)(PT ? 2 * gi_ : gi_) * hplane;
             const bool has2 = PT && 2 * gi_ + 1 < G;
+            const float* p2 = has2 ? p + hplane : p;
+            const unsigned keep2 = has2 ? ~0u : 0u;
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
                 if (u >= 0 && k % U != u) continue;
                 const int off = k ? (MIRROR ? -64 * k : 64 * k) : c0off;
                 c[k] = p[off];
-                if constexpr (PT) c2[k] = has2 ? p[hplane + off] : 0.f;
+                if constexpr (PT) c2[k] = __uint_as_float(__float_as_uint(p2[off]) & keep2);   // (see inv_cols_sym_body's fetch)
             }
         };
         fetch(0, -1);
