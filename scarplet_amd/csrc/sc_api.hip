@@ -534,10 +534,20 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
             const long long wg1 = (long long)((g.cx1 - g.cx0 + 255) / 256) * ((g.cy1 - g.cy0 + 7) / 8);
             const int want = plan->method == SC_METHOD_FFT ? fft_batch_orientations(ctx, fg, runs[r].n, group)
                                                            : (wg1 <= 1024 ? 32 : 1);
-            while (nb < want && r + nb < runs.size() && runs[r + nb].n == runs[r].n &&
-                   runs[r + nb].parity == runs[r].parity && runs[r + nb].full == runs[r].full &&
-                   (plan->method == SC_METHOD_FFT || runs[r + nb].long_runs == runs[r].long_runs))
-                ++nb;
+            // compatible runs ahead, up to what one launch can hold (64 templates, 64 curvature planes)
+            const int hard = plan->method == SC_METHOD_FFT ? std::min(SC_MAX_ORIENT, SC_MAX_GROUP / std::max(1, runs[r].n)) : 32;
+            int avail = 1;
+            while (avail < hard && r + avail < runs.size() && runs[r + avail].n == runs[r].n &&
+                   runs[r + avail].parity == runs[r].parity && runs[r + avail].full == runs[r].full &&
+                   (plan->method == SC_METHOD_FFT || runs[r + avail].long_runs == runs[r].long_runs))
+                ++avail;
+            // `want` fills the chip; a tail of a few orientations costs a whole launch sequence of its
+            // own (C1: 35 orientations were 32 + 3), so a remainder up to a quarter of `want` rides along
+            // and a larger one is split evenly
+            if (want <= 1) nb = 1;
+            else if (avail <= want + want / 4) nb = avail;
+            else if (avail < 2 * want) nb = (avail + 1) / 2;
+            else nb = want;
         }
         size_t off = 0, doff = 0;
         int wh = 0, ww = 0, soff = 0;
@@ -619,7 +629,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
         if (hit) {
             have_curv = false;                    // (the curvature plane itself was not rebuilt)
         } else if (c.nb > 1) {
-            float coef[32][3];
+            float coef[SC_MAX_ORIENT][3];
             for (int b = 0; b < c.nb; ++b) {
                 const sc_template& sb = t[c.first + b * c.n];
                 coef[b][0] = (float)sb.cc; coef[b][1] = (float)sb.sc2; coef[b][2] = (float)sb.ss;

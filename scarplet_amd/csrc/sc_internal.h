@@ -66,6 +66,7 @@ struct WindowSlot {
 
 // templates per inverse launch (sc_match batches an orientation run in chunks)
 #define SC_MAX_GROUP 64
+#define SC_MAX_ORIENT 64         // orientations (curvature planes) one launch sequence can carry
 
 struct sc_ctx {
     int device = 0;

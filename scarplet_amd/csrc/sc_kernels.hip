@@ -863,7 +863,7 @@ int launch_curv_planes(sc_ctx* ctx) {
 
 // the same for the nb orientations of a batched launch sequence: plane blockIdx.y with its own
 // coefficients (a 512^2 search spent 40 % of its time in 905 five-microsecond launches of k_curv_alpha)
-struct CurvCoefs { float c[32][3]; };
+struct CurvCoefs { float c[SC_MAX_ORIENT][3]; };
 __global__ void __launch_bounds__(256)
 k_curv_alpha_batch(const float* __restrict__ A, const float* __restrict__ B,
                    const float* __restrict__ C, CurvCoefs k, float* __restrict__ out, size_t n) {
@@ -890,7 +890,7 @@ k_curv_alpha_batch(const float* __restrict__ A, const float* __restrict__ B,
 }
 
 int launch_curv_alpha_batch(sc_ctx* ctx, const float (*coef)[3], int nb) {
-    if (nb < 1 || nb > 32) return sc_fail(ctx, SC_ERR_INVALID, "curvature batch of %d planes", nb);
+    if (nb < 1 || nb > SC_MAX_ORIENT) return sc_fail(ctx, SC_ERR_INVALID, "curvature batch of %d planes", nb);
     size_t n = (size_t)ctx->g.ly * ctx->g.lx;
     // plane p starts at element p * n: float4 accesses need n to be a multiple of 4
     if (nb > 1 && (n & 3)) {
