@@ -61,6 +61,21 @@ def test_tile_choice():
         _plan.choose_tile(10000, 5000, 10000, True)
 
 
+def test_circular_axes_have_one_origin_for_every_template():
+    """A circular axis needs no halo, so its tile origin does not follow the template's support:
+    T/2 for every scale - the tile (and the curvature spectra a search keeps, sc_set_option
+    "spectra_mb") is then the same for all scales of a multi-scale job.  Tiled axes keep the
+    support's own extent."""
+    plans = [_plan.Plan(512, 512, (0, 512, 0, 512), bbox) for bbox in
+             [(-12, 12, -12, 12), (-80, 79, -60, 60), (-255, 255, -200, 199)]]
+    for p in plans:
+        assert p.circ_y and p.circ_x and (p.Py, p.Qx) == (256, 256)
+        assert p.Py >= p.bbox[1] and p.Py - p.bbox[0] <= p.Ty        # what sc_match checks
+        assert p.tiles() == plans[0].tiles()
+    q = _plan.Plan(900, 512, (0, 900, 0, 512), (-40, 39, -30, 30))     # tiled in y, circular in x
+    assert not q.circ_y and q.circ_x and q.Py == 39 and q.Qx == 256
+
+
 def test_search_grids_match_reference():
     assert len(_plan.angle_grid()) == 181 and len(_plan.age_grid()) == 35
     assert np.array_equal(_plan.angle_grid(-0.4, 0.4), orc.angle_grid(-0.4, 0.4))
