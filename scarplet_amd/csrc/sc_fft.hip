@@ -1147,7 +1147,13 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
 // the transform idle, two TEMPLATES ride in it: Y = IFFT(X (a_g + i a_g+1) P), whose
 // real part is template g's result and whose imaginary part is template g+1's
 // (X is the spectrum of ONE real tile).  Plane k of Y holds templates 2k, 2k+1.
-template <int TY, bool MIRROR, bool PT>
+// XP ("paired orientations", with PT): searches with ONE template per orientation would leave
+// that imaginary half idle all the same.  There two ORIENTATIONS ride together: job j serves
+// orientations 2j and 2j+1 of the batch, Y = IFFT((X_2j a_2j + i X_2j+1 a_2j+1) P) - each
+// product is the spectrum of a real plane, so the real part is orientation 2j's result and the
+// imaginary part orientation 2j+1's.  Two spectra are parked; `tstride` carries the batch's
+// orientation count, `ystride` is 1 (plane j of Y), one tile pair per launch.
+template <int TY, bool MIRROR, bool PT, bool XP = false>
 __device__ __forceinline__ void
 inv_cols_sym_body(const int cbx, const float2* __restrict__ uc, const float2* __restrict__ uc2,
                const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
@@ -1165,10 +1171,23 @@ inv_cols_sym_body(const int cbx, const float2* __restrict__ uc, const float2* __
     twr.load(tw);
     constexpr int NT = fft_threads(TY);
     constexpr int EP = 4 * TY / (2 * NT);     // 2-cell loads per thread per stream
+    static_assert(!XP || PT, "paired orientations are a paired-template mode");
     float4* xs = reinterpret_cast<float4*>(sm + 4 * fft_line(TY));   // parked spectrum, linear
+    float4* xsB = xs + 2 * TY;                                       // XP: the second orientation's
     const int cb = cb0 + cbx;
+    int pairB = 0;
     // several jobs per launch (grid.y), see k_inv_cols
-    {
+    if constexpr (XP) {
+        const int oA = 2 * (int)blockIdx.y;                          // the job's first orientation
+        G = min(2, tstride - oA);                                    // templates of the job (1: no partner)
+        if (py_valid >= 0) {
+            const int vy = max(tiles[2 * pair].vy, tiles[2 * pair + 1].vy);
+            rp_hi = min(rp_hi, (py_valid + vy - 1) >> 1);
+        }
+        pair += oA * np;
+        pairB = pair + (G > 1 ? np : 0);
+        vfirst += oA;
+    } else {
         const int ob = blockIdx.y / pcj, q = blockIdx.y - ob * pcj;
         // rows beyond the valid extent of both tiles of the pair (the DEM's last tile row) are
         // never read by the row pass: do not store them (py_valid < 0: circular axis, all rows)
@@ -1210,37 +1229,56 @@ inv_cols_sym_body(const int cbx, const float2* __restrict__ uc, const float2* __
                 }
             }
         };
-        // cell value: x * a (one template) or x * (a + i a2) (two templates)
-        auto prod = [&](float2 x, float a, float a2) {
+        // cell value: x * a (one template), x * (a + i a2) (two templates) or x a + i xb a2 (two orientations)
+        auto prod = [&](float2 x, float2 xb, float a, float a2) {
+            if constexpr (XP) return make_float2(x.x * a - xb.y * a2, x.y * a + xb.x * a2);
             return PT ? make_float2(x.x * a - x.y * a2, x.x * a2 + x.y * a) : make_float2(a * x.x, a * x.y);
         };
+        const float4* uuB = reinterpret_cast<const float4*>((pl ? uc2 : uc) + (size_t)pairB * plane + col);
         const bool rot = pl == 0 && parity == 1;          // odd W: factor i (direct) / -i (mirrored)
         // (the spectrum's loads all first: fetched where they are used, one instantiation of this
         //  loop waited for each of them in turn - eight latencies per plane, a quarter of a
         //  fifteen-template launch at T = 512)
-        float4 xall[EP];
-#pragma unroll
-        for (int u = 0; u < EP; ++u) xall[u] = uu[threadIdx.x + u * NT];
+        // order of issue: the phase factors first (table entries, back quickly), then the spectrum -
+        // waiting for a phase factor then does not wait for the spectrum loads behind it
+        float2 pvv[EP][2];
 #pragma unroll
         for (int u = 0; u < EP; ++u) {
             const int e = 2 * (threadIdx.x + u * NT);
             const int cc = e / TY, fy = e - cc * TY, fx = 4 * cb + cc;
-            const float4 x = xall[u];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (!mirrored)
+                    pvv[u][k] = phase_tab(tw + TY, phx, fy + k, fx);
+                else {
+                    pvv[u][k] = phase_tab(tw + TY, phx, (TY - fy - k) & (TY - 1), (Tx - fx) & (Tx - 1));
+                    pvv[u][k].y = -pvv[u][k].y;
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        float4 xall[EP], xallB[XP ? EP : 1];
+#pragma unroll
+        for (int u = 0; u < EP; ++u) xall[u] = uu[threadIdx.x + u * NT];
+        if constexpr (XP) {
+#pragma unroll
+            for (int u = 0; u < EP; ++u) xallB[u] = uuB[threadIdx.x + u * NT];
+        }
+        auto park = [&](const float4 x, const float2 (&pv)[2], float4* dst, int u) {
             float2 xv[2] = {make_float2(x.x, x.y), make_float2(x.z, x.w)};
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                float2 pv;
-                if (!mirrored)
-                    pv = phase_tab(tw + TY, phx, fy + k, fx);
-                else {
-                    pv = phase_tab(tw + TY, phx, (TY - fy - k) & (TY - 1), (Tx - fx) & (Tx - 1));
-                    pv.y = -pv.y;
-                }
-                float2 v = cmul(xv[k], pv);
+                float2 v = cmul(xv[k], pv[k]);
                 if (rot) v = mirrored ? make_float2(v.y, -v.x) : make_float2(-v.y, v.x);
                 xv[k] = v;
             }
-            xs[threadIdx.x + u * NT] = make_float4(xv[0].x, xv[0].y, xv[1].x, xv[1].y);
+            dst[threadIdx.x + u * NT] = make_float4(xv[0].x, xv[0].y, xv[1].x, xv[1].y);
+        };
+#pragma unroll
+        for (int u = 0; u < EP; ++u) park(xall[u], pvv[u], xs, u);
+        if constexpr (XP) {
+#pragma unroll
+            for (int u = 0; u < EP; ++u) park(xallB[u], pvv[u], xsB, u);
         }
         if (SC_DBGBIT(dbg, 2) || (mirrored && SC_DBGBIT(dbg, 1))) {
 #pragma unroll
@@ -1254,14 +1292,15 @@ inv_cols_sym_body(const int cbx, const float2* __restrict__ uc, const float2* __
                 for (int u = 0; u < EP; ++u) {
                     int e = 2 * (threadIdx.x + u * NT);
                     int cc = e / TY, fy = e - cc * TY;
-                    float4 x = xs[threadIdx.x + u * NT];
-                    sm[lidx<TY>(cc, fy)] = prod(make_float2(x.x, x.y), hreg[u].x, hreg2[PT ? u : 0].x);
-                    sm[lidx<TY>(cc, fy + 1)] = prod(make_float2(x.z, x.w), hreg[u].y, hreg2[PT ? u : 0].y);
+                    const float4 x = xs[threadIdx.x + u * NT], xb = XP ? xsB[threadIdx.x + u * NT] : x;
+                    sm[lidx<TY>(cc, fy)] = prod(make_float2(x.x, x.y), make_float2(xb.x, xb.y), hreg[u].x, hreg2[PT ? u : 0].x);
+                    sm[lidx<TY>(cc, fy + 1)] = prod(make_float2(x.z, x.w), make_float2(xb.z, xb.w), hreg[u].y, hreg2[PT ? u : 0].y);
                 }
             } else {
                 // source cell (column 3-cc of the run, row m) pairs with target cell
                 // (column cc, row (TY - m) % TY)
                 const float2* x2 = reinterpret_cast<const float2*>(xs);
+                const float2* x2B = reinterpret_cast<const float2*>(XP ? xsB : xs);
 #pragma unroll
                 for (int u = 0; u < EP; ++u) {
                     int e = 2 * (threadIdx.x + u * NT);
@@ -1269,8 +1308,8 @@ inv_cols_sym_body(const int cbx, const float2* __restrict__ uc, const float2* __
                     int cc = 3 - sc;
                     int f0 = (TY - m) & (TY - 1), f1 = (TY - m - 1) & (TY - 1);
                     float2 x0 = x2[cc * TY + f0], x1 = x2[cc * TY + f1];
-                    sm[lidx<TY>(cc, f0)] = prod(x0, hreg[u].x, hreg2[PT ? u : 0].x);
-                    sm[lidx<TY>(cc, f1)] = prod(x1, hreg[u].y, hreg2[PT ? u : 0].y);
+                    sm[lidx<TY>(cc, f0)] = prod(x0, x2B[cc * TY + f0], hreg[u].x, hreg2[PT ? u : 0].x);
+                    sm[lidx<TY>(cc, f1)] = prod(x1, x2B[cc * TY + f1], hreg[u].y, hreg2[PT ? u : 0].y);
                 }
             }
             lds_barrier();
@@ -1326,7 +1365,7 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
 // paired templates: 985 against 2 x 557.  (Giving every XCD a CONTIGUOUS range of blocks, so
 // that the fourth column is shared too, is 13 % slower: each XCD then writes a 2-KB stripe of
 // every row and loads a few L2 channels only.)  profiles/r02_i1_xcd_paired.txt
-template <int TY, bool PT>
+template <int TY, bool PT, bool XP = false>
 __global__ void __launch_bounds__(fft_threads(TY), 2)
 k_inv_cols_symx(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                 const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
@@ -1336,11 +1375,11 @@ k_inv_cols_symx(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                 const TileDev* __restrict__ tiles, int py_valid) {
     const int j = blockIdx.x, i = ((j >> 4) << 3) | (j & 7);
     if ((j >> 3) & 1)
-        inv_cols_sym_body<TY, true, PT>((Tx >> 2) - 1 - i, uc, uc2, wa, mb, Tx, 0, pair, vfirst, G, rp_lo, rp_hi, phx,
-                                        parity, tw, yw, ym, ystride, dbg, np, pcj, tstride, tiles, py_valid);
+        inv_cols_sym_body<TY, true, PT, XP>((Tx >> 2) - 1 - i, uc, uc2, wa, mb, Tx, 0, pair, vfirst, G, rp_lo, rp_hi, phx,
+                                            parity, tw, yw, ym, ystride, dbg, np, pcj, tstride, tiles, py_valid);
     else
-        inv_cols_sym_body<TY, false, PT>(i, uc, uc2, wa, mb, Tx, 0, pair, vfirst, G, rp_lo, rp_hi, phx,
-                                         parity, tw, yw, ym, ystride, dbg, np, pcj, tstride, tiles, py_valid);
+        inv_cols_sym_body<TY, false, PT, XP>(i, uc, uc2, wa, mb, Tx, 0, pair, vfirst, G, rp_lo, rp_hi, phx,
+                                             parity, tw, yw, ym, ystride, dbg, np, pcj, tstride, tiles, py_valid);
 }
 
 // ---- I1 for symmetric templates, one WAVE per column ----------------------------------
@@ -1580,6 +1619,7 @@ struct RowArgs {
     int nb, np, pcj;
     SibSync sib;                        // sibling rendezvous of the fast kernel (rows 2rp, 2rp+1)
     unsigned long long* stats;          // {wins, wins near the resolution floor} of the search (sc_get_resolution_stats)
+    int xp;                             // paired ORIENTATIONS (k_inv_cols_sym, XP): G templates, one per orientation; norms entry id*np + pair
 };
 // One launch may serve several tile pairs (grid.y): pair = ra.pair + blockIdx.y,
 // its Y planes ystride planes further on.  More workgroups per launch fill the
@@ -1851,7 +1891,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     //   =>  amp = xr*ka, T1 = xr^2*kt, floor = |xr|*kx2 + fl0
     if (id < GT) {
         const int it = ra.first + id;
-        const int nrm = (id / ra.G) * ra.np + ra.pair;      // tile-pair norms of the template's orientation
+        const int nrm = (ra.xp ? id : id / ra.G) * ra.np + ra.pair;      // tile-pair norms of the template's orientation
         EpiScal es = sc_epi_scalars(sums, it);
         sc_epi_floor(es, sums[2 * it], sums[2 * it + 1], wl1[it], norms[2 * nrm],
                      norms[2 * nrm + 1], (double)ra.Ty * TX, kappa);
@@ -2458,6 +2498,11 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         constexpr bool PTV = decltype(ptc)::value;
         for (int g0 = 0; g0 < n; g0 += group) {
             int G = std::min(group, n - g0);
+            // Paired orientations (inv_cols_sym_body, XP): a paired-template chunk with ONE template per
+            // orientation and a batch of orientations would run every transform half empty
+            // (option "variant" 12: off, for the cross-check of the two forms)
+            const bool xp = PTV && n == 1 && nb >= 2 && pc == 1 && sym && symx && fg.Ty == 512 &&
+                            ctx->variant != 12 && !to_maps;
             // I1: as many tile pairs per launch as it takes to fill the chip once
             // (one 2048-tile pair does; longer launches lost 6 % on the sustained C3 run)
             const size_t lds_c = (size_t)4 * fft_line(fg.Ty) * sizeof(float2) +
@@ -2541,7 +2586,17 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             hipLaunchKernelGGL((k_inv_cols<T, true>), dim3(nhi, nb * pcc), dim3(fft_threads(T)), \
                                inv_cols_lds<T>(), COL_ARGS(nlo));              \
     }
-            if (w8 && (!PTV || (fg.Ty == 1024 && ctx->variant != 1))) {
+            if (xp) {
+                // paired orientations: job j = orientations 2j, 2j+1; plane j of Y; tstride carries nb
+                const size_t ldsx = inv_cols_lds<512>() + (size_t)4 * 512 * sizeof(float2);
+                int rc = set_lds(ctx, k_inv_cols_symx<512, PTV, PTV>, ldsx);
+                if (rc) return rc;
+                hipLaunchKernelGGL((k_inv_cols_symx<512, PTV, PTV>), dim3(fg.Tx / 4, (nb + 1) / 2), dim3(fft_threads(512)),
+                                   ldsx, ctx->stream, (const float2*)ctx->uc.p + ctx->uc_off, (const float2*)ctx->uc2.p + ctx->uc_off,
+                                   (const float*)ctx->wh.p, (const float*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo, rp_hi,
+                                   (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, 1,
+                                   ctx->dbg, np, 1, nb, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py);
+            } else if (w8 && (!PTV || (fg.Ty == 1024 && ctx->variant != 1))) {
                 if (fg.Ty == 2048) FN_W8(2048) else FN_W8(1024)
             } else if (w8 && PTV && fg.Ty == 2048 && ctx->variant != 1) {
                 FN_W4(2048)
@@ -2576,7 +2631,10 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             const int pair = pair0;
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
                        ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg, group,
-                       nb, np, pc, SibSync{nullptr, 0}, (unsigned long long*)ctx->res_stats.p};
+                       nb, np, pc, SibSync{nullptr, 0}, (unsigned long long*)ctx->res_stats.p, 0};
+            if (xp) {                            // to the row pass: ONE orientation of nb templates, in pairs
+                ra.G = nb; ra.nb = 1; ra.ystride = 1; ra.xp = 1;
+            }
             dim3 gridr(fast ? ((rp_n + 7) / 8) * 16 : (rp_n + 1) / 2, pc);
             if (fast && (ctx->sib & 1)) {
                 int rc = sib_slots(ctx, (size_t)gridr.x * gridr.y, ra.sib);
