@@ -8,7 +8,7 @@ flt = sys.argv[2] if len(sys.argv) > 2 else ""
 names = re.findall(r"^(_Z\w+):\s*;? *@", txt, re.M) or re.findall(r"^(_Z\w+):", txt, re.M)
 print("%-58s %6s %6s %6s %7s %7s %6s %6s" % ("kernel", "lines", "gload", "gstore", "scr_ld", "scr_st", "vm(0)", "branch"))
 for n in names:
-    m = re.search(r"^%s:.*?s_endpgm" % re.escape(n), txt, re.M | re.S)
+    m = re.search(r"^%s:.*?^\.Lfunc_end" % re.escape(n), txt, re.M | re.S)      # (a kernel may hold several s_endpgm)
     if not m:
         continue
     body = m.group(0)
