@@ -2249,7 +2249,15 @@ int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group, in
         const long long sig[24] = {fg.Ty, fg.Tx, fg.Vy, fg.Vx, fg.nty, fg.ntx, fg.circ_y, fg.circ_x, fg.Py, fg.Qx,
                                    gg.ly, gg.lx, gg.gy0, gg.gx0, gg.ny, gg.nx, gg.cy0, gg.cy1, gg.cx0, gg.cx1,
                                    gg.wrap, n_slots, 0, 0};
-        const bool keep = n_slots > 0 && 2.0 * (double)plane * np * n_slots <= ctx->spec_mb * 1048576.0;
+        bool keep = n_slots > 0 && 2.0 * (double)plane * np * n_slots <= ctx->spec_mb * 1048576.0;
+        if (keep) {
+            // (and only while what it adds is a small part of the memory that is free: the slots are a
+            //  convenience, a search must not fail for them)
+            const double add = 2.0 * (double)plane * np * n_slots - (double)(ctx->uc.cap + ctx->uc2.cap);
+            size_t free_b = 0, total_b = 0;
+            if (add > 0.0 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || add > 0.25 * (double)free_b))
+                keep = false;
+        }
         const int slots = keep ? n_slots : 0;
         const void *p0 = ctx->uc.p, *p1 = ctx->uc2.p, *p2 = ctx->norms.p;
         const size_t have = std::max(nb, slots);
