@@ -16,7 +16,7 @@ from scarplet_amd import _plan, synthetic
 from scarplet_amd import WindowedTemplate as WT
 from conftest import golden
 from test_gpu_parity import (AMP_RTOL, AMP_ATOL, SNR_RTOL, SNR_ATOL, TIE_RTOL, EXACT_MIN,
-                             fold_check, grid, report)
+                             fold_check, grid, report, CLS)
 
 pytestmark = pytest.mark.gpu
 
@@ -431,3 +431,22 @@ def test_kept_curvature_spectra_are_reused_and_change_nothing():
     for a, b in zip(m3.ctx.get_best(), fresh(g2, 40., other)):
         assert np.array_equal(a, b)
     ctx.close()
+
+
+@pytest.mark.parametrize("kind,n_ang", [("scarp", 13), ("ricker", 12), ("right_upper_break", 7)])
+def test_paired_orientations_against_oracle(gpu_ctx, kind, n_ang):
+    """One tile, ONE template per orientation: the batch's orientations ride in pairs through the inverse
+    transforms (inv_cols_sym_body, XP) - an odd count leaves the last one alone, an odd template (Scarp)
+    takes the factor i, a masked one (UpperBreak) the full epilogue.  Each against the oracle's stack of
+    all its templates."""
+    rng = np.random.default_rng(404)
+    z = (np.cumsum(np.cumsum(rng.standard_normal((512, 512)), 0), 1) * 0.01
+         + rng.standard_normal((512, 512)) * 0.05).astype(np.float32).astype(float)
+    angles = np.linspace(-1.4, 1.3, n_ang)
+    m = sl.Matcher(grid(z, 1.0), ctx=gpu_ctx)
+    res = m.search(CLS[kind], 12, [4.0], angles, method="fft").result()
+    assert m.plan.circ_y and m.plan.Ty == 512                    # (the plan the paired form applies to)
+    chk = fold_check(res, z, 1.0, 1.0, kind, 12, [4.0], angles)
+    report("paired orientations %s x %d" % (kind, n_ang), chk, "fft")
+    assert chk["n_bad"] == 0, chk
+    assert chk["exact_frac"] >= EXACT_MIN, chk
