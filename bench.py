@@ -269,6 +269,108 @@ def measured_traffic(default_workload):
         return None
 
 
+# ----------------------------------------------------------------------------- rank launcher
+def rank_environments(n, port, base=None):
+    """The environment of each of the n ranks started by `--gpus n` (what torch.distributed.run
+    would set): RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT, the loopback
+    address because the container's host name may not resolve."""
+    envs = []
+    for r in range(n):
+        e = dict(os.environ if base is None else base)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it here
+        envs.append(e)
+    return envs
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(cmd, n, port=None, timeout=None):
+    """Start n rank processes of `cmd` (a list; one per GPU, like the reference's pool that starts
+    and joins its own workers, core.py:180-188) and wait for them.  Called from a parent that has
+    made NO HIP call and forked nothing.  Rank 0's stdout is captured (the JSON line); the other
+    ranks' stdout goes to stderr.  Returns (exit code, rank 0's stdout): the code is 0 only if
+    EVERY rank exited 0; as soon as one rank fails the others are terminated (they would sit in a
+    collective until its timeout)."""
+    import subprocess
+    port = port or free_port()
+    procs = []
+    for r, env in enumerate(rank_environments(n, port)):
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=sys.stderr))
+    import threading
+    out0 = []
+    rd = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    t0 = time.time()
+    codes = [None] * n
+    failed = None
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+                if codes[r] not in (None, 0) and failed is None:
+                    failed = r
+        timed_out = timeout is not None and time.time() - t0 > timeout
+        if failed is not None or timed_out:
+            for r, p in enumerate(procs):           # exact PIDs we started, nothing by pattern
+                if codes[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[r] = p.wait()
+            if timed_out and failed is None:
+                failed = -1
+            break
+        time.sleep(0.05)
+    rd.join(timeout=10)
+    text = (out0[0] if out0 else b"").decode("utf-8", "replace")
+    rc = 0
+    if failed is not None:
+        rc = codes[failed] if failed >= 0 and codes[failed] else 1
+        print("bench.py: rank %s of %d failed (exit codes %r)" % (failed if failed >= 0 else "timeout", n, codes),
+              file=sys.stderr)
+    return (0 if rc == 0 else (rc if rc > 0 else 1)), text      # (a rank killed by a signal: 1)
+
+
+def world_or_launch(a, argv=None):
+    """`--gpus N` against the environment.  Under a launcher (RANK / WORLD_SIZE set, the contract's
+    torch.distributed.run): WORLD_SIZE must equal --gpus, anything else exits non-zero - a line
+    that says "n_gpus": 1 for --gpus 8 must never be printed.  Without one and N > 1: this process
+    becomes the launcher - before any HIP call, before the oracle pool is forked - starts N ranks
+    of itself, relays rank 0's JSON line and exits with their status.  Returns (rank, world,
+    local) for a process that is to do the work."""
+    in_env = "RANK" in os.environ or "WORLD_SIZE" in os.environ
+    if in_env:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world != a.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report one as the other "
+                             "(start N ranks with `python bench.py --gpus N`, or torch.distributed.run "
+                             "--nproc-per-node N ... --gpus N)" % (a.gpus, world))
+        return int(os.environ.get("RANK", "0")), world, int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    if a.gpus <= 1:
+        return 0, 1, 0
+    argv = sys.argv[1:] if argv is None else argv
+    rc, text = launch_ranks([sys.executable, os.path.abspath(__file__)] + list(argv), a.gpus)
+    lines = [ln for ln in text.splitlines() if ln.strip()]
+    if rc == 0 and not lines:
+        print("bench.py: the ranks exited 0 but rank 0 printed nothing", file=sys.stderr)
+        rc = 1
+    if lines:
+        print(lines[-1], flush=True)
+    raise SystemExit(rc)
+
+
 # ----------------------------------------------------------------------------- main
 def timed_loop(step, ctx, a, dist, after_warmup=None):
     """The contract's timing: W untimed steps, then EXACTLY K steps between a device sync + rank
@@ -342,6 +444,7 @@ def roofline_block(value, world, prof, units, steps, method, default_workload):
 
 def main():
     a = parse()
+    rank, world, local = world_or_launch(a)      # --gpus N > 1 without a launcher: start the N ranks, relay, exit
     # stdout carries exactly ONE line, the JSON: whatever libraries print on the way (gloo announces
     # its ranks on stdout, RCCL its version) goes to stderr - file descriptor 1 points at stderr until
     # emit() restores it
@@ -354,9 +457,6 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(obj, ensure_ascii=False), flush=True)
         os.dup2(2, 1)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     transport = None
 
@@ -379,7 +479,12 @@ def main():
         from torch_transport import TorchTransport
         transport = TorchTransport()
     ndev = max(1, _lib.load().sc_device_count())
-    device = local % ndev                      # one rank per GPU; wraps only in bring-up runs
+    if world > ndev and a.halo == "rccl":
+        # two ranks on one device cannot form an RCCL communicator, and a line that calls them N GPUs
+        # would be a lie: only the bring-up transport (--halo host: host arrays over gloo) may wrap
+        raise SystemExit("bench.py: --gpus %d but %d device(s) visible; RCCL needs one GPU per rank "
+                         "(bring-up on fewer devices: --halo host)" % (world, ndev))
+    device = local % ndev                      # one rank per GPU; wraps only in bring-up runs (--halo host)
     n_templates = len(params) * len(angles) * len(scales)
     units = float(ny) * nx * n_templates               # px.template per step
     default_workload = (world == 1 and not a.emulate_ranks and a.config == "C3" and label.startswith("C3:")
@@ -429,6 +534,8 @@ def main():
                   dm.m.params, dm.m.angles = np.asarray(params, float), np.asarray(angles, float)
                   ctx = dm.m.ctx
                   halo_s = [0.0]
+                  gather_s = [0.0]
+                  full_box, gather_out = [None], [None]
 
                   def step():
                       t_ = time.perf_counter()
@@ -436,16 +543,23 @@ def main():
                       halo_s[0] += time.perf_counter() - t_
                       dm.m.ctx.reset_best()
                       dm.m.ctx.match(arr, sp, sync=True)
+                      # ... and so is the gather: the orientation sharding's step ends with the folded
+                      # record on every rank, this one's with the assembled maps on rank 0
+                      t_ = time.perf_counter()
+                      if rank == 0 and gather_out[0] is None:
+                          gather_out[0] = np.zeros((4, ny, nx))
+                      full_box[0] = dm.gather(0, out=gather_out[0])
+                      gather_s[0] += time.perf_counter() - t_
 
                   def after_warmup():
                       halo_s[0] = 0.0
+                      gather_s[0] = 0.0
               dt, prof = timed_loop(step, ctx, a, dist, after_warmup)
               # what RCCL itself says about the communicator this sharding ran on, from every rank
               infos = transport.gather(ctx.comm_info(), 0)
               extra = transport.gather(om.fold_seconds / a.steps if sh == "orientations" else halo_s[0] / a.steps, 0)
-              full = None
-              if sh == "tiles":
-                  full = dm.gather(0)                    # collective; the assembled maps on rank 0
+              full = full_box[0] if sh == "tiles" else None
+              gath = transport.gather(gather_s[0] / a.steps, 0) if sh == "tiles" else None
               if rank == 0:
                   ms = 1e3 * dt / a.steps
                   line = base_line(units / (dt / a.steps) / 1e6, ms, plan, "%d (%s)" % (world, part), prof, world)
@@ -458,6 +572,11 @@ def main():
                                "note": "wall time per step inside the collective on a rank; the minimum is the rank that "
                                        "arrived last, i.e. the collective itself" if sh == "orientations" else
                                        "upload of the rank's core, pack, grouped ncclSend/ncclRecv, unpack, per step"}
+                  if sh == "tiles":
+                      line["gather_ms"] = {"min_over_ranks": round(1e3 * min(gath), 3), "max_over_ranks": round(1e3 * max(gath), 3),
+                                           "note": "inside the step: every rank's four float64 planes to rank 0 "
+                                                   "(sc_gather_result: ncclSend/ncclRecv, pinned D2H)"}
+                  line["distinct_devices"] = len({(i_["device"], i_["bus_id"]) for i_ in infos})
                   if pool is not None:
                       res = om.result_array() if sh == "orientations" else np.stack(full)
                       ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan)

@@ -392,12 +392,17 @@ class Context(object):
         """Collective fold of the ranks' running-best records (orientation-sharded search)."""
         self._check(self.lib.sc_fold_ranks(self._h), "sc_fold_ranks")
 
-    def gather_result(self, root, cores, shape, param_of_id, angle_of_id, is_root):
-        """Collective final gather over RCCL; returns (4, ny, nx) on root."""
+    def gather_result(self, root, cores, shape, param_of_id, angle_of_id, is_root, out=None):
+        """Collective final gather over RCCL; returns (4, ny, nx) on root (``out``: a float64
+        array of that shape to fill instead of a new one - the cores tile the DEM, every cell
+        is written)."""
         cores = np.ascontiguousarray(cores, dtype=np.int32)
         par = np.ascontiguousarray(param_of_id, dtype=np.float64)
         ang = np.ascontiguousarray(angle_of_id, dtype=np.float64)
-        out = np.zeros((4,) + tuple(shape), dtype=np.float64) if is_root else None
+        if is_root and out is None:
+            out = np.zeros((4,) + tuple(shape), dtype=np.float64)
+        if is_root:
+            assert out.dtype == np.float64 and out.flags.c_contiguous and out.shape == (4,) + tuple(shape)
         self._check(self.lib.sc_gather_result(
             self._h, int(root), cores.ctypes.data_as(C.POINTER(C.c_int32)), int(shape[0]),
             int(shape[1]), _as(par, _dp), _as(ang, _dp), len(par),

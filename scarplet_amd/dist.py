@@ -365,17 +365,19 @@ class DistMatcher(object):
         """This rank's tile of (amp, age, angle, snr)."""
         return self.m.result()
 
-    def gather(self, dst=0):
+    def gather(self, dst=0, out=None):
         """Assemble the full maps on rank ``dst`` (None elsewhere): over RCCL
         (sc_gather_result, device to root's host array) with the 'rccl' backend,
-        through ``transport.gather`` with the host backend."""
+        through ``transport.gather`` with the host backend.  ``out``: a (4, ny, nx)
+        float64 array to fill on rank ``dst`` (a search repeated on the same DEM need
+        not fault in 32 bytes per cell of fresh memory every time)."""
         if self.backend == "rccl":
             lay = self._layout((0, 0, 0, 0))
             cores = [lay.core(r) for r in range(self.nranks)]
             m = self.m
             out = m.ctx.gather_result(dst, cores, (self.ny, self.nx),
                                       np.repeat(m.params, len(m.angles)),
-                                      np.tile(m.angles, len(m.params)), self.rank == dst)
+                                      np.tile(m.angles, len(m.params)), self.rank == dst, out=out)
             return tuple(out) if self.rank == dst else None
         if self.nranks == 1:
             tiles = [(self.core(), self.result())]
@@ -383,7 +385,7 @@ class DistMatcher(object):
             tiles = self.transport.gather((self.core(), self.result()), dst)
         if self.rank != dst:
             return None
-        out = [np.zeros((self.ny, self.nx)) for _ in range(4)]
+        out = [np.zeros((self.ny, self.nx)) for _ in range(4)] if out is None else list(out)
         for core, res in tiles:
             for k in range(4):
                 out[k][core[0]:core[1], core[2]:core[3]] = res[k]
