@@ -213,7 +213,7 @@ def cpu_baseline(pool, g, params, angles, max_workers=32):
 
 
 # ----------------------------------------------------------------------------- verification
-def verify_window(pool, res, g, kind, scale, params, angles, plan):
+def verify_window(pool, res, g, kind, scale, params, angles, plan, method="fft"):
     """A window of the finished search against the oracle, every template of the
     grid (oracle.snr_stack_window + check_fold, tolerances oracle.PARITY).  The
     window straddles the corner where four FFT tiles meet when the plan is tiled."""
@@ -236,13 +236,14 @@ def verify_window(pool, res, g, kind, scale, params, angles, plan):
     sub = tuple(np.asarray(r)[win[0]:win[1], win[2]:win[3]] for r in res)
     P = orc.PARITY
     chk = orc.check_fold(sub, a_st.reshape(T, h, wd), s_st.reshape(T, h, wd), np.repeat(params, len(angles)),
-                         np.tile(angles, len(params)), tie_rtol=P["tie_rtol"],
+                         np.tile(angles, len(params)), tie_rtol=orc.tie_window(method),
                          amp_tol=(P["amp"][0], P["amp"][1] * np.max(np.abs(a_st))),
                          snr_tol=(P["snr"][0], P["snr"][1] * np.max(s_st)))
     return {"ok": chk["n_bad"] == 0, "window": list(win), "templates": T, "cells": chk["n"], "bad": chk["n_bad"],
-            "exact_argmax_frac": round(chk["exact_frac"], 5), "near_tie_cells": chk["n_tie"],
+            "cells_off_the_oracle_argmax": chk["n_inexact"], "cells_below_abs_tolerance": chk["n_below_only"],
+            "exact_argmax_frac": round(chk["exact_frac"], 6), "near_tie_cells": chk["n_tie"],
             "max_rel_snr_err": float("%.3g" % chk["snr_err"]), "max_rel_amp_err": float("%.3g" % chk["amp_err"]),
-            "tie_rtol": P["tie_rtol"], "oracle_s": round(time.time() - t0, 1)}
+            "tie_rtol": orc.tie_window(method), "oracle_s": round(time.time() - t0, 1)}
 
 
 def so_sha256():
@@ -579,7 +580,7 @@ def main():
                   line["distinct_devices"] = len({(i_["device"], i_["bus_id"]) for i_ in infos})
                   if pool is not None:
                       res = om.result_array() if sh == "orientations" else np.stack(full)
-                      ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan)
+                      ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan, a.method)
                       line["verified"], line["verification"] = ver["ok"], ver
                   runs[sh] = line
               dist.barrier()
@@ -707,7 +708,7 @@ def main():
         if not a.no_verify:
             # the record the timed loop left behind (the last scale's, for C5)
             res = ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
-            ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan)
+            ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan, a.method)
             del res
             out["verified"] = ver["ok"]
             out["verification"] = ver

@@ -724,7 +724,7 @@ def check_fold(res, amp_stack, snr_stack, ages, angles, tie_rtol=1e-6,
     # (~1e-13) and which of the two the reference itself returns depends on its
     # FFT library.  All-zero records count where every template is masked.
     co_thr = smax * (1.0 - 1e-9)
-    exact = (zero & (smax == 0)) | below
+    exact = zero & (smax == 0)
     s_at = np.zeros(smax.shape)
     a_at = np.zeros(smax.shape)
     for t in range(T):
@@ -739,8 +739,18 @@ def check_fold(res, amp_stack, snr_stack, ages, angles, tie_rtol=1e-6,
     s_floor, a_floor = 1e-3 * float(np.max(smax)), 1e-3 * float(np.max(np.abs(amp_stack)))
     snr_err = float(np.max(np.abs(snr[sel] - s_at[sel]) / np.maximum(s_at[sel], s_floor))) if sel.any() else 0.0
     amp_err = float(np.max(np.abs(amp[sel] - a_at[sel]) / np.maximum(np.abs(a_at[sel]), a_floor))) if sel.any() else 0.0
+    # Integers, not fractions: n_exact cells carry the oracle's own argmax; n_below_only cells
+    # carry something else but lie below the absolute SNR tolerance on both sides (rule (c):
+    # nothing float32 can decide - reported separately, NOT counted as exact); n_inexact is the
+    # rest: cells with a decidable argmax that the result does not carry.  exact_frac is n_exact
+    # over the decidable cells.
+    n = int(ok.size)
+    below_only = below & ~exact
+    n_exact, n_below_only = int(np.sum(exact)), int(np.sum(below_only))
+    n_inexact = n - n_exact - n_below_only
     return dict(ok=ok, n_bad=int(np.sum(~ok)), n_strict=int(np.sum(strict)),
-                n_tie=int(np.sum(ok & ~strict)), n=int(ok.size),
-                n_exact=int(np.sum(exact)), exact_frac=float(np.mean(exact)),
+                n_tie=int(np.sum(ok & ~strict)), n=n,
+                n_exact=n_exact, n_inexact=n_inexact, n_below_only=n_below_only,
+                exact_frac=float(n_exact) / max(n - n_below_only, 1),
                 n_slack=n_slack, n_below=int(np.sum(below)),
                 snr_err=snr_err, amp_err=amp_err)

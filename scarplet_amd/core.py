@@ -386,6 +386,17 @@ class Matcher(object):
         self.method_used = "direct" if sp.method == _plan.METHOD_DIRECT else "fft"
         if method == "auto" and reset and sync and self.method_used == "fft":
             self._exact_path_if_unresolved(arr, bbox, max_area, group, len(params))
+        elif method == "fft" and reset and sync:
+            # the FFT path was asked for by name: it is handed out as it is, but not silently where
+            # the device's own statistic says it cannot resolve this surface in float32
+            wins, near = self.ctx.resolution_stats()
+            self.unresolved_frac = near / wins if wins else 0.0
+            if self.unresolved_frac > self.UNRESOLVED_MAX:
+                import warnings
+                warnings.warn("method='fft': %.1f %% of the cells this search won lie within the float32 "
+                              "resolution floor of the FFT convolution (a surface without a noise floor of its "
+                              "own); their argmax is rounding noise - method='auto' or 'direct' gives the exact "
+                              "real-space answer" % (100 * self.unresolved_frac))
         self.params, self.angles = params, angles
         self.n_templates = len(arr)
         self._id_par = np.concatenate([self._id_par, np.repeat(params, len(angles))])
@@ -524,7 +535,7 @@ def _reference_fold_one_age(m, Template, scale, age, ang_min, ang_max, method):
         for angle in _plan.angle_grid(ang_min, ang_max):
             amp, snr = m.match_template(Template, scale, age, angle, method=method)
             yield amp, age, angle, snr
-    return np.stack(_fold.compare(maps(), ny, nx))
+    return np.stack(_fold.compare(maps(), ny, nx, device=m.ctx.device))
 
 
 def match(data, Template, **kwargs):
@@ -562,7 +573,7 @@ def match(data, Template, **kwargs):
             # (a list, not a generator: the context holds ONE compare session at a time)
             per_age = [_reference_fold_one_age(m, Template, scale, age, ang_min, ang_max, method)
                        for age in (_plan.age_grid() if ages is None else ages)]
-            return _fold.compare(per_age, m.ny, m.nx)
+            return _fold.compare(per_age, m.ny, m.nx, device=m.ctx.device)
         finally:
             m.ctx.clear_windows()
     if 'age' in kwargs:

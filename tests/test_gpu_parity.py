@@ -27,18 +27,28 @@ pytestmark = pytest.mark.gpu
 AMP_RTOL, AMP_ATOL = orc.PARITY["amp"]
 SNR_RTOL, SNR_ATOL = orc.PARITY["snr"]
 TIE_RTOL = orc.PARITY["tie_rtol"]      # twice the measured SNR error (oracle.PARITY)
-EXACT_MIN = 0.99                       # cells that must carry the oracle's own argmax
+EXACT_MIN = 0.99                       # surfaces WITHOUT a noise floor only: share of cells on the oracle's argmax
 
 
-def report(name, chk, method="fft", window=None):
-    """One line per fold check in the test log (pytest -s / GPUTEST output), and the policy
-    behind the tie window: the SNR error this check measured is at most half the window of the
-    device path that ran ('auto' searches are judged by the wider FFT window)."""
+def report(name, chk, method="fft", window=None, noise_floor=True):
+    """One line per fold check in the test log (pytest -s / GPUTEST output), and the two policies:
+    the SNR error this check measured is at most half the tie window of the device path that
+    ran ('auto' searches are judged by the wider FFT window); and the argmax is EXACT as an
+    integer - `inexact` = cells with a decidable argmax (above the absolute SNR tolerance) that
+    do not carry the oracle's own (age, angle) - which must be 0 on every DEM with a noise floor
+    of its own (lidar, the benchmark DEM, every synthetic DEM with sigma > 0).  Cells below the
+    absolute tolerance on both sides are reported as `below`, not counted as exact.  Only the
+    surfaces WITHOUT a noise floor (noise_floor=False: test_noise_free_surfaces_resolution_floor
+    and the like) are held to a fraction, EXACT_MIN."""
     window = orc.tie_window(method) if window is None else window
-    print("fold %-44s bad=%d exact=%.4f strict=%d tie=%d of %d snr_err=%.2e amp_err=%.2e (window %.0e)"
-          % (name, chk["n_bad"], chk["exact_frac"], chk["n_strict"], chk["n_tie"], chk["n"],
-             chk["snr_err"], chk["amp_err"], window))
+    print("fold %-44s bad=%d inexact=%d below=%d exact=%.6f strict=%d tie=%d of %d snr_err=%.2e amp_err=%.2e (window %.0e)"
+          % (name, chk["n_bad"], chk["n_inexact"], chk["n_below_only"], chk["exact_frac"], chk["n_strict"],
+             chk["n_tie"], chk["n"], chk["snr_err"], chk["amp_err"], window))
     assert chk["snr_err"] <= 0.5 * window, (name, chk["snr_err"], window)
+    if noise_floor:
+        assert chk["n_inexact"] == 0, (name, "cells off the oracle's argmax:", chk["n_inexact"], "of", chk["n"])
+    else:
+        assert chk["exact_frac"] >= EXACT_MIN, (name, chk["exact_frac"])
 
 CLS = {"scarp": WT.Scarp, "ricker": WT.Ricker,
        "right_upper_break": WT.RightFacingUpperBreakScarp,

@@ -65,7 +65,8 @@ def test_tiled_blocks_against_oracle():
                          np.repeat(params, len(angles)), np.tile(angles, len(params)),
                          tie_rtol=orc.PARITY["tie_rtol"], amp_tol=(2e-4, 2e-6 * np.abs(a_st).max()),
                          snr_tol=(2e-3, 2e-6 * s_st.max()))
-    print("tiled blocks vs oracle: exact=%.4f tie=%d of %d" % (chk["exact_frac"], chk["n_tie"], chk["n"]))
+    print("tiled blocks vs oracle: inexact=%d below=%d exact=%.6f tie=%d of %d"
+          % (chk["n_inexact"], chk["n_below_only"], chk["exact_frac"], chk["n_tie"], chk["n"]))
     assert chk["n_bad"] == 0, chk
     assert chk["exact_frac"] >= 0.99, chk
 
