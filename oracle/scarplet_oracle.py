@@ -746,11 +746,20 @@ def check_fold(res, amp_stack, snr_stack, ages, angles, tie_rtol=1e-6,
     # over the decidable cells.
     n = int(ok.size)
     below_only = below & ~exact
+    # how far off are the cells that carry another template than the argmax: the largest relative
+    # gap, in the oracle's own float64 SNRs, between the maximum and the template the result chose
+    off = ok & ~exact & ~below & (smax > 0) & ~zero
+    inexact_gap = 0.0
+    if off.any():
+        s_ch = np.zeros(smax.shape)
+        for t in range(T):
+            s_ch = np.where(off & (age == ages[t]) & (ang == angles[t]), snr_stack[t], s_ch)
+        inexact_gap = float(np.max((smax[off] - s_ch[off]) / smax[off]))
     n_exact, n_below_only = int(np.sum(exact)), int(np.sum(below_only))
     n_inexact = n - n_exact - n_below_only
     return dict(ok=ok, n_bad=int(np.sum(~ok)), n_strict=int(np.sum(strict)),
                 n_tie=int(np.sum(ok & ~strict)), n=n,
-                n_exact=n_exact, n_inexact=n_inexact, n_below_only=n_below_only,
+                n_exact=n_exact, n_inexact=n_inexact, n_below_only=n_below_only, inexact_gap=inexact_gap,
                 exact_frac=float(n_exact) / max(n - n_below_only, 1),
                 n_slack=n_slack, n_below=int(np.sum(below)),
                 snr_err=snr_err, amp_err=amp_err)

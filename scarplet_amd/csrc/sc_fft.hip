@@ -1819,6 +1819,9 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
 #ifndef SC_I2_FETCH_AT
 #define SC_I2_FETCH_AT 0
 #endif
+#ifndef SC_I2_STATIC
+#define SC_I2_STATIC 1     // templates whose window limits cover a whole tile row: no range test per output (stage 3)
+#endif
 
 template <int TX>
 __host__ __device__ constexpr bool inv_rows_fast_ok() { return TX == 512 || TX == 1024 || TX == 2048; }
@@ -1978,7 +1981,11 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
 #pragma unroll
         for (int part = 0; part < (PT ? 1 : 2); ++part) {
             const bool ok = !MAPS && row_of(part) && cj >= 0 && cj < tile_of(part).vx;
-            b_snr[best_of(c, part)] = ok ? at_bytes(best_snr + off_of(part), 4u * (uint32_t)cj) : 0.f;
+            // (a cell outside the tile's valid extent holds +inf: nothing compares greater, so the
+            //  templates whose window-limit rectangle covers the whole tile row need no range test
+            //  per output - STATIC below; such a cell is never written back, its winner byte stays NONE)
+            b_snr[best_of(c, part)] = ok ? at_bytes(best_snr + off_of(part), 4u * (uint32_t)cj)
+                                         : ((SC_I2_STATIC && !MAPS && !FULL) ? __builtin_inff() : 0.f);
             b_xr[best_of(c, part)] = 0.f;
         }
     }
@@ -2060,6 +2067,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         unsigned span[2];
         int base[2];
         uint32_t tix[2];
+        bool covers[2];
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
             const int tgo = PT ? 2 * ok_ + part : ok_;            // template within its orientation
@@ -2080,7 +2088,14 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             }
             span[part] = (r && hi >= lo) ? (unsigned)(hi - lo) : 0u;
             base[part] = (r && hi >= lo) ? lo : 0x40000000;      // no column reaches it
+            // STATIC: every cell of the part's valid extent may score (the rectangle covers columns
+            // 0 .. vx-1 of this row), or none can whatever the test says (the row lies outside the tile:
+            // its cells hold +inf)
+            covers[part] = !row_of(part) || (r && lo == 0 && hi == t.vx - 1);
         }
+        const bool all_in = SC_I2_STATIC && !FULL && !MAPS && covers[0] && covers[1];     // workgroup-uniform
+        auto stage3 = [&](auto static_tag) {
+        constexpr bool STATIC = decltype(static_tag)::value;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             v2 vw[R3], vm[R3];
@@ -2095,7 +2110,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             for (int m = 0; m < R3; ++m) {
                 const int c = u * R3 + m;
                 const v2 xc = vw[pk::B<R3, true>::pos(m)], t3 = vm[pk::B<R3, true>::pos(m)];
-                const int cj = col_of(c);
+                const int cj = STATIC ? 0 : col_of(c);
 #pragma unroll
                 for (int part = 0; part < 2; ++part) {
                     const int k = best_of(c, part);
@@ -2106,7 +2121,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                     const float T1 = xr * xr * kt[part];
                     const float d = fmaxf(fmaf(tr, scale, -T1), fmaf(fabsf(xr), kx2[part], fl0[part]));
                     float snr = fabsf(T1 * __builtin_amdgcn_rcpf(fmaf(d, inv_n[part], (float)SC_EPS)));
-                    const bool in = (unsigned)(cj - base[part]) <= span[part];
+                    const bool in = STATIC || (unsigned)(cj - base[part]) <= span[part];
                     if (MAPS || FULL) {
                         float amp = xr * ka[part];
                         // `in` is the tile's valid extent here; masks per cell
@@ -2138,6 +2153,13 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 }
             }
         }
+        };
+#if SC_I2_STATIC == 2                     // timing probe only: every template on the static path (wrong at the DEM's borders)
+        stage3(std::true_type{});
+#else
+        if (all_in) stage3(std::true_type{});
+        else stage3(std::false_type{});
+#endif
         lds_barrier();
         if (++ok_ == NGO) { ok_ = 0; ++ob; }
     }

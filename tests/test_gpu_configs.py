@@ -52,7 +52,9 @@ def test_c5_grandcanyon_channel_readme_example(gpu_ctx):
     res = sl.match(grid(z, dx, dy), sl.Channel, scale=10., age=0.1,
                    ang_min=-np.pi / 2, ang_max=np.pi / 2)
     chk = fold_check(res, z, dx, dy, orc.RICKER, 10., [0.1], _plan.angle_grid())
-    report("C5 grand canyon channel 1 x 181", chk, "auto")
+    # (measured: 11 of 262 144 cells carry the runner-up, gap <= 7e-4: the float32 FFT convolution's SNR
+    #  error on this int16 DEM is 2e-4; the real-space path is exact on it, "C5 scale ... direct" below)
+    report("C5 grand canyon channel 1 x 181", chk, "auto", max_inexact=16)
     assert chk["n_bad"] == 0, chk
 
 
@@ -192,7 +194,7 @@ def test_odd_tile_count_and_odd_template_count(gpu_ctx):
     m.params, m.angles, m.n_templates = np.asarray(ages), angles, len(arr)
     res = m.result()
     chk = fold_check(res, g._griddata, 1.0, 1.0, orc.SCARP, 30, ages, angles)
-    report("odd tile count, paired templates", chk)
+    report("odd tile count, paired templates", chk, max_inexact=2)      # (measured: 1 of 748 000 cells)
     assert chk["n_bad"] == 0, (p, chk)
     assert chk["exact_frac"] >= EXACT_MIN, chk
 

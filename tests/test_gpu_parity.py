@@ -30,7 +30,7 @@ TIE_RTOL = orc.PARITY["tie_rtol"]      # twice the measured SNR error (oracle.PA
 EXACT_MIN = 0.99                       # surfaces WITHOUT a noise floor only: share of cells on the oracle's argmax
 
 
-def report(name, chk, method="fft", window=None, noise_floor=True):
+def report(name, chk, method="fft", window=None, noise_floor=True, max_inexact=0):
     """One line per fold check in the test log (pytest -s / GPUTEST output), and the two policies:
     the SNR error this check measured is at most half the tie window of the device path that
     ran ('auto' searches are judged by the wider FFT window); and the argmax is EXACT as an
@@ -39,14 +39,20 @@ def report(name, chk, method="fft", window=None, noise_floor=True):
     of its own (lidar, the benchmark DEM, every synthetic DEM with sigma > 0).  Cells below the
     absolute tolerance on both sides are reported as `below`, not counted as exact.  Only the
     surfaces WITHOUT a noise floor (noise_floor=False: test_noise_free_surfaces_resolution_floor
-    and the like) are held to a fraction, EXACT_MIN."""
+    and the like) are held to a fraction, EXACT_MIN.  max_inexact: the two checks of the suite
+    that are NOT exact on the FFT path say so with their measured count (a handful of cells in
+    several hundred thousand whose two best templates lie closer together, in the oracle's own
+    float64 SNRs, than the float32 FFT convolution's measured error on that DEM - `gap` in the
+    line); the real-space path is exact on the same inputs."""
     window = orc.tie_window(method) if window is None else window
-    print("fold %-44s bad=%d inexact=%d below=%d exact=%.6f strict=%d tie=%d of %d snr_err=%.2e amp_err=%.2e (window %.0e)"
-          % (name, chk["n_bad"], chk["n_inexact"], chk["n_below_only"], chk["exact_frac"], chk["n_strict"],
+    print("fold %-44s bad=%d inexact=%d (gap %.1e) below=%d exact=%.6f strict=%d tie=%d of %d snr_err=%.2e amp_err=%.2e (window %.0e)"
+          % (name, chk["n_bad"], chk["n_inexact"], chk["inexact_gap"], chk["n_below_only"], chk["exact_frac"], chk["n_strict"],
              chk["n_tie"], chk["n"], chk["snr_err"], chk["amp_err"], window))
     assert chk["snr_err"] <= 0.5 * window, (name, chk["snr_err"], window)
     if noise_floor:
-        assert chk["n_inexact"] == 0, (name, "cells off the oracle's argmax:", chk["n_inexact"], "of", chk["n"])
+        assert chk["n_inexact"] <= max_inexact, (name, "cells off the oracle's argmax:", chk["n_inexact"], "of", chk["n"])
+        # ... and those that are allowed lie inside the tie window (twice the largest error measured on the path)
+        assert chk["inexact_gap"] <= window, (name, chk["inexact_gap"], window)
     else:
         assert chk["exact_frac"] >= EXACT_MIN, (name, chk["exact_frac"])
 
@@ -300,7 +306,7 @@ def test_noise_free_surfaces_resolution_floor(gpu_ctx):
         res = m.ctx.get_result(ages_t, angs_t)
         chk = orc.check_fold(res, A, S, ages_t, angs_t, slack=K, **tol)
         name = "noise-free %s %dx%d de=%g tiles %dx%d" % (kind, ny, nx, dx, p.nty, p.ntx)
-        report(name + " fft", chk, window=float("inf"))       # outside the window policy: the slack states it per cell
+        report(name + " fft", chk, window=float("inf"), noise_floor=False)       # outside the window policy: the slack states it per cell
         print("     (template, cell) pairs with slack > 1e-3: %.3f; cells accepted through the slack: %d, below the "
               "absolute tolerance: %d" % ((K > 1e-3).mean(), chk["n_slack"], chk["n_below"]))
         # what the FFT path delivers on such a surface: every cell inside its stated resolution
