@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 4
+#define SC_ABI_VERSION 5
 
 #define SC_OK               0
 #define SC_ERR_INVALID     -1   /* bad argument                                */
@@ -122,6 +122,23 @@ int sc_set_dem(sc_ctx* ctx, const double* z, int ly, int lx, int gy0, int gx0,
                int ny, int nx, int cy0, int cy1, int cx0, int cx1,
                double dx, double dy, int wrap,
                const double* xaxis, const double* yaxis);
+
+/*
+ * What the device found in the block handed over last (one pass over it in HBM, part of
+ * sc_set_dem / sc_set_dem_device):
+ *   nan_cells  cells that are NaN.  One NaN turns every output of the reference NaN (its
+ *              whole-grid FFTs spread it, core.py:349-363): the host layer answers such a DEM
+ *              with the reference's maps and does not search it (scarplet_amd/core.py);
+ *   hash2      128-bit fingerprint of the float64 bit patterns (two 64-bit words);
+ *   unchanged  1: the block, its geometry and cell size equal what the context held before this
+ *              hand-over - the curvature planes were kept, and so were the curvature spectra of
+ *              the last search (option "spectra_mb"): the next scale of a multi-scale job, which
+ *              the reference runs as one sl.match per scale on the same data
+ *              (docs/source/examples/channels.ipynb).
+ * Replaces two host passes over the DEM (np.isnan(z).any(), a hash of the values) per call.
+ * Any pointer may be NULL.
+ */
+int sc_dem_info(sc_ctx* ctx, long long* nan_cells, unsigned long long* hash2, int* unchanged);
 
 /* Same, with z already in device memory (used after sc_halo_exchange). */
 int sc_set_dem_device(sc_ctx* ctx, const void* z_dev, int ly, int lx, int gy0,

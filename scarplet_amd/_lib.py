@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCARPLET_HIP_LIB") or os.path.join(_HERE, "libscarplet_hip.so")
 
 SC_OK = 0
-ABI_VERSION = 4
+ABI_VERSION = 5
 ID_NONE = 0xFFFFFFFF
 COMM_ID_BYTES = 128
 
@@ -75,6 +75,7 @@ SIGNATURES = {
     "sc_last_error": (C.c_char_p, [_P]),
     "sc_set_dem": (C.c_int, [_P, _dp] + [C.c_int] * 10 + [C.c_double] * 2
                    + [C.c_int, _dp, _dp]),
+    "sc_dem_info": (C.c_int, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]),
     "sc_set_dem_device": (C.c_int, [_P, _P] + [C.c_int] * 10
                           + [C.c_double] * 2 + [C.c_int, _dp, _dp]),
     "sc_upload_window": (C.c_int, [_P, _dp, C.c_int, C.c_int,
@@ -170,7 +171,9 @@ class Context(object):
                                    % (device, rc))
         self.device = int(device)
         self.core = None
-        self.dem_key = None        # Matcher.set_data: fingerprint of the DEM resident in this context
+        self.dem_key = None        # (geometry, cell size, the device's 128-bit fingerprint) of the resident block
+        self.dem_nan = 0           # NaN cells the device found in it
+        self.dem_unchanged = False # the last set_dem handed over what the context already held
         self.spectra_mb = 0.0
         # searches small enough for it keep their curvature spectra (sc_set_option "spectra_mb"): the
         # next search of the same DEM with the same tiles and orientations - the next scale of a
@@ -242,6 +245,15 @@ class Context(object):
         self._check(self.lib.sc_set_dem(
             self._h, _as(z, _dp), *args, float(dx), float(dy), int(bool(wrap)),
             _as(xa, _dp), _as(ya, _dp)), "sc_set_dem")
+        self._dem_info(args, dx, dy, wrap)
+
+    def _dem_info(self, args, dx, dy, wrap):
+        """What the device found in the block just handed over (sc_dem_info): NaN cells, the
+        fingerprint, and whether it is the block the context already held."""
+        nan, h2, same = C.c_longlong(0), (C.c_ulonglong * 2)(), C.c_int(0)
+        self._check(self.lib.sc_dem_info(self._h, C.byref(nan), h2, C.byref(same)), "sc_dem_info")
+        self.dem_nan, self.dem_unchanged = int(nan.value), bool(same.value)
+        self.dem_key = (tuple(args), float(dx), float(dy), bool(wrap), int(h2[0]), int(h2[1]))
 
     def set_dem_device(self, z_dev, ly, lx, dx, dy, xaxis, yaxis, origin,
                        shape, core):
@@ -252,6 +264,7 @@ class Context(object):
         self._check(self.lib.sc_set_dem_device(
             self._h, z_dev, *args, float(dx), float(dy), 0, _as(xa, _dp),
             _as(ya, _dp)), "sc_set_dem_device")
+        self._dem_info(args, dx, dy, False)
 
     def core_shape(self):
         cy0, cy1, cx0, cx1 = self.core
@@ -330,7 +343,9 @@ class Context(object):
         h, w = self.core_shape()
         par = np.ascontiguousarray(param_of_id, dtype=np.float64)
         ang = np.ascontiguousarray(angle_of_id, dtype=np.float64)
-        out = np.empty((4, h, w), dtype=np.float64)
+        # (large results are views of recycled host blocks, already faulted in: _hostpool)
+        from scarplet_amd import _hostpool
+        out = _hostpool.empty((4, h, w), dtype=np.float64)
         self._check(self.lib.sc_get_result(self._h, _as(par, _dp), _as(ang, _dp),
                                            len(par), _as(out, _dp)), "sc_get_result")
         return out

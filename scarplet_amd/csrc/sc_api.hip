@@ -45,7 +45,7 @@ size_t sc_total_bytes(sc_ctx* c) {
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->norm_part, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
-                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats};
+                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats, &c->digest};
     size_t s = 0;
     for (DevBuf* b : arr) s += b->cap;
     for (auto& w : c->windows) s += (size_t)w.h * w.wd * 5;
@@ -204,7 +204,7 @@ extern "C" void sc_destroy(sc_ctx* c) {
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->norm_part, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
-                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats};
+                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats, &c->digest};
     for (DevBuf* b : arr) buf_free(*b);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp[k]);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp_in[k]);
@@ -256,11 +256,39 @@ static int set_dem_common(sc_ctx* ctx, int ly, int lx, int gy0, int gx0, int ny,
                                hipMemcpyHostToDevice, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(ctx->yaxis.p, yaxis, sizeof(double) * ny,
                                hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = launch_curv_planes(ctx))) return rc;
-    fft_spectra_forget(ctx);
+    // the block's digest; a block equal to the one this context already holds - same geometry, same cell
+    // size, same bits: the next sl.match of a multi-scale job on the same data (the reference runs one
+    // call per scale, docs/source/examples/channels.ipynb) - keeps its curvature planes and the
+    // curvature spectra kept from the last search (option "spectra_mb")
+    if ((rc = sc_ensure(ctx, ctx->digest, 3 * sizeof(unsigned long long)))) return rc;
+    if ((rc = launch_dem_digest(ctx, (unsigned long long*)ctx->digest.p))) return rc;
+    unsigned long long dg[3] = {0, 0, 0};
+    SC_HIP(ctx, hipMemcpyAsync(dg, ctx->digest.p, sizeof(dg), hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const double sig[16] = {(double)ly, (double)lx, (double)gy0, (double)gx0, (double)ny, (double)nx, (double)cy0,
+                            (double)cy1, (double)cx0, (double)cx1, dx, dy, (double)(wrap ? 1 : 0), 0, 0, 0};
+    ctx->dem_unchanged = ctx->have_dem && dg[2] == 0 && dg[0] == ctx->dem_hash[0] && dg[1] == ctx->dem_hash[1] &&
+                         memcmp(sig, ctx->dem_sig, sizeof(sig)) == 0;
+    ctx->dem_hash[0] = dg[0];
+    ctx->dem_hash[1] = dg[1];
+    ctx->dem_nan = (long long)dg[2];
+    memcpy(ctx->dem_sig, sig, sizeof(sig));
+    if (!ctx->dem_unchanged) {
+        if ((rc = launch_curv_planes(ctx))) return rc;
+        fft_spectra_forget(ctx);
+    }
     ctx->have_dem = true;
     if ((rc = sc_reset_best(ctx))) return rc;
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SC_OK;
+}
+
+extern "C" int sc_dem_info(sc_ctx* ctx, long long* nan_cells, unsigned long long* hash2, int* unchanged) {
+    if (!ctx) return SC_ERR_INVALID;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    if (nan_cells) *nan_cells = ctx->dem_nan;
+    if (hash2) { hash2[0] = ctx->dem_hash[0]; hash2[1] = ctx->dem_hash[1]; }
+    if (unchanged) *unchanged = ctx->dem_unchanged ? 1 : 0;
     return SC_OK;
 }
 

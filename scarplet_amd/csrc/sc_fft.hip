@@ -1820,7 +1820,7 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
 #define SC_I2_FETCH_AT 0
 #endif
 #ifndef SC_I2_STATIC
-#define SC_I2_STATIC 1     // templates whose window limits cover a whole tile row: no range test per output (stage 3)
+#define SC_I2_STATIC 0     // 1: templates whose window limits cover a whole tile row skip the range test per output (stage 3); measured, see DESIGN.md
 #endif
 
 template <int TX>
@@ -2281,8 +2281,18 @@ int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group, in
                 keep = false;
         }
         const int slots = keep ? n_slots : 0;
-        const void *p0 = ctx->uc.p, *p1 = ctx->uc2.p, *p2 = ctx->norms.p;
         const size_t have = std::max(nb, slots);
+        // a search that keeps nothing does not sit on the slots of an earlier one that did (up to 8 GiB
+        // taken from other contexts on this GPU and from this search's own hand-off buffers)
+        if (ctx->uc.cap > 2 * plane * np * have + ((size_t)256 << 20)) {
+            SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (DevBuf* b : {&ctx->uc, &ctx->uc2}) {
+                if (b->p) SC_HIP(ctx, hipFree(b->p));
+                b->p = nullptr;
+                b->cap = 0;
+            }
+        }
+        const void *p0 = ctx->uc.p, *p1 = ctx->uc2.p, *p2 = ctx->norms.p;
         if ((rc = sc_ensure(ctx, ctx->norms, sizeof(double) * 2 * np * have))) return rc;
         if ((rc = sc_ensure(ctx, ctx->uc, plane * np * have))) return rc;
         if ((rc = sc_ensure(ctx, ctx->uc2, plane * np * have))) return rc;

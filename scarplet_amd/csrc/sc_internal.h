@@ -78,6 +78,13 @@ struct sc_ctx {
     DevBuf z, xaxis, yaxis, A, B, C, curv;
     bool z_borrowed = false;
     const double* z_dev = nullptr;
+    // digest of the elevation block (k_dem_digest): fingerprint, NaN cells; dem_sig = the geometry and cell
+    // size it belongs to; dem_unchanged = the last sc_set_dem found the block the context already held
+    unsigned long long dem_hash[2] = {0, 0};
+    long long dem_nan = 0;
+    double dem_sig[16] = {0};
+    bool dem_unchanged = false;
+    DevBuf digest;
     DevBuf best_snr, best_amp, best_id;
     DevBuf map_amp, map_snr;
     DevBuf cmp[4], cmp_in[4];   // sc_compare_*: amp, age, angle, snr (float64); inputs amp, snr, age, angle
@@ -155,6 +162,7 @@ void sc_prof_collect(sc_ctx* ctx);
 
 // ---- launchers implemented in sc_kernels.hip --------------------------------
 int launch_curv_planes(sc_ctx* ctx);
+int launch_dem_digest(sc_ctx* ctx, unsigned long long* out_dev);
 int launch_curv_alpha(sc_ctx* ctx, float cc, float sc2, float ss, int plane = 0);
 int launch_curv_f64(sc_ctx* ctx, double c2, double sn, double cs, double s2, double* out_dev);
 int launch_curv_alpha_batch(sc_ctx* ctx, const float (*coef)[3], int nb);

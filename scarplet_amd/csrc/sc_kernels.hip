@@ -82,6 +82,46 @@ k_curv_f64(const double* __restrict__ z, Geom g, double dx, double dy, double c2
     out[(size_t)i * g.lx + j] = __dadd_rn(__dsub_rn(t1, t2), t3);
 }
 
+// Digest of the elevation block as it sits in HBM: the number of NaN cells (one NaN turns every reference
+// output NaN, core.py:349-363 - the host answers such a DEM without a search) and a 128-bit fingerprint of
+// the float64 bit patterns, position-dependent and summed (order-free, so plain atomics do).  The host used
+// to walk the 800 MB of a 10000 x 10000 DEM twice for the two (np.isnan, a hash): 53 ms of every call; here
+// it is one pass at HBM speed over data the device holds anyway.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void __launch_bounds__(256)
+k_dem_digest(const unsigned long long* __restrict__ z, size_t n, unsigned long long* __restrict__ out) {
+    unsigned long long h0 = 0, h1 = 0, nan = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const unsigned long long w = z[i];
+        h0 += mix64(w ^ (0x9E3779B97F4A7C15ull * (i + 1)));
+        h1 += mix64((w + 0xD6E8FEB86659FD93ull) ^ (0xC2B2AE3D27D4EB4Full * (i + 1)));
+        nan += ((w & 0x7FFFFFFFFFFFFFFFull) > 0x7FF0000000000000ull) ? 1ull : 0ull;
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        h0 += __shfl_down(h0, sft, 64);
+        h1 += __shfl_down(h1, sft, 64);
+        nan += __shfl_down(nan, sft, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out, h0);
+        atomicAdd(out + 1, h1);
+        if (nan) atomicAdd(out + 2, nan);
+    }
+}
+int launch_dem_digest(sc_ctx* ctx, unsigned long long* out_dev) {
+    const size_t n = (size_t)ctx->g.ly * ctx->g.lx;
+    SC_HIP(ctx, hipMemsetAsync(out_dev, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_dem_digest, dim3(blocks), dim3(256), 0, ctx->stream,
+                       (const unsigned long long*)ctx->z_dev, n, out_dev);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
 int launch_curv_f64(sc_ctx* ctx, double c2, double sn, double cs, double s2, double* out_dev) {
     const Geom& g = ctx->g;
     dim3 grid((g.lx + 255) / 256, g.ly);

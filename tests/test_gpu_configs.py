@@ -435,6 +435,41 @@ def test_kept_curvature_spectra_are_reused_and_change_nothing():
     ctx.close()
 
 
+def test_device_digest_tells_dems_apart():
+    """sc_dem_info: the device's fingerprint of the block it was handed (geometry, cell size, the
+    float64 bit patterns), its NaN count, and `unchanged` - the same data handed over again keeps
+    the curvature planes; anything else does not."""
+    from scarplet_amd import _lib
+    ctx = _lib.Context(0)
+    rng = np.random.default_rng(0)
+    z = rng.standard_normal((40, 50))
+
+    def key(zz, dx=1.0, dy=1.0):
+        m = sl.Matcher(sl.DEMGrid.from_array(zz, dx, dy), ctx=ctx)
+        return ctx.dem_key, ctx.dem_unchanged, ctx.dem_nan, m
+    k0, same, nan, _ = key(z)
+    assert not same and nan == 0
+    k1, same, nan, _ = key(z.copy())
+    assert k1 == k0 and same                              # equal data: recognised on the device
+    k2, same, _, _ = key(np.asfortranarray(z))
+    assert k2 == k0 and same                              # ... also through a non-contiguous array
+    z2 = z.copy(); z2[7, 9] += 1e-12
+    k3, same, _, _ = key(z2)
+    assert k3 != k0 and not same                          # one bit of one cell
+    z3 = z.copy(); z3[[3, 4]] = z3[[4, 3]]
+    assert key(z3)[0] != k0                               # the same values elsewhere
+    assert key(z, 2.0, 1.0)[0] != k0 and key(z, 1.0, -1.0)[0] != k0
+    assert key(z.reshape(50, 40))[0] != k0
+    z4 = z.copy(); z4[5, 6] = np.nan; z4[9, 9] = -np.nan
+    with pytest.warns(UserWarning, match="NaN"):
+        _, same, nan, m = key(z4)
+    assert nan == 2 and not same and m.nan_dem
+    with pytest.warns(UserWarning, match="NaN"):
+        assert not key(z4)[1]                             # a NaN block is never "unchanged"
+    assert not key(z)[3].nan_dem
+    ctx.close()
+
+
 @pytest.mark.parametrize("kind,n_ang", [("scarp", 13), ("ricker", 12), ("right_upper_break", 7)])
 def test_paired_orientations_against_oracle(gpu_ctx, kind, n_ang):
     """One tile, ONE template per orientation: the batch's orientations ride in pairs through the inverse

@@ -1,0 +1,27 @@
+"""scarplet_amd._hostpool: result blocks are recycled only when no view of them is alive."""
+import numpy as np
+
+from scarplet_amd import _hostpool as hp
+
+
+def test_blocks_are_reused_only_when_unreferenced(monkeypatch):
+    monkeypatch.setattr(hp, "MIN_BYTES", 1024)
+    monkeypatch.setattr(hp, "_blocks", [])
+    a = hp.empty((4, 16, 16))
+    assert a.dtype == np.float64 and a.shape == (4, 16, 16) and a.flags.c_contiguous
+    pa = a.ctypes.data
+    v = a[1]                                   # a slice the caller keeps
+    w = v.reshape(-1)[3:9]                     # ... and a view of a view
+    del a, v
+    b = hp.empty((4, 16, 16))
+    assert b.ctypes.data != pa                 # still referenced through w: not handed out again
+    del w
+    c = hp.empty((4, 16, 16))
+    assert c.ctypes.data == pa                 # every view dropped: recycled
+    d = hp.empty((4, 16, 16))                  # b and c alive: a third block, not kept beyond MAX_BLOCKS
+    assert d.ctypes.data not in (b.ctypes.data, c.ctypes.data) and len(hp._blocks) == hp.MAX_BLOCKS
+    e = hp.empty((2, 8))                       # small: plain numpy
+    assert e.base is None
+    del b, c, d
+    hp.release()
+    assert hp._blocks == []

@@ -162,19 +162,3 @@ def test_nan_dem_fold_without_template_objects(cls):
             snr[np.isnan(s)] = np.nan
     assert np.array_equal(fast[0], amp, equal_nan=True) and np.array_equal(fast[3], snr, equal_nan=True)
     assert not fast[1].any() and not fast[2].any()
-
-
-def test_dem_fingerprint_tells_dems_apart():
-    """Matcher.set_data keys the DEM resident in a context by shape, dtype, cell size and a 128-bit hash of
-    the values: equal data (also as a non-contiguous view) gives the same key, anything else another."""
-    from scarplet_amd.core import _dem_fingerprint
-    rng = np.random.default_rng(0)
-    z = rng.standard_normal((40, 50))
-    k = _dem_fingerprint(z, 1.0, 1.0)
-    assert k == _dem_fingerprint(z.copy(), 1.0, 1.0)
-    assert k == _dem_fingerprint(np.asfortranarray(z), 1.0, 1.0)
-    z2 = z.copy(); z2[7, 9] += 1e-12
-    assert k != _dem_fingerprint(z2, 1.0, 1.0)
-    assert k != _dem_fingerprint(z, 2.0, 1.0) and k != _dem_fingerprint(z, 1.0, -1.0)
-    assert k != _dem_fingerprint(z.astype(np.float32), 1.0, 1.0)
-    assert k != _dem_fingerprint(z.reshape(50, 40), 1.0, 1.0)
