@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the other_configs block (C1, C2, C5 timed and verified after the headline)")
     ap.add_argument("--prof-stride", type=int, default=16)
     ap.add_argument("--shard", default="auto", choices=["auto", "orientations", "tiles"],
                     help="multi-rank sharding: 'orientations' = every rank the whole DEM and a chunk of the "
@@ -268,6 +270,51 @@ def measured_traffic(default_workload):
         return t.get("bytes_per_launch", {})
     except Exception:
         return None
+
+
+# ----------------------------------------------------------------------------- the other BASELINE configs
+OTHER_CONFIGS = (("C1", 40, 5), ("C2", 8, 2), ("C5", 20, 3))      # (config, timed steps, warm-up steps)
+
+
+def other_config_line(a, cfg, steps, warmup, device, pool):
+    """One of BASELINE.json's other single-GPU configs (configs[0], [1], [4] as SURVEY.md 8d defines
+    them), timed like the headline - W warm-up steps, K steps between device syncs, DEM resident -
+    and verified against the oracle like the headline.  Part of the default line so that these
+    numbers are driver-run, not builder-run."""
+    import copy
+    import scarplet_amd as sl
+    b = copy.copy(a)
+    b.config, b.n, b.ages, b.angles, b.steps, b.warmup, b.group = cfg, 0, 0, 0, steps, warmup, 0
+    g, Template, scales, params, angles, label, kind = workload(b)
+    ny, nx = g._griddata.shape
+    units = float(ny) * nx * len(params) * len(angles) * len(scales)
+    m = sl.Matcher(g, device=device)
+    descs = []
+    for sc in scales:
+        arr, bbox, area = m.describe(Template, sc, params, angles)
+        plan, sp = m.plan_for(bbox, area, b.method, None, n_params=len(params))
+        descs.append((arr, sp, plan))
+
+    def step():
+        for (arr_, sp_, _) in descs:               # one result set per scale (C5)
+            m.ctx.reset_best()
+            m.ctx.match(arr_, sp_, sync=True)
+    dt, prof = timed_loop(step, m.ctx, b, None)
+    ms = 1e3 * dt / steps
+    value = units / (dt / steps) / 1e6
+    plan = descs[-1][2]
+    line = {"workload": label, "value": round(value, 1), "unit": "Mpx·template/s", "ms_per_step": round(ms, 3),
+            "steps": steps, "warmup": warmup,
+            "tiles": "%dx%d of %dx%d" % (plan.nty, plan.ntx, plan.Ty, plan.Tx),
+            "roofline_frac": round(value * 1e6 * ALGO_BYTES_PER_UNIT / 1e9 / HBM_PEAK_GBS, 4),
+            "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in prof.items() if v[0]}}
+    if pool is not None and not a.no_verify:
+        res = m.ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
+        ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan, b.method)
+        line["verified"] = ver["ok"]
+        line["verification"] = {k: ver[k] for k in ("window", "templates", "cells", "bad", "cells_off_the_oracle_argmax",
+                                                    "max_rel_snr_err", "note") if k in ver}
+    return line
 
 
 # ----------------------------------------------------------------------------- rank launcher
@@ -753,6 +800,17 @@ def main():
                                              "template descriptors, search, float64 (4,ny,nx) result conversion and D2H; "
                                              "the second of two calls (first_call_seconds: the one that faults in the "
                                              "result's host memory, after the GPU idled through the verification)"}
+        if default_workload and not a.no_other_configs:
+            # (after the end-to-end call: these load their own DEMs into the same context)
+            oc = {}
+            for cfg, k_, w_ in OTHER_CONFIGS:
+                try:
+                    oc[cfg] = other_config_line(a, cfg, k_, w_, device, pool)
+                except Exception as e:                 # must not cost the headline its line
+                    import traceback
+                    traceback.print_exc()
+                    oc[cfg] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["other_configs"] = oc
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pool, g, params, angles)
     if pool is not None:

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-LEAN="--no-cpu-baseline --no-verify --no-e2e"
+LEAN="--no-cpu-baseline --no-verify --no-e2e --no-other-configs"
 python3 bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py "$@" $LEAN > $OUT/trace.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py "$@" $LEAN --angles 2 > $OUT/pmc_fetch.log 2>&1
