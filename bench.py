@@ -272,54 +272,6 @@ def measured_traffic(default_workload):
         return None
 
 
-class CtxGroup(object):
-    """The contexts of a MultiScale job behind the one-context interface timed_loop uses."""
-
-    def __init__(self, ctxs):
-        self.ctxs = list(ctxs)
-
-    def sync(self):
-        for c in self.ctxs:
-            c.sync()
-
-    def forget_spectra(self):
-        for c in self.ctxs:
-            c.forget_spectra()
-
-    def profile(self, stride):
-        for c in self.ctxs:
-            c.profile(stride)
-
-    def profile_get(self):
-        out = {}
-        for c in self.ctxs:
-            for k, (n, ms) in c.profile_get().items():
-                n0, ms0 = out.get(k, (0, 0.0))
-                out[k] = (n0 + n, ms0 + ms)
-        return out
-
-
-def scale_jobs(a, g, Template, scales, params, angles, device):
-    """(step, ctx, plan, result getter) of a single-GPU workload: one search, or - several scales,
-    BASELINE config C5 - one search per scale side by side (scarplet_amd.MultiScale: a context,
-    i.e. a stream, and a host thread per scale; one result set per scale as in the reference's
-    loop of sl.match calls)."""
-    import scarplet_amd as sl
-    if len(scales) > 1:
-        ms = sl.MultiScale(g, len(scales), device=device)
-        ms.describe(Template, scales, params, angles, method=a.method, group=a.group or None)
-        last = ms.jobs[-1][0]
-        return ms.run, CtxGroup(m.ctx for (m, _, _) in ms.jobs), last.plan, last.ctx
-    m = sl.Matcher(g, device=device)
-    arr, bbox, area = m.describe(Template, scales[0], params, angles)
-    plan, sp = m.plan_for(bbox, area, a.method, a.group or None, n_params=len(params))
-
-    def step():
-        m.ctx.reset_best()
-        m.ctx.match(arr, sp, sync=True)
-    return step, m.ctx, plan, m.ctx
-
-
 # ----------------------------------------------------------------------------- the other BASELINE configs
 OTHER_CONFIGS = (("C1", 40, 5), ("C2", 8, 2), ("C5", 20, 3))      # (config, timed steps, warm-up steps)
 
@@ -336,17 +288,28 @@ def other_config_line(a, cfg, steps, warmup, device, pool):
     g, Template, scales, params, angles, label, kind = workload(b)
     ny, nx = g._griddata.shape
     units = float(ny) * nx * len(params) * len(angles) * len(scales)
-    step, ctxg, plan, last_ctx = scale_jobs(b, g, Template, scales, params, angles, device)
-    dt, prof = timed_loop(step, ctxg, b, None)
+    m = sl.Matcher(g, device=device)
+    descs = []
+    for sc in scales:
+        arr, bbox, area = m.describe(Template, sc, params, angles)
+        plan, sp = m.plan_for(bbox, area, b.method, None, n_params=len(params))
+        descs.append((arr, sp, plan))
+
+    def step():
+        for (arr_, sp_, _) in descs:               # one result set per scale (C5)
+            m.ctx.reset_best()
+            m.ctx.match(arr_, sp_, sync=True)
+    dt, prof = timed_loop(step, m.ctx, b, None)
     ms = 1e3 * dt / steps
     value = units / (dt / steps) / 1e6
+    plan = descs[-1][2]
     line = {"workload": label, "value": round(value, 1), "unit": "Mpx·template/s", "ms_per_step": round(ms, 3),
             "steps": steps, "warmup": warmup,
             "tiles": "%dx%d of %dx%d" % (plan.nty, plan.ntx, plan.Ty, plan.Tx),
             "roofline_frac": round(value * 1e6 * ALGO_BYTES_PER_UNIT / 1e9 / HBM_PEAK_GBS, 4),
             "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in prof.items() if v[0]}}
     if pool is not None and not a.no_verify:
-        res = last_ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
+        res = m.ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
         ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan, b.method)
         line["verified"] = ver["ok"]
         line["verification"] = {k: ver[k] for k in ("window", "templates", "cells", "bad", "cells_off_the_oracle_argmax",
@@ -747,7 +710,19 @@ def main():
         ctx = m.ctx
         emu = (R, part_label, [lay.core(r) for r in range(R)], per_block, halo_bytes, plans)
     else:
-        step, ctx, plan, last_ctx = scale_jobs(a, g, Template, scales, params, angles, device)
+        m = sl.Matcher(g, device=device)
+        descs = []
+        for sc in scales:
+            arr, bbox, area = m.describe(Template, sc, params, angles)
+            plan, sp = m.plan_for(bbox, area, a.method, a.group or None, n_params=len(params))
+            descs.append((arr, sp, plan))
+
+        def step():
+            for (arr_, sp_, _) in descs:               # one result set per scale (C5)
+                m.ctx.reset_best()
+                m.ctx.match(arr_, sp_, sync=True)
+        ctx = m.ctx
+        plan = descs[-1][2]
 
     def after_warmup():
         if emu:
@@ -779,7 +754,7 @@ def main():
     else:
         if not a.no_verify:
             # the record the timed loop left behind (the last scale's, for C5)
-            res = last_ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
+            res = ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
             ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan, a.method)
             del res
             out["verified"] = ver["ok"]

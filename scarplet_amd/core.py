@@ -33,22 +33,18 @@ from scarplet_amd import _lib, _plan
 from scarplet_amd import WindowedTemplate as _WT
 from scarplet_amd.dem import DEMGrid
 
-__all__ = ["match", "match_scales", "MultiScale", "match_template", "compare", "load",
+__all__ = ["match", "match_template", "compare", "load",
            "calculate_best_fit_parameters",
            "calculate_best_fit_parameters_serial", "Matcher"]
 
 _CONTEXTS = {}
 
 
-def _context(device, lane=0):
-    """The process-wide context of GPU ``device`` (lane 0), or one of its extra contexts: a
-    context is one HIP stream with its own buffers, and searches on different contexts of one
-    GPU run side by side (MultiScale)."""
-    key = device if lane == 0 else (device, lane)
-    ctx = _CONTEXTS.get(key)
+def _context(device):
+    ctx = _CONTEXTS.get(device)
     if ctx is None:
         ctx = _lib.Context(device)
-        _CONTEXTS[key] = ctx
+        _CONTEXTS[device] = ctx
     return ctx
 
 
@@ -448,87 +444,6 @@ class Matcher(object):
         self.plan, sp = self.plan_for(bbox, max_area, method)
         amp, snr = self.ctx.match_template(arr[0], sp)
         return amp.astype(np.float64), snr.astype(np.float64)
-
-
-class MultiScale(object):
-    """Several searches of ONE DEM side by side on one GPU - the scales of a multi-scale job.
-
-    The reference runs such a job as a Python loop, one ``sl.match`` per scale
-    (docs/source/examples/channels.ipynb: Channel widths 5 .. 80 over the Grand Canyon DEM), each
-    with its own result set.  The searches are independent, and a small DEM does not fill the chip:
-    a 512 x 512 search is a chain of launches of a few microseconds on a few hundred workgroups.
-    Here every scale gets its own context (a HIP stream with its own buffers, the DEM uploaded
-    to each) and its own host thread; the device runs their kernels concurrently.  Every scale's
-    record is, bit for bit, what the same search alone produces."""
-
-    def __init__(self, data, n, device=0):
-        from concurrent.futures import ThreadPoolExecutor
-        self.matchers = [Matcher(data, ctx=_context(device, lane)) for lane in range(n)]
-        self._pool = ThreadPoolExecutor(max_workers=n)
-        self.jobs = None
-
-    def describe(self, Template, scales, params, angles, method="auto", group=None, **kwargs):
-        """Descriptors and plans of one search per scale (scale k on context k)."""
-        assert len(scales) <= len(self.matchers)
-        params = np.atleast_1d(np.asarray(params, dtype=float))
-        angles = np.atleast_1d(np.asarray(angles, dtype=float))
-        self.jobs = []
-        for m, sc in zip(self.matchers, scales):
-            arr, bbox, area = m.describe(Template, sc, params, angles, **kwargs)
-            m.plan, sp = m.plan_for(bbox, area, method, group, n_params=len(params))
-            m.params, m.angles, m._id_par = params, angles, None
-            self.jobs.append((m, arr, sp))
-        return self
-
-    def run(self):
-        """All searches, concurrently; returns when every one has finished on the device."""
-        def one(job):
-            m, arr, sp = job
-            m.ctx.reset_best()
-            m.ctx.match(arr, sp, sync=True)      # (a ctypes call: the GIL is released while it runs)
-        list(self._pool.map(one, self.jobs))
-        return self
-
-    def results(self):
-        return [m.result_array() for (m, _, _) in self.jobs]
-
-    def close(self):
-        self._pool.shutdown()
-
-
-def match_scales(data, Template, scales, **kwargs):
-    """``[match(data, Template, scale=s, **kwargs) for s in scales]`` with the searches run side by
-    side on the GPU (MultiScale).  Same keyword arguments and return values as ``match``
-    (core.py:266-294) per scale; NaN DEMs and ``fold="reference"`` take the plain loop."""
-    scales = list(scales)
-    if kwargs.get("fold", "fused") != "fused" or len(scales) < 2:
-        return [match(data, Template, scale=s, **kwargs) for s in scales]
-    kw = dict(kwargs)
-    kw.pop("fold", None)
-    device = kw.pop("device", 0)
-    method = kw.pop("method", "auto")
-    ages = kw.pop("ages", None)
-    ang_max = kw.pop("ang_max", np.pi / 2)
-    ang_min = kw.pop("ang_min", -np.pi / 2)
-    one_age = "age" in kw
-    params = [kw.pop("age")] if one_age else (_plan.age_grid() if ages is None else ages)
-    ms = MultiScale(data, len(scales), device=device)
-    try:
-        if any(m.nan_dem for m in ms.matchers) or method == "auto":
-            # ('auto' may search twice - the exact path where the FFT path cannot resolve the surface -:
-            #  per scale, through Matcher.search)
-            def one(job):
-                m, s = job
-                m.search(Template, s, params, _plan.angle_grid(ang_min, ang_max), method=method, **kw)
-                return m.result_array()
-            out = list(ms._pool.map(one, zip(ms.matchers, scales)))
-        else:
-            out = ms.describe(Template, scales, params, _plan.angle_grid(ang_min, ang_max), method=method, **kw).run().results()
-        return out if one_age else [tuple(o) for o in out]
-    finally:
-        for m in ms.matchers:
-            m.ctx.clear_windows()
-        ms.close()
 
 
 # ------------------------------------------------------------------------------

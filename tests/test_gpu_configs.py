@@ -487,31 +487,3 @@ def test_paired_orientations_against_oracle(gpu_ctx, kind, n_ang):
     report("paired orientations %s x %d" % (kind, n_ang), chk, "fft")
     assert chk["n_bad"] == 0, chk
     assert chk["exact_frac"] >= EXACT_MIN, chk
-
-
-def test_scales_side_by_side_equal_the_loop_bit_for_bit():
-    """match_scales / MultiScale: the scales of a multi-scale job (BASELINE config C5: the
-    reference's loop of one sl.match per Channel width, docs/source/examples/channels.ipynb) run
-    side by side on one GPU - a context, i.e. a stream, and a host thread per scale.  Every
-    scale's result must equal the plain loop's in every bit, repeatedly (the searches share the
-    device, nothing else)."""
-    z, dx, dy = dem_fixture("dem_grandcanyon.npz")
-    g = grid(z, dx, dy)
-    scales = [5.0, 10.0, 20.0, 40.0, 80.0]
-    loop = [sl.match(g, sl.Channel, scale=s, age=0.1, method="fft") for s in scales]
-    for rep in range(3):
-        par = sl.match_scales(g, sl.Channel, scales, age=0.1, method="fft")
-        assert len(par) == len(scales)
-        for s, a, b in zip(scales, loop, par):
-            assert b.shape == a.shape == (4,) + z.shape and b.dtype == np.float64
-            assert np.array_equal(a, b), (rep, s)
-    # the 35-age grid (4-tuples), method='auto' through Matcher.search per scale
-    rng = np.random.default_rng(3)
-    zs = (np.cumsum(rng.standard_normal((120, 100)), 1) * 0.05 + rng.standard_normal((120, 100)) * 0.04).astype(np.float32)
-    gs = grid(zs, 1.0)
-    loop = [sl.match(gs, sl.Scarp, scale=s, ang_min=-0.3, ang_max=0.3) for s in (8, 12)]
-    par = sl.match_scales(gs, sl.Scarp, (8, 12), ang_min=-0.3, ang_max=0.3)
-    for a, b in zip(loop, par):
-        assert isinstance(b, tuple) and len(b) == 4
-        for x, y in zip(a, b):
-            assert np.array_equal(x, y)
