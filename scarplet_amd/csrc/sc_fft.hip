@@ -1416,7 +1416,7 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
                  int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
                  int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
                  float2* __restrict__ ym, int ystride, int np, int pcj, int tstride,
-                 const TileDev* __restrict__ tiles, int py_valid) {
+                 const TileDev* __restrict__ tiles, int py_valid, const TemplDev* __restrict__ tl) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     constexpr int S = TY / 16;                 // 16-point sets per line
     static_assert(S % 64 == 0 && S / 64 <= 2, "one wave per line: 64 or 128 sets");
@@ -1425,15 +1425,41 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
     constexpr int LINE = w8_line<TY>();
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float2* line = sm + w * LINE;
+    // rows the templates' window limits mask out (WindowedTemplate.py:66-84: up to 350 rows at either
+    // end of the DEM at scale 100, 2.4 % of all rows on average over the 35 x 181 grid) are not stored
+    // either: the row pass scores nothing there (its range test fails for every cell of such a row,
+    // whatever the transform of the stale cells says).  i0A / i0B: first global row of the pair's tiles.
+    int i0A = 0, i0B = 0, vyA = 0, vyB = 0;
     {
         const int ob = jobx / pcj, q = jobx - ob * pcj;
+        const TileDev tA_ = tiles[2 * (pair + q)], tB_ = tiles[2 * (pair + q) + 1];
+        i0A = tA_.i0; i0B = tB_.i0; vyA = tA_.vy; vyB = tB_.vy;
         if (py_valid >= 0) {
-            const int vy = max(tiles[2 * (pair + q)].vy, tiles[2 * (pair + q) + 1].vy);
+            const int vy = max(tA_.vy, tB_.vy);
             rp_hi = min(rp_hi, (py_valid + vy - 1) >> 1);
         }
         pair += ob * np + q;
         vfirst += ob * tstride;
     }
+    // [lo, hi] of the row pairs transform gi_ has to store: rp_lo .. rp_hi cut to the rows some
+    // template of the transform keeps on some tile of the pair (tile row ri = 2 rp + {0, 1} - py_valid
+    // is global row i0 + ri); circular axes (py_valid < 0) and launches without descriptors: all
+    auto kept_rows = [&](int gi_, int& lo, int& hi) {
+        lo = rp_lo; hi = rp_hi;
+        if (!tl || py_valid < 0) return;
+        int klo = INT_MAX, khi = INT_MIN;
+#pragma unroll
+        for (int k = 0; k < (PT ? 2 : 1); ++k) {
+            const int ti = vfirst + (PT ? 2 * gi_ + k : gi_);
+            if (PT && k == 1 && 2 * gi_ + 1 >= G) break;
+            const int ilo = tl[ti].ilo, ihi = tl[ti].ihi;
+            if (vyA > 0) { klo = min(klo, ilo - i0A); khi = max(khi, ihi - i0A); }
+            if (vyB > 0) { klo = min(klo, ilo - i0B); khi = max(khi, ihi - i0B); }
+        }
+        if (khi < klo) { lo = 1; hi = 0; return; }
+        lo = max(lo, (max(klo, 0) + py_valid) >> 1);
+        hi = min(hi, (min(khi, TY) + py_valid) >> 1);
+    };
     const size_t plane = (size_t)TY * Tx, hplane = half_plane(TY, Tx);
     yw += (size_t)jobx * ystride * plane;
     ym += (size_t)jobx * ystride * plane;
@@ -1545,8 +1571,10 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
                         (NC == 8 ? (size_t)B * 16 : (size_t)(B >> 1) * 16 + (B & 1) * 8) + 2 * (ln & (NC - 1));
             const float2* lc = sm + (ln & (NC - 1)) * LINE;
             constexpr int RQ = 64 / NC;                      // row pairs per store instruction
+            int s_lo, s_hi;
+            kept_rows(gi_, s_lo, s_hi);
 #pragma unroll 2
-            for (int rp = rp_lo + RQ * w + ln / NC; rp <= rp_hi; rp += RQ * NC)
+            for (int rp = s_lo + RQ * w + ln / NC; rp <= s_hi; rp += RQ * NC)
                 store_stream(o + (size_t)rp * (Tx >> 3) * 16, lc[ph(2 * rp)], lc[ph(2 * rp + 1)]);
         }
         lds_barrier();                                       // (the next plane's first barrier would do; kept simple)
@@ -1563,14 +1591,14 @@ k_inv_cols_w8(const float2* __restrict__ uc, const float2* __restrict__ uc2,
               int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
               int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
               float2* __restrict__ ym, int ystride, int np, int pcj, int tstride,
-              const TileDev* __restrict__ tiles, int py_valid) {
+              const TileDev* __restrict__ tiles, int py_valid, const TemplDev* __restrict__ tl) {
     const int j = blockIdx.x, i = ((j >> 4) << 3) | (j & 7);
     if ((j >> 3) & 1)
         inv_cols_w8_body<TY, true, PT, 8>((Tx >> 3) - 1 - i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
-                                   rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid);
+                                   rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid, tl);
     else
         inv_cols_w8_body<TY, false, PT, 8>(i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
-                                    rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid);
+                                    rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid, tl);
 }
 
 // The same with FOUR columns and four waves per workgroup, one wave per SIMD: a wave may then use
@@ -1585,14 +1613,14 @@ k_inv_cols_w4(const float2* __restrict__ uc, const float2* __restrict__ uc2,
               int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
               int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
               float2* __restrict__ ym, int ystride, int np, int pcj, int tstride,
-              const TileDev* __restrict__ tiles, int py_valid) {
+              const TileDev* __restrict__ tiles, int py_valid, const TemplDev* __restrict__ tl) {
     const int j = blockIdx.x, i = ((j >> 4) << 3) | (j & 7);
     if ((j >> 3) & 1)
         inv_cols_w8_body<TY, true, PT, 4>((Tx >> 2) - 1 - i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
-                                          rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid);
+                                          rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid, tl);
     else
         inv_cols_w8_body<TY, false, PT, 4>(i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
-                                           rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid);
+                                           rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid, tl);
 }
 
 // ---- I2: inverse row FFT -> epilogue -> fold ---------------------------------
@@ -1620,6 +1648,7 @@ struct RowArgs {
     SibSync sib;                        // sibling rendezvous of the fast kernel (rows 2rp, 2rp+1)
     unsigned long long* stats;          // {wins, wins near the resolution floor} of the search (sc_get_resolution_stats)
     int xp;                             // paired ORIENTATIONS (k_inv_cols_sym, XP): G templates, one per orientation; norms entry id*np + pair
+    int skip;                           // fast kernel: skip the templates whose window limits mask the workgroup's whole row
 };
 // One launch may serve several tile pairs (grid.y): pair = ra.pair + blockIdx.y,
 // its Y planes ystride planes further on.  More workgroups per launch fill the
@@ -1840,7 +1869,8 @@ __host__ __device__ constexpr int inv_rows_fast_threads() { return TX / 8; }
 template <int TX>
 __host__ __device__ constexpr size_t inv_rows_fast_lds() {
     return fft_lds_bytes(TX) / 2 + (size_t)SC_MAX_GROUP * EPI_FLOATS * sizeof(float) +
-           (size_t)(TX / 16) * 2 * sizeof(float2) + (size_t)(TX / 256) * 16 * sizeof(float2);
+           (size_t)(TX / 16) * 2 * sizeof(float2) + (size_t)(TX / 256) * 16 * sizeof(float2) +
+           sizeof(unsigned long long);                  // + the mask of the transforms this row takes part in
 }
 
 template <int TX, bool FULL, bool MAPS, bool PT>
@@ -1946,6 +1976,24 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         if (sib_mine && id == 0) sib_publish(sib_mine, ra.sib.base + SIB_DONE);
         return;
     }
+    // Transforms this row takes part in, one bit each (at most SC_MAX_GROUP = 64).  A template whose
+    // window limits (WindowedTemplate.py:66-84) mask the whole row on both tiles scores nothing here:
+    // its planes are not fetched, not transformed (and k_inv_cols_w8 has not stored the row for it).
+    // 2.4 % of all (row, template) pairs of the 10000 x 10000 benchmark; one orientation per launch only.
+    unsigned long long* const actm = reinterpret_cast<unsigned long long*>(tw2 + S);
+    const bool skip_ok = !PT && !FULL && !MAPS && ra.skip && ra.nb == 1 && !ra.xp && ra.sib.slots == nullptr;
+    if (id < 64) {                                               // the first wave, whole
+        bool act = id < (PT ? ra.nb * ((ra.G + 1) / 2) : GT);
+        if (skip_ok && act) {
+            const TemplDev* tp = templ + ra.first + id;
+            const int ilo = tp->ilo, ihi = tp->ihi, jlo = tp->jlo, jhi = tp->jhi;
+            const bool a0 = rowA && ri >= ilo - tA.i0 && ri <= ihi - tA.i0 && min(tA.vx - 1, jhi - tA.j0) >= max(0, jlo - tA.j0);
+            const bool a1 = rowB && ri >= ilo - tB.i0 && ri <= ihi - tB.i0 && min(tB.vx - 1, jhi - tB.j0) >= max(0, jlo - tB.j0);
+            act = a0 || a1;
+        }
+        const unsigned long long m = __ballot(act);
+        if (id == 0) *actm = m;
+    }
     int cj0 = rem3 - ra.Qx;
     const int cmask = ra.circ_x ? TX - 1 : -1;
     auto col_of = [&](int c) { return (cj0 + (c / R3) * 2 * S + 256 * (c % R3)) & cmask; };
@@ -2005,17 +2053,33 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         fp += plane * sizeof(float2);
         if (++fk == NGO) { fk = 0; fp += ostep; }
     };
+    lds_barrier();                                               // tables, scalars and the mask are in place
+    unsigned long long am;                                       // transforms still to do (workgroup-uniform: scalar)
+    {
+        const uint32_t* mp = reinterpret_cast<const uint32_t*>(actm);
+        am = ((unsigned long long)__builtin_amdgcn_readfirstlane(mp[1]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(mp[0]);
+    }
+    if (am == 0) {                                               // every template masks this row
+        if (sib_mine && id == 0) sib_publish(sib_mine, ra.sib.base + SIB_DONE);
+        return;
+    }
+    int cur = __builtin_ctzll(am);                               // the transform in hand (0 unless transforms are skipped)
+    am &= am - 1;
+    fp += (size_t)cur * plane * sizeof(float2);
     fetch();
     if (sib_mine && id == 0) sib_publish(sib_mine, ra.sib.base + 1);
-    lds_barrier();                                               // tables and scalars are in place
-    int ob = 0, ok_ = 0;                                         // orientation / transform within it of gi_
+    int ob = 0, ok_ = 0;                                         // orientation / transform within it of the one in hand
     bool sib_on = sib_mine != nullptr;
     uint32_t sib_seen = 0;
-    for (int gi_ = 0; gi_ < NG; ++gi_) {
+    for (int gi_ = 0;; ++gi_) {                                  // gi_: transforms done so far
+        const int nxt = am ? __builtin_ctzll(am) : -1;           // the next one this row takes part in
+        am &= am - 1;
+        const bool more = nxt >= 0;
+        if (skip_ok) ok_ = cur;                                  // (one orientation, one template per transform)
         // the columns are two instructions away from cj0: keep them out of the
         // loop-invariant registers (eight of them would not fit)
         asm volatile("" : "+v"(cj0));
-        if (sib_on && id == 0 && gi_ + 1 < NG) sib_seen = sib_peek(sib_theirs);
+        if (sib_on && id == 0 && more) sib_seen = sib_peek(sib_theirs);
 
         // ---- stage 1 (radix 16, stride 1) from registers: outputs 16 tt1 + m
         {
@@ -2036,10 +2100,11 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         }
         // (the sibling must have issued fetch gi_ before this workgroup issues fetch gi_ + 1;
         //  its word was looked at before stage 1, the load has had the stage to come back)
-        if (sib_on && id == 0 && gi_ + 1 < NG && (int32_t)(sib_seen - (ra.sib.base + gi_ + 1)) < 0)
+        if (sib_on && id == 0 && more && (int32_t)(sib_seen - (ra.sib.base + gi_ + 1)) < 0)
             sib_on = sib_wait(sib_theirs, ra.sib.base + gi_ + 1);
         lds_barrier();
-        if (FETCH_AT == 0 && gi_ + 1 < NG) {
+        if (more) fp += (size_t)(nxt - cur - 1) * plane * sizeof(float2);      // (planes of skipped transforms)
+        if (FETCH_AT == 0 && more) {
             fetch();                                             // in flight through stages 2-3
             if (sib_mine && id == 0) sib_publish(sib_mine, ra.sib.base + gi_ + 2);
         }
@@ -2054,7 +2119,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
 #pragma unroll
             for (int m = 1; m < 16; ++m) wr2[17 * m] = pk::cmul(b[pk::B<16, true>::pos(m)], twp2[m]);
         }
-        if (FETCH_AT == 1 && gi_ + 1 < NG) fetch();              // in flight through stage 3
+        if (FETCH_AT == 1 && more) fetch();                      // in flight through stage 3
         lds_barrier();
         // ---- stage 3 (radix R3, stride 256) fused with the epilogue: every
         // output is scored as soon as its two butterflies have produced it.
@@ -2161,6 +2226,8 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         else stage3(std::false_type{});
 #endif
         lds_barrier();
+        if (!more) break;
+        cur = nxt;
         if (++ok_ == NGO) { ok_ = 0; ++ob; }
     }
     if (sib_mine && id == 0) sib_publish(sib_mine, ra.sib.base + SIB_DONE);
@@ -2551,6 +2618,10 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             // (nb > 1, batched orientations: every job of the chunk in one launch - job
             //  ob * pc + q, the numbering the row kernel expects)
             const int pi1 = nb > 1 ? pc : std::max(1, std::min(pc, (slots + fg.Tx / 8 - 1) / (fg.Tx / 8)));
+            // rows masked by the templates' window limits are neither stored by the wave-per-column
+            // kernels nor scored by the row pass (not with explicit per-cell masks or single-template
+            // maps: those write every cell; option "variant" 13 switches it off for the cross-check)
+            const bool row_skip = !full_masks && !to_maps && ctx->variant != 13;
             sc_prof_begin(ctx, SC_K_INV_COLS);
             int n_i1 = 0;
             for (int pl0 = 0; pl0 < pc; pl0 += pi1) {
@@ -2586,7 +2657,8 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                            w8_lds<T>(), ctx->stream, (const float2*)ctx->uc.p + ctx->uc_off, (const float2*)ctx->uc2.p + ctx->uc_off, \
                            (const float*)ctx->wh.p, (const float*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo, rp_hi, \
                            (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group, \
-                           np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py); \
+                           np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py, \
+                           row_skip ? (const TemplDev*)ctx->templ.p + first : nullptr); \
     }
 #define FN_W4(T)                                                               \
     {                                                                          \
@@ -2598,7 +2670,8 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                            lds4, ctx->stream, (const float2*)ctx->uc.p + ctx->uc_off, (const float2*)ctx->uc2.p + ctx->uc_off, \
                            (const float*)ctx->wh.p, (const float*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo, rp_hi, \
                            (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group, \
-                           np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py); \
+                           np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py, \
+                           row_skip ? (const TemplDev*)ctx->templ.p + first : nullptr); \
     }
 #define FN_SYM(T)                                                              \
     {                                                                          \
@@ -2671,7 +2744,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             const int pair = pair0;
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
                        ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg, group,
-                       nb, np, pc, SibSync{nullptr, 0}, (unsigned long long*)ctx->res_stats.p, 0};
+                       nb, np, pc, SibSync{nullptr, 0}, (unsigned long long*)ctx->res_stats.p, 0, row_skip ? 1 : 0};
             if (xp) {                            // to the row pass: ONE orientation of nb templates, in pairs
                 ra.G = nb; ra.nb = 1; ra.ystride = 1; ra.xp = 1;
             }
