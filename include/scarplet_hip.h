@@ -170,7 +170,9 @@ int sc_clear_windows(sc_ctx* ctx);
  *              real-space kernel (walks the support box; one orientation per launch), 11 the
  *              real-space kernel with T3 accumulated tap by tap on every row (no sum shared
  *              between a lane's adjacent outputs), 12 no paired orientations (one-tile searches
- *              with one template per orientation then leave half of every transform empty)
+ *              with one template per orientation then leave half of every transform empty),
+ *              13 the inverse passes store and transform every valid tile row (default: rows
+ *              that a template's window limits mask are skipped for that template)
  *   "batch"    1 (default): searches whose single orientation does not fill the
  *              chip send several orientations through every launch; 0: one
  *              orientation per launch sequence.  Results are bit-identical.

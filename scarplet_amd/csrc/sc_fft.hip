@@ -2039,7 +2039,6 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     }
 
     const int NGO = PT ? (ra.G + 1) / 2 : ra.G;                  // transforms per orientation
-    const int NG = ra.nb * NGO;                                  // transforms of the launch
     const size_t ostep = ((size_t)ra.pcj * ra.ystride - NGO) * plane * sizeof(float2);   // last plane of a job -> first of the next
     v2 a[16];
     // transforms are fetched in order: fp walks the planes of a job, then steps to the same
