@@ -1573,9 +1573,15 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
             constexpr int RQ = 64 / NC;                      // row pairs per store instruction
             int s_lo, s_hi;
             kept_rows(gi_, s_lo, s_hi);
+#ifdef SC_I1_PRIO
+            __builtin_amdgcn_s_setprio(3);                   // (experiment: the store pass ahead of other waves' butterflies)
+#endif
 #pragma unroll 2
             for (int rp = s_lo + RQ * w + ln / NC; rp <= s_hi; rp += RQ * NC)
                 store_stream(o + (size_t)rp * (Tx >> 3) * 16, lc[ph(2 * rp)], lc[ph(2 * rp + 1)]);
+#ifdef SC_I1_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         lds_barrier();                                       // (the next plane's first barrier would do; kept simple)
     }
@@ -1621,6 +1627,26 @@ k_inv_cols_w4(const float2* __restrict__ uc, const float2* __restrict__ uc2,
     else
         inv_cols_w8_body<TY, false, PT, 4>(i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
                                            rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid, tl);
+}
+
+// Experiment (option "variant" 14): the four-column form with TWO workgroups of four waves per CU instead
+// of one workgroup of eight - the same waves per SIMD, but the two workgroups meet at their own barriers,
+// so one's store pass can run under the other's butterflies; the price is 64-byte store pieces.
+template <int TY>
+__global__ void __launch_bounds__(256, 2)
+k_inv_cols_w4x2(const float2* __restrict__ uc, const float2* __restrict__ uc2,
+                const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
+                int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
+                int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
+                float2* __restrict__ ym, int ystride, int np, int pcj, int tstride,
+                const TileDev* __restrict__ tiles, int py_valid, const TemplDev* __restrict__ tl) {
+    const int j = blockIdx.x, i = ((j >> 4) << 3) | (j & 7);
+    if ((j >> 3) & 1)
+        inv_cols_w8_body<TY, true, false, 4>((Tx >> 2) - 1 - i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
+                                             rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid, tl);
+    else
+        inv_cols_w8_body<TY, false, false, 4>(i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
+                                              rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid, tl);
 }
 
 // ---- I2: inverse row FFT -> epilogue -> fold ---------------------------------
@@ -2698,7 +2724,17 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             hipLaunchKernelGGL((k_inv_cols<T, true>), dim3(nhi, nb * pcc), dim3(fft_threads(T)), \
                                inv_cols_lds<T>(), COL_ARGS(nlo));              \
     }
-            if (xp) {
+            if (ctx->variant == 14 && w8 && !PTV && fg.Ty == 2048) {
+                const size_t lds4 = ((size_t)4 * w8_line<2048>() + 4 * (2048 / 16) + 4 * (2048 / 256)) * sizeof(float2);
+                int rc = set_lds(ctx, k_inv_cols_w4x2<2048>, lds4);
+                if (rc) return rc;
+                hipLaunchKernelGGL((k_inv_cols_w4x2<2048>), dim3(fg.Tx / 4, nb * pcc), dim3(256), lds4, ctx->stream,
+                                   (const float2*)ctx->uc.p + ctx->uc_off, (const float2*)ctx->uc2.p + ctx->uc_off,
+                                   (const float*)ctx->wh.p, (const float*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo, rp_hi,
+                                   (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group,
+                                   np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py,
+                                   row_skip ? (const TemplDev*)ctx->templ.p + first : nullptr);
+            } else if (xp) {
                 // paired orientations: job j = orientations 2j, 2j+1; plane j of Y; tstride carries nb
                 const size_t ldsx = inv_cols_lds<512>() + (size_t)4 * 512 * sizeof(float2);
                 int rc = set_lds(ctx, k_inv_cols_symx<512, PTV, PTV>, ldsx);

@@ -454,6 +454,8 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
     const int cw = g.cx1 - g.cx0;
 
     // running best of the lane's cells: row w RW + rr, columns j0 + 256 n + 4 lane + u
+    // (kept in memory instead - read and written at every template's fold - the 512 x 16 form spills MORE:
+    //  268 B of scratch against 84; the 48 registers are not what it runs out of)
     float b_snr[RW][NB][4], b_amp[RW][NB][4];
     uint32_t b_id[RW][NB][4];
     unsigned dirty = 0;
@@ -602,8 +604,10 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                             for (int rr = 0; rr < RW; ++rr)
 #pragma unroll
                                 for (int n = 0; n < NB; ++n) {
-                                    const f4 q = v[rr][n] * v[rr][n];
-                                    csum[rr][n] += (q.x + q.y) + (q.z + q.w);
+                                    // (four fused multiply-adds: as squares first - two packed multiplies - and a
+                                    //  sum tree this was 8 issue slots per chunk next to the 16 of its xcorr FMAs)
+                                    const f4 c4 = v[rr][n];
+                                    csum[rr][n] = fmaf(c4.w, c4.w, fmaf(c4.z, c4.z, fmaf(c4.y, c4.y, fmaf(c4.x, c4.x, csum[rr][n]))));
                                 }
                         }
                     };
