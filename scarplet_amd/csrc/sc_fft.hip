@@ -1406,7 +1406,7 @@ template <int TY>
 __host__ __device__ constexpr int w8_line() { return TY + TY / 16 + 4; }   // lines 8 banks apart: the store pass reads 8 lines x 2 cells
 template <int TY>
 __host__ __device__ constexpr size_t w8_lds() {          // eight lines + the twiddle bases of stages 1 and 2
-    return ((size_t)8 * w8_line<TY>() + 4 * (TY / 16) + 4 * (TY / 256)) * sizeof(float2);
+    return ((size_t)8 * w8_line<TY>() + 4 * (TY / 16) + 4 * (TY / 256) + SC_MAX_GROUP) * sizeof(float2);   // + the stored row range per transform
 }
 
 template <int TY, bool MIRROR, bool PT, int NC>
@@ -1443,23 +1443,37 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
     }
     // [lo, hi] of the row pairs transform gi_ has to store: rp_lo .. rp_hi cut to the rows some
     // template of the transform keeps on some tile of the pair (tile row ri = 2 rp + {0, 1} - py_valid
-    // is global row i0 + ri); circular axes (py_valid < 0) and launches without descriptors: all
-    auto kept_rows = [&](int gi_, int& lo, int& hi) {
-        lo = rp_lo; hi = rp_hi;
-        if (!tl || py_valid < 0) return;
-        int klo = INT_MAX, khi = INT_MIN;
+    // is global row i0 + ri); circular axes (py_valid < 0) and launches without descriptors: all.
+    // Worked out ONCE, by thread gi_, before the first coefficient is fetched, and parked in LDS behind
+    // the twiddle tables: read from the descriptors inside the transform loop, the loads made the
+    // compiler lose count of the coefficient prefetch in flight - every use of a prefetched value
+    // then waited for ALL outstanding loads (s_waitcnt vmcnt(0): 70 of them in the four-wave
+    // paired-template kernel instead of 8, 1 416 us per C2 launch instead of 878).
+    int2* const rng = reinterpret_cast<int2*>(sm + NC * LINE + 4 * S + 4 * (S / 16));
+    {
+        const int NGt = PT ? (G + 1) / 2 : G;
+        const int gi_ = threadIdx.x;
+        if (gi_ < NGt) {
+            int lo = rp_lo, hi = rp_hi;
+            if (tl && py_valid >= 0) {
+                int klo = INT_MAX, khi = INT_MIN;
 #pragma unroll
-        for (int k = 0; k < (PT ? 2 : 1); ++k) {
-            const int ti = vfirst + (PT ? 2 * gi_ + k : gi_);
-            if (PT && k == 1 && 2 * gi_ + 1 >= G) break;
-            const int ilo = tl[ti].ilo, ihi = tl[ti].ihi;
-            if (vyA > 0) { klo = min(klo, ilo - i0A); khi = max(khi, ihi - i0A); }
-            if (vyB > 0) { klo = min(klo, ilo - i0B); khi = max(khi, ihi - i0B); }
+                for (int k = 0; k < (PT ? 2 : 1); ++k) {
+                    const int ti = vfirst + (PT ? 2 * gi_ + k : gi_);
+                    if (PT && k == 1 && 2 * gi_ + 1 >= G) break;
+                    const int ilo = tl[ti].ilo, ihi = tl[ti].ihi;
+                    if (vyA > 0) { klo = min(klo, ilo - i0A); khi = max(khi, ihi - i0A); }
+                    if (vyB > 0) { klo = min(klo, ilo - i0B); khi = max(khi, ihi - i0B); }
+                }
+                if (khi < klo) { lo = 1; hi = 0; }
+                else {
+                    lo = max(lo, (max(klo, 0) + py_valid) >> 1);
+                    hi = min(hi, (min(khi, TY) + py_valid) >> 1);
+                }
+            }
+            rng[gi_] = make_int2(lo, hi);
         }
-        if (khi < klo) { lo = 1; hi = 0; return; }
-        lo = max(lo, (max(klo, 0) + py_valid) >> 1);
-        hi = min(hi, (min(khi, TY) + py_valid) >> 1);
-    };
+    }
     const size_t plane = (size_t)TY * Tx, hplane = half_plane(TY, Tx);
     yw += (size_t)jobx * ystride * plane;
     ym += (size_t)jobx * ystride * plane;
@@ -1571,8 +1585,8 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
                         (NC == 8 ? (size_t)B * 16 : (size_t)(B >> 1) * 16 + (B & 1) * 8) + 2 * (ln & (NC - 1));
             const float2* lc = sm + (ln & (NC - 1)) * LINE;
             constexpr int RQ = 64 / NC;                      // row pairs per store instruction
-            int s_lo, s_hi;
-            kept_rows(gi_, s_lo, s_hi);
+            const int2 sr = rng[gi_];                        // (one LDS word pair, the same for every lane)
+            const int s_lo = __builtin_amdgcn_readfirstlane(sr.x), s_hi = __builtin_amdgcn_readfirstlane(sr.y);
 #ifdef SC_I1_PRIO
             __builtin_amdgcn_s_setprio(3);                   // (experiment: the store pass ahead of other waves' butterflies)
 #endif
@@ -2008,6 +2022,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     // 2.4 % of all (row, template) pairs of the 10000 x 10000 benchmark; one orientation per launch only.
     unsigned long long* const actm = reinterpret_cast<unsigned long long*>(tw2 + S);
     const bool skip_ok = !PT && !FULL && !MAPS && ra.skip && ra.nb == 1 && !ra.xp && ra.sib.slots == nullptr;
+    // (a row no tile of the pair holds has returned above; with PT / FULL / MAPS the mask is all ones)
     if (id < 64) {                                               // the first wave, whole
         bool act = id < (PT ? ra.nb * ((ra.G + 1) / 2) : GT);
         if (skip_ok && act) {
@@ -2078,6 +2093,8 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         fp += plane * sizeof(float2);
         if (++fk == NGO) { fk = 0; fp += ostep; }
     };
+    constexpr bool CAN_SKIP = !PT && !FULL && !MAPS;             // (else every transform is taken: the first fetch need not wait for the mask)
+    if constexpr (!CAN_SKIP) fetch();
     lds_barrier();                                               // tables, scalars and the mask are in place
     unsigned long long am;                                       // transforms still to do (workgroup-uniform: scalar)
     {
@@ -2090,8 +2107,10 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     }
     int cur = __builtin_ctzll(am);                               // the transform in hand (0 unless transforms are skipped)
     am &= am - 1;
-    fp += (size_t)cur * plane * sizeof(float2);
-    fetch();
+    if constexpr (CAN_SKIP) {
+        fp += (size_t)cur * plane * sizeof(float2);
+        fetch();
+    }
     if (sib_mine && id == 0) sib_publish(sib_mine, ra.sib.base + 1);
     int ob = 0, ok_ = 0;                                         // orientation / transform within it of the one in hand
     bool sib_on = sib_mine != nullptr;
@@ -2725,7 +2744,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                                inv_cols_lds<T>(), COL_ARGS(nlo));              \
     }
             if (ctx->variant == 14 && w8 && !PTV && fg.Ty == 2048) {
-                const size_t lds4 = ((size_t)4 * w8_line<2048>() + 4 * (2048 / 16) + 4 * (2048 / 256)) * sizeof(float2);
+                const size_t lds4 = ((size_t)4 * w8_line<2048>() + 4 * (2048 / 16) + 4 * (2048 / 256) + SC_MAX_GROUP) * sizeof(float2);
                 int rc = set_lds(ctx, k_inv_cols_w4x2<2048>, lds4);
                 if (rc) return rc;
                 hipLaunchKernelGGL((k_inv_cols_w4x2<2048>), dim3(fg.Tx / 4, nb * pcc), dim3(256), lds4, ctx->stream,
