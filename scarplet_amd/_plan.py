@@ -139,6 +139,17 @@ class Plan(object):
             # T/2 serves every template that fits the grid, so that the tile - and with it the
             # curvature spectra a search keeps (sc_set_option "spectra_mb") - is the same for
             # every scale of a multi-scale job
+            # ONE tile of column length 2048 (a 2048 x 2048 DEM: BASELINE config C2) is the inverse column
+            # pass's worst case: no second tile to pair with, so templates ride in pairs, and at column length
+            # 2048 two coefficient planes next to the parked spectrum only fit a wave that has a SIMD to itself
+            # (k_inv_cols_w4: 1.9 x the time per output of the eight-wave kernel).  Three tiles of column
+            # length 1024 - a pair on the eight-wave kernel and a paired-template tile that fits it at 1024 -
+            # transform 1.5 x the cells and are still faster: 33.9 ms against 37.3 at C2
+            # (tools/c2_plans.py, profiles/r04_c2_plans.txt).
+            if self.nty * self.ntx == 1 and self.Ty == 2048 and t_max >= 2048:
+                alt = choose_tile(cy1 - cy0, pmax - pmin, ny, False, 1024)
+                if alt[0] == 1024 and alt[2] * 1024 <= 1.6 * self.Ty:
+                    self.Ty, self.Vy, self.nty, self.circ_y = alt
             if self.circ_y:
                 self.Py = self.Ty // 2
             if self.circ_x:
