@@ -145,7 +145,7 @@ class Plan(object):
             # (k_inv_cols_w4: 1.9 x the time per output of the eight-wave kernel).  Three tiles of column
             # length 1024 - a pair on the eight-wave kernel and a paired-template tile that fits it at 1024 -
             # transform 1.5 x the cells and are still faster: 33.9 ms against 37.3 at C2
-            # (tools/c2_plans.py, profiles/r04_c2_plans.txt).
+            # (tools/plan_lab.py, profiles/r04_c2_plans.txt).
             if self.nty * self.ntx == 1 and self.Ty == 2048 and t_max >= 2048:
                 alt = choose_tile(cy1 - cy0, pmax - pmin, ny, False, 1024)
                 if alt[0] == 1024 and alt[2] * 1024 <= 1.6 * self.Ty:
