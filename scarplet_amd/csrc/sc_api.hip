@@ -161,6 +161,9 @@ extern "C" int sc_set_option(sc_ctx* ctx, const char* name, double value) {
 #endif
     } else if (!strcmp(name, "batch")) {
         ctx->batch_off = value == 0.0;
+    } else if (!strcmp(name, "batch_fill")) {
+        if (!(value >= 0.0)) return sc_fail(ctx, SC_ERR_INVALID, "batch_fill must be >= 0");
+        ctx->batch_fill = (int)value;
     } else if (!strcmp(name, "sib")) {
         ctx->sib = (int)value;
     } else if (!strcmp(name, "spectra_mb")) {
@@ -564,8 +567,12 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
                                                            : (wg1 <= 1024 ? 32 : 1);
             // compatible runs ahead, up to what one launch can hold (64 templates, 64 curvature planes)
             const int hard = plan->method == SC_METHOD_FFT ? std::min(SC_MAX_ORIENT, SC_MAX_GROUP / std::max(1, runs[r].n)) : 32;
+            // (counted beyond what one launch can hold, up to two full batches: whether a remainder rides
+            //  along or the rest is split evenly is decided on what is really left - capped at `hard`, 91
+            //  orientations of ten templates went six at a time as 3 + 3 instead of 4 + 4 + ...)
+            const int look = std::max(hard, 2 * want + 1);
             int avail = 1;
-            while (avail < hard && r + avail < runs.size() && runs[r + avail].n == runs[r].n &&
+            while (avail < look && r + avail < runs.size() && runs[r + avail].n == runs[r].n &&
                    runs[r + avail].parity == runs[r].parity && runs[r + avail].full == runs[r].full &&
                    (plan->method == SC_METHOD_FFT || runs[r + avail].long_runs == runs[r].long_runs))
                 ++avail;
@@ -576,6 +583,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
             else if (avail <= want + want / 4) nb = avail;
             else if (avail < 2 * want) nb = (avail + 1) / 2;
             else nb = want;
+            nb = std::min(nb, hard);
         }
         size_t off = 0, doff = 0;
         int wh = 0, ww = 0, soff = 0;

@@ -2456,7 +2456,7 @@ int fft_batch_orientations(const sc_ctx* ctx, const FftGeom& fg, int n_per, int 
     if (!fast) return 1;
     const int np = (fg.ntiles + 1) / 2;
     const int by_table = SC_MAX_GROUP / n_per;
-    const int by_fill = 2048 / std::max(1, np * (fg.Tx / 8));
+    const int by_fill = (ctx->batch_fill > 0 ? ctx->batch_fill : 2048) / std::max(1, np * (fg.Tx / 8));
     return std::max(1, std::min(std::min(by_table, by_fill), 32));
 }
 
