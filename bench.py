@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the other_configs block (C1, C2, C5 timed and verified after the headline)")
     ap.add_argument("--prof-stride", type=int, default=16)
+    ap.add_argument("--opt", default="", help="engine options for lab runs: name=value[,name=value...] (sc_set_option)")
     ap.add_argument("--shard", default="auto", choices=["auto", "orientations", "tiles"],
                     help="multi-rank sharding: 'orientations' = every rank the whole DEM and a chunk of the "
                          "orientation grid, records folded over RCCL (scarplet_amd.dist.OrientationMatcher); "
@@ -428,6 +429,10 @@ def timed_loop(step, ctx, a, dist, after_warmup=None):
         if dist is not None:
             dist.barrier()
     inner = step
+
+    for kv in (getattr(a, "opt", "") or "").split(","):
+        if kv:
+            ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 
     def step():
         # every step pays for its own curvature spectra: what an earlier step kept (option

@@ -176,8 +176,8 @@ int sc_clear_windows(sc_ctx* ctx);
  *   "batch"    1 (default): searches whose single orientation does not fill the
  *              chip send several orientations through every launch; 0: one
  *              orientation per launch sequence.  Results are bit-identical.
- *   "batch_fill"  column-pass workgroups a batched launch sequence aims at (0: the default, 2048):
- *              orientations per launch = batch_fill / (tile pairs x Tx / 8), at most 32 and what the
+ *   "batch_fill"  column-pass workgroups a batched launch sequence aims at (0: the default, 4096):
+ *              orientations per launch = batch_fill / (tile pairs x Tx / 8), at most 64 and what the
  *              row pass's tables hold.  Results are bit-identical whatever the batch.
  *   "y_gb"     memory budget of the column -> row pass hand-off buffers in GB
  *              (0: a quarter of the free memory, at most 32)
