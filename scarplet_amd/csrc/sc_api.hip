@@ -45,7 +45,7 @@ size_t sc_total_bytes(sc_ctx* c) {
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->norm_part, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
-                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats, &c->digest};
+                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats, &c->digest, &c->split_s, &c->split_a, &c->split_i};
     size_t s = 0;
     for (DevBuf* b : arr) s += b->cap;
     for (auto& w : c->windows) s += (size_t)w.h * w.wd * 5;
@@ -207,7 +207,7 @@ extern "C" void sc_destroy(sc_ctx* c) {
                      &c->best_snr, &c->best_amp, &c->best_id, &c->map_amp,
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->norm_part, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
-                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats, &c->digest};
+                     &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats, &c->digest, &c->split_s, &c->split_a, &c->split_i};
     for (DevBuf* b : arr) buf_free(*b);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp[k]);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp_in[k]);
@@ -411,6 +411,8 @@ extern "C" int sc_reset_best(sc_ctx* ctx) {
     SC_HIP(ctx, hipMemsetAsync(ctx->best_snr.p, 0, sizeof(float) * nc, ctx->stream));
     SC_HIP(ctx, hipMemsetAsync(ctx->best_amp.p, 0, sizeof(float) * nc, ctx->stream));
     SC_HIP(ctx, hipMemsetAsync(ctx->best_id.p, 0xFF, sizeof(uint32_t) * nc, ctx->stream));
+    // (scratch records of a split row pass: a share left by an earlier search must not score against the new record)
+    if (ctx->split_s.p) SC_HIP(ctx, hipMemsetAsync(ctx->split_s.p, 0, ctx->split_s.cap, ctx->stream));
     int rc = sc_ensure(ctx, ctx->res_stats, 2 * sizeof(unsigned long long));
     if (rc) return rc;
     SC_HIP(ctx, hipMemsetAsync(ctx->res_stats.p, 0, 2 * sizeof(unsigned long long), ctx->stream));

@@ -1689,6 +1689,13 @@ struct RowArgs {
     unsigned long long* stats;          // {wins, wins near the resolution floor} of the search (sc_get_resolution_stats)
     int xp;                             // paired ORIENTATIONS (k_inv_cols_sym, XP): G templates, one per orientation; norms entry id*np + pair
     int skip;                           // fast kernel: skip the templates whose window limits mask the workgroup's whole row
+    // fast kernel, SPLITK (small grids): the launch's transforms are dealt out over nsplit workgroups per row
+    // (blockIdx.z), part h > 0 folding into a scratch record of its own - planes (h - 1) * nc .. of s2 / a2 / i2,
+    // every valid cell written - that k_merge_split folds into the record in order afterwards
+    int nsplit;
+    size_t nc;
+    float *s2, *a2;
+    uint32_t* i2;
 };
 // One launch may serve several tile pairs (grid.y): pair = ra.pair + blockIdx.y,
 // its Y planes ystride planes further on.  More workgroups per launch fill the
@@ -1913,7 +1920,7 @@ __host__ __device__ constexpr size_t inv_rows_fast_lds() {
            sizeof(unsigned long long);                  // + the mask of the transforms this row takes part in
 }
 
-template <int TX, bool FULL, bool MAPS, bool PT>
+template <int TX, bool FULL, bool MAPS, bool PT, bool SPLITK = false>
 __global__ void __launch_bounds__(inv_rows_fast_threads<TX>(), SC_I2_WAVES)
 k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 RowArgs ra, Geom g, const TileDev* __restrict__ tiles,
@@ -2069,7 +2076,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         const int cj = col_of(c);
 #pragma unroll
         for (int part = 0; part < (PT ? 1 : 2); ++part) {
-            const bool ok = !MAPS && row_of(part) && cj >= 0 && cj < tile_of(part).vx;
+            const bool ok = !MAPS && row_of(part) && cj >= 0 && cj < tile_of(part).vx && !(SPLITK && blockIdx.z > 0);
             // (a cell outside the tile's valid extent holds +inf: nothing compares greater, so the
             //  templates whose window-limit rectangle covers the whole tile row need no range test
             //  per output - STATIC below; such a cell is never written back, its winner byte stays NONE)
@@ -2094,28 +2101,54 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         if (++fk == NGO) { fk = 0; fp += ostep; }
     };
     constexpr bool CAN_SKIP = !PT && !FULL && !MAPS;             // (else every transform is taken: the first fetch need not wait for the mask)
-    if constexpr (!CAN_SKIP) fetch();
+    int ob = 0, ok_ = 0;                                         // orientation / transform within it of the one in hand
+    // transform k of the launch: job k / NGO (the same pair's block of the next orientation), plane k % NGO of it
+    auto seek = [&](int k) {
+        ob = k / NGO; ok_ = k - ob * NGO; fk = ok_;
+        fp = src1 + ((size_t)ob * ra.pcj * ra.ystride + ok_) * plane * sizeof(float2);
+    };
+    // SPLITK: this workgroup's share [k0, k1) of the launch's transforms
+    int k0 = 0, k1 = ra.nb * NGO;
+    if constexpr (SPLITK) {
+        const int ng = k1;
+        k0 = (int)(((long long)ng * blockIdx.z) / ra.nsplit);
+        k1 = (int)(((long long)ng * (blockIdx.z + 1)) / ra.nsplit);
+    }
+    if constexpr (!CAN_SKIP) {
+        if constexpr (SPLITK) seek(k0);
+        fetch();
+    }
     lds_barrier();                                               // tables, scalars and the mask are in place
     unsigned long long am;                                       // transforms still to do (workgroup-uniform: scalar)
     {
         const uint32_t* mp = reinterpret_cast<const uint32_t*>(actm);
         am = ((unsigned long long)__builtin_amdgcn_readfirstlane(mp[1]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(mp[0]);
     }
-    if (am == 0) {                                               // every template masks this row
+    if constexpr (SPLITK) {
+        const unsigned long long hi_ = k1 >= 64 ? ~0ull : ((1ull << k1) - 1), lo_ = (1ull << k0) - 1;
+        am &= hi_ & ~lo_;
+    }
+    if (am == 0 && !(SPLITK && blockIdx.z > 0)) {                // every template masks this row
         if (sib_mine && id == 0) sib_publish(sib_mine, ra.sib.base + SIB_DONE);
         return;
     }
-    int cur = __builtin_ctzll(am);                               // the transform in hand (0 unless transforms are skipped)
+    int cur = am ? __builtin_ctzll(am) : -1;                     // the transform in hand (the first one unless transforms are skipped)
     am &= am - 1;
     if constexpr (CAN_SKIP) {
-        fp += (size_t)cur * plane * sizeof(float2);
-        fetch();
+        if constexpr (SPLITK) {
+            if (cur >= 0) {
+                seek(cur);
+                fetch();
+            }
+        } else {
+            fp += (size_t)cur * plane * sizeof(float2);          // (transforms are skipped in one-orientation launches only)
+            fetch();
+        }
     }
     if (sib_mine && id == 0) sib_publish(sib_mine, ra.sib.base + 1);
-    int ob = 0, ok_ = 0;                                         // orientation / transform within it of the one in hand
     bool sib_on = sib_mine != nullptr;
     uint32_t sib_seen = 0;
-    for (int gi_ = 0;; ++gi_) {                                  // gi_: transforms done so far
+    for (int gi_ = 0; !SPLITK || cur >= 0; ++gi_) {              // gi_: transforms done so far
         const int nxt = am ? __builtin_ctzll(am) : -1;           // the next one this row takes part in
         am &= am - 1;
         const bool more = nxt >= 0;
@@ -2282,6 +2315,26 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         // argmax is the transform's rounding noise.  Recovered from the record at the write-back
         // (d = (T1 / snr - eps) n), not in the template loop.
         int n_won = 0, n_near = 0;
+        if constexpr (SPLITK) {
+            if (blockIdx.z > 0) {
+                // a later share of the launch's transforms: its own record, EVERY valid cell written (zero where
+                // none of its templates scored), for k_merge_split to fold into the record in order
+                const size_t pl_ = (size_t)(blockIdx.z - 1) * ra.nc;
+#pragma unroll
+                for (int k = 0; k < NBEST; ++k) {
+                    const int c = PT ? k : k >> 1, part = PT ? 0 : (k & 1);
+                    const int cj = col_of(c);
+                    if (!(row_of(part) && cj >= 0 && cj < tile_of(part).vx)) continue;
+                    const uint32_t ix = (b_ix[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                    const bool won = ix != 0xFFu;
+                    const uint32_t o = 4u * (uint32_t)cj;
+                    at_bytes(ra.s2 + pl_ + off_of(part), o) = won ? b_snr[k] : 0.f;
+                    at_bytes(ra.a2 + pl_ + off_of(part), o) = won ? b_xr[k] * epi[EPI_FLOATS * (won ? ix : 0)] : 0.f;
+                    at_bytes(ra.i2 + pl_ + off_of(part), o) = won ? templ[ra.first + (won ? ix : 0)].id : SC_ID_NONE;
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NBEST; ++k) {
             const uint32_t ix = (b_ix[k >> 2] >> (8 * (k & 3))) & 0xFFu;
@@ -2308,6 +2361,26 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 atomicAdd(ra.stats + 1, (unsigned long long)n_near);
             }
         }
+    }
+}
+
+// The shares h = 1 .. nparts of a split row pass (k_inv_rows_fast, SPLITK) into the record, in order: a later
+// share's template takes a cell only where it scored strictly higher - what the one fold over all of the
+// launch's templates does (sc_fold).  Cells the launch did not cover hold what an earlier launch of the
+// search left there, already merged: nothing is greater than itself.
+__global__ void __launch_bounds__(256)
+k_merge_split(float* __restrict__ best_snr, float* __restrict__ best_amp, uint32_t* __restrict__ best_id,
+              const float* __restrict__ s2, const float* __restrict__ a2, const uint32_t* __restrict__ i2,
+              size_t nc, int nparts) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nc; i += (size_t)gridDim.x * 256) {
+        float bs = best_snr[i], ba = 0.f;
+        uint32_t bi = 0;
+        bool took = false;
+        for (int h = 0; h < nparts; ++h) {
+            const float s = s2[(size_t)h * nc + i];
+            if (s > bs) { bs = s; ba = a2[(size_t)h * nc + i]; bi = i2[(size_t)h * nc + i]; took = true; }
+        }
+        if (took) { best_snr[i] = bs; best_amp[i] = ba; best_id[i] = bi; }
     }
 }
 
@@ -2801,11 +2874,40 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             const int pair = pair0;
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
                        ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg, group,
-                       nb, np, pc, SibSync{nullptr, 0}, (unsigned long long*)ctx->res_stats.p, 0, row_skip ? 1 : 0};
+                       nb, np, pc, SibSync{nullptr, 0}, (unsigned long long*)ctx->res_stats.p, 0, row_skip ? 1 : 0,
+                       1, 0, nullptr, nullptr, nullptr};
             if (xp) {                            // to the row pass: ONE orientation of nb templates, in pairs
                 ra.G = nb; ra.nb = 1; ra.ystride = 1; ra.xp = 1;
             }
             dim3 gridr(fast ? ((rp_n + 7) / 8) * 16 : (rp_n + 1) / 2, pc);
+            // Small grids: a row workgroup folds the launch's transforms one after the other, and a 512 x 512
+            // search has 512 rows of ONE wave each for 1 024 SIMDs (BASELINE config C5: the row pass was a
+            // third of the search, a chain of single-wave transforms at half the issue rate).  There the
+            // transforms are dealt out over nsplit workgroups per row, each folding its share in order into a
+            // record of its own; k_merge_split folds the shares into the record in order.  Same winners, same
+            // ties (option "variant" 15: off).
+            int nsplit = 1;
+            if (fast && !to_maps && !full_masks && fg.Tx <= 1024 && ctx->variant != 15 && !(ctx->sib & 1)) {
+                const long long waves = (long long)rp_n * 2 * pc * (inv_rows_fast_threads<512>() * (fg.Tx / 512) / 64);
+                const int ngl = nb * (PTV ? (G + 1) / 2 : G);
+                while (nsplit < 4 && waves * nsplit * 2 <= 2048 && ngl / (nsplit * 2) >= 4) nsplit *= 2;
+            }
+            if (nsplit > 1) {
+                const size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
+                const size_t need = (size_t)3 * nc * sizeof(float);          // up to four shares: three scratch records
+                const bool fresh = ctx->split_s.cap < need;
+                int rc;
+                if ((rc = sc_ensure(ctx, ctx->split_s, need))) return rc;
+                if ((rc = sc_ensure(ctx, ctx->split_a, need))) return rc;
+                if ((rc = sc_ensure(ctx, ctx->split_i, need))) return rc;
+                if (fresh) SC_HIP(ctx, hipMemsetAsync(ctx->split_s.p, 0, need, ctx->stream));   // (sc_reset_best clears it from then on)
+                ra.nsplit = nsplit;
+                ra.nc = nc;
+                ra.s2 = (float*)ctx->split_s.p;
+                ra.a2 = (float*)ctx->split_a.p;
+                ra.i2 = (uint32_t*)ctx->split_i.p;
+                gridr.z = nsplit;
+            }
             if (fast && (ctx->sib & 1)) {
                 int rc = sib_slots(ctx, (size_t)gridr.x * gridr.y, ra.sib);
                 if (rc) return rc;
@@ -2834,7 +2936,20 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     }
 #define LAUNCH_FAST(T, FULLV)                                                  \
     { if (to_maps) LAUNCH_FAST2(T, FULLV, true) else LAUNCH_FAST2(T, FULLV, false) }
-            if (fast) {
+#define LAUNCH_SPLIT(T)                                                        \
+    {                                                                          \
+        int rc = set_lds(ctx, k_inv_rows_fast<T, false, false, PTV, true>, inv_rows_fast_lds<T>()); \
+        if (rc) return rc;                                                     \
+        hipLaunchKernelGGL((k_inv_rows_fast<T, false, false, PTV, true>), gridr,   \
+                           dim3(inv_rows_fast_threads<T>()), inv_rows_fast_lds<T>(), FAST_ARGS); \
+        const unsigned mb_ = (unsigned)std::min<size_t>((ra.nc + 255) / 256, 2048); \
+        hipLaunchKernelGGL(k_merge_split, dim3(mb_), dim3(256), 0, ctx->stream, (float*)ctx->best_snr.p, \
+                           (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p, (const float*)ra.s2,   \
+                           (const float*)ra.a2, (const uint32_t*)ra.i2, ra.nc, nsplit - 1);            \
+    }
+            if (nsplit > 1) {
+                if (fg.Tx == 512) LAUNCH_SPLIT(512) else LAUNCH_SPLIT(1024)
+            } else if (fast) {
                 switch (fg.Tx) {
                     case 512: if (full_masks) LAUNCH_FAST(512, true) else LAUNCH_FAST(512, false) break;
                     case 1024: if (full_masks) LAUNCH_FAST(1024, true) else LAUNCH_FAST(1024, false) break;
@@ -2848,6 +2963,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
 #undef LAUNCH_ROWS
 #undef LAUNCH_FAST
 #undef LAUNCH_FAST2
+#undef LAUNCH_SPLIT
 #undef ROW_ARGS
 #undef FAST_ARGS
             sc_prof_end(ctx);

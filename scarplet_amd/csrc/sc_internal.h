@@ -116,6 +116,7 @@ struct sc_ctx {
     int batch_fill = 0;        // sc_set_option "batch_fill": column workgroups a batched launch aims at (0: 4096)
     double y_gb = 0.0;         // sc_set_option "y_gb": memory budget of the I1 -> I2 hand-off (0: automatic)
     int sib = 0;               // sc_set_option "sib": sibling rendezvous, bit 0 row pass, bit 1 column pass (sc_fft.hip SibSync)
+    DevBuf split_s, split_a, split_i;   // scratch records of a split row pass (k_inv_rows_fast SPLITK, k_merge_split)
     DevBuf sib_buf;
     uint32_t sib_epoch = 0;
     int dbg = 0;               // timing-only ablation bits; only an SC_ABLATE build reads them (tools/ablate.sh)

@@ -489,3 +489,36 @@ def test_paired_orientations_against_oracle(gpu_ctx, kind, n_ang):
     report("paired orientations %s x %d" % (kind, n_ang), chk, "fft")
     assert chk["n_bad"] == 0, chk
     assert chk["exact_frac"] >= EXACT_MIN, chk
+
+
+def test_split_row_pass_is_bit_identical():
+    """Small grids deal a launch's transforms out over several row workgroups (k_inv_rows_fast SPLITK,
+    k_merge_split; option variant=15 switches it off): every share folds in order into a record of its
+    own and the shares are merged in order - the record must equal the one-workgroup fold in every bit,
+    ties included (a noise-free surface has many)."""
+    gc = dem_fixture("dem_grandcanyon.npz")
+    cz = dem_fixture("dem_carrizo.npz")
+    from scipy.special import erf
+    y, x = np.mgrid[-256:256, -256:256].astype(float)
+    flat = (-erf((-x * np.sin(1.1) + y * np.cos(1.1)) / (2 * np.sqrt(10.0))) + 0.01 * x).astype(np.float32)
+    lim = 17 * np.pi / 180
+    cases = [(grid(gc[0], gc[1], gc[2]), sl.Channel, 10.0, [0.1], _plan.angle_grid()),                 # C5: paired orientations
+             (grid(gc[0], gc[1], gc[2]), sl.Channel, 20.0, [0.05, 0.1, 0.2], _plan.angle_grid()[::3]),  # paired templates
+             (grid(cz[0], cz[1], cz[2]), sl.Scarp, 100.0, [10.0], _plan.angle_grid(-lim, lim)),        # C1: a tile pair, 35 jobs
+             (synthetic.synthetic_scarp(700, seed=41), sl.Scarp, 12.0, [1.0, 3.0, 10.0], _plan.angle_grid()[::5]),
+             (grid(flat, 1.0), sl.Scarp, 20.0, [3.0, 10.0, 30.0], _plan.angle_grid()[::4])]            # exact ties
+    for (g, cls, scale, params, angles) in cases:
+        out = []
+        for variant in (0, 15):
+            ctx = sl._lib.Context(0)
+            ctx.set_option("variant", variant)
+            m = sl.Matcher(g, ctx=ctx)
+            ctx.profile(1)
+            m.search(cls, scale, params, angles, method="fft")
+            out.append((m.ctx.get_best(), ctx.profile_get()["k_inv_rows"][0], m.plan))
+            ctx.close()
+        (b0, n0, plan), (b1, n1, _) = out
+        print("split row pass:", plan, "row-pass launches", n0, n1)
+        for a, b, name in zip(b0, b1, ("amp", "snr", "id")):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (str(plan), name, int((a != b).sum()))
+        assert (b0[1] > 0).any()
