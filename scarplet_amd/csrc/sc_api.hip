@@ -500,8 +500,18 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
 
     // Orientation runs: consecutive templates with equal (cc, sc2, ss) share one curvature
     // plane (at most CHUNK of them per run).
-    std::vector<TemplDev> h(n);
-    std::vector<double> sums(2 * (size_t)n, 0.0), wl1(n, 0.0);
+    // (the context's own vectors: the uploads below are asynchronous and nothing waits for them before
+    //  the launches; the stream was drained at the end of the previous call, so they are free to reuse -
+    //  after an sc_match_async without sc_sync it is drained here)
+    if (ctx->async_in_flight) {
+        SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->async_in_flight = false;
+    }
+    std::vector<TemplDev>& h = ctx->h_templ;
+    std::vector<double>&sums = ctx->h_sums, &wl1 = ctx->h_wl1;
+    h.assign(n, TemplDev{});
+    sums.assign(2 * (size_t)n, 0.0);
+    wl1.assign(n, 0.0);
     struct Run { int first, n, parity; bool full, long_runs; };
     std::vector<Run> runs;
     for (int i = 0; i < n;) {
@@ -644,7 +654,6 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
                                hipMemcpyHostToDevice, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(ctx->wl1.p, wl1.data(), sizeof(double) * n,
                                hipMemcpyHostToDevice, ctx->stream));
-    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));   // h / sums leave scope below
     ctx->last_batch = n;
 
     double cur[3] = {0, 0, 0};
@@ -711,13 +720,16 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
 }
 
 extern "C" int sc_match_async(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* plan) {
-    return match_impl(ctx, t, n, plan, false);
+    int rc = match_impl(ctx, t, n, plan, false);
+    if (ctx) ctx->async_in_flight = true;
+    return rc;
 }
 
 extern "C" int sc_sync(sc_ctx* ctx) {
     if (!ctx) return SC_ERR_INVALID;
     SC_HIP(ctx, hipSetDevice(ctx->device));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->async_in_flight = false;
     sc_prof_collect(ctx);
     return SC_OK;
 }

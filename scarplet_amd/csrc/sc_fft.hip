@@ -2443,9 +2443,18 @@ int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group, in
         }
         h[k] = t;
     }
-    if ((rc = sc_ensure(ctx, ctx->tiles, sizeof(TileDev) * h.size()))) return rc;
-    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    SC_HIP(ctx, hipMemcpy(ctx->tiles.p, h.data(), sizeof(TileDev) * h.size(), hipMemcpyHostToDevice));
+    {
+        // (uploaded only when it differs from what the device holds: a multi-scale job plans the same
+        //  tiles search after search; the host copy lives in the context, the upload is asynchronous)
+        const size_t bytes = sizeof(TileDev) * h.size();
+        const void* before = ctx->tiles.p;
+        if ((rc = sc_ensure(ctx, ctx->tiles, bytes))) return rc;
+        if (before != ctx->tiles.p || ctx->h_tiles.size() != bytes || memcmp(ctx->h_tiles.data(), h.data(), bytes) != 0) {
+            SC_HIP(ctx, hipStreamSynchronize(ctx->stream));      // (h_tiles may still be the source of a copy in flight)
+            ctx->h_tiles.assign((const unsigned char*)h.data(), (const unsigned char*)h.data() + bytes);
+            SC_HIP(ctx, hipMemcpyAsync(ctx->tiles.p, ctx->h_tiles.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
     size_t plane = (size_t)fg.Ty * fg.Tx * sizeof(float2);
     size_t nblk = std::max((size_t)2 * np * nb, (size_t)n_templ_chunk);
     if ((rc = sc_ensure(ctx, ctx->blk, plane * nblk))) return rc;

@@ -109,6 +109,12 @@ struct sc_ctx {
     int fft_pb = 1;            // tile pairs per inverse launch (fft_prepare)
     DevBuf blk, uc, uc2, vh, wh, mh, yw, ym, tiles;
     std::vector<WindowSlot> windows;
+    // host copies of what a search uploads asynchronously (descriptors, sums, tile list): they must outlive
+    // the copy, so they live here - no stream synchronisation between the upload and the launches
+    std::vector<TemplDev> h_templ;
+    std::vector<double> h_sums, h_wl1;
+    std::vector<unsigned char> h_tiles;  // the tile list the device holds (bytes), to skip its re-upload
+    bool async_in_flight = false;        // an sc_match_async has not been followed by sc_sync yet
     int last_batch = 0;
     float kappa = 4.f;         // float32 resolution floor of the FFT path, in units of eps (sc_set_option "kappa")
     int variant = 0;           // sc_set_option "variant": alternative kernel paths kept for cross-checks
