@@ -46,6 +46,11 @@ struct TileDev {
     int i0, j0, vy, vx, gi0, gj0;
 };
 
+#ifndef SC_I1_TWTAB
+#define SC_I1_TWTAB 0      // 1: the wave-per-column kernels read all fifteen twiddles of a set from LDS tables
+#endif
+
+
 // ---------------------------------------------------------------------------
 // In-LDS FFT of 4 lines of length T (complex float32).
 //
@@ -429,10 +434,43 @@ __device__ __forceinline__ void twiddle16(const pk::v2 (&v)[16], const float2 (&
     }
 }
 
-// butterflies of the set (tt) in the stage (R, LST) and store to `line`
-template <int T, int R, int LST, bool INV>
+// The fifteen twiddles w^k, k = 1 .. 15, of a radix-16 set as twiddle16 forms them from the four bases -
+// the same products in the same order, so that a table of them gives the same bits as forming them in place.
+__device__ __forceinline__ void twiddle16_expand(const float2 (&w)[4], pk::v2 (&wk)[16]) {
+    using pk::v2;
+    const v2 w1 = v2{w[0].x, w[0].y}, w2 = v2{w[1].x, w[1].y}, w4 = v2{w[2].x, w[2].y}, w8 = v2{w[3].x, w[3].y};
+    wk[0] = v2{1.f, 0.f};
+    wk[8] = w8;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        v2 x = (k & 1) ? w1 : v2{1.f, 0.f};
+        if (k == 2 || k == 6) x = w2;
+        if (k == 3 || k == 7) x = pk::cmul(w1, w2);
+        if (k == 4) x = w4;
+        if (k >= 5) x = pk::cmul(x, w4);
+        wk[k] = x;
+        wk[k + 8] = pk::cmul(x, w8);
+    }
+}
+// twiddle16 with the fifteen twiddles read from a table (get(k), k = 1 .. 15) instead of formed from four bases
+template <bool INV, typename GET, typename PUT>
+__device__ __forceinline__ void twiddle16_tab(const pk::v2 (&v)[16], GET get, PUT put) {
+    using pk::v2;
+    auto tw = [](v2 a, v2 wk) { return INV ? pk::cmulc(a, wk) : pk::cmul(a, wk); };
+    put(0, v[pk::B<16, INV>::pos(0)]);
+    put(8, tw(v[pk::B<16, INV>::pos(8)], get(8)));
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        put(k, tw(v[pk::B<16, INV>::pos(k)], get(k)));
+        put(k + 8, tw(v[pk::B<16, INV>::pos(k + 8)], get(k + 8)));
+    }
+}
+
+// butterflies of the set (tt) in the stage (R, LST) and store to `line`; TAB: the twiddles of a radix-16 stage
+// come from a table of all fifteen (wtab[k * wstride], k = 1 .. 15) instead of the four bases w
+template <int T, int R, int LST, bool INV, bool TAB = false>
 __device__ __forceinline__ void set_compute_store(float2* line_, int tt, float2 (&a)[16],
-                                                  const float2 (&w)[4]) {
+                                                  const float2 (&w)[4], const float2* wtab = nullptr, int wstride = 0) {
     using pk::v2;
     constexpr int S = T / 16;
     constexpr int NB = 16 / R;
@@ -463,6 +501,8 @@ __device__ __forceinline__ void set_compute_store(float2* line_, int tt, float2 
         if constexpr (LAST) {
 #pragma unroll
             for (int m = 0; m < R; ++m) put(m, v[pk::B<R, INV>::pos(m)]);
+        } else if constexpr (TAB) {
+            twiddle16_tab<INV>(v, [&](int k) { const float2 x = wtab[k * wstride]; return v2{x.x, x.y}; }, put);
         } else {
             twiddle16<INV>(v, w, put);
         }
@@ -1406,7 +1446,7 @@ template <int TY>
 __host__ __device__ constexpr int w8_line() { return TY + TY / 16 + 4; }   // lines 8 banks apart: the store pass reads 8 lines x 2 cells
 template <int TY>
 __host__ __device__ constexpr size_t w8_lds() {          // eight lines + the twiddle bases of stages 1 and 2
-    return ((size_t)8 * w8_line<TY>() + 4 * (TY / 16) + 4 * (TY / 256) + SC_MAX_GROUP) * sizeof(float2);   // + the stored row range per transform
+    return ((size_t)8 * w8_line<TY>() + (SC_I1_TWTAB ? 16 : 4) * (TY / 16 + TY / 256) + SC_MAX_GROUP) * sizeof(float2);   // + the stored row range per transform
 }
 
 template <int TY, bool MIRROR, bool PT, int NC>
@@ -1449,7 +1489,7 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
     // compiler lose count of the coefficient prefetch in flight - every use of a prefetched value
     // then waited for ALL outstanding loads (s_waitcnt vmcnt(0): 70 of them in the four-wave
     // paired-template kernel instead of 8, 1 416 us per C2 launch instead of 878).
-    int2* const rng = reinterpret_cast<int2*>(sm + NC * LINE + 4 * S + 4 * (S / 16));
+    int2* const rng = reinterpret_cast<int2*>(sm + NC * LINE + (SC_I1_TWTAB ? 16 : 4) * (S + S / 16));
     {
         const int NGt = PT ? (G + 1) / 2 : G;
         const int gi_ = threadIdx.x;
@@ -1483,9 +1523,26 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
     // 1, 2, 4, 8) in an LDS table behind the lines, [m][tt] and [m][tt >> 4]: 64 registers of
     // parked spectrum leave no room for them
     float2* t1 = sm + NC * LINE;
+#if SC_I1_TWTAB
+    // all fifteen twiddles per set, [k][tt] and [k][tt >> 4] (entry k = 0 unused): forming w^3, w^5 .. w^15 from the
+    // four bases in every transform was 88 of its 640 packed instructions.  The same products in the same order
+    // (twiddle16_expand): the same bits.
+    float2* t2 = t1 + 16 * S;
+    for (int i = threadIdx.x; i < S + S / 16; i += 64 * NC) {
+        const bool st2 = i >= S;
+        const int e = st2 ? (i - S) << 4 : i, n = st2 ? S / 16 : S;
+        float2* t = st2 ? t2 + (i - S) : t1 + i;
+        const float2 wb[4] = {tw[e], tw[2 * e], tw[4 * e], tw[8 * e]};
+        pk::v2 wk[16];
+        twiddle16_expand(wb, wk);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t[k * n] = make_float2(wk[k].x, wk[k].y);
+    }
+#else
     float2* t2 = t1 + 4 * S;
     for (int i = threadIdx.x; i < 4 * S; i += 64 * NC) t1[i] = tw[(i % S) << (i / S)];
     for (int i = threadIdx.x; i < 4 * (S / 16); i += 64 * NC) t2[i] = tw[((i % (S / 16)) << 4) << (i / (S / 16))];
+#endif
     auto tw_of = [&](const float2* t, int n, int idx, float2 (&wq)[4]) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) wq[m] = t[m * n + idx];
@@ -1548,8 +1605,12 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
                     a1[j] = PT ? make_float2(xp[k].x * c[k] - xp[k].y * c2[k], xp[k].x * c2[k] + xp[k].y * c[k])
                                : make_float2(c[k] * xp[k].x, c[k] * xp[k].y);
                 }
+#if SC_I1_TWTAB
+                set_compute_store<TY, 16, 0, true, true>(line, lt + 64 * u, a1, wq, t1 + lt + 64 * u, S);
+#else
                 tw_of(t1, S, lt + 64 * u, wq);
                 set_compute_store<TY, 16, 0, true>(line, lt + 64 * u, a1, wq);
+#endif
             }
             // next coefficients: all of them now - or, two planes of them (PT) and two sets per lane,
             // the second set's only once the transform's registers are free again
@@ -1561,8 +1622,12 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
             for (int u = 0; u < U; ++u) set_load<TY>(line, lt + 64 * u, a[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+#if SC_I1_TWTAB
+                set_compute_store<TY, 16, 4, true, true>(line, lt + 64 * u, a[u], wq, t2 + ((lt + 64 * u) >> 4), S / 16);
+#else
                 tw_of(t2, S / 16, (lt + 64 * u) >> 4, wq);
                 set_compute_store<TY, 16, 4, true>(line, lt + 64 * u, a[u], wq);
+#endif
             }
             asm volatile("" ::: "memory");
             if constexpr (TY > 256) {
@@ -1641,26 +1706,6 @@ k_inv_cols_w4(const float2* __restrict__ uc, const float2* __restrict__ uc2,
     else
         inv_cols_w8_body<TY, false, PT, 4>(i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
                                            rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid, tl);
-}
-
-// Experiment (option "variant" 14): the four-column form with TWO workgroups of four waves per CU instead
-// of one workgroup of eight - the same waves per SIMD, but the two workgroups meet at their own barriers,
-// so one's store pass can run under the other's butterflies; the price is 64-byte store pieces.
-template <int TY>
-__global__ void __launch_bounds__(256, 2)
-k_inv_cols_w4x2(const float2* __restrict__ uc, const float2* __restrict__ uc2,
-                const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
-                int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
-                int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
-                float2* __restrict__ ym, int ystride, int np, int pcj, int tstride,
-                const TileDev* __restrict__ tiles, int py_valid, const TemplDev* __restrict__ tl) {
-    const int j = blockIdx.x, i = ((j >> 4) << 3) | (j & 7);
-    if ((j >> 3) & 1)
-        inv_cols_w8_body<TY, true, false, 4>((Tx >> 2) - 1 - i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
-                                             rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid, tl);
-    else
-        inv_cols_w8_body<TY, false, false, 4>(i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
-                                              rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid, tl);
 }
 
 // ---- I2: inverse row FFT -> epilogue -> fold ---------------------------------
@@ -2828,17 +2873,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             hipLaunchKernelGGL((k_inv_cols<T, true>), dim3(nhi, nb * pcc), dim3(fft_threads(T)), \
                                inv_cols_lds<T>(), COL_ARGS(nlo));              \
     }
-            if (ctx->variant == 14 && w8 && !PTV && fg.Ty == 2048) {
-                const size_t lds4 = ((size_t)4 * w8_line<2048>() + 4 * (2048 / 16) + 4 * (2048 / 256) + SC_MAX_GROUP) * sizeof(float2);
-                int rc = set_lds(ctx, k_inv_cols_w4x2<2048>, lds4);
-                if (rc) return rc;
-                hipLaunchKernelGGL((k_inv_cols_w4x2<2048>), dim3(fg.Tx / 4, nb * pcc), dim3(256), lds4, ctx->stream,
-                                   (const float2*)ctx->uc.p + ctx->uc_off, (const float2*)ctx->uc2.p + ctx->uc_off,
-                                   (const float*)ctx->wh.p, (const float*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo, rp_hi,
-                                   (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group,
-                                   np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py,
-                                   row_skip ? (const TemplDev*)ctx->templ.p + first : nullptr);
-            } else if (xp) {
+            if (xp) {
                 // paired orientations: job j = orientations 2j, 2j+1; plane j of Y; tstride carries nb
                 const size_t ldsx = inv_cols_lds<512>() + (size_t)4 * 512 * sizeof(float2);
                 int rc = set_lds(ctx, k_inv_cols_symx<512, PTV, PTV>, ldsx);
