@@ -147,8 +147,11 @@ class Plan(object):
             # transform 1.5 x the cells and are still faster: 33.9 ms against 37.3 at C2
             # (tools/plan_lab.py, profiles/r04_c2_plans.txt).
             if self.nty * self.ntx == 1 and self.Ty == 2048 and t_max >= 2048:
-                alt = choose_tile(cy1 - cy0, pmax - pmin, ny, False, 1024)
-                if alt[0] == 1024 and alt[2] * 1024 <= 1.6 * self.Ty:
+                try:
+                    alt = choose_tile(cy1 - cy0, pmax - pmin, ny, False, 1024)
+                except ValueError:                  # (a support no 1024-tile holds)
+                    alt = None
+                if alt is not None and alt[0] == 1024 and alt[2] * 1024 <= 1.6 * self.Ty:
                     self.Ty, self.Vy, self.nty, self.circ_y = alt
             if self.circ_y:
                 self.Py = self.Ty // 2

@@ -80,3 +80,22 @@ def test_search_grids_match_reference():
     assert len(_plan.angle_grid()) == 181 and len(_plan.age_grid()) == 35
     assert np.array_equal(_plan.angle_grid(-0.4, 0.4), orc.angle_grid(-0.4, 0.4))
     assert np.array_equal(_plan.age_grid(), orc.age_grid())
+
+
+def test_single_tile_of_column_length_2048_is_replanned():
+    """One tile of column length 2048 (BASELINE config C2) would send every template through the paired-template
+    four-wave column pass; the planner takes three tiles of 1024 rows instead (profiles/r04_c2_plans.txt) - as long
+    as that costs at most 1.6 x the cells and 1024 is the tile the axis would choose below 2048."""
+    bbox = (-154, 153, -154, 153)
+    p = _plan.Plan(2048, 2048, (0, 2048, 0, 2048), bbox)
+    assert (p.Ty, p.nty, p.circ_y, p.Vy) == (1024, 3, False, 1024 - 307) and (p.Tx, p.ntx, p.circ_x) == (2048, 1, True)
+    assert p.nty * p.Vy >= 2048 and p.Py == bbox[1] and p.Qx == 1024
+    # small supports (512 would be the axis' choice) and supports 1024 cannot hold keep the circular tile
+    for bb in ((-30, 30, -30, 30), (-600, 600, -154, 153)):
+        q = _plan.Plan(2048, 2048, (0, 2048, 0, 2048), bb)
+        assert (q.Ty, q.nty, q.circ_y) == (2048, 1, True), q
+    # several tiles already: nothing to re-plan
+    r = _plan.Plan(10000, 10000, (0, 10000, 0, 10000), bbox)
+    assert (r.Ty, r.Tx, r.nty, r.ntx) == (2048, 2048, 6, 6)
+    # the cap of an explicit t_max is respected
+    assert _plan.Plan(2048, 2048, (0, 2048, 0, 2048), bbox, t_max=1024).Ty == 1024
