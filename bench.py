@@ -239,14 +239,14 @@ def verify_window(pool, res, g, kind, scale, params, angles, plan, method="fft")
     sub = tuple(np.asarray(r)[win[0]:win[1], win[2]:win[3]] for r in res)
     P = orc.PARITY
     chk = orc.check_fold(sub, a_st.reshape(T, h, wd), s_st.reshape(T, h, wd), np.repeat(params, len(angles)),
-                         np.tile(angles, len(params)), tie_rtol=orc.tie_window(method),
+                         np.tile(angles, len(params)), tie_rtol=orc.tie_window(method, kind),
                          amp_tol=(P["amp"][0], P["amp"][1] * np.max(np.abs(a_st))),
                          snr_tol=(P["snr"][0], P["snr"][1] * np.max(s_st)))
     return {"ok": chk["n_bad"] == 0, "window": list(win), "templates": T, "cells": chk["n"], "bad": chk["n_bad"],
             "cells_off_the_oracle_argmax": chk["n_inexact"], "cells_below_abs_tolerance": chk["n_below_only"],
             "exact_argmax_frac": round(chk["exact_frac"], 6), "near_tie_cells": chk["n_tie"],
             "max_rel_snr_err": float("%.3g" % chk["snr_err"]), "max_rel_amp_err": float("%.3g" % chk["amp_err"]),
-            "tie_rtol": orc.tie_window(method), "oracle_s": round(time.time() - t0, 1)}
+            "tie_rtol": orc.tie_window(method, kind), "oracle_s": round(time.time() - t0, 1)}
 
 
 def so_sha256():

@@ -525,8 +525,12 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                 }
             }
             __syncthreads();
+            // (the span of row a + 1 is fetched while row a is worked on: read where it is needed, every
+            //  row of a thin window - a handful of groups - began with a scalar-load round trip)
+            int4 sp_next = spans[span_off + a0];
             for (int a = 0; a < na; ++a) {
-                const int4 sp = spans[span_off + a0 + a];         // (first group, groups, s, e): wave-uniform
+                const int4 sp = sp_next;                          // (first group, groups, s, e): wave-uniform
+                sp_next = spans[span_off + a0 + min(a + 1, na - 1)];
                 const int ng = sp.y;
                 if (ng == 0) continue;
                 const float2* wrow = dw + (size_t)(a0 + a) * P + 4 * sp.x;

@@ -26,7 +26,7 @@ def check_window(res, z, kind, scale, ages, angles, win, margin, pool):
     sub = tuple(np.asarray(r)[i0:i1, j0:j1] for r in res)
     return orc.check_fold(sub, a_st.reshape(T, i1 - i0, j1 - j0), s_st.reshape(T, i1 - i0, j1 - j0),
                           np.repeat(ages, len(angles)), np.tile(angles, len(ages)),
-                          tie_rtol=P["tie_rtol"], amp_tol=(P["amp"][0], P["amp"][1] * np.max(np.abs(a_st))),
+                          tie_rtol=orc.tie_window("fft", kind), amp_tol=(P["amp"][0], P["amp"][1] * np.max(np.abs(a_st))),
                           snr_tol=(P["snr"][0], P["snr"][1] * np.max(s_st)))
 
 
@@ -60,7 +60,7 @@ def test_bench_plan_windows_against_oracle(gpu_ctx, oracle_pool):
         assert chk["n_inexact"] == 0, (name, chk["n_inexact"])       # the benchmark DEM has a noise floor: exact, as an integer
         worst = max(worst, chk["snr_err"])
     # the tie window is meant to be twice the measured error
-    assert worst <= 0.5 * P["tie_rtol"], worst
+    assert worst <= 0.5 * orc.tie_window("fft", orc.SCARP), worst
 
 
 def test_c3_full_grid_windows_against_oracle(gpu_ctx, oracle_pool):
@@ -101,7 +101,7 @@ def test_c3_full_grid_windows_against_oracle(gpu_ctx, oracle_pool):
         worst, cells, ties = max(worst, chk["snr_err"]), cells + chk["n"], ties + chk["n_tie"]
     print("C3 full grid: %d cells x %d templates, 0 cells off the oracle's argmax (%d with a second candidate inside "
           "the tie window), largest SNR error %.2e" % (cells, len(ages) * len(angles), ties, worst))
-    assert worst <= 0.5 * P["tie_rtol"], worst
+    assert worst <= 0.5 * orc.tie_window("fft", orc.SCARP), worst
     m.search(sl.Scarp, 100, ages, angles, method="fft")
     b = m.ctx.get_best()
     same = [bool(np.array_equal(x.view(np.uint32), y.view(np.uint32))) for x, y in zip(b, best0)]

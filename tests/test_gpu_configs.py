@@ -72,7 +72,7 @@ def test_c5_grandcanyon_channel_five_scales(gpu_ctx):
             res = m.search(WT.Channel, scale, [0.1], angles, method=method).result()
             chk = orc.check_fold(res, a_st.reshape(T, *z.shape), s_st.reshape(T, *z.shape),
                                  np.repeat([0.1], T), angles,
-                                 tie_rtol=orc.tie_window(method), amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
+                                 tie_rtol=orc.tie_window(method, orc.RICKER), amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
                                  snr_tol=(SNR_RTOL, SNR_ATOL * np.max(s_st)))
             report("C5 scale %g %s" % (scale, method), chk, method)
             assert chk["n_bad"] == 0, (scale, method, chk["n_bad"])
@@ -149,7 +149,7 @@ def test_c2_windows_against_all_910_templates(gpu_ctx, oracle_pool):
         sub = tuple(np.asarray(r)[i0:i1, j0:j1] for r in res)
         chk = orc.check_fold(sub, a_st.reshape(T, i1 - i0, j1 - j0), s_st.reshape(T, i1 - i0, j1 - j0),
                              np.repeat(ages, len(angles)), np.tile(angles, len(ages)),
-                             tie_rtol=orc.tie_window("fft"), amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
+                             tie_rtol=orc.tie_window("fft", orc.SCARP), amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
                              snr_tol=(SNR_RTOL, SNR_ATOL * np.max(s_st)))
         report("C2 all 910 templates, window %s" % name, chk, "fft")
         assert chk["n_bad"] == 0, (name, chk["n_bad"])

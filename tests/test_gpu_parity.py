@@ -44,7 +44,8 @@ def report(name, chk, method="fft", window=None, noise_floor=True, max_inexact=0
     several hundred thousand whose two best templates lie closer together, in the oracle's own
     float64 SNRs, than the float32 FFT convolution's measured error on that DEM - `gap` in the
     line); the real-space path is exact on the same inputs."""
-    window = orc.tie_window(method) if window is None else window
+    # (the window the check itself ran with - per path AND per template family, oracle.tie_window)
+    window = chk.get("tie_rtol", orc.tie_window(method)) if window is None else window
     print("fold %-44s bad=%d inexact=%d (gap %.1e) below=%d exact=%.6f strict=%d tie=%d of %d snr_err=%.2e amp_err=%.2e (window %.0e)"
           % (name, chk["n_bad"], chk["n_inexact"], chk["inexact_gap"], chk["n_below_only"], chk["exact_frac"], chk["n_strict"],
              chk["n_tie"], chk["n"], chk["snr_err"], chk["amp_err"], window))
@@ -168,7 +169,7 @@ def fold_check(res, z, dx, dy, kind, scale, params, angles, method="fft"):
     ages = np.repeat(np.asarray(params, float), len(angles))
     angs = np.tile(np.asarray(angles, float), len(params))
     return orc.check_fold(res, a_st.reshape(T, ny, nx), s_st.reshape(T, ny, nx), ages, angs,
-                          tie_rtol=orc.tie_window(method), amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
+                          tie_rtol=orc.tie_window(method, kind), amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
                           snr_tol=(SNR_RTOL, SNR_ATOL * np.max(s_st)))
 
 

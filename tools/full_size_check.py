@@ -42,15 +42,15 @@ for name, (i0, j0) in list(wins.items())[:k]:
     a_st, s_st = orc.snr_stack_window(g._griddata, 1.0, 1.0, orc.SCARP, 100, ages, angles, win, 160, pool=pool)
     sub = tuple(np.asarray(r)[win[0]:win[1], win[2]:win[3]] for r in res)
     chk = orc.check_fold(sub, a_st.reshape(T, w, w), s_st.reshape(T, w, w), np.repeat(ages, len(angles)),
-                         np.tile(angles, len(ages)), tie_rtol=orc.tie_window("fft"),
+                         np.tile(angles, len(ages)), tie_rtol=orc.tie_window("fft", orc.SCARP),
                          amp_tol=(P["amp"][0], P["amp"][1] * np.max(np.abs(a_st))), snr_tol=(P["snr"][0], P["snr"][1] * np.max(s_st)))
     print("window %-28s (%5d, %5d)  bad=%d exact=%.4f strict=%d tie=%d of %d  snr_err=%.2e amp_err=%.2e  (oracle %.0f s)"
           % (name, i0, j0, chk["n_bad"], chk["exact_frac"], chk["n_strict"], chk["n_tie"], chk["n"], chk["snr_err"], chk["amp_err"],
              time.time() - t1), flush=True)
     assert chk["n_bad"] == 0, name
     worst, exact_min, cells = max(worst, chk["snr_err"]), min(exact_min, chk["exact_frac"]), cells + chk["n"]
-print("%d cells x %d templates: exact argmax >= %.4f, largest SNR error %.2e (window of the FFT path %.0e)" % (cells, T, exact_min, worst, orc.tie_window("fft")))
-assert worst <= 0.5 * orc.tie_window("fft")
+print("%d cells x %d templates: exact argmax >= %.4f, largest SNR error %.2e (window of the FFT path %.0e)" % (cells, T, exact_min, worst, orc.tie_window("fft", orc.SCARP)))
+assert worst <= 0.5 * orc.tie_window("fft", orc.SCARP)
 pool.terminate()
 for rep in range(3):
     m.search(sl.Scarp, 100, ages, angles, method="fft")
