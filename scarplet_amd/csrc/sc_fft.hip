@@ -1965,8 +1965,13 @@ __host__ __device__ constexpr size_t inv_rows_fast_lds() {
            sizeof(unsigned long long);                  // + the mask of the transforms this row takes part in
 }
 
+// (FULL - error masks, per-cell masks of generic plugins - carries the mask test's float64 coordinates: at four
+//  waves per SIMD it spilled 76 - 92 B per lane inside the template loop; SC_I2_WAVES_FULL waves, 168 registers)
+#ifndef SC_I2_WAVES_FULL
+#define SC_I2_WAVES_FULL 3
+#endif
 template <int TX, bool FULL, bool MAPS, bool PT, bool SPLITK = false>
-__global__ void __launch_bounds__(inv_rows_fast_threads<TX>(), SC_I2_WAVES)
+__global__ void __launch_bounds__(inv_rows_fast_threads<TX>(), (FULL && !MAPS) ? SC_I2_WAVES_FULL : SC_I2_WAVES)
 k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 RowArgs ra, Geom g, const TileDev* __restrict__ tiles,
                 const TemplDev* __restrict__ templ, const double* __restrict__ sums,
