@@ -1406,7 +1406,7 @@ k_inv_cols_sym(const float2* __restrict__ uc, const float2* __restrict__ uc2,
 // that the fourth column is shared too, is 13 % slower: each XCD then writes a 2-KB stripe of
 // every row and loads a few L2 channels only.)  profiles/r02_i1_xcd_paired.txt
 template <int TY, bool PT, bool XP = false>
-__global__ void __launch_bounds__(fft_threads(TY), 2)
+__global__ void __launch_bounds__(fft_threads(TY), 2)      // (XP spills 32 B at 256 registers; uncapped - 274 - it loses a wave per SIMD: C5 1.65 -> 1.87 ms)
 k_inv_cols_symx(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                 const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
                 int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
