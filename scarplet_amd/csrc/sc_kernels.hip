@@ -394,6 +394,9 @@ k_direct(const float* __restrict__ curv, Geom g,
 //  * per-cell float32 sums as before: exact per cell, no resolution floor.
 // ---------------------------------------------------------------------------
 #define DR2_LDS_FLOATS (39 * 1024 + 512)        // 158 KB
+#ifndef SC_DR_VMEMW
+#define SC_DR_VMEMW 1      // the real-space kernel's weights through vector loads (0: scalar loads, rounds 3 - 4a)
+#endif
 #define DR2_WAVES 8
 
 // grid = (ceil(wh_max / 4), n_templates), block = 256: one wave per window row.
@@ -447,6 +450,8 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
     constexpr int TXW = 256 * NB, TY = DR2_WAVES * RW;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int zlane = 0;                                   // zero the compiler cannot see through: makes a load a vector load
+    asm volatile("" : "+v"(zlane));
     // nb orientations per launch (small DEMs: fewer, longer launches), folded IN ORDER by the one
     // workgroup that owns the patch: orientation b's curvature plane lies b * curv_stride floats
     // further on, its n_per templates follow those of orientation b - 1
@@ -579,6 +584,64 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                 // shorter than 16 taps keep the weighted form.
                 const bool shared = SHARE && sp.w >= 0 && sp.w - sp.z >= 15;
                 if (!shared) {
+#if SC_DR_VMEMW
+                  if constexpr (!SHARE) {
+                    // (the group's four (w, m) pairs through the vector memory path, one group ahead: see the shared form)
+                    const float* wv = reinterpret_cast<const float*>(wrow) + zlane;
+                    auto wload = [&](int gq, f4& lo, f4& hi) {
+                        lo = *reinterpret_cast<const f4*>(wv + 8 * gq);
+                        hi = *reinterpret_cast<const f4*>(wv + 8 * gq + 4);
+                    };
+                    auto group_v = [&](const float (&w4)[4], const float (&m4)[4], const f4 (&v0)[RW][NB], const f4 (&v1)[RW][NB],
+                                       const f4 (&q0)[RW][NB], const f4 (&q1)[RW][NB]) {
+#pragma unroll
+                        for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                            for (int n = 0; n < NB; ++n) {
+                                const float v[8] = {v0[rr][n].x, v0[rr][n].y, v0[rr][n].z, v0[rr][n].w,
+                                                    v1[rr][n].x, v1[rr][n].y, v1[rr][n].z, v1[rr][n].w};
+                                const float q[8] = {q0[rr][n].x, q0[rr][n].y, q0[rr][n].z, q0[rr][n].w,
+                                                    q1[rr][n].x, q1[rr][n].y, q1[rr][n].z, q1[rr][n].w};
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) {
+                                        xc[rr][n][u] = fmaf(w4[k], v[u + k], xc[rr][n][u]);
+                                        t3[rr][n][u] = fmaf(m4[k], q[u + k], t3[rr][n][u]);
+                                    }
+                            }
+                    };
+                    f4 wAl, wAh, wBl, wBh;
+                    wload(0, wAl, wAh);
+                    chunk(0, ca, qa);
+                    for (int gq = 0; gq < ng; gq += 2) {
+                        wload(min(gq + 1, ng - 1), wBl, wBh);
+                        chunk(gq + 1, cb, qb);
+                        {
+                            const float w4[4] = {wAl.x, wAl.z, wAh.x, wAh.z}, m4[4] = {wAl.y, wAl.w, wAh.y, wAh.w};
+                            group_v(w4, m4, ca, cb, qa, qb);
+                        }
+                        if (gq + 1 < ng) {
+                            wload(min(gq + 2, ng - 1), wAl, wAh);
+                            chunk(gq + 2, ca, qa);
+                            const float w4[4] = {wBl.x, wBl.z, wBh.x, wBh.z}, m4[4] = {wBl.y, wBl.w, wBh.y, wBh.w};
+                            group_v(w4, m4, cb, ca, qb, qa);
+                        }
+                    }
+                  } else {
+                    // (kernels with the shared form: rows without it - holes, short runs - keep the scalar loads;
+                    //  with both forms on vector loads the 512 x 16 patch spills 164 B instead of 92)
+                    chunk(0, ca, qa);
+                    for (int gq = 0; gq < ng; gq += 2) {
+                        chunk(gq + 1, cb, qb);
+                        group(gq, ca, cb, qa, qb);
+                        if (gq + 1 < ng) {
+                            chunk(gq + 2, ca, qa);
+                            group(gq + 1, cb, ca, qb, qa);
+                        }
+                    }
+                  }
+#else
                     chunk(0, ca, qa);
                     // two groups per trip: the chunks swap roles (carried / new) instead of being copied
                     // (the copies were 16 v_mov_b64 per 128 FMAs: +9 % on large supports)
@@ -590,6 +653,7 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                             group(gq + 1, cb, ca, qb, qa);
                         }
                     }
+#endif
                 } else {
                     const int jlo = (sp.z + 6) >> 2;              // first chunk inside s + 3 .. e
                     const int jhi = ((sp.w + 1) >> 2) - 1;        // last chunk inside it
@@ -615,6 +679,49 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                                 }
                         }
                     };
+#if SC_DR_VMEMW
+                    // The four weights of a group through the VECTOR memory path (every lane the same address), one
+                    // group ahead: as scalar loads they shared the lgkmcnt counter with the slab's LDS reads, scalar
+                    // loads return out of order, so every group waited for lgkmcnt(0) - its weights AND every LDS
+                    // read in flight - before its first FMA.  vmcnt counts in order and counts nothing else here.
+                    const float* wv = reinterpret_cast<const float*>(wrow) + zlane;
+                    auto wload = [&](int gq, f4& lo, f4& hi) {
+                        lo = *reinterpret_cast<const f4*>(wv + 8 * gq);
+                        hi = *reinterpret_cast<const f4*>(wv + 8 * gq + 4);
+                    };
+                    auto group_x = [&](const float (&w4)[4], const f4 (&v0)[RW][NB], const f4 (&v1)[RW][NB]) {
+#pragma unroll
+                        for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                            for (int n = 0; n < NB; ++n) {
+                                const float v[8] = {v0[rr][n].x, v0[rr][n].y, v0[rr][n].z, v0[rr][n].w,
+                                                    v1[rr][n].x, v1[rr][n].y, v1[rr][n].z, v1[rr][n].w};
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) xc[rr][n][u] = fmaf(w4[k], v[u + k], xc[rr][n][u]);
+                            }
+                    };
+                    // (two buffers in vector registers, used from there: moved on to scalar registers first - one
+                    //  buffer, v_readfirstlane - every group waited for its own load: 84 TFLOP/s against 90)
+                    f4 wAl, wAh, wBl, wBh;
+                    wload(0, wAl, wAh);
+                    chunk_s(0, ca);
+                    for (int gq = 0; gq < ng; gq += 2) {
+                        wload(min(gq + 1, ng - 1), wBl, wBh);
+                        chunk_s(gq + 1, cb);
+                        {
+                            const float w4[4] = {wAl.x, wAl.z, wAh.x, wAh.z};
+                            group_x(w4, ca, cb);
+                        }
+                        if (gq + 1 < ng) {
+                            wload(min(gq + 2, ng - 1), wAl, wAh);
+                            chunk_s(gq + 2, ca);
+                            const float w4[4] = {wBl.x, wBl.z, wBh.x, wBh.z};
+                            group_x(w4, cb, ca);
+                        }
+                    }
+#else
                     auto group_x = [&](int gq, const f4 (&v0)[RW][NB], const f4 (&v1)[RW][NB]) {
                         float2 wm[4];
 #pragma unroll
@@ -640,6 +747,7 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                             group_x(gq + 1, cb, ca);
                         }
                     }
+#endif
                     // the end cells: cell s + i (below the first whole chunk) belongs to the outputs u <= i,
                     // cell c above the last whole chunk (c <= e + 3) to the outputs u >= c - e
 #pragma unroll
@@ -1065,7 +1173,7 @@ int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_ma
     const bool share = ctx->variant != 11 && long_runs;
     // (the 512-wide patch needs a slab of 512 + the padded window width cells x 16 rows)
     const bool fits512 = (long long)(512 + ((ww_max + 3) & ~3)) * 16 <= DR2_LDS_FLOATS;
-    if (fits512 && wgs(512, 16) >= 512) { if (share) DR2_LAUNCH(2, 2, true) else DR2_LAUNCH(2, 2, false) }
+    if (fits512 && wgs(512, 16) >= 512 && ctx->variant != 16) { if (share) DR2_LAUNCH(2, 2, true) else DR2_LAUNCH(2, 2, false) }
     else if (wgs(256, 16) >= 256) { if (share) DR2_LAUNCH(1, 2, true) else DR2_LAUNCH(1, 2, false) }
     else { if (share) DR2_LAUNCH(1, 1, true) else DR2_LAUNCH(1, 1, false) }
 #undef DR2_LAUNCH

@@ -10,6 +10,8 @@ from scarplet_amd import _plan, synthetic
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 g = synthetic.synthetic_scarp(n)
 m = sl.Matcher(g)
+if len(sys.argv) > 2:                                   # engine option "variant" (16: the 256 x 16 patch of the real-space kernel throughout)
+    m.ctx.set_option("variant", float(sys.argv[2]))
 angs = _plan.angle_grid()[[30, 90, 150]]
 print("DEM %dx%d; per row: scale, age, taps(n), direct ms/template, fft ms/template, plan" % (n, n))
 for scale in (5, 10, 20, 50, 100):
