@@ -702,3 +702,24 @@ def test_full_size_properties(gpu_ctx):
     assert np.allclose(amp3, 2 * amp, rtol=1e-4, atol=1e-6)
     assert np.allclose(snr3, snr, rtol=2e-3, atol=1e-5)
     assert (age3 == age).mean() > 0.999
+
+
+def test_async_searches_back_to_back_equal_the_synchronous_ones(gpu_ctx):
+    """sc_match_async twice without sc_sync in between (two grids folded into one record): the
+    descriptors of a search are uploaded asynchronously from host copies the context keeps, and the
+    second call must not overwrite them while the first call's copy may still be in flight.  The
+    record must equal, bit for bit, the one the same two searches leave when each is waited for."""
+    rng = np.random.default_rng(77)
+    z = (np.cumsum(rng.standard_normal((300, 260)), 1) * 0.04 + rng.standard_normal((300, 260)) * 0.05).astype(np.float32)
+    g = grid(z, 1.0)
+    grids = [([1.0, 10.0], _plan.angle_grid()[::9]), ([3.0, 30.0, 100.0], _plan.angle_grid()[4::11])]
+    out = []
+    for sync in (True, False):
+        m = sl.Matcher(g, ctx=gpu_ctx)
+        for k, (params, angles) in enumerate(grids):
+            m.search(WT.Scarp, 12, params, angles, method="fft", reset=(k == 0), sync=sync)
+        m.ctx.sync()
+        out.append(m.ctx.get_best())
+    for a, b, name in zip(out[0], out[1], ("amp", "snr", "id")):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
+    assert (out[0][1] > 0).any()
