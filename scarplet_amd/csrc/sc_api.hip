@@ -403,19 +403,31 @@ extern "C" int sc_set_masks(sc_ctx* ctx, int slot, const uint8_t* limits, const 
 // ---------------------------------------------------------------------------
 // the hot path
 // ---------------------------------------------------------------------------
+// compare()'s start state (core.py:222-225) in ONE launch: the record (snr 0, amp 0, no id), the resolution
+// statistic, and the scratch records of a split row pass (a share left by an earlier search must not score
+// against the new record).  Five memsets before: a fifth of a millisecond per five-scale C5 step in fills and gaps.
+__global__ void __launch_bounds__(256)
+k_reset_best(float* __restrict__ snr, float* __restrict__ amp, uint32_t* __restrict__ id, size_t nc,
+             float* __restrict__ s2, size_t n2, unsigned long long* __restrict__ stats) {
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+    for (size_t i = i0; i < nc; i += step) { snr[i] = 0.f; amp[i] = 0.f; id[i] = SC_ID_NONE; }
+    for (size_t i = i0; i < n2; i += step) s2[i] = 0.f;
+    if (i0 < 2) stats[i0] = 0ull;
+}
+
 extern "C" int sc_reset_best(sc_ctx* ctx) {
     if (!ctx) return SC_ERR_INVALID;
     if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
     SC_HIP(ctx, hipSetDevice(ctx->device));
     size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
-    SC_HIP(ctx, hipMemsetAsync(ctx->best_snr.p, 0, sizeof(float) * nc, ctx->stream));
-    SC_HIP(ctx, hipMemsetAsync(ctx->best_amp.p, 0, sizeof(float) * nc, ctx->stream));
-    SC_HIP(ctx, hipMemsetAsync(ctx->best_id.p, 0xFF, sizeof(uint32_t) * nc, ctx->stream));
-    // (scratch records of a split row pass: a share left by an earlier search must not score against the new record)
-    if (ctx->split_s.p) SC_HIP(ctx, hipMemsetAsync(ctx->split_s.p, 0, ctx->split_s.cap, ctx->stream));
     int rc = sc_ensure(ctx, ctx->res_stats, 2 * sizeof(unsigned long long));
     if (rc) return rc;
-    SC_HIP(ctx, hipMemsetAsync(ctx->res_stats.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    const size_t n2 = ctx->split_s.p ? ctx->split_s.cap / sizeof(float) : 0;
+    const unsigned blocks = (unsigned)std::min<size_t>((std::max(nc, n2) + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_reset_best, dim3(blocks), dim3(256), 0, ctx->stream, (float*)ctx->best_snr.p,
+                       (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p, nc, (float*)ctx->split_s.p, n2,
+                       (unsigned long long*)ctx->res_stats.p);
+    SC_HIP(ctx, hipGetLastError());
     return SC_OK;
 }
 
