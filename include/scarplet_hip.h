@@ -172,7 +172,10 @@ int sc_clear_windows(sc_ctx* ctx);
  *              between a lane's adjacent outputs), 12 no paired orientations (one-tile searches
  *              with one template per orientation then leave half of every transform empty),
  *              13 the inverse passes store and transform every valid tile row (default: rows
- *              that a template's window limits mask are skipped for that template)
+ *              that a template's window limits mask are skipped for that template), 15 the row
+ *              pass of small grids folds a launch's transforms in ONE workgroup per row (default:
+ *              dealt out over up to four, the shares merged in order), 16 the real-space kernel's
+ *              256 x 16 patch also where the 512 x 16 patch would be taken
  *   "batch"    1 (default): searches whose single orientation does not fill the
  *              chip send several orientations through every launch; 0: one
  *              orientation per launch sequence.  Results are bit-identical.
