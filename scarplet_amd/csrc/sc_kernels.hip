@@ -533,6 +533,10 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
             // (the span of row a + 1 is fetched while row a is worked on: read where it is needed, every
             //  row of a thin window - a handful of groups - began with a scalar-load round trip)
             int4 sp_next = spans[span_off + a0];
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4 ca[RW][NB], cb[RW][NB];                            // two chunks of four cells (across rows: see `pre`)
+            f4 pwl = {0.f, 0.f, 0.f, 0.f}, pwh = pwl;             // first weights of the next row, fetched ahead
+            bool pre = false;                                     // ca / pwl / pwh hold the NEXT row's first chunk and weights
             for (int a = 0; a < na; ++a) {
                 const int4 sp = sp_next;                          // (first group, groups, s, e): wave-uniform
                 sp_next = spans[span_off + a0 + min(a + 1, na - 1)];
@@ -541,8 +545,9 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                 const float2* wrow = dw + (size_t)(a0 + a) * P + 4 * sp.x;
                 // the lane's slab cells of its rows: row (w RW + rr) + (na - 1 - a), column 4 lane + 4 g (+ 256 n)
                 const float* lrow = lds + (w * RW + (na - 1 - a)) * lwp + 4 * lane + 4 * sp.x;
-                typedef float f4 __attribute__((ext_vector_type(4)));
-                f4 ca[RW][NB], cb[RW][NB], qa[RW][NB], qb[RW][NB];   // two chunks of four cells and their squares
+                f4 qa[RW][NB], qb[RW][NB];                        // the chunks' squares (rows without the shared form)
+                const bool was_pre = pre;
+                pre = false;
                 auto chunk = [&](int j, f4 (&v)[RW][NB], f4 (&q)[RW][NB]) {
 #pragma unroll
                     for (int rr = 0; rr < RW; ++rr)
@@ -662,11 +667,13 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                     for (int rr = 0; rr < RW; ++rr)
 #pragma unroll
                         for (int n = 0; n < NB; ++n) csum[rr][n] = 0.f;
-                    auto chunk_s = [&](int j, f4 (&v)[RW][NB]) {
+                    auto cload = [&](const float* lr, int j, f4 (&v)[RW][NB]) {
 #pragma unroll
                         for (int rr = 0; rr < RW; ++rr)
 #pragma unroll
-                            for (int n = 0; n < NB; ++n) v[rr][n] = *reinterpret_cast<const f4*>(lrow + rr * lwp + 256 * n + 4 * j);
+                            for (int n = 0; n < NB; ++n) v[rr][n] = *reinterpret_cast<const f4*>(lr + rr * lwp + 256 * n + 4 * j);
+                    };
+                    auto caccum = [&](int j, const f4 (&v)[RW][NB]) {
                         if (j >= jlo && j <= jhi) {
 #pragma unroll
                             for (int rr = 0; rr < RW; ++rr)
@@ -678,6 +685,10 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                                     csum[rr][n] = fmaf(c4.w, c4.w, fmaf(c4.z, c4.z, fmaf(c4.y, c4.y, fmaf(c4.x, c4.x, csum[rr][n]))));
                                 }
                         }
+                    };
+                    auto chunk_s = [&](int j, f4 (&v)[RW][NB]) {
+                        cload(lrow, j, v);
+                        caccum(j, v);
                     };
 #if SC_DR_VMEMW
                     // The four weights of a group through the VECTOR memory path (every lane the same address), one
@@ -704,9 +715,13 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                     };
                     // (two buffers in vector registers, used from there: moved on to scalar registers first - one
                     //  buffer, v_readfirstlane - every group waited for its own load: 84 TFLOP/s against 90)
+                    // The row's first weights and first chunk were fetched at the end of the previous row where that
+                    // one had the shared form too (`pre`): a row used to begin by waiting for a vector load and an
+                    // LDS read with nothing to do - a fifth of a row of a dozen taps.
                     f4 wAl, wAh, wBl, wBh;
-                    wload(0, wAl, wAh);
-                    chunk_s(0, ca);
+                    if (was_pre) { wAl = pwl; wAh = pwh; }
+                    else { wload(0, wAl, wAh); cload(lrow, 0, ca); }
+                    caccum(0, ca);
                     for (int gq = 0; gq < ng; gq += 2) {
                         wload(min(gq + 1, ng - 1), wBl, wBh);
                         chunk_s(gq + 1, cb);
@@ -720,6 +735,14 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                             const float w4[4] = {wBl.x, wBl.z, wBh.x, wBh.z};
                             group_x(w4, cb, ca);
                         }
+                    }
+                    // the next row's first loads, under this row's end cells
+                    if (a + 1 < na && sp_next.y > 0 && sp_next.w >= 0 && sp_next.w - sp_next.z >= 15) {
+                        const float* wvn = reinterpret_cast<const float*>(dw + (size_t)(a0 + a + 1) * P + 4 * sp_next.x) + zlane;
+                        pwl = *reinterpret_cast<const f4*>(wvn);
+                        pwh = *reinterpret_cast<const f4*>(wvn + 4);
+                        cload(lds + (w * RW + (na - 2 - a)) * lwp + 4 * lane + 4 * sp_next.x, 0, ca);
+                        pre = true;
                     }
 #else
                     auto group_x = [&](int gq, const f4 (&v0)[RW][NB], const f4 (&v1)[RW][NB]) {
