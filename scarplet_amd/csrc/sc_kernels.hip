@@ -662,7 +662,7 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                 } else {
                     const int jlo = (sp.z + 6) >> 2;              // first chunk inside s + 3 .. e
                     const int jhi = ((sp.w + 1) >> 2) - 1;        // last chunk inside it
-                    float csum[RW][NB];
+                    float csum[RW][NB];                       // squares of the cells common to a lane's four outputs, this row
 #pragma unroll
                     for (int rr = 0; rr < RW; ++rr)
 #pragma unroll
@@ -771,39 +771,56 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                         }
                     }
 #endif
-                    // the end cells: cell s + i (below the first whole chunk) belongs to the outputs u <= i,
-                    // cell c above the last whole chunk (c <= e + 3) to the outputs u >= c - e
+                    // The end cells (read again, one at a time, all wave-uniform addresses).  Cells s, s + 1, s + 2
+                    // belong to the outputs u <= i and cells e + 1 .. e + 3 to the outputs u >= k; the cells between
+                    // s + 3 and the first whole chunk and between the last whole chunk and e are common to the four
+                    // like the chunks themselves: one FMA into the common sum each.  (Every end cell as four masked
+                    // adds was 60 instructions per block and row - four and a half tap groups' worth on a row of a
+                    // dozen; this is 24.)
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) {
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                            for (int n = 0; n < NB; ++n) {
+                                const float v = lrow[rr * lwp + 256 * n + sp.z + i], q = v * v;
+#pragma unroll
+                                for (int u = 0; u <= i; ++u) t3[rr][n][u] += q;
+                            }
+#pragma unroll
+                    for (int i = 3; i < 6; ++i) {
                         const int c = sp.z + i;
                         if (c >= 4 * jlo) break;
 #pragma unroll
                         for (int rr = 0; rr < RW; ++rr)
 #pragma unroll
                             for (int n = 0; n < NB; ++n) {
-                                const float v = lrow[rr * lwp + 256 * n + c], q = v * v;
-#pragma unroll
-                                for (int u = 0; u < 4; ++u)
-                                    if (u <= i) t3[rr][n][u] += q;
+                                const float v = lrow[rr * lwp + 256 * n + c];
+                                csum[rr][n] = fmaf(v, v, csum[rr][n]);
                             }
                     }
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) {
+                    for (int i = 0; i < 3; ++i) {
                         const int c = 4 * (jhi + 1) + i;
-                        if (c > sp.w + 3) break;
-                        const int umin = c - sp.w;
-                        float mu[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) mu[u] = u >= umin ? 1.f : 0.f;
+                        if (c > sp.w) break;
 #pragma unroll
                         for (int rr = 0; rr < RW; ++rr)
 #pragma unroll
                             for (int n = 0; n < NB; ++n) {
-                                const float v = lrow[rr * lwp + 256 * n + c], q = v * v;
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) t3[rr][n][u] = fmaf(mu[u], q, t3[rr][n][u]);
+                                const float v = lrow[rr * lwp + 256 * n + c];
+                                csum[rr][n] = fmaf(v, v, csum[rr][n]);
                             }
                     }
+#pragma unroll
+                    for (int k = 1; k < 4; ++k)
+#pragma unroll
+                        for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                            for (int n = 0; n < NB; ++n) {
+                                const float v = lrow[rr * lwp + 256 * n + sp.w + k], q = v * v;
+#pragma unroll
+                                for (int u = k; u < 4; ++u) t3[rr][n][u] += q;
+                            }
 #pragma unroll
                     for (int rr = 0; rr < RW; ++rr)
 #pragma unroll
