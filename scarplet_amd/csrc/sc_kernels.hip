@@ -461,8 +461,9 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
     // running best of the lane's cells: row w RW + rr, columns j0 + 256 n + 4 lane + u
     // (kept in memory instead - read and written at every template's fold - the 512 x 16 form spills MORE:
     //  268 B of scratch against 84; the 48 registers are not what it runs out of)
-    float b_snr[RW][NB][4], b_amp[RW][NB][4];
-    uint32_t b_id[RW][NB][4];
+    // (round 4b: only the SNR; the amplitude and the id of a cell are stored when a template WINS it - a win
+    //  needs no read of them, and 32 registers fewer are live across the template loops)
+    float b_snr[RW][NB][4];
     unsigned dirty = 0;
     auto cell = [&](int rr, int n, int u, int& gi, int& gj) {
         gi = i0 + w * RW + rr;
@@ -478,8 +479,6 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                 int gi, gj;
                 const bool in = cell(rr, n, u, gi, gj);
                 b_snr[rr][n][u] = (in && !map_amp) ? best_snr[(size_t)(gi - g.cy0) * cw + (gj - g.cx0)] : 0.f;
-                b_amp[rr][n][u] = 0.f;
-                b_id[rr][n][u] = SC_ID_NONE;
             }
 
     const int n_templ = n_per * nb;
@@ -832,6 +831,8 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
         }
         const EpiScal es = sc_epi_scalars(sums, first + it);
         const TemplDev t = *tp;
+        int zt = 0;
+        asm volatile("" : "+v"(zt));
 #pragma unroll
         for (int rr = 0; rr < RW; ++rr)
 #pragma unroll
@@ -844,11 +845,20 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                     sc_epilogue(xc[rr][n][u], t3[rr][n][u], es, amp, snr);
                     sc_apply_masks(t, g, xaxis, yaxis, gi, gj, amp, snr);
                     if (map_amp) {
-                        const size_t o = (size_t)(gi - g.cy0) * cw + (gj - g.cx0);
+                        const size_t o = (size_t)(gi - g.cy0 + zt) * cw + (gj - g.cx0);
                         map_amp[o] = amp;
                         map_snr[o] = snr;
-                    } else if (sc_fold(b_snr[rr][n][u], b_amp[rr][n][u], b_id[rr][n][u], snr, amp, t.id)) {
-                        dirty |= 1u << ((rr * NB + n) * 4 + u);
+                    } else {
+                        float w_amp = 0.f;
+                        uint32_t w_id = SC_ID_NONE;
+                        if (sc_fold(b_snr[rr][n][u], w_amp, w_id, snr, amp, t.id)) {
+                            // (zt: the cells' offsets are worked out here, at a win - hoisted out of the template loop
+                            //  they are 32 registers that live through every row of every template)
+                            const size_t o = (size_t)(gi - g.cy0 + zt) * cw + (gj - g.cx0);
+                            best_amp[o] = w_amp;
+                            best_id[o] = w_id;
+                            dirty |= 1u << ((rr * NB + n) * 4 + u);
+                        }
                     }
                 }
     }
@@ -864,8 +874,6 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                     cell(rr, n, u, gi, gj);
                     const size_t o = (size_t)(gi - g.cy0) * cw + (gj - g.cx0);
                     best_snr[o] = b_snr[rr][n][u];
-                    best_amp[o] = b_amp[rr][n][u];
-                    best_id[o] = b_id[rr][n][u];
                 }
     }
 }
