@@ -556,6 +556,7 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                             q[rr][n] = v[rr][n] * v[rr][n];
                         }
                 };
+#if !SC_DR_VMEMW
                 // the four taps of group gq on the carried cells v0 (the first four) and the new cells v1
                 auto group = [&](int gq, const f4 (&v0)[RW][NB], const f4 (&v1)[RW][NB], const f4 (&q0)[RW][NB],
                                  const f4 (&q1)[RW][NB]) {
@@ -579,6 +580,7 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                                 }
                         }
                 };
+#endif
                 // T3 of a lane's four adjacent outputs over a run WITHOUT holes, taps s .. e: output u sums
                 // curv^2 over the cells s + u .. e + u.  The cells s + 3 .. e are common to the four: whole
                 // chunks of them go into ONE sum per block (3 adds for the chunk's four squares + 1,
@@ -589,61 +591,49 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                 const bool shared = SHARE && sp.w >= 0 && sp.w - sp.z >= 15;
                 if (!shared) {
 #if SC_DR_VMEMW
-                  if constexpr (!SHARE) {
-                    // (the group's four (w, m) pairs through the vector memory path, one group ahead: see the shared form)
-                    const float* wv = reinterpret_cast<const float*>(wrow) + zlane;
-                    auto wload = [&](int gq, f4& lo, f4& hi) {
-                        lo = *reinterpret_cast<const f4*>(wv + 8 * gq);
-                        hi = *reinterpret_cast<const f4*>(wv + 8 * gq + 4);
-                    };
-                    auto group_v = [&](const float (&w4)[4], const float (&m4)[4], const f4 (&v0)[RW][NB], const f4 (&v1)[RW][NB],
-                                       const f4 (&q0)[RW][NB], const f4 (&q1)[RW][NB]) {
+                  // (the group's four (w, m) pairs through the vector memory path, one group ahead: see the shared form.  While the
+                    //  512 x 16 patch spilled, the kernels that carry the shared form kept scalar loads here; without scratch
+                    //  - round 4b - both forms on vector loads are 1 % faster on every support)
+                  const float* wv = reinterpret_cast<const float*>(wrow) + zlane;
+                  auto wload = [&](int gq, f4& lo, f4& hi) {
+                      lo = *reinterpret_cast<const f4*>(wv + 8 * gq);
+                      hi = *reinterpret_cast<const f4*>(wv + 8 * gq + 4);
+                  };
+                  auto group_v = [&](const float (&w4)[4], const float (&m4)[4], const f4 (&v0)[RW][NB], const f4 (&v1)[RW][NB],
+                                     const f4 (&q0)[RW][NB], const f4 (&q1)[RW][NB]) {
 #pragma unroll
-                        for (int rr = 0; rr < RW; ++rr)
+                      for (int rr = 0; rr < RW; ++rr)
 #pragma unroll
-                            for (int n = 0; n < NB; ++n) {
-                                const float v[8] = {v0[rr][n].x, v0[rr][n].y, v0[rr][n].z, v0[rr][n].w,
-                                                    v1[rr][n].x, v1[rr][n].y, v1[rr][n].z, v1[rr][n].w};
-                                const float q[8] = {q0[rr][n].x, q0[rr][n].y, q0[rr][n].z, q0[rr][n].w,
-                                                    q1[rr][n].x, q1[rr][n].y, q1[rr][n].z, q1[rr][n].w};
+                          for (int n = 0; n < NB; ++n) {
+                              const float v[8] = {v0[rr][n].x, v0[rr][n].y, v0[rr][n].z, v0[rr][n].w,
+                                                  v1[rr][n].x, v1[rr][n].y, v1[rr][n].z, v1[rr][n].w};
+                              const float q[8] = {q0[rr][n].x, q0[rr][n].y, q0[rr][n].z, q0[rr][n].w,
+                                                  q1[rr][n].x, q1[rr][n].y, q1[rr][n].z, q1[rr][n].w};
 #pragma unroll
-                                for (int k = 0; k < 4; ++k)
+                              for (int k = 0; k < 4; ++k)
 #pragma unroll
-                                    for (int u = 0; u < 4; ++u) {
-                                        xc[rr][n][u] = fmaf(w4[k], v[u + k], xc[rr][n][u]);
-                                        t3[rr][n][u] = fmaf(m4[k], q[u + k], t3[rr][n][u]);
-                                    }
-                            }
-                    };
-                    f4 wAl, wAh, wBl, wBh;
-                    wload(0, wAl, wAh);
-                    chunk(0, ca, qa);
-                    for (int gq = 0; gq < ng; gq += 2) {
-                        wload(min(gq + 1, ng - 1), wBl, wBh);
-                        chunk(gq + 1, cb, qb);
-                        {
-                            const float w4[4] = {wAl.x, wAl.z, wAh.x, wAh.z}, m4[4] = {wAl.y, wAl.w, wAh.y, wAh.w};
-                            group_v(w4, m4, ca, cb, qa, qb);
-                        }
-                        if (gq + 1 < ng) {
-                            wload(min(gq + 2, ng - 1), wAl, wAh);
-                            chunk(gq + 2, ca, qa);
-                            const float w4[4] = {wBl.x, wBl.z, wBh.x, wBh.z}, m4[4] = {wBl.y, wBl.w, wBh.y, wBh.w};
-                            group_v(w4, m4, cb, ca, qb, qa);
-                        }
-                    }
-                  } else {
-                    // (kernels with the shared form: rows without it - holes, short runs - keep the scalar loads;
-                    //  with both forms on vector loads the 512 x 16 patch spills 164 B instead of 92)
-                    chunk(0, ca, qa);
-                    for (int gq = 0; gq < ng; gq += 2) {
-                        chunk(gq + 1, cb, qb);
-                        group(gq, ca, cb, qa, qb);
-                        if (gq + 1 < ng) {
-                            chunk(gq + 2, ca, qa);
-                            group(gq + 1, cb, ca, qb, qa);
-                        }
-                    }
+                                  for (int u = 0; u < 4; ++u) {
+                                      xc[rr][n][u] = fmaf(w4[k], v[u + k], xc[rr][n][u]);
+                                      t3[rr][n][u] = fmaf(m4[k], q[u + k], t3[rr][n][u]);
+                                  }
+                          }
+                  };
+                  f4 wAl, wAh, wBl, wBh;
+                  wload(0, wAl, wAh);
+                  chunk(0, ca, qa);
+                  for (int gq = 0; gq < ng; gq += 2) {
+                      wload(min(gq + 1, ng - 1), wBl, wBh);
+                      chunk(gq + 1, cb, qb);
+                      {
+                          const float w4[4] = {wAl.x, wAl.z, wAh.x, wAh.z}, m4[4] = {wAl.y, wAl.w, wAh.y, wAh.w};
+                          group_v(w4, m4, ca, cb, qa, qb);
+                      }
+                      if (gq + 1 < ng) {
+                          wload(min(gq + 2, ng - 1), wAl, wAh);
+                          chunk(gq + 2, ca, qa);
+                          const float w4[4] = {wBl.x, wBl.z, wBh.x, wBh.z}, m4[4] = {wBl.y, wBl.w, wBh.y, wBh.w};
+                          group_v(w4, m4, cb, ca, qb, qa);
+                      }
                   }
 #else
                     chunk(0, ca, qa);
