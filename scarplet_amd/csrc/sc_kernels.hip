@@ -378,8 +378,10 @@ k_direct(const float* __restrict__ curv, Geom g,
 //    A group of four taps needs the eight slab cells x .. x + 7 of the row: four carried from
 //    the previous group, four new ones from ONE ds_read_b128 (64 lanes read 1 KB of one slab
 //    row: conflict-free) - 32 FMAs for xcorr and 32 for T3 per LDS read instruction;
-//  * the four (w, m) pairs of a group are wave-uniform: one s_load_dwordx8, the FMAs take them
-//    as scalar operands;
+//  * the four (w, m) pairs of a group are wave-uniform.  Round 3: one s_load_dwordx8, scalar operands
+//    of the FMAs.  Round 4: vector loads from one address (two register buffers, one group ahead) -
+//    scalar loads share lgkmcnt with the LDS reads and return out of order, so every group waited
+//    for all of them;
 //  * T3 over a run without holes is SHARED by a lane's four adjacent outputs: the cells common to
 //    the four (all but three at either end) are summed once per block, whole chunks at a time
 //    (3 adds + 1 per chunk instead of 16 weighted FMAs), the end cells are read again after the
@@ -391,7 +393,9 @@ k_direct(const float* __restrict__ curv, Geom g,
 //  * eight waves per workgroup (two per SIMD: one wave alone issues a VALU instruction every
 //    four cycles, two share the SIMD at two), the patch is 8 RW rows x 256 NB columns, slabs of
 //    as many template rows as the 158 KB of LDS hold;
-//  * per-cell float32 sums as before: exact per cell, no resolution floor.
+//  * per-cell float32 sums as before: exact per cell, no resolution floor;
+//  * of the running best only the SNR lives in registers; the amplitude and the id of a cell are
+//    stored when a template wins it (round 4: no scratch in any form of the kernel).
 // ---------------------------------------------------------------------------
 #define DR2_LDS_FLOATS (39 * 1024 + 512)        // 158 KB
 #ifndef SC_DR_VMEMW
