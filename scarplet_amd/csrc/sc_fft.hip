@@ -1940,6 +1940,9 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
 #ifndef SC_I2_FETCH_AT
 #define SC_I2_FETCH_AT 0
 #endif
+#ifndef SC_I2_RAREWIN
+#define SC_I2_RAREWIN 1     // the row pass records a winner's output and index under a rarely taken branch (0: selects per output)
+#endif
 #ifndef SC_I2_STATIC
 #define SC_I2_STATIC 0     // 1: templates whose window limits cover a whole tile row skip the range test per output (stage 3); measured, see DESIGN.md
 #endif
@@ -2298,6 +2301,11 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             }
             pk::B<R3, true>::run(vw);
             pk::B<R3, true>::run(vm);
+            // (RARE: rows of 1024 cells and more; the 512-cell kernels keep the selects - there the deferred form
+            //  costs a scratch reload inside the template loop)
+            constexpr bool RARE = SC_I2_RAREWIN && TX >= 1024;
+            bool wonm[R3][2];                  // lane masks (scalar register pairs): which outputs won their cell
+            bool anyw = false;
 #pragma unroll
             for (int m = 0; m < R3; ++m) {
                 const int c = u * R3 + m;
@@ -2338,7 +2346,31 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                         // the range (lean variant) or masked to 0 never wins
                         const bool won = (FULL || in) && snr > b_snr[k];
                         b_snr[k] = won ? snr : b_snr[k];
-                        b_xr[k] = won ? xr : b_xr[k];
+                        if constexpr (RARE) {
+                            wonm[m][part] = won;
+                            anyw = anyw || won;
+                        } else {
+                            b_xr[k] = won ? xr : b_xr[k];
+                            const uint32_t bm = 0xFFu << (8 * (k & 3));
+                            b_ix[k >> 2] = won ? ((b_ix[k >> 2] & ~bm) | (tix[part] & bm)) : b_ix[k >> 2];
+                        }
+                    }
+                }
+            }
+            // A cell is won a handful of times in a whole search: the winner's transform output and index are
+            // recorded under a wave-uniform branch - taken when any of the wave's 1 024 cells was won, which is
+            // still most templates early in a search and few later - instead of with two selects and two bit
+            // operations per output of every template (the kernel is bound by vector issue: 48 of its ~600
+            // vector instructions per template and thread).  Same order, same values: the record is identical.
+            if (RARE && !MAPS && __builtin_amdgcn_ballot_w64(anyw) != 0ull) {
+#pragma unroll
+                for (int m = 0; m < R3; ++m) {
+                    const v2 xc = vw[pk::B<R3, true>::pos(m)];
+#pragma unroll
+                    for (int part = 0; part < 2; ++part) {
+                        const int k = best_of(u * R3 + m, part);
+                        const bool won = wonm[m][part];
+                        b_xr[k] = won ? (part ? xc.y : xc.x) : b_xr[k];
                         const uint32_t bm = 0xFFu << (8 * (k & 3));
                         b_ix[k >> 2] = won ? ((b_ix[k >> 2] & ~bm) | (tix[part] & bm)) : b_ix[k >> 2];
                     }
