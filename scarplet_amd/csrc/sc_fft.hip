@@ -1940,6 +1940,9 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
 #ifndef SC_I2_FETCH_AT
 #define SC_I2_FETCH_AT 0
 #endif
+#ifndef SC_I2_GRP
+#define SC_I2_GRP 8         // output pairs per record branch of the row pass (SC_I2_RAREWIN); 4, 2, 1: the 2048 kernel spills 44 - 92 B
+#endif
 #ifndef SC_I2_RAREWIN
 #define SC_I2_RAREWIN 1     // the row pass records a winner's output and index under a rarely taken branch (0: selects per output)
 #endif
@@ -2304,10 +2307,15 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             // (RARE: rows of 1024 cells and more; the 512-cell kernels keep the selects - there the deferred form
             //  costs a scratch reload inside the template loop)
             constexpr bool RARE = SC_I2_RAREWIN && TX >= 1024;
-            bool wonm[R3][2];                  // lane masks (scalar register pairs): which outputs won their cell
+            // (GRP outputs pairs per branch: the fewer cells a branch stands for, the more rarely it is taken)
+            constexpr int GRP = (RARE && SC_I2_GRP < R3) ? SC_I2_GRP : R3;
+#pragma unroll
+            for (int m0 = 0; m0 < R3; m0 += GRP) {
+            bool wonm[GRP][2];                 // lane masks (scalar register pairs): which outputs won their cell
+            float snrs[GRP][2];
             bool anyw = false;
 #pragma unroll
-            for (int m = 0; m < R3; ++m) {
+            for (int m = m0; m < m0 + GRP; ++m) {
                 const int c = u * R3 + m;
                 const v2 xc = vw[pk::B<R3, true>::pos(m)], t3 = vm[pk::B<R3, true>::pos(m)];
                 const int cj = STATIC ? 0 : col_of(c);
@@ -2345,11 +2353,12 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                         // sc_fold: take if greater, ties keep the incumbent; a cell outside
                         // the range (lean variant) or masked to 0 never wins
                         const bool won = (FULL || in) && snr > b_snr[k];
-                        b_snr[k] = won ? snr : b_snr[k];
                         if constexpr (RARE) {
-                            wonm[m][part] = won;
+                            wonm[m - m0][part] = won;
+                            snrs[m - m0][part] = snr;
                             anyw = anyw || won;
                         } else {
+                            b_snr[k] = won ? snr : b_snr[k];
                             b_xr[k] = won ? xr : b_xr[k];
                             const uint32_t bm = 0xFFu << (8 * (k & 3));
                             b_ix[k >> 2] = won ? ((b_ix[k >> 2] & ~bm) | (tix[part] & bm)) : b_ix[k >> 2];
@@ -2357,24 +2366,28 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                     }
                 }
             }
-            // A cell is won a handful of times in a whole search: the winner's transform output and index are
-            // recorded under a wave-uniform branch - taken when any of the wave's 1 024 cells was won, which is
-            // still most templates early in a search and few later - instead of with two selects and two bit
-            // operations per output of every template (the kernel is bound by vector issue: 48 of its ~600
-            // vector instructions per template and thread).  Same order, same values: the record is identical.
+            // A cell is won a handful of times in a whole search: the record - best SNR, the winner's transform
+            // output, its index - is updated under a wave-uniform branch, taken when one of the GRP x 128 cells the
+            // branch stands for was won, instead of with three selects and two bit operations per output of every
+            // template (the kernel is bound by vector issue).  The compare against the record is repeated under the
+            // branch: where two templates ride one transform (PT) the second meets the first's update there.
+            // Same order, same values: the record is identical.
             if (RARE && !MAPS && __builtin_amdgcn_ballot_w64(anyw) != 0ull) {
 #pragma unroll
-                for (int m = 0; m < R3; ++m) {
+                for (int m = m0; m < m0 + GRP; ++m) {
                     const v2 xc = vw[pk::B<R3, true>::pos(m)];
 #pragma unroll
                     for (int part = 0; part < 2; ++part) {
                         const int k = best_of(u * R3 + m, part);
-                        const bool won = wonm[m][part];
+                        const float snr = snrs[m - m0][part];
+                        const bool won = wonm[m - m0][part] && snr > b_snr[k];
+                        b_snr[k] = won ? snr : b_snr[k];
                         b_xr[k] = won ? (part ? xc.y : xc.x) : b_xr[k];
                         const uint32_t bm = 0xFFu << (8 * (k & 3));
                         b_ix[k >> 2] = won ? ((b_ix[k >> 2] & ~bm) | (tix[part] & bm)) : b_ix[k >> 2];
                     }
                 }
+            }
             }
         }
         };
