@@ -182,6 +182,9 @@ int sc_clear_windows(sc_ctx* ctx);
  *   "batch_fill"  column-pass workgroups a batched launch sequence aims at (0: the default, 4096):
  *              orientations per launch = batch_fill / (tile pairs x Tx / 8), at most 64 and what the
  *              row pass's tables hold.  Results are bit-identical whatever the batch.
+ *   "i1_pairs" tile pairs per launch of the wave-per-column inverse pass (default 2; 1: one pair per
+ *              launch), interleaved so that the workgroups which stream the same template
+ *              coefficients run on one XCD at the same time.  Results are bit-identical.
  *   "y_gb"     memory budget of the column -> row pass hand-off buffers in GB
  *              (0: a quarter of the free memory, at most 32)
  *   "sib"      sibling rendezvous (bit 0: row pass): the two workgroups that read the two

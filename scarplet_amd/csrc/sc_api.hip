@@ -164,6 +164,9 @@ extern "C" int sc_set_option(sc_ctx* ctx, const char* name, double value) {
     } else if (!strcmp(name, "batch_fill")) {
         if (!(value >= 0.0)) return sc_fail(ctx, SC_ERR_INVALID, "batch_fill must be >= 0");
         ctx->batch_fill = (int)value;
+    } else if (!strcmp(name, "i1_pairs")) {
+        if (!(value >= 1.0 && value <= 64.0)) return sc_fail(ctx, SC_ERR_INVALID, "i1_pairs must be 1 .. 64");
+        ctx->i1_pairs = (int)value;
     } else if (!strcmp(name, "sib")) {
         ctx->sib = (int)value;
     } else if (!strcmp(name, "spectra_mb")) {

@@ -1676,13 +1676,18 @@ k_inv_cols_w8(const float2* __restrict__ uc, const float2* __restrict__ uc2,
               int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
               int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
               float2* __restrict__ ym, int ystride, int np, int pcj, int tstride,
-              const TileDev* __restrict__ tiles, int py_valid, const TemplDev* __restrict__ tl) {
-    const int j = blockIdx.x, i = ((j >> 4) << 3) | (j & 7);
+              const TileDev* __restrict__ tiles, int py_valid, const TemplDev* __restrict__ tl, int jil) {
+    // jil jobs (tile pairs of one orientation) interleaved along x: the 16 workgroups of eight column blocks and their
+    // mirrors are followed by the same 16 of the next job, so that the workgroups which stream the SAME coefficient
+    // lines - they do not depend on the tile pair - run on one XCD at the same time, 2 jil of them per column block
+    // (grid.x = jil Tx/8, grid.y = jobs / jil).  jil = 1: one job per blockIdx.y as before.
+    const int L = blockIdx.x, g16 = L / (16 * jil), r16 = L - g16 * 16 * jil, jq = r16 >> 4, j = r16 & 15;
+    const int i = (g16 << 3) | (j & 7), jobx = (int)blockIdx.y * jil + jq;
     if ((j >> 3) & 1)
-        inv_cols_w8_body<TY, true, PT, 8>((Tx >> 3) - 1 - i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
+        inv_cols_w8_body<TY, true, PT, 8>((Tx >> 3) - 1 - i, jobx, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
                                    rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid, tl);
     else
-        inv_cols_w8_body<TY, false, PT, 8>(i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
+        inv_cols_w8_body<TY, false, PT, 8>(i, jobx, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
                                     rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid, tl);
 }
 
@@ -2841,7 +2846,15 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             const int slots = 256 * (int)std::max<size_t>(1, (size_t)(160 * 1024) / lds_c);
             // (nb > 1, batched orientations: every job of the chunk in one launch - job
             //  ob * pc + q, the numbering the row kernel expects)
-            const int pi1 = nb > 1 ? pc : std::max(1, std::min(pc, (slots + fg.Tx / 8 - 1) / (fg.Tx / 8)));
+            int pi1 = nb > 1 ? pc : std::max(1, std::min(pc, (slots + fg.Tx / 8 - 1) / (fg.Tx / 8)));
+            // Wave-per-column kernel, one orientation: i1_pairs tile pairs per launch, INTERLEAVED along x (k_inv_cols_w8,
+            // jil) - a launch of several pairs one after the other along y lost 6 % (the pairs' workgroups drift apart);
+            // interleaved, the 2 x i1_pairs workgroups that stream the same coefficient lines run together on one XCD
+            int jil = 1;
+            if (nb == 1 && w8 && (!PTV || fg.Ty == 1024) && ctx->variant != 1 && !xp && ctx->i1_pairs > 1) {
+                jil = std::min(pc, ctx->i1_pairs);
+                pi1 = jil;
+            }
             // rows masked by the templates' window limits are neither stored by the wave-per-column
             // kernels nor scored by the row pass (not with explicit per-cell masks or single-template
             // maps: those write every cell; option "variant" 13 switches it off for the cross-check)
@@ -2850,6 +2863,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             int n_i1 = 0;
             for (int pl0 = 0; pl0 < pc; pl0 += pi1) {
             const int pcc = std::min(pi1, pc - pl0);
+            const int jilc = jil > 1 ? pcc : 1;                 // (the last launch of a chunk may hold fewer pairs)
             const int pair = pair0 + pl0;
             float2* ywp = (float2*)ctx->yw.p + (size_t)pl0 * yblock;
             float2* ymp = (float2*)ctx->ym.p + (size_t)pl0 * yblock;
@@ -2877,12 +2891,12 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     {                                                                          \
         int rc = set_lds(ctx, k_inv_cols_w8<T, PTV>, w8_lds<T>());             \
         if (rc) return rc;                                                     \
-        hipLaunchKernelGGL((k_inv_cols_w8<T, PTV>), dim3(fg.Tx / 8, nb * pcc), dim3(512),  \
+        hipLaunchKernelGGL((k_inv_cols_w8<T, PTV>), dim3(fg.Tx / 8 * jilc, nb * pcc / jilc), dim3(512),  \
                            w8_lds<T>(), ctx->stream, (const float2*)ctx->uc.p + ctx->uc_off, (const float2*)ctx->uc2.p + ctx->uc_off, \
                            (const float*)ctx->wh.p, (const float*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo, rp_hi, \
                            (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group, \
                            np, pcc, n, (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py, \
-                           row_skip ? (const TemplDev*)ctx->templ.p + first : nullptr); \
+                           row_skip ? (const TemplDev*)ctx->templ.p + first : nullptr, jilc); \
     }
 #define FN_W4(T)                                                               \
     {                                                                          \

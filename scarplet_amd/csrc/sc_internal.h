@@ -119,6 +119,7 @@ struct sc_ctx {
     float kappa = 4.f;         // float32 resolution floor of the FFT path, in units of eps (sc_set_option "kappa")
     int variant = 0;           // sc_set_option "variant": alternative kernel paths kept for cross-checks
     int batch_off = 0;         // sc_set_option "batch" = 0: no orientation batching (cross-check in the tests)
+    int i1_pairs = 2;          // sc_set_option "i1_pairs": tile pairs per launch of the wave-per-column pass, interleaved (1: one pair per launch)
     int batch_fill = 0;        // sc_set_option "batch_fill": column workgroups a batched launch aims at (0: 4096)
     double y_gb = 0.0;         // sc_set_option "y_gb": memory budget of the I1 -> I2 hand-off (0: automatic)
     int sib = 0;               // sc_set_option "sib": sibling rendezvous, bit 0 row pass, bit 1 column pass (sc_fft.hip SibSync)
