@@ -46,6 +46,9 @@ struct TileDev {
     int i0, j0, vy, vx, gi0, gj0;
 };
 
+#ifndef SC_LDS_WR1
+#define SC_LDS_WR1 0      // ... and written one ds_write_b64 each (wave-per-column kernels)
+#endif
 #ifndef SC_LDS_RD1
 #define SC_LDS_RD1 1      // LDS cells read one ds_read_b64 each (0: the compiler's ds_read2_b64 pairs)
 #endif
@@ -487,7 +490,7 @@ __device__ __forceinline__ void twiddle16_tab(const pk::v2 (&v)[16], GET get, PU
 
 // butterflies of the set (tt) in the stage (R, LST) and store to `line`; TAB: the twiddles of a radix-16 stage
 // come from a table of all fifteen (wtab[k * wstride], k = 1 .. 15) instead of the four bases w
-template <int T, int R, int LST, bool INV, bool TAB = false>
+template <int T, int R, int LST, bool INV, bool TAB = false, bool WR1 = false>
 __device__ __forceinline__ void set_compute_store(float2* line_, int tt, float2 (&a)[16],
                                                   const float2 (&w)[4], const float2* wtab = nullptr, int wstride = 0) {
     using pk::v2;
@@ -514,8 +517,13 @@ __device__ __forceinline__ void set_compute_store(float2* line_, int tt, float2 
         v2* const wb = STRIDED ? line + ph(o) : (UNIT ? line + 17 * bt : line);
         constexpr int wstep = STRIDED ? ST + ST / 16 : 1;      // padded distance of ST elements
         auto put = [&](int m, v2 val) {
-            if constexpr (STRIDED || UNIT) wb[m * wstep] = val;
-            else line[ph(o + (m << LST))] = val;
+            v2* dst = (STRIDED || UNIT) ? wb + m * wstep : line + ph(o + (m << LST));
+            if constexpr (WR1 && SC_LDS_WR1) {       // (one ds_write_b64 per cell, see lds_cell)
+                typedef volatile __attribute__((address_space(3))) unsigned long long* lds_u64w;
+                *(lds_u64w)(dst) = (unsigned long long)__float_as_uint(val.x) | ((unsigned long long)__float_as_uint(val.y) << 32);
+            } else {
+                *dst = val;
+            }
         };
         if constexpr (LAST) {
 #pragma unroll
@@ -1564,7 +1572,7 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
 #endif
     auto tw_of = [&](const float2* t, int n, int idx, float2 (&wq)[4]) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) wq[m] = t[m * n + idx];
+        for (int m = 0; m < 4; ++m) wq[m] = lds_cell<true>(t + m * n + idx);
     };
     float c[NK], c2[PT ? NK : 1];
     const int NG = PT ? (G + 1) / 2 : G;       // inverse transforms per plane (PT: templates 2k, 2k+1 in one)
@@ -1628,7 +1636,7 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
                 set_compute_store<TY, 16, 0, true, true>(line, lt + 64 * u, a1, wq, t1 + lt + 64 * u, S);
 #else
                 tw_of(t1, S, lt + 64 * u, wq);
-                set_compute_store<TY, 16, 0, true>(line, lt + 64 * u, a1, wq);
+                set_compute_store<TY, 16, 0, true, false, true>(line, lt + 64 * u, a1, wq);
 #endif
             }
             // next coefficients: all of them now - or, two planes of them (PT) and two sets per lane,
@@ -1645,7 +1653,7 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
                 set_compute_store<TY, 16, 4, true, true>(line, lt + 64 * u, a[u], wq, t2 + ((lt + 64 * u) >> 4), S / 16);
 #else
                 tw_of(t2, S / 16, (lt + 64 * u) >> 4, wq);
-                set_compute_store<TY, 16, 4, true>(line, lt + 64 * u, a[u], wq);
+                set_compute_store<TY, 16, 4, true, false, true>(line, lt + 64 * u, a[u], wq);
 #endif
             }
             asm volatile("" ::: "memory");
@@ -1654,7 +1662,7 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
 #pragma unroll
                 for (int u = 0; u < U; ++u) set_load<TY, true>(line, lt + 64 * u, a[u]);
 #pragma unroll
-                for (int u = 0; u < U; ++u) set_compute_store<TY, R3, 8, true>(line, lt + 64 * u, a[u], wq);
+                for (int u = 0; u < U; ++u) set_compute_store<TY, R3, 8, true, false, true>(line, lt + 64 * u, a[u], wq);
             }
             lds_barrier();                                   // all eight lines are complete
             if (SPLIT && gi_ + 1 < NG) fetch(gi_ + 1, 1);
@@ -1676,7 +1684,7 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
 #endif
 #pragma unroll 2
             for (int rp = s_lo + RQ * w + ln / NC; rp <= s_hi; rp += RQ * NC)
-                store_stream(o + (size_t)rp * (Tx >> 3) * 16, lc[ph(2 * rp)], lc[ph(2 * rp + 1)]);
+                store_stream(o + (size_t)rp * (Tx >> 3) * 16, lds_cell<true>(lc + ph(2 * rp)), lds_cell<true>(lc + ph(2 * rp + 1)));
 #ifdef SC_I1_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
