@@ -46,6 +46,9 @@ struct TileDev {
     int i0, j0, vy, vx, gi0, gj0;
 };
 
+#ifndef SC_I2_RD1
+#define SC_I2_RD1 1        // the row pass's stage-2 and stage-3 cells read singly too
+#endif
 #ifndef SC_LDS_WR1
 #define SC_LDS_WR1 0      // ... and written one ds_write_b64 each (wave-per-column kernels)
 #endif
@@ -408,6 +411,13 @@ struct FftTw {
 //  ds_read_b64 (MI355X_MICROARCH.md, LDS table: 128 against 256 B/clk/CU).  The wave-per-column pass issues 39 of
 //  them per transform and plane, eight waves at a time: a sixth of its LDS cycles.  RD1: that kernel only - the
 //  forward row pass is 13 % slower with single reads.)
+template <bool RD1, typename V2>
+__device__ __forceinline__ V2 lds_cell2(const V2* p) {            // the same for the packed two-float vector type
+    if constexpr (!RD1 || !SC_LDS_RD1) return *p;
+    typedef const volatile __attribute__((address_space(3))) unsigned long long* lds_u64p;
+    const unsigned long long v = *(lds_u64p)(p);
+    return V2{__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32))};
+}
 template <bool RD1>
 __device__ __forceinline__ float2 lds_cell(const float2* p) {
     if constexpr (!RD1) return *p;
@@ -2277,7 +2287,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         {
             v2 b[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) b[j] = rd2[j * (S + S / 16)];
+            for (int j = 0; j < 16; ++j) b[j] = lds_cell2<SC_I2_RD1 != 0>(rd2 + j * (S + S / 16));
             lds_barrier();
             pk::B<16, true>::run(b);
             wr2[0] = b[pk::B<16, true>::pos(0)];
@@ -2331,8 +2341,8 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             v2 vw[R3], vm[R3];
 #pragma unroll
             for (int k = 0; k < R3; ++k) {
-                vw[k] = lineW[u * (2 * S + 2 * S / 16) + k * 272];
-                vm[k] = lineM[u * (2 * S + 2 * S / 16) + k * 272];
+                vw[k] = lds_cell2<SC_I2_RD1 != 0>(lineW + u * (2 * S + 2 * S / 16) + k * 272);
+                vm[k] = lds_cell2<SC_I2_RD1 != 0>(lineM + u * (2 * S + 2 * S / 16) + k * 272);
             }
             pk::B<R3, true>::run(vw);
             pk::B<R3, true>::run(vm);
