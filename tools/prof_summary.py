@@ -53,7 +53,7 @@ SLOTS = (("k_curv", ("k_curv",)), ("k_windows", ("k_windows",)), ("k_direct", ("
 out = {"so_sha256": h, "bytes_per_launch": {}, "detail": {},
        "_note": "bytes per kernel launch, per profiling slot of the library, from rocprofv3 --pmc FETCH_SIZE / "
                 "WRITE_SIZE (separate passes, bench.py --angles 2), FETCH_SIZE doubled per MI355X_MICROARCH.md; "
-                "k_inv_cols = mean k_inv_cols_w8 launch (one tile pair, 35 templates, all columns), k_inv_rows = "
+                "k_inv_cols = mean k_inv_cols_w8 launch (option i1_pairs: two tile pairs, the last of a chunk one; 35 templates, all columns), k_inv_rows = "
                 "mean k_inv_rows_fast launch; the forward slots average their curvature and template launches"}
 for key, pats in SLOTS:
     pred = lambda n, pats=pats: any(p_ in n for p_ in pats)
