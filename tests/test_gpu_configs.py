@@ -342,7 +342,8 @@ def test_column_pass_forms_are_bit_identical():
     tile pairs and a partial last tile row, at T = 1024 / 512, on non-square tiles, with an odd
     tile count (paired-template mode) and with batched orientations on a circular tile.  Round 4:
     the wave-per-column kernel does not store, and the row pass does not transform, the rows a
-    template's window limits mask (variant=13 switches both off): the record must not notice."""
+    template's window limits mask (variant=13 switches both off): the record must not notice.  Nor
+    must it notice how many tile pairs share a launch of the wave-per-column pass (option i1_pairs)."""
     a9 = _plan.age_grid()[::4]                          # 9 ages
     cases = [(synthetic.synthetic_scarp(3900, ny=3700, seed=31), sl.Scarp, 100, a9, _plan.angle_grid()[3::45]),
              (synthetic.synthetic_scarp(1500, ny=1400, seed=32), sl.Scarp, 40, a9, _plan.angle_grid()[::30]),
@@ -352,11 +353,16 @@ def test_column_pass_forms_are_bit_identical():
              (synthetic.synthetic_scarp(900, ny=505, seed=36), sl.Scarp, 50, a9, _plan.angle_grid()[::18]),
              (synthetic.synthetic_scarp(420, ny=3000, seed=37), sl.Scarp, 60, a9, _plan.angle_grid()[::25]),
              (synthetic.synthetic_scarp(1024, seed=34), sl.Channel, 15, [0.05, 0.07, 0.1, 0.14, 0.2, 0.28, 0.4, 0.56], _plan.angle_grid()[::12])]
-    for (g, cls, scale, params, angles) in cases:
+    for ci, (g, cls, scale, params, angles) in enumerate(cases):
         out = []
-        for variant in (0, 2, 6, 13):                   # 13: no skipping of the rows masked by window limits
+        # (i1_pairs: tile pairs per launch of the wave-per-column pass, interleaved along x - default 2; one pair per
+        #  launch and three - a chunk's last launch then holds fewer - must give the same record)
+        runs = [(0, None), (2, None), (6, None), (13, None)] + ([(0, 1), (0, 3)] if ci < 2 else [])
+        for variant, pairs in runs:                      # 13: no skipping of the rows masked by window limits
             ctx = sl._lib.Context(0)
             ctx.set_option("variant", variant)
+            if pairs is not None:
+                ctx.set_option("i1_pairs", pairs)
             m = sl.Matcher(g, ctx=ctx)
             m.search(cls, scale, params, angles, method="fft")
             out.append(m.ctx.get_best())
