@@ -46,6 +46,9 @@ struct TileDev {
     int i0, j0, vy, vx, gi0, gj0;
 };
 
+#ifndef SC_I1_XLANE
+#define SC_I1_XLANE 1      // k_inv_cols_w8<2048>: stage 2 -> 3 exchanged across lanes (v_permlane swaps), not through the LDS
+#endif
 #ifndef SC_I2_RD1
 #define SC_I2_RD1 1        // the row pass's stage-2 and stage-3 cells read singly too
 #endif
@@ -500,6 +503,40 @@ __device__ __forceinline__ void twiddle16_tab(const pk::v2 (&v)[16], GET get, PU
 
 // butterflies of the set (tt) in the stage (R, LST) and store to `line`; TAB: the twiddles of a radix-16 stage
 // come from a table of all fifteen (wtab[k * wstride], k = 1 .. 15) instead of the four bases w
+// ---- stage 2 -> stage 3 of a length-2048 line WITHOUT the LDS (k_inv_cols_w8, SC_I1_XLANE) --------------------------------
+// Stage 2 (radix 16, stride 16) of the wave's line leaves output m of lane L's set u at element
+//   (L & 15) + 16 m + 256 ((L >> 4) + 4 u);
+// stage 3 (radix 8, stride 256) wants, in lane L3, for its butterflies bt3 = L3 + 64 u' + 128 b, the elements bt3 + 256 j:
+// output m = (L3 >> 4) + 4 (u' + 2 b) of the lanes (L3 & 15) + 16 k, sets u, with j = k + 4 u.  The exchange stays inside the
+// four lanes that share L & 15 - a 4 x 4 transpose between the 16-lane row L >> 4 and m & 3 for each of (u, m >> 2, re / im):
+// two v_permlane32_swap and two v_permlane16_swap per four registers, 64 of them for the 32 cells, instead of 32 cells
+// written to the LDS (6 cycles each, eight waves at a time) and read back.  Data movement only: the same values.
+__device__ __forceinline__ void xlane_swap32(float& a, float& b) {        // a's lanes 32-63 <-> b's lanes 0-31
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void xlane_swap16(float& a, float& b) {        // a's odd rows of 16 lanes <-> b's even rows
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+// r[k] of the lane in row q <- r[q] of the lane in row k (rows of 16 lanes, same lane & 15)
+__device__ __forceinline__ void xlane_transpose4(float& r0, float& r1, float& r2, float& r3) {
+    xlane_swap32(r0, r2);
+    xlane_swap32(r1, r3);
+    xlane_swap16(r0, r1);
+    xlane_swap16(r2, r3);
+}
+// a radix-16 stage's butterfly and twiddles with the outputs kept: out[m] = output m (set_compute_store's arithmetic)
+template <bool INV>
+__device__ __forceinline__ void set_compute_regs(const float2 (&a)[16], const float2 (&w)[4], float2 (&out)[16]) {
+    using pk::v2;
+    v2 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = v2{a[k].x, a[k].y};
+    pk::B<16, INV>::run(v);
+    twiddle16<INV>(v, w, [&](int m, v2 val) { out[m] = make_float2(val.x, val.y); });
+}
+
 template <int T, int R, int LST, bool INV, bool TAB = false, bool WR1 = false>
 __device__ __forceinline__ void set_compute_store(float2* line_, int tt, float2 (&a)[16],
                                                   const float2 (&w)[4], const float2* wtab = nullptr, int wstride = 0) {
@@ -1657,6 +1694,34 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
             float2 a[U][16];
 #pragma unroll
             for (int u = 0; u < U; ++u) set_load<TY, true>(line, lt + 64 * u, a[u]);
+            constexpr bool XLANE = SC_I1_XLANE && TY == 2048 && !SC_I1_TWTAB;
+            if constexpr (XLANE) {
+                // stage 2 into registers, the exchange across lanes, stage 3 from registers (see xlane_transpose4)
+                float2 o2[U][16];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    tw_of(t2, S / 16, (lt + 64 * u) >> 4, wq);
+                    set_compute_regs<true>(a[u], wq, o2[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int mh = 0; mh < 4; ++mh) {
+                        xlane_transpose4(o2[u][4 * mh].x, o2[u][4 * mh + 1].x, o2[u][4 * mh + 2].x, o2[u][4 * mh + 3].x);
+                        xlane_transpose4(o2[u][4 * mh].y, o2[u][4 * mh + 1].y, o2[u][4 * mh + 2].y, o2[u][4 * mh + 3].y);
+                    }
+#pragma unroll
+                for (int u3 = 0; u3 < U; ++u3) {
+                    // butterfly b of set u3 takes a[b + 2 j] = element (lt + 64 u3 + 128 b) + 256 j: set j >> 2, output
+                    // 4 (u3 + 2 b) + (lane row), of the lane in row j & 3
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a[u3][b + 2 * j] = o2[j >> 2][4 * (u3 + 2 * b) + (j & 3)];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) set_compute_store<TY, TY / 256, 8, true, false, true>(line, lt + 64 * u, a[u], wq);
+            } else {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
 #if SC_I1_TWTAB
@@ -1667,7 +1732,8 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
 #endif
             }
             asm volatile("" ::: "memory");
-            if constexpr (TY > 256) {
+            }
+            if constexpr (TY > 256 && !XLANE) {
                 constexpr int R3 = TY / 256;
 #pragma unroll
                 for (int u = 0; u < U; ++u) set_load<TY, true>(line, lt + 64 * u, a[u]);
