@@ -47,7 +47,7 @@ struct TileDev {
 };
 
 #ifndef SC_I1_XLANE
-#define SC_I1_XLANE 1      // k_inv_cols_w8<2048>: stage 2 -> 3 exchanged across lanes (v_permlane swaps), not through the LDS
+#define SC_I1_XLANE 1      // k_inv_cols_w8 / w4: stage 2 -> 3 exchanged across lanes (v_permlane swaps), not through the LDS
 #endif
 #ifndef SC_I2_RD1
 #define SC_I2_RD1 1        // the row pass's stage-2 and stage-3 cells read singly too
@@ -503,7 +503,8 @@ __device__ __forceinline__ void twiddle16_tab(const pk::v2 (&v)[16], GET get, PU
 
 // butterflies of the set (tt) in the stage (R, LST) and store to `line`; TAB: the twiddles of a radix-16 stage
 // come from a table of all fifteen (wtab[k * wstride], k = 1 .. 15) instead of the four bases w
-// ---- stage 2 -> stage 3 of a length-2048 line WITHOUT the LDS (k_inv_cols_w8, SC_I1_XLANE) --------------------------------
+// ---- stage 2 -> stage 3 of a length-2048 (1024) line WITHOUT the LDS (k_inv_cols_w8, SC_I1_XLANE) --------------------------
+// (written for 2048 = 16 x 16 x 8, two sets per lane; 1024 = 16 x 16 x 4 is the same exchange with one set and four butterflies)
 // Stage 2 (radix 16, stride 16) of the wave's line leaves output m of lane L's set u at element
 //   (L & 15) + 16 m + 256 ((L >> 4) + 4 u);
 // stage 3 (radix 8, stride 256) wants, in lane L3, for its butterflies bt3 = L3 + 64 u' + 128 b, the elements bt3 + 256 j:
@@ -1694,7 +1695,7 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
             float2 a[U][16];
 #pragma unroll
             for (int u = 0; u < U; ++u) set_load<TY, true>(line, lt + 64 * u, a[u]);
-            constexpr bool XLANE = SC_I1_XLANE && TY == 2048 && !SC_I1_TWTAB;
+            constexpr bool XLANE = SC_I1_XLANE && (TY == 2048 || TY == 1024) && !SC_I1_TWTAB;
             if constexpr (XLANE) {
                 // stage 2 into registers, the exchange across lanes, stage 3 from registers (see xlane_transpose4)
                 float2 o2[U][16];
@@ -1710,14 +1711,15 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
                         xlane_transpose4(o2[u][4 * mh].x, o2[u][4 * mh + 1].x, o2[u][4 * mh + 2].x, o2[u][4 * mh + 3].x);
                         xlane_transpose4(o2[u][4 * mh].y, o2[u][4 * mh + 1].y, o2[u][4 * mh + 2].y, o2[u][4 * mh + 3].y);
                     }
+                constexpr int R3x = TY / 256, NB3 = 16 / R3x;      // stage 3: radix 8 / 4, two / four butterflies per set
 #pragma unroll
                 for (int u3 = 0; u3 < U; ++u3) {
-                    // butterfly b of set u3 takes a[b + 2 j] = element (lt + 64 u3 + 128 b) + 256 j: set j >> 2, output
-                    // 4 (u3 + 2 b) + (lane row), of the lane in row j & 3
+                    // butterfly b of set u3 takes a[b + NB3 j] = element (lt + 64 u3 + S b) + 256 j: set j >> 2, output
+                    // 4 (u3 + U b) + (lane row), of the lane in row j & 3
 #pragma unroll
-                    for (int b = 0; b < 2; ++b)
+                    for (int b = 0; b < NB3; ++b)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) a[u3][b + 2 * j] = o2[j >> 2][4 * (u3 + 2 * b) + (j & 3)];
+                        for (int j = 0; j < R3x; ++j) a[u3][b + NB3 * j] = o2[j >> 2][4 * (u3 + U * b) + (j & 3)];
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) set_compute_store<TY, TY / 256, 8, true, false, true>(line, lt + 64 * u, a[u], wq);
