@@ -528,14 +528,19 @@ __device__ __forceinline__ void xlane_transpose4(float& r0, float& r1, float& r2
     xlane_swap16(r2, r3);
 }
 // a radix-16 stage's butterfly and twiddles with the outputs kept: out[m] = output m (set_compute_store's arithmetic)
-template <bool INV>
-__device__ __forceinline__ void set_compute_regs(const float2 (&a)[16], const float2 (&w)[4], float2 (&out)[16]) {
+template <bool INV, bool TAB = false>
+__device__ __forceinline__ void set_compute_regs(const float2 (&a)[16], const float2 (&w)[4], float2 (&out)[16],
+                                                 const float2* wtab = nullptr, int wstride = 0) {
     using pk::v2;
     v2 v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = v2{a[k].x, a[k].y};
     pk::B<16, INV>::run(v);
-    twiddle16<INV>(v, w, [&](int m, v2 val) { out[m] = make_float2(val.x, val.y); });
+    auto put = [&](int m, v2 val) { out[m] = make_float2(val.x, val.y); };
+    if constexpr (TAB)
+        twiddle16_tab<INV>(v, [&](int k) { const float2 x = lds_cell<true>(wtab + k * wstride); return v2{x.x, x.y}; }, put);
+    else
+        twiddle16<INV>(v, w, put);
 }
 
 template <int T, int R, int LST, bool INV, bool TAB = false, bool WR1 = false>
@@ -1695,14 +1700,18 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
             float2 a[U][16];
 #pragma unroll
             for (int u = 0; u < U; ++u) set_load<TY, true>(line, lt + 64 * u, a[u]);
-            constexpr bool XLANE = SC_I1_XLANE && (TY == 2048 || TY == 1024) && !SC_I1_TWTAB;
+            constexpr bool XLANE = SC_I1_XLANE && (TY == 2048 || TY == 1024);
             if constexpr (XLANE) {
                 // stage 2 into registers, the exchange across lanes, stage 3 from registers (see xlane_transpose4)
                 float2 o2[U][16];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
+#if SC_I1_TWTAB
+                    set_compute_regs<true, true>(a[u], wq, o2[u], t2 + ((lt + 64 * u) >> 4), S / 16);
+#else
                     tw_of(t2, S / 16, (lt + 64 * u) >> 4, wq);
                     set_compute_regs<true>(a[u], wq, o2[u]);
+#endif
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u)
