@@ -99,3 +99,63 @@ def test_single_tile_of_column_length_2048_is_replanned():
     assert (r.Ty, r.Tx, r.nty, r.ntx) == (2048, 2048, 6, 6)
     # the cap of an explicit t_max is respected
     assert _plan.Plan(2048, 2048, (0, 2048, 0, 2048), bbox, t_max=1024).Ty == 1024
+
+
+# ---- the wave-per-column pass's stage 2 -> stage 3 exchange across lanes (sc_fft.hip: xlane_transpose4, SC_I1_XLANE) ----------
+def _xlane_model(T):
+    """Lanes as numpy arrays: the Stockham placement of stage 2 (radix 16, stride 16) of one wave's line, the 4 x 4
+    transposes between the 16-lane row and m & 3 that v_permlane32_swap / v_permlane16_swap perform, and the register
+    the kernel then hands to input j of stage-3 butterfly b of set u3.  Returns (what the kernel feeds, what the LDS
+    path reads) as element indices of the line."""
+    S, U = T // 16, T // 1024                    # 16-point sets per line, sets per lane
+    R3, NB3 = T // 256, 16 // (T // 256)         # stage 3: radix, butterflies per set
+    lanes = np.arange(64)
+    # stage 2: output m of lane L's set u lies at element (bt & 15) + 16 m + 256 (bt >> 4), bt = L + 64 u
+    o2 = np.empty((U, 16, 64), dtype=int)
+    for u in range(U):
+        bt = lanes + 64 * u
+        for m in range(16):
+            o2[u, m] = (bt & 15) + 16 * m + 256 * (bt >> 4)
+
+    def swap32(a, b):                            # a's lanes 32-63 <-> b's lanes 0-31
+        a, b = a.copy(), b.copy()
+        a[32:], b[:32] = b[:32].copy(), a[32:].copy()
+        return a, b
+
+    def swap16(a, b):                            # a's odd rows of 16 lanes <-> b's even rows
+        a, b = a.copy(), b.copy()
+        for r in (1, 3):
+            lo, hi = 16 * r, 16 * r + 16
+            elo, ehi = 16 * (r - 1), 16 * (r - 1) + 16
+            a[lo:hi], b[elo:ehi] = b[elo:ehi].copy(), a[lo:hi].copy()
+        return a, b
+
+    for u in range(U):
+        for mh in range(4):
+            r = [o2[u, 4 * mh + k] for k in range(4)]
+            r[0], r[2] = swap32(r[0], r[2])
+            r[1], r[3] = swap32(r[1], r[3])
+            r[0], r[1] = swap16(r[0], r[1])
+            r[2], r[3] = swap16(r[2], r[3])
+            for k in range(4):
+                o2[u, 4 * mh + k] = r[k]
+    fed = np.empty((U, 16, 64), dtype=int)
+    want = np.empty((U, 16, 64), dtype=int)
+    for u3 in range(U):
+        for b in range(NB3):
+            for j in range(R3):
+                fed[u3, b + NB3 * j] = o2[j >> 2, 4 * (u3 + U * b) + (j & 3)]
+                # set_load of stage 3: a[i] = element tt + i S, tt = lane + 64 u3; butterfly b takes a[b + NB3 j]
+                want[u3, b + NB3 * j] = (lanes + 64 * u3) + (b + NB3 * j) * S
+    return fed, want
+
+
+def test_cross_lane_exchange_feeds_stage_3_what_the_lds_path_reads():
+    """k_inv_cols_w8 (round 4) hands stage 2's outputs to stage 3 through v_permlane swaps instead of the LDS
+    (profiles/r04_xlane_exchange.txt).  The GPU suite checks the result bit for bit against the four-column kernels;
+    this is the index algebra on its own - for column lengths 2048 (16 x 16 x 8) and 1024 (16 x 16 x 4) every
+    stage-3 input register must hold exactly the element the LDS path would have read."""
+    for T in (2048, 1024):
+        fed, want = _xlane_model(T)
+        assert np.array_equal(fed, want), T
+        assert len(np.unique(fed)) == fed.size == T          # every element of the line exactly once
