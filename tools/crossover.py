@@ -18,6 +18,7 @@ for scale in (5, 10, 20, 50, 100):
     for age in (1.0, 10.0, 100.0, 1000.0):
         row = []
         nn_last = 0
+        dev_ms = float("nan")
         for meth in ("direct", "fft"):
             arr, bbox, area = m.describe(sl.Scarp, scale, np.array([age]), angs)
             if meth == "direct" and nn_last > 40000:         # (the largest supports take seconds in real space)
@@ -27,8 +28,15 @@ for scale in (5, 10, 20, 50, 100):
             for _ in range(3):
                 m.search(sl.Scarp, scale, [age], angs, method=meth)
             row.append((time.perf_counter() - t0) / 3 / len(angs) * 1e3)
+            if meth == "direct":                                      # the kernel alone (HIP events around every launch)
+                m.ctx.profile(1)
+                m.search(sl.Scarp, scale, [age], angs, method=meth)
+                kn, kms = m.ctx.profile_get()["k_direct"]
+                m.ctx.profile(0)
+                dev_ms = kms / len(angs)
         nn, _ = m.ctx.template_sums(1)
         # FP32 rate of the real-space path on its FMA count: 2 FMA = 4 flop per tap and output cell
         tf = 4.0 * nn[0] * n * n / (row[0] * 1e-3) / 1e12 if row[0] == row[0] else float("nan")
-        print("scale %4d age %7.1f taps %7d  direct %8.3f ms (%5.1f TFLOP/s, %4.1f %% of 157)  fft %8.3f  %s"
-              % (scale, age, nn[0], row[0], tf, 100 * tf / 157.3, row[1], m.plan))
+        tfd = 4.0 * nn[0] * n * n / (dev_ms * 1e-3) / 1e12 if row[0] == row[0] else float("nan")
+        print("scale %4d age %7.1f taps %7d  direct %8.3f ms (%5.1f TFLOP/s, %4.1f %% of 157; kernel alone %7.3f ms = %4.1f %%)  fft %8.3f  %s"
+              % (scale, age, nn[0], row[0], tf, 100 * tf / 157.3, dev_ms, 100 * tfd / 157.3, row[1], m.plan))
