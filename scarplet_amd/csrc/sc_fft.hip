@@ -1783,8 +1783,11 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
 // grid.x = Tx/8 workgroups j: index i = 8 (j / 16) + j % 8 in [0, Tx/16); (j / 8) & 1 = 0: column
 // block i (columns 8i .. 8i+7), 1: the mirror block Tx/8 - 1 - i, whose coefficient columns
 // are 8i+1 .. 8i+8 - the partner's but one, eight workgroup ids away on the same XCD.
+// (column length 1024, one template per transform: capped at 128 registers = two workgroups per CU, four waves per SIMD -
+//  6 % faster on a C3-like load with 1024-long columns, profiles/r04_c3_plans.txt; at 2048 and with paired templates the
+//  kernel needs its 256)
 template <int TY, bool PT>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(512, (TY == 1024 && !PT) ? 4 : 2)
 k_inv_cols_w8(const float2* __restrict__ uc, const float2* __restrict__ uc2,
               const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
               int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
