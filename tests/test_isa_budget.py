@@ -1,0 +1,56 @@
+"""Register and scratch budgets of the hot kernels, read from the device assembly (CPU: hipcc cross-compiles).
+
+The performance of this path rests on a few occupancy facts that a harmless-looking edit can break without
+failing any numeric test: the real-space kernel has NO scratch in any form (round 4: DESIGN.md section 0,
+item 6), the row pass of the headline configuration fits 128 registers without scratch (four waves per
+SIMD), the wave-per-column pass fits 256.  The numbers are the compiler's own (.amdhsa metadata of
+`hipcc -S --cuda-device-only`), with the flags of scarplet_amd/csrc/Makefile."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "scarplet_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def kernel_table(src, extra=()):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = os.path.join("/tmp", "isa_budget_%s_%d.s" % (os.path.basename(src), os.getpid()))
+    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", *extra, "-S", "--cuda-device-only",
+           os.path.join(CSRC, src), "-o", out]
+    subprocess.run(cmd, check=True, capture_output=True, cwd=CSRC)
+    txt = open(out).read()
+    os.remove(out)
+    meta = txt[txt.index("amdhsa.kernels:"):]
+    table = {}
+    for blk in re.split(r"\n  - \.agpr_count:", meta)[1:]:
+        f = lambda k: re.search(r"\.%s:\s*(\S+)" % k, blk).group(1)
+        name = subprocess.run(["c++filt", f("name")], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void ", "")
+        table[name] = {"vgpr": int(f("vgpr_count")), "agpr": int(blk.split("\n")[0].strip()),
+                       "scratch": int(f("private_segment_fixed_size"))}
+    return table
+
+
+def test_real_space_kernel_has_no_scratch():
+    t = kernel_table("sc_kernels.hip", ("-fno-slp-vectorize",))
+    forms = {k: v for k, v in t.items() if k.startswith("k_direct2<")}
+    assert len(forms) == 6, sorted(forms)
+    for name, r in forms.items():
+        assert r["scratch"] == 0, (name, r)
+        assert r["vgpr"] <= 256, (name, r)          # two waves per SIMD
+
+
+@pytest.mark.slow
+def test_fft_kernels_fit_their_occupancy():
+    t = kernel_table("sc_fft.hip")
+    row = t["k_inv_rows_fast<2048, false, false, false, false>"]
+    assert row["scratch"] == 0 and row["vgpr"] <= 128, row             # four waves per SIMD, nothing spilled
+    col = t["k_inv_cols_w8<2048, false>"]
+    assert col["vgpr"] + col["agpr"] <= 256, col                       # two waves per SIMD (its scratch lies outside the template loop)
+    c1024 = t["k_inv_cols_w8<1024, false>"]
+    assert c1024["vgpr"] <= 128, c1024                                 # two workgroups per CU
