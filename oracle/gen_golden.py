@@ -281,6 +281,48 @@ def main():
         os.path.join(OUT, "ref_shifted.npz"), n=len(sh),
         **{"%s_%d" % (k, i): np.array(v) for i, c in enumerate(sh) for k, v in c.items()})
 
+    # ------------------------------------------------------------------ a11
+    print("calculate_best_fit_parameters_serial (core.py:65-136): reference capture, Shifted template")
+    rng11 = np.random.default_rng(11)            # (own stream: the fixtures above keep their draws)
+    ny, nx = 48, 52
+    z = (np.cumsum(rng11.standard_normal((ny, nx)), 1) * 0.05
+         + rng11.standard_normal((ny, nx)) * 0.02).astype(np.float32)
+    kw = dict(ang_max=0.05, ang_min=-0.05, dx=2, dy=1)
+    r = sl.calculate_best_fit_parameters_serial(ref_grid(dem, z, 1.0, 1.0),
+                                                WT.ShiftedLeftFacingUpperBreakScarp, 6, **kw)
+    angs = orc.angle_grid(kw["ang_min"], kw["ang_max"])
+    ages = orc.age_grid()
+    # the oracle's fold over the reference's own template objects, angle-outer / age-inner
+    def serial_results():
+        for ang in angs:
+            curv = orc.directional_curvature(z, 1.0, 1.0, ang)
+            for age in ages:
+                t = WT.ShiftedLeftFacingUpperBreakScarp(6, age, ang, nx, ny, 1.0, dx=2, dy=1)
+                a, s_ = orc.match_arrays(curv, t.template(), t.get_window_limits(), t.get_err_mask())
+                yield a, age, ang, s_
+    o = orc.compare(serial_results(), ny, nx)
+    for i, nm in enumerate(["amp", "age", "angle", "snr"]):
+        close(o[i], r[i], rtol=1e-7, atol=1e-10, what="serial driver %s" % nm)
+    np.savez_compressed(os.path.join(OUT, "ref_serial.npz"), z=z, de=1.0, scale=6.0,
+                        ang_max=kw["ang_max"], ang_min=kw["ang_min"], sdx=kw["dx"], sdy=kw["dy"],
+                        res=np.stack(r))
+
+    # ------------------------------------------------------------------ b (plugin contract)
+    print("the reference's own built-in classes are recognised (scarplet_amd.WindowedTemplate.builtin_twin)")
+    sys.path.insert(0, ROOT)
+    from scarplet_amd import WindowedTemplate as OWT
+    for nm in ("Scarp", "RightFacingUpperBreakScarp", "LeftFacingUpperBreakScarp", "Ricker", "Channel"):
+        twin = OWT.builtin_twin(getattr(WT, nm))
+        print("  %-58s %s" % ("reference %s -> device descriptor of" % nm, twin.__name__ if twin else "NONE"))
+        if twin is not getattr(OWT, nm):
+            raise SystemExit("builtin_twin does not recognise the reference's " + nm)
+    for nm in ("ShiftedLeftFacingUpperBreakScarp", "Crater", "WindowedTemplate"):
+        if OWT.builtin_twin(getattr(WT, nm)) is not None:
+            raise SystemExit("builtin_twin takes the reference's %s for a built-in" % nm)
+    g = OWT.grid_descriptors(WT.Scarp, 100, orc.age_grid(), orc.angle_grid(-0.3, 0.3), 505, 900, 2.0)
+    h = OWT.grid_descriptors(OWT.Scarp, 100, orc.age_grid(), orc.angle_grid(-0.3, 0.3), 505, 900, 2.0)
+    assert all(np.array_equal(np.asarray(g[k]), np.asarray(h[k])) for k in g)
+
     # ------------------------------------------------------------------ sample DEMs
     print("sample DEM fixtures (rasters of scarplet/datasets/data as arrays; crops as TIFF)")
     DATA = os.path.join(REF, "scarplet/datasets/data")

@@ -347,21 +347,93 @@ class Channel(Ricker):
     pass
 
 
+# ---- the reference's own built-in classes ------------------------------------------------------
+_TWIN_CACHE = {}
+# probe grids of builtin_twin: (scale d, second argument, orientation, nx, ny, de) - odd and even
+# sizes, a non-unit cell size, the three orientations at which a Scarp window has a zero column
+_TWIN_PROBES = [(6.0, 0.7, -1.1, 23, 18, 1.5), (5.0, 3.0, 0.4, 20, 24, 1.0), (4.0, 1.3, np.pi / 2, 17, 17, 1.0),
+                (7.0, 0.15, 0.0, 26, 21, 2.0), (5.0, 0.4, -np.pi / 2, 19, 22, 1.0)]
+
+
+def _same_template_behaviour(Theirs, Ours):
+    """True when ``Theirs`` answers the plugin contract (core.py:345-346, 369-375) exactly as this
+    package's class ``Ours`` does on the probe grids: the same window half-widths and alpha, the
+    same support ``W != 0`` cell for cell, the same window-limit and error masks in every cell, and
+    W equal to 1e-13 of its largest value (the reference's Ricker and UpperBreak classes evaluate
+    through numexpr, WT.py:205-213, 514-515, whose exp may differ from numpy's in the last place;
+    the device synthesises W in its own float64 arithmetic from the descriptor either way)."""
+    for d, par, ang, nx, ny, de in _TWIN_PROBES:
+        a, b = Theirs(d, par, ang, nx, ny, de), Ours(d, par, ang, nx, ny, de)
+        for k in ("c", "d", "alpha", "nx", "ny", "de"):
+            if getattr(a, k, None) != getattr(b, k):
+                return False
+        wa, wb = np.asarray(a.template(), dtype=np.float64), np.asarray(b.template(), dtype=np.float64)
+        if wa.shape != wb.shape or not np.array_equal(wa != 0, wb != 0):
+            return False
+        if not np.all(np.abs(wa - wb) <= 1e-13 * np.abs(wb).max()):
+            return False
+        if not np.array_equal(np.asarray(a.get_window_limits(), dtype=bool), b.get_window_limits()):
+            return False
+        if hasattr(a, "get_err_mask") != hasattr(b, "get_err_mask"):
+            return False
+        if hasattr(a, "get_err_mask") and not np.array_equal(np.asarray(a.get_err_mask(), dtype=bool),
+                                                              b.get_err_mask()):
+            return False
+    return True
+
+
+def builtin_twin(Template):
+    """This package's built-in class that ``Template`` stands for, or None.
+
+    A user script written against the reference does ``from scarplet.WindowedTemplate import
+    Scarp`` (WT.py:87-215, 434-525) and hands THAT class to ``match``.  It has no
+    ``_device_descriptor`` and would take the generic plugin path - a full-grid numpy
+    ``template()`` and two full-grid masks per (age, orientation).  A class is taken for one of
+    the built-ins when it carries a built-in's name, lives in a module called
+    ``WindowedTemplate``, describes nothing to the device itself, and behaves like this package's
+    class of that name on five small probe grids (_same_template_behaviour: supports and masks
+    cell for cell).  Anything else - a subclass, a renamed or edited copy - stays on the generic
+    path, which evaluates whatever the class computes.  The verdict is cached per class object."""
+    own = (Scarp, RightFacingUpperBreakScarp, LeftFacingUpperBreakScarp, Ricker, Channel)
+    if Template in own:
+        return Template
+    try:
+        return _TWIN_CACHE[Template]
+    except (KeyError, TypeError):
+        pass
+    twin = None
+    name = getattr(Template, "__name__", None)
+    mod = str(getattr(Template, "__module__", "")).rsplit(".", 1)[-1]
+    cand = {c.__name__: c for c in own}.get(name)
+    if cand is not None and mod == "WindowedTemplate" and not hasattr(Template, "_device_descriptor"):
+        try:
+            if _same_template_behaviour(Template, cand):
+                twin = cand
+        except Exception:
+            twin = None
+    try:
+        _TWIN_CACHE[Template] = twin
+    except TypeError:
+        pass
+    return twin
+
+
 # ---- descriptors of a whole (angle, parameter) grid at once ------------------------------------
 def grid_descriptors(Template, scale, params, angles, nx, ny, de):
     """``_device_descriptor()`` of ``Template(scale, p, a, nx, ny, de)`` for every angle a and
-    parameter p, as arrays of shape (n_angles, n_params) - or None when ``Template`` is not
-    exactly one of the built-in classes (a subclass may override anything) or the grid axes are
-    not ascending.  A search builds thousands of descriptors; one Python object and three dozen
+    parameter p, as arrays of shape (n_angles, n_params) - or None when ``Template`` is neither
+    exactly one of the built-in classes (a subclass may override anything) nor the reference's own
+    class of that name (builtin_twin), or the grid axes are not ascending.  A search builds thousands of descriptors; one Python object and three dozen
     numpy scalar calls each cost more than the device spends on a small search.
 
     Bit-identical to the per-template path: every transcendental (cos, sin, sqrt, pow) is still
     evaluated per scalar exactly as there; only the additions, multiplications and the bisection
     are done on arrays (tests/test_templates.py compares the two exhaustively)."""
+    Template = builtin_twin(Template)
+    if Template is None:
+        return None
     scarp_like = Template in (Scarp, RightFacingUpperBreakScarp, LeftFacingUpperBreakScarp)
     ricker_like = Template in (Ricker, Channel)
-    if not (scarp_like or ricker_like):
-        return None
     x, y = centred_axis(nx, de), centred_axis(ny, de)
     if not (x[0] <= x[-1] and y[0] <= y[-1]):
         return None

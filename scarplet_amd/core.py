@@ -199,6 +199,8 @@ class Matcher(object):
         boxes = []
         k = 0
         max_area = 0
+        import time
+        t_start = time.perf_counter()
         for ib, ang in enumerate(angles):
             cc, sc2, ss = _plan.curvature_coefficients(ang)
             for ia, par in enumerate(params):
@@ -207,7 +209,12 @@ class Matcher(object):
                 desc = t._device_descriptor() \
                     if hasattr(t, "_device_descriptor") else None
                 if desc is None:
+                    # one full-grid template() and up to two full-grid masks at a time: t, W and
+                    # the masks of the previous template are dropped before the next is built
                     desc = self._describe_generic(t)
+                    del t
+                    if k == 0:
+                        self._warn_generic_cost(time.perf_counter() - t_start, n_par * n_ang)
                 s = arr[k]
                 s.kind, s.flags = desc["kind"], desc["flags"]
                 s.cos_a, s.sin_a = desc["cos_a"], desc["sin_a"]
@@ -271,6 +278,22 @@ class Matcher(object):
         taps = (2 * c_eff / self.de + 1) * (2 * np.asarray(g["d"]) / self.de + 1)
         area = int(np.minimum(box, taps).max())
         return bbox, area
+
+    # projected host seconds of a generic-plugin search above which describe() says so
+    GENERIC_WARN_SECONDS = 60.0
+
+    def _warn_generic_cost(self, first_seconds, n_templates):
+        """A plugin that does not describe itself to the device is evaluated on the host: one
+        full-grid numpy template() (+ masks) per (age, orientation) - 800 MB and seconds each at
+        10000 x 10000.  Said once per search, from the measured cost of the first template."""
+        total = first_seconds * n_templates
+        if total > self.GENERIC_WARN_SECONDS:
+            import warnings
+            warnings.warn("generic template plugin: template() and the masks are evaluated on the host for "
+                          "each of the %d templates (%.2f s for the first on this %d x %d grid: about %.0f s "
+                          "in all, one full-grid array at a time); the built-in classes - this package's or "
+                          "the reference's own - are synthesised on the device instead"
+                          % (n_templates, first_seconds, self.ny, self.nx, total))
 
     def _describe_generic(self, t):
         """Any WindowedTemplate-like plugin: evaluate its numpy methods on the

@@ -162,3 +162,149 @@ def test_nan_dem_fold_without_template_objects(cls):
             snr[np.isnan(s)] = np.nan
     assert np.array_equal(fast[0], amp, equal_nan=True) and np.array_equal(fast[3], snr, equal_nan=True)
     assert not fast[1].any() and not fast[2].any()
+
+
+# ---- the reference's own built-in classes handed to match() (builtin_twin) ---------------------
+def _standin_module(edit=None):
+    """A module called ``<pkg>.WindowedTemplate`` with plugin classes written the way a user's
+    own copy would be - meshgrid coordinates, masks as full arrays - NOT this package's classes
+    and not the reference's text: what builtin_twin has to recognise by behaviour.  ``edit``
+    changes one class so that it no longer behaves like the built-in of its name."""
+    import types
+    from scipy.special import erfinv
+    mod = types.ModuleType("userpkg.WindowedTemplate")
+
+    class Base(object):
+        def _xy(self):
+            gx = self.de * np.linspace(1, self.nx, num=self.nx)
+            gy = self.de * np.linspace(1, self.ny, num=self.ny)
+            return gx - np.mean(gx), gy - np.mean(gy)
+
+        def get_coordinates(self):
+            gx, gy = self._xy()
+            X, Y = np.meshgrid(gx, gy)
+            return X * np.cos(self.alpha) + Y * np.sin(self.alpha), -X * np.sin(self.alpha) + Y * np.cos(self.alpha)
+
+        def get_mask(self):
+            xr, yr = self.get_coordinates()
+            return (abs(xr) < self.c) & (abs(yr) < self.d)
+
+        def get_window_limits(self):
+            a, q = self.alpha, self.alpha - np.pi / 2
+            an_y = abs((self.d * np.cos(q) - self.d * np.cos(a)) + 2 * self.c * np.cos(q))
+            an_x = abs((self.d * np.sin(a) - self.d * np.sin(q)) + 2 * self.c * np.sin(q))
+            gx, gy = self._xy()
+            X, Y = np.meshgrid(gx, gy)
+            return (X < (min(gx) + an_x)) | (X > (max(gx) - an_x)) | (Y < (min(gy) + an_y)) | (Y > (max(gy) - an_y))
+
+    class Scarp(Base):
+        def __init__(self, d, kt, alpha, nx, ny, de):
+            self.d, self.kt, self.alpha, self.nx, self.ny, self.de = d, kt, -alpha, nx, ny, de
+            self.c = abs(2 * np.sqrt(kt) * erfinv(0.9))
+
+        def template(self):
+            xr, _ = self.get_coordinates()
+            W = (-xr / (2. * self.kt ** (3 / 2.) * np.sqrt(np.pi))) * np.exp(-xr ** 2. / (4. * self.kt))
+            if edit == "scarp_value":
+                W = W * 1.0001
+            return W * self.get_mask()
+
+    class LeftFacingUpperBreakScarp(Scarp):
+        def get_err_mask(self):
+            xr, _ = self.get_coordinates()
+            return (xr > 0) if edit == "err_mask" else (xr >= 0)
+
+    class RightFacingUpperBreakScarp(Scarp):
+        def template(self):
+            return -Scarp.template(self)
+
+        def get_err_mask(self):
+            xr, _ = self.get_coordinates()
+            return xr <= 0
+
+    class Ricker(Base):
+        def __init__(self, d, f, alpha, nx, ny, de):
+            self.d, self.f, self.alpha, self.nx, self.ny, self.de = d, f, -alpha, nx, ny, de
+            self.c = nx
+
+        def get_window_limits(self):
+            return np.zeros((self.ny, self.nx), dtype=bool)
+
+        def template(self):
+            xr, _ = self.get_coordinates()
+            u = (np.pi * self.f * xr) ** 2.
+            return (1. - 2. * u) * np.exp(-u) * self.get_mask()
+
+    class Channel(Ricker):
+        pass
+
+    class Crater(Base):                       # a name this package has no device form for
+        def __init__(self, d, kt, alpha, nx, ny, de):
+            self.d, self.alpha, self.nx, self.ny, self.de, self.c = d, -alpha, nx, ny, de, 1.0
+
+        def template(self):
+            return np.zeros((self.ny, self.nx))
+
+    for cls in (Scarp, LeftFacingUpperBreakScarp, RightFacingUpperBreakScarp, Ricker, Channel, Crater):
+        cls.__module__ = mod.__name__
+        setattr(mod, cls.__name__, cls)
+    return mod
+
+
+def test_foreign_builtin_classes_are_recognised_by_behaviour():
+    """A script written against the reference hands ITS Scarp / Ricker / ... to match()
+    (WT.py:87-215, 434-525).  Such a class gets the device descriptors of this package's class of
+    that name when it behaves like it; an edited copy, a subclass or an unknown name does not."""
+    mod = _standin_module()
+    for name in ("Scarp", "LeftFacingUpperBreakScarp", "RightFacingUpperBreakScarp", "Ricker", "Channel"):
+        assert WT.builtin_twin(getattr(mod, name)) is getattr(WT, name), name
+    assert WT.builtin_twin(mod.Crater) is None
+    # the same descriptors as for this package's class, for a whole grid
+    ages, angles = [1.0, 12.5, 300.0], np.linspace(-np.pi / 2, np.pi / 2, 7)
+    a = WT.grid_descriptors(mod.Scarp, 20, ages, angles, 120, 90, 2.0)
+    b = WT.grid_descriptors(WT.Scarp, 20, ages, angles, 120, 90, 2.0)
+    assert a is not None and all(np.array_equal(np.asarray(a[k]), np.asarray(b[k])) for k in b)
+    # own classes: themselves; a subclass of an own class may override anything: generic
+    assert WT.builtin_twin(WT.Scarp) is WT.Scarp
+
+    class Mine(WT.Scarp):
+        pass
+    assert WT.builtin_twin(Mine) is None and WT.grid_descriptors(Mine, 20, ages, angles, 120, 90, 2.0) is None
+    # edited copies keep the name but not the behaviour
+    assert WT.builtin_twin(_standin_module("scarp_value").Scarp) is None
+    assert WT.builtin_twin(_standin_module("err_mask").LeftFacingUpperBreakScarp) is None
+    # the right name in a module of another name is not trusted either
+    other = _standin_module()
+    other.Scarp.__module__ = "userpkg.templates"
+    assert WT.builtin_twin(other.Scarp) is None
+
+
+def test_describe_uses_the_device_descriptors_for_foreign_builtins(monkeypatch):
+    """Matcher.describe() with the stand-in Scarp fills the struct array the built-in fills - no
+    template object, no full-grid template(): the stand-in's template() must not be called for
+    the search grid."""
+    from scarplet_amd import core, _lib
+    mod = _standin_module()
+    assert WT.builtin_twin(mod.Scarp) is WT.Scarp          # (probed on the small grids here)
+    calls = []
+    monkeypatch.setattr(mod.Scarp, "template", lambda self: calls.append(1) or np.zeros((self.ny, self.nx)))
+    m = core.Matcher.__new__(core.Matcher)
+    m.nx, m.ny, m.de = 400, 300, 1.0
+    ages, angles = [1.0, 10.0, 100.0], np.linspace(-0.5, 0.5, 9)
+    arr_f, bbox_f, area_f = m.describe(mod.Scarp, 30, ages, angles)
+    arr_o, bbox_o, area_o = m.describe(WT.Scarp, 30, ages, angles)
+    assert not calls
+    assert bytes(arr_f) == bytes(arr_o) and bbox_f == bbox_o and area_f == area_o
+    assert all(t.kind == WT.KIND_SCARP and t.window == -1 for t in arr_f)
+
+
+def test_generic_plugins_say_what_they_will_cost():
+    from scarplet_amd import core
+    m = core.Matcher.__new__(core.Matcher)
+    m.nx, m.ny = 10000, 10000
+    with pytest.warns(UserWarning, match="evaluated on the host"):
+        m._warn_generic_cost(2.5, 6335)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        m._warn_generic_cost(0.001, 35)
