@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C5"])
+    ap.add_argument("--config", default="C3", choices=["C1", "C1F", "C2", "C3", "C5"])
     ap.add_argument("--size", dest="n", type=int, default=0, help="synthetic DEM size (default: the config's)")
     ap.add_argument("--ages", type=int, default=0, help="ages of the grid (default: the config's)")
     ap.add_argument("--angles", type=int, default=0, help="orientations (default: the config's)")
@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the other_configs block (C1, C2, C5 timed and verified after the headline)")
+    ap.add_argument("--other-configs-budget", type=float, default=150.0,
+                    help="seconds the other_configs block may take in all (timing + oracle verification); configs "
+                         "that would start beyond it are reported as skipped")
     ap.add_argument("--prof-stride", type=int, default=16)
     ap.add_argument("--opt", default="", help="engine options for lab runs: name=value[,name=value...] (sc_set_option)")
     ap.add_argument("--shard", default="auto", choices=["auto", "orientations", "tiles"],
@@ -73,6 +76,10 @@ def parse():
                          "even grid (scarplet_amd.dist.tile_cores), or always the even grid")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="run the R blocks of the R-rank tiled search sequentially on this GPU")
+    ap.add_argument("--ipc-legacy", default="auto", choices=["auto", "0", "env"],
+                    help="HSA_ENABLE_IPC_MODE_LEGACY of the ranks this script starts itself (--gpus N without a "
+                         "launcher): '0' sets it to 0 where the environment does not set it, 'env' leaves the "
+                         "environment untouched, 'auto' tries '0' and, if the ranks fail, 'env'")
     ap.add_argument("--halo", default="rccl", choices=["rccl", "host", "gloo"],
                     help="halo exchange executor for --gpus > 1 (host: host arrays over gloo, for bring-up)")
     return ap.parse_args()
@@ -102,8 +109,14 @@ def workload(a):
         label = "C2: %dx%d synthetic DEM, Scarp, scale=100, %d ages x %d orientations" % (n, n, len(ages), len(angles))
         return synthetic.synthetic_scarp(n), sl.Scarp, [100.0], ages, angles, label, "scarp"
     f = np.load(os.path.join(ROOT, "tests", "golden",
-                             "dem_carrizo.npz" if a.config == "C1" else "dem_grandcanyon.npz"))
+                             "dem_carrizo.npz" if a.config in ("C1", "C1F") else "dem_grandcanyon.npz"))
     g = sl.DEMGrid.from_array(f["z"].astype(float), float(f["dx"]), float(f["dy"]))
+    if a.config == "C1F":
+        # the reference's own flagship call, docs/source/examples/scarps.ipynb cell 12:
+        # `res = sl.match(data, Scarp, scale=100.)` on load_carrizo() - "This can be slow on a laptop!"
+        return g, sl.Scarp, [100.0], pick(ages35, a.ages), pick(ang181, a.angles), \
+            "C1F: load_carrizo() 900x505 lidar DEM at 2 m, Scarp, scale=100, the full 35 ages x 181 orientations " \
+            "(scarps.ipynb: sl.match(data, Scarp, scale=100.))", "scarp"
     if a.config == "C1":
         lim = 17 * np.pi / 180
         angles = _plan.angle_grid(-lim, lim)
@@ -274,7 +287,7 @@ def measured_traffic(default_workload):
 
 
 # ----------------------------------------------------------------------------- the other BASELINE configs
-OTHER_CONFIGS = (("C1", 40, 5), ("C2", 8, 2), ("C5", 20, 3))      # (config, timed steps, warm-up steps)
+OTHER_CONFIGS = (("C1", 40, 5), ("C2", 8, 2), ("C5", 20, 3), ("C1F", 6, 2))      # (config, timed steps, warm-up steps)
 
 
 def other_config_line(a, cfg, steps, warmup, device, pool):
@@ -318,17 +331,107 @@ def other_config_line(a, cfg, steps, warmup, device, pool):
     return line
 
 
+# ----------------------------------------------------------------------------- clocks and power of the timed loop
+class GpuTelemetry(object):
+    """Shader clock and board power of one GPU while the timed loop runs, read from sysfs by a
+    thread of this process (no child process, no rocm-smi: a process that holds the GPU starts
+    nothing): <pci device>/hwmon/hwmon*/freq1_input (Hz) and power1_average | power1_input (uW),
+    pp_dpm_sclk's starred level where there is no hwmon clock.  Box-to-box spread of the headline is
+    5 %; with these two numbers in the line a slow box can be told from a regression.  Every
+    field is None where the files are not there or not readable (the line is printed anyway)."""
+
+    def __init__(self, bus_id=None, root="/sys/bus/pci/devices", period=0.05):
+        import glob
+        self.period, self.clk, self.pw, self._run, self._thr = period, [], [], False, None
+        self.dev = None
+        cands = []
+        if bus_id:
+            cands = [os.path.join(root, bus_id.lower()), os.path.join(root, bus_id.upper()), os.path.join(root, bus_id)]
+        self.dev = next((c for c in cands if os.path.isdir(c)), None)
+        hw = sorted(glob.glob(os.path.join(self.dev, "hwmon", "hwmon*"))) if self.dev else []
+        self.f_clk = next((os.path.join(h, "freq1_input") for h in hw if os.path.exists(os.path.join(h, "freq1_input"))), None)
+        self.f_pw = next((os.path.join(h, n) for h in hw for n in ("power1_average", "power1_input")
+                          if os.path.exists(os.path.join(h, n))), None)
+        self.f_dpm = os.path.join(self.dev, "pp_dpm_sclk") if self.dev and os.path.exists(os.path.join(self.dev, "pp_dpm_sclk")) else None
+
+    @staticmethod
+    def _num(path):
+        try:
+            with open(path) as f:
+                return float(f.read().split()[0])
+        except (OSError, ValueError, IndexError):
+            return None
+
+    def _sclk_mhz(self):
+        v = self._num(self.f_clk) if self.f_clk else None
+        if v is not None:
+            return v / 1e6
+        if self.f_dpm:
+            try:
+                for line in open(self.f_dpm):
+                    if "*" in line:
+                        return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+            except (OSError, ValueError, IndexError):
+                pass
+        return None
+
+    def sample(self):
+        c = self._sclk_mhz()
+        p = self._num(self.f_pw) if self.f_pw else None
+        if c is not None:
+            self.clk.append(c)
+        if p is not None:
+            self.pw.append(p / 1e6)
+
+    def start(self):
+        import threading
+        self.clk, self.pw, self._run = [], [], True
+
+        def loop():
+            while self._run:
+                self.sample()
+                time.sleep(self.period)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+        return self
+
+    def stop(self):
+        self._run = False
+        if self._thr is not None:
+            self._thr.join(timeout=2)
+        mean = lambda v: round(float(np.mean(v)), 1) if v else None
+        return {"clock_mhz": mean(self.clk), "clock_mhz_min": round(min(self.clk), 1) if self.clk else None,
+                "power_w": mean(self.pw), "samples": len(self.clk) or len(self.pw),
+                "source": "sysfs %s (hwmon freq1_input / power1_average, every %d ms over the timed loop)"
+                          % (self.dev, int(1e3 * self.period)) if (self.clk or self.pw) else "not readable on this box"}
+
+
+def device_bus_id(ctx):
+    try:
+        return ctx.comm_info().get("bus_id") or None
+    except Exception:
+        return None
+
+
 # ----------------------------------------------------------------------------- rank launcher
-def rank_environments(n, port, base=None):
+IPC_VAR = "HSA_ENABLE_IPC_MODE_LEGACY"
+
+
+def rank_environments(n, port, base=None, ipc_legacy="0"):
     """The environment of each of the n ranks started by `--gpus n` (what torch.distributed.run
     would set): RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT, the loopback
-    address because the container's host name may not resolve."""
+    address because the container's host name may not resolve.  ipc_legacy "0": the ranks get
+    HSA_ENABLE_IPC_MODE_LEGACY=0 unless the caller's environment already says something else (the
+    host driver of these boxes only supports dmabuf IPC; without it RCCL across processes fails with
+    hipIpcGetMemHandle: invalid argument); "env": the caller's environment untouched."""
     envs = []
     for r in range(n):
         e = dict(os.environ if base is None else base)
         e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
                   "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
-        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it here
+        if ipc_legacy == "0":
+            e.setdefault(IPC_VAR, "0")
+        e["SCARPLET_BENCH_IPC_ATTEMPT"] = ipc_legacy       # (recorded in the line: which attempt this run was)
         envs.append(e)
     return envs
 
@@ -340,7 +443,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(cmd, n, port=None, timeout=None):
+def launch_ranks(cmd, n, port=None, timeout=None, ipc_legacy="0"):
     """Start n rank processes of `cmd` (a list; one per GPU, like the reference's pool that starts
     and joins its own workers, core.py:180-188) and wait for them.  Called from a parent that has
     made NO HIP call and forked nothing.  Rank 0's stdout is captured (the JSON line); the other
@@ -350,7 +453,7 @@ def launch_ranks(cmd, n, port=None, timeout=None):
     import subprocess
     port = port or free_port()
     procs = []
-    for r, env in enumerate(rank_environments(n, port)):
+    for r, env in enumerate(rank_environments(n, port, ipc_legacy=ipc_legacy)):
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
                                       stderr=sys.stderr))
     import threading
@@ -410,7 +513,17 @@ def world_or_launch(a, argv=None):
     if a.gpus <= 1:
         return 0, 1, 0
     argv = sys.argv[1:] if argv is None else argv
-    rc, text = launch_ranks([sys.executable, os.path.abspath(__file__)] + list(argv), a.gpus)
+    # --ipc-legacy auto: first with HSA_ENABLE_IPC_MODE_LEGACY=0 (setdefault), and if the ranks fail, once
+    # more with the environment untouched - fresh processes both times (the variable is read when a process
+    # initialises the GPU); the line says which attempt produced it ("ipc": {...})
+    attempts = ["0", "env"] if a.ipc_legacy == "auto" else [a.ipc_legacy]
+    for k, mode in enumerate(attempts):
+        rc, text = launch_ranks([sys.executable, os.path.abspath(__file__)] + list(argv), a.gpus, ipc_legacy=mode)
+        if rc == 0 and any(ln.strip() for ln in text.splitlines()):
+            break
+        if k + 1 < len(attempts):
+            print("bench.py: the ranks failed with %s=%s; trying again with the environment untouched"
+                  % (IPC_VAR, "0 (default)" if mode == "0" else "as found"), file=sys.stderr)
     lines = [ln for ln in text.splitlines() if ln.strip()]
     if rc == 0 and not lines:
         print("bench.py: the ranks exited 0 but rank 0 printed nothing", file=sys.stderr)
@@ -421,7 +534,10 @@ def world_or_launch(a, argv=None):
 
 
 # ----------------------------------------------------------------------------- main
-def timed_loop(step, ctx, a, dist, after_warmup=None):
+LAST_TELEMETRY = {}          # clocks / power of the most recent timed loop of this process (GpuTelemetry.stop())
+
+
+def timed_loop(step, ctx, a, dist, after_warmup=None, max_over_ranks=None):
     """The contract's timing: W untimed steps, then EXACTLY K steps between a device sync + rank
     barrier on both sides; the MAX over ranks.  Returns (seconds, per-kernel profile of this rank)."""
     def barrier():
@@ -444,13 +560,19 @@ def timed_loop(step, ctx, a, dist, after_warmup=None):
     if after_warmup:
         after_warmup()
     ctx.profile(a.prof_stride)
+    tel = GpuTelemetry(device_bus_id(ctx))
     barrier()
+    tel.start()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
+    LAST_TELEMETRY.clear()
+    LAST_TELEMETRY.update(tel.stop())
+    if max_over_ranks is not None:
+        dt = max_over_ranks(dt)
+    elif dist is not None:
         import torch
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -458,6 +580,185 @@ def timed_loop(step, ctx, a, dist, after_warmup=None):
     prof = ctx.profile_get()
     ctx.profile(0)
     return dt, prof
+
+
+def all_ranks_ok(transport, ok):
+    """True only if EVERY rank says ok (gathered on rank 0, the verdict broadcast back through the launcher's
+    transport): whether a sharding's set-up or its first collective failed on some rank is decided together,
+    so that all ranks fall back together and none is left inside a collective the others never enter."""
+    flags = transport.gather(bool(ok), 0)
+    verdict = b"1" if (flags is not None and all(flags)) else b"0"
+    return transport.broadcast_bytes(verdict) == b"1"
+
+
+def max_over(transport, v):
+    """The maximum of a float over the ranks, on every rank (the contract's max-over-ranks of the timed loop)."""
+    import struct
+    vals = transport.gather(float(v), 0)
+    m = struct.pack("d", max(vals) if vals is not None else 0.0)
+    return struct.unpack("d", transport.broadcast_bytes(m))[0]
+
+
+def drop_communicator(device):
+    """The RCCL communicator of this process's context on `device`, if any (sc_comm_destroy)."""
+    try:
+        from scarplet_amd import core as _core
+        _core._context(device).comm_destroy()
+    except Exception:
+        pass
+
+
+def build_sharding(sh, backend, a, rank, world, device, transport, g, Template, scales, params, angles):
+    """Everything one sharding needs on this rank with the given transport ('rccl' or 'host'):
+    {step, after_warmup, plan, ctx, part, extras()}.  Raises whatever the set-up raises (communicator
+    initialisation, the first halo exchange)."""
+    from scarplet_amd import dist as sd
+    ny, nx = g._griddata.shape
+    if sh == "orientations":
+        om = sd.OrientationMatcher(rank, world, g, device=device, backend=backend, transport=transport)
+        mine, sp = om.describe(Template, scales[0], params, angles, a.method, a.group or None)
+
+        def step():
+            om.run(mine, sp)                   # reset, this rank's orientations, fold over RCCL
+
+        def after_warmup():
+            om.fold_seconds = 0.0
+        return {"step": step, "after_warmup": after_warmup, "plan": om.m.plan, "ctx": om.m.ctx,
+                "part": "orientation grid in %d chunks, whole DEM on every rank, records folded by two all-reduces" % world,
+                "extra_seconds": lambda: om.fold_seconds, "gather_seconds": lambda: None,
+                "result": lambda: om.result_array()}
+    dm = sd.DistMatcher(rank, world, (ny, nx), float(g._georef_info.dx), float(g._georef_info.dy),
+                        device=device, backend=backend, transport=transport)
+    arr, bbox, area = dm.m.describe(Template, scales[0], params, angles)
+    c = dm.partition_for(bbox) if a.partition == "tiles" else dm.core()
+    part = ("BASELINE config C4: %d rectangles of whole FFT tiles, halo exchange" % world) if dm.cores else \
+        "BASELINE config C4: %s even grid, halo exchange" % "x".join(map(str, sd.grid_dims(world, ny, nx)))
+    z_core = np.ascontiguousarray(g._griddata[c[0]:c[1], c[2]:c[3]])
+    dm.load(z_core, bbox)                  # halo exchange over RCCL
+    plan, sp = dm.m.plan_for(bbox, area, a.method, a.group or None, n_params=len(params))
+    dm.m.params, dm.m.angles = np.asarray(params, float), np.asarray(angles, float)
+    halo_s, gather_s = [0.0], [0.0]
+    full_box, gather_out = [None], [None]
+
+    def step():
+        t_ = time.perf_counter()
+        dm.load(z_core, bbox)              # the exchange is part of a search
+        halo_s[0] += time.perf_counter() - t_
+        dm.m.ctx.reset_best()
+        dm.m.ctx.match(arr, sp, sync=True)
+        # ... and so is the gather: the orientation sharding's step ends with the folded
+        # record on every rank, this one's with the assembled maps on rank 0
+        t_ = time.perf_counter()
+        if rank == 0 and gather_out[0] is None:
+            gather_out[0] = np.zeros((4, ny, nx))
+        full_box[0] = dm.gather(0, out=gather_out[0])
+        gather_s[0] += time.perf_counter() - t_
+
+    def after_warmup():
+        halo_s[0] = 0.0
+        gather_s[0] = 0.0
+    return {"step": step, "after_warmup": after_warmup, "plan": plan, "ctx": dm.m.ctx, "part": part,
+            "extra_seconds": lambda: halo_s[0], "gather_seconds": lambda: gather_s[0],
+            "result": lambda: np.stack(full_box[0]) if full_box[0] is not None else None}
+
+
+def run_shardings(a, rank, world, device, dist, transport, pool, g, Template, scales, params, angles, kind, units,
+                  base_line):
+    """Both shardings of the N-rank search (or the one --shard names), each with its own warm-up and
+    barrier-bracketed K steps; returns rank 0's JSON object (None on the other ranks).
+
+    A run on N GPUs must not come back empty: where RCCL fails on ANY rank - the communicator's
+    initialisation or the first collective, found by one untimed probe step - all ranks agree on it
+    (all_ranks_ok), drop their communicators and run that sharding over the host transport instead
+    (host arrays through the launcher's process group, the bring-up path of --halo host); the line then says
+    "transport": "host (RCCL failed: <message>)" and rccl.nranks 0.  Same process, nothing restarted."""
+    shards = ["orientations", "tiles"] if a.shard == "auto" else [a.shard]
+    first_backend = "host" if a.halo in ("host", "gloo") else "rccl"
+    runs = {}
+    for sh in shards:
+        label, built, errors = None, None, []
+        for backend in ([first_backend] + (["host"] if first_backend == "rccl" else [])):
+            err = None
+            try:
+                built = build_sharding(sh, backend, a, rank, world, device, transport, g, Template, scales, params, angles)
+                built["step"]()                        # the probe: the sharding's first collective, untimed
+            except Exception as e:
+                import traceback
+                traceback.print_exc()
+                err = "%s: %s" % (type(e).__name__, e)
+            msgs = [m_ for m_ in (transport.gather(err, 0) or []) if m_]
+            if all_ranks_ok(transport, err is None):
+                label = backend if not errors else "host (RCCL failed: %s)" % errors[0]
+                break
+            if rank == 0:
+                errors.append(msgs[0] if msgs else "a rank failed")
+            else:
+                errors.append(err or "another rank failed")
+            drop_communicator(device)                  # the communicator of a half-built attempt must go
+            built = None
+        try:
+            if built is None:
+                raise RuntimeError("; ".join(errors) or "set-up failed")
+            dt, prof = timed_loop(built["step"], built["ctx"], a, dist, built["after_warmup"],
+                                  max_over_ranks=lambda v: max_over(transport, v))
+            ctx, plan = built["ctx"], built["plan"]
+            # what RCCL itself says about the communicator this sharding ran on, from every rank
+            infos = transport.gather(ctx.comm_info(), 0)
+            extra = transport.gather(built["extra_seconds"]() / a.steps, 0)
+            gs = built["gather_seconds"]()
+            gath = transport.gather(gs / a.steps, 0) if gs is not None else None
+            tels = transport.gather(dict(LAST_TELEMETRY), 0)
+            if rank == 0:
+                ms = 1e3 * dt / a.steps
+                line = base_line(units / (dt / a.steps) / 1e6, ms, plan, "%d (%s)" % (world, built["part"]), prof, world)
+                line["transport"] = label
+                line["rccl"] = {"nranks": int(infos[0]["nranks"]),
+                                "devices": [{"rank": i_["rank"], "device": i_["device"], "bus_id": i_["bus_id"]} for i_ in infos],
+                                "note": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice of every rank's communicator "
+                                        "(sc_comm_info); nranks 0 = no RCCL communicator (host transport)"}
+                line["gpu_per_rank"] = tels
+                line["ipc"] = {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get(IPC_VAR),
+                               "attempt": os.environ.get("SCARPLET_BENCH_IPC_ATTEMPT", "launcher's environment")}
+                key = "fold_ms" if sh == "orientations" else "halo_exchange_ms"
+                line[key] = {"min_over_ranks": round(1e3 * min(extra), 3), "max_over_ranks": round(1e3 * max(extra), 3),
+                             "note": "wall time per step inside the collective on a rank; the minimum is the rank that "
+                                     "arrived last, i.e. the collective itself" if sh == "orientations" else
+                                     "upload of the rank's core, pack, grouped ncclSend/ncclRecv, unpack, per step"}
+                if gath is not None:
+                    line["gather_ms"] = {"min_over_ranks": round(1e3 * min(gath), 3), "max_over_ranks": round(1e3 * max(gath), 3),
+                                         "note": "inside the step: every rank's float32 record (12 B per cell) to rank 0, "
+                                                 "converted there to the four float64 planes (sc_gather_result: grouped "
+                                                 "ncclSend/ncclRecv, one conversion kernel per rank, D2H)"}
+                line["distinct_devices"] = len({(i_["device"], i_["bus_id"]) for i_ in infos})
+                if pool is not None:
+                    ver = verify_window(pool, built["result"](), g, kind, scales[-1], params, angles, plan, a.method)
+                    line["verified"], line["verification"] = ver["ok"], ver
+                runs[sh] = line
+            dist.barrier()
+        except Exception as e:                         # a sharding that fails on this node must not cost the other its line
+            import traceback
+            traceback.print_exc()
+            if rank == 0:
+                runs[sh] = {"error": "%s: %s" % (type(e).__name__, e), "ms_per_step": None}
+    if rank != 0:
+        return None
+    first = min(runs, key=lambda k: runs[k]["ms_per_step"] if runs[k]["ms_per_step"] is not None else float("inf"))
+    out = runs[first]
+    if "error" in out:
+        # nothing ran: the line is still printed - value null, the errors in it - and the exit code says so
+        out = {"metric": "Mpixel·template/s (DEM pixels × ages × orientations / s)", "value": None,
+               "unit": "Mpx·template/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": None,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+               "error": "every sharding failed on both transports", "shardings": runs}
+        out["failed"] = True
+        return out
+    out["sharding"] = first
+    for k, v in runs.items():
+        if k != first:
+            out["c4_tiles" if k == "tiles" else "orientations"] = v
+    return out
+
+
 
 
 def roofline_block(value, world, prof, units, steps, method, default_workload):
@@ -555,107 +856,26 @@ def main():
                        "group": int(getattr(plan, "group", 0)), "ranks": ranks_label},
             "roofline": roofline_block(value, n_gpus, prof, units, a.steps, a.method, default_workload),
             "kernels_ms_per_step": {k: round(v[1] / a.steps, 2) for k, v in prof.items() if v[0]},
+            # shader clock and board power of this rank's GPU over the timed loop (sysfs): box spread vs regression
+            "gpu": dict(LAST_TELEMETRY),
+            # which sources the library that ran was compiled from (sc_build_id) and the file's own hash
+            "library": {"build_id": _lib.load().sc_build_id().decode(), "so_sha256": so_sha256()[:16],
+                        "abi": int(_lib.load().sc_abi_version())},
         }
 
     # ------------------------------------------------------------------ N > 1: both shardings
     if world > 1:
-        shards = ["orientations", "tiles"] if a.shard == "auto" else [a.shard]
-        runs = {}
-        for sh in shards:
-          try:
-              if sh == "orientations":
-                  om = sd.OrientationMatcher(rank, world, g, device=device, backend=a.halo, transport=transport)
-                  mine, sp = om.describe(Template, scales[0], params, angles, a.method, a.group or None)
-                  plan, ctx = om.m.plan, om.m.ctx
-                  part = "orientation grid in %d chunks, whole DEM on every rank, records folded by two all-reduces" % world
-
-                  def step():
-                      om.run(mine, sp)                   # reset, this rank's orientations, fold over RCCL
-
-                  def after_warmup():
-                      om.fold_seconds = 0.0
-              else:
-                  dm = sd.DistMatcher(rank, world, (ny, nx), float(g._georef_info.dx), float(g._georef_info.dy),
-                                      device=device, backend=a.halo, transport=transport)
-                  arr, bbox, area = dm.m.describe(Template, scales[0], params, angles)
-                  c = dm.partition_for(bbox) if a.partition == "tiles" else dm.core()
-                  part = ("BASELINE config C4: %d rectangles of whole FFT tiles, halo exchange" % world) if dm.cores else \
-                      "BASELINE config C4: %s even grid, halo exchange" % "x".join(map(str, sd.grid_dims(world, ny, nx)))
-                  z_core = np.ascontiguousarray(g._griddata[c[0]:c[1], c[2]:c[3]])
-                  dm.load(z_core, bbox)                  # halo exchange over RCCL
-                  plan, sp = dm.m.plan_for(bbox, area, a.method, a.group or None, n_params=len(params))
-                  dm.m.params, dm.m.angles = np.asarray(params, float), np.asarray(angles, float)
-                  ctx = dm.m.ctx
-                  halo_s = [0.0]
-                  gather_s = [0.0]
-                  full_box, gather_out = [None], [None]
-
-                  def step():
-                      t_ = time.perf_counter()
-                      dm.load(z_core, bbox)              # the exchange is part of a search
-                      halo_s[0] += time.perf_counter() - t_
-                      dm.m.ctx.reset_best()
-                      dm.m.ctx.match(arr, sp, sync=True)
-                      # ... and so is the gather: the orientation sharding's step ends with the folded
-                      # record on every rank, this one's with the assembled maps on rank 0
-                      t_ = time.perf_counter()
-                      if rank == 0 and gather_out[0] is None:
-                          gather_out[0] = np.zeros((4, ny, nx))
-                      full_box[0] = dm.gather(0, out=gather_out[0])
-                      gather_s[0] += time.perf_counter() - t_
-
-                  def after_warmup():
-                      halo_s[0] = 0.0
-                      gather_s[0] = 0.0
-              dt, prof = timed_loop(step, ctx, a, dist, after_warmup)
-              # what RCCL itself says about the communicator this sharding ran on, from every rank
-              infos = transport.gather(ctx.comm_info(), 0)
-              extra = transport.gather(om.fold_seconds / a.steps if sh == "orientations" else halo_s[0] / a.steps, 0)
-              full = full_box[0] if sh == "tiles" else None
-              gath = transport.gather(gather_s[0] / a.steps, 0) if sh == "tiles" else None
-              if rank == 0:
-                  ms = 1e3 * dt / a.steps
-                  line = base_line(units / (dt / a.steps) / 1e6, ms, plan, "%d (%s)" % (world, part), prof, world)
-                  line["rccl"] = {"nranks": int(infos[0]["nranks"]),
-                                  "devices": [{"rank": i_["rank"], "device": i_["device"], "bus_id": i_["bus_id"]} for i_ in infos],
-                                  "note": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice of every rank's communicator "
-                                          "(sc_comm_info); nranks 0 = no RCCL communicator (--halo host)"}
-                  key = "fold_ms" if sh == "orientations" else "halo_exchange_ms"
-                  line[key] = {"min_over_ranks": round(1e3 * min(extra), 3), "max_over_ranks": round(1e3 * max(extra), 3),
-                               "note": "wall time per step inside the collective on a rank; the minimum is the rank that "
-                                       "arrived last, i.e. the collective itself" if sh == "orientations" else
-                                       "upload of the rank's core, pack, grouped ncclSend/ncclRecv, unpack, per step"}
-                  if sh == "tiles":
-                      line["gather_ms"] = {"min_over_ranks": round(1e3 * min(gath), 3), "max_over_ranks": round(1e3 * max(gath), 3),
-                                           "note": "inside the step: every rank's four float64 planes to rank 0 "
-                                                   "(sc_gather_result: ncclSend/ncclRecv, pinned D2H)"}
-                  line["distinct_devices"] = len({(i_["device"], i_["bus_id"]) for i_ in infos})
-                  if pool is not None:
-                      res = om.result_array() if sh == "orientations" else np.stack(full)
-                      ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan, a.method)
-                      line["verified"], line["verification"] = ver["ok"], ver
-                  runs[sh] = line
-              dist.barrier()
-          except Exception as e:                     # a sharding that fails on this node must not cost the other its line
-            import traceback
-            traceback.print_exc()
-            if rank == 0:
-                runs[sh] = {"error": "%s: %s" % (type(e).__name__, e), "ms_per_step": None}
+        out = run_shardings(a, rank, world, device, dist, transport, pool, g, Template, scales, params, angles,
+                            kind, units, base_line)
         if rank == 0:
-            first = min(runs, key=lambda k: runs[k]["ms_per_step"] if runs[k]["ms_per_step"] is not None else float("inf"))
-            out = runs[first]
-            if "error" in out:
-                raise SystemExit("every sharding failed: %r" % runs)
-            out["sharding"] = first
-            for k, v in runs.items():
-                if k != first:
-                    out["c4_tiles" if k == "tiles" else "orientations"] = v
             if pool is not None:
                 pool.terminate()
                 pool.join()
             emit(out)
         dist.barrier()
         dist.destroy_process_group()
+        if rank == 0 and out.get("failed"):
+            raise SystemExit(1)
         return
 
     # ------------------------------------------------------------------ N = 1
@@ -757,13 +977,7 @@ def main():
                      "included) searched alone on one GPU; the slowest block bounds the %d-GPU step, the halo "
                      "exchange (exchanged_bytes_per_rank over xGMI) comes on top" % R)}
     else:
-        if not a.no_verify:
-            # the record the timed loop left behind (the last scale's, for C5)
-            res = ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
-            ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan, a.method)
-            del res
-            out["verified"] = ver["ok"]
-            out["verification"] = ver
+        res = None
         if not a.no_e2e and len(scales) == 1:
             # the whole call a user makes: upload of z, curvature planes, descriptors, search,
             # float64 result planes, D2H
@@ -775,40 +989,56 @@ def main():
                                     ang_max=float(angles[-1]), device=device, method=a.method)
                 return sl.Matcher(g, device=device).search(Template, scales[0], params, angles, method=a.method,
                                                            group=a.group or None).result()
-            # Two calls, the second one reported: the GPU has idled through the oracle's verification above
-            # (its clocks have dropped; the first hundred milliseconds of the next search run slow), and the
-            # first call of a process faults in the 32 bytes per cell of its result - a repeated call, as in a
-            # multi-scale job, gets that block back recycled (scarplet_amd/_hostpool.py).  Both are printed.
+            # Two calls right after the timed loop (the GPU still at its working clocks), BOTH reported as peers:
+            # `value` / `seconds` is the FIRST - what a single sl.match of a fresh process pays, the 32 bytes per
+            # cell of its result faulted in as fresh host pages under the copy; `repeat_call_seconds` is the same
+            # call again after the first result was dropped - as in a multi-scale job - whose result block comes
+            # back recycled (scarplet_amd/_hostpool.py).  The second call's result is what gets verified below:
+            # the array the public API returned, not a copy fetched behind its back.
             secs = []
-            for _ in range(2):
+            for k_ in range(2):
                 ctx.sync()
                 t1 = time.perf_counter()
                 r_ = call()
                 secs.append(time.perf_counter() - t1)
-                del r_
-            # where the time outside the search goes, stage by stage (a third pass, by hand)
+                if k_ == 0:
+                    del r_
+            res = r_
+            # where the time outside the search goes, stage by stage (by hand)
             st = {}
             t1 = time.perf_counter(); m2 = sl.Matcher(g, device=device); st["upload_and_digest"] = time.perf_counter() - t1
             t1 = time.perf_counter(); d_ = m2.describe(Template, scales[0], params, angles); st["describe"] = time.perf_counter() - t1
-            t1 = time.perf_counter(); m2.search(Template, scales[0], params, angles, method=a.method, group=a.group or None)
-            st["search"] = time.perf_counter() - t1
-            t1 = time.perf_counter(); r_ = m2.result_array(); st["result"] = time.perf_counter() - t1
-            del r_, d_
-            e2e = secs[1]
+            del d_
+            e2e = secs[0]
             out["end_to_end"] = {"value": round(units / e2e / 1e6, 1), "unit": "Mpx·template/s",
-                                 "seconds": round(e2e, 3), "first_call_seconds": round(secs[0], 3),
+                                 "seconds": round(e2e, 3), "repeat_call_seconds": round(secs[1], 3),
                                  "overhead_ms": round(1e3 * e2e - ms, 1),
+                                 "repeat_overhead_ms": round(1e3 * secs[1] - ms, 1),
                                  "stages_ms": {k: round(1e3 * v, 1) for k, v in st.items()},
                                  "call": "sl.match(data, Template, scale=...)" if (default_workload or len(params) == 1)
                                          else "Matcher(data).search(...).result()",
                                  "includes": "H2D of the float64 DEM and its digest on the device, curvature planes, "
-                                             "template descriptors, search, float64 (4,ny,nx) result conversion and D2H; "
-                                             "the second of two calls (first_call_seconds: the one that faults in the "
-                                             "result's host memory, after the GPU idled through the verification)"}
+                                             "template descriptors, search, float64 (4,ny,nx) result conversion and D2H. "
+                                             "seconds: the first call (fresh result pages); repeat_call_seconds: the "
+                                             "same call again, result block recycled"}
+        if not a.no_verify:
+            # the result of the public call above; without it, the record the timed loop left behind
+            # (the last scale's, for C5)
+            if res is None:
+                res = ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
+            ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan, a.method)
+            out["verified"] = ver["ok"]
+            out["verification"] = ver
+            out["verification"]["of"] = "the arrays sl.match returned" if "end_to_end" in out else "the timed loop's record"
+        del res
         if default_workload and not a.no_other_configs:
             # (after the end-to-end call: these load their own DEMs into the same context)
             oc = {}
+            t_oc = time.time()
             for cfg, k_, w_ in OTHER_CONFIGS:
+                if time.time() - t_oc > a.other_configs_budget:   # bounded: the default run must finish within minutes
+                    oc[cfg] = {"skipped": "other_configs time budget of %.0f s spent" % a.other_configs_budget}
+                    continue
                 try:
                     oc[cfg] = other_config_line(a, cfg, k_, w_, device, pool)
                 except Exception as e:                 # must not cost the headline its line

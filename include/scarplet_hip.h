@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 5
+#define SC_ABI_VERSION 6
 
 #define SC_OK               0
 #define SC_ERR_INVALID     -1   /* bad argument                                */
@@ -101,6 +101,12 @@ typedef struct sc_plan {
 
 /* ---- lifetime ---------------------------------------------------------- */
 int  sc_abi_version(void);
+/* Which sources this binary was compiled from: the first 16 hex digits of the SHA-256 over the
+ * library's sources (the four .hip files of csrc, sc_internal.h, this header) in the Makefile's order, worked out
+ * at build time - `make -C scarplet_amd/csrc print-build-id` prints the same string for the tree
+ * at hand.  bench.py prints it in every line and __graft_entry__.build() compares the two: a
+ * stale prebuilt binary is visible instead of silently benchmarked. */
+const char* sc_build_id(void);
 int  sc_device_count(void);
 int  sc_create(int device, sc_ctx** out);
 void sc_destroy(sc_ctx* ctx);
@@ -355,8 +361,10 @@ int sc_halo_exchange(sc_ctx* ctx, const double* core, int core_h, int core_w,
                      const sc_xfer* x, int n, void** z_dev);
 /*
  * Final gather of a tiled search (results are disjoint rectangles): every rank
- * converts its record like sc_get_result and sends the four float64 planes of its
- * core to `root` over RCCL; root places them in out = 4 x ny x nx doubles (host).
+ * sends the float32 record of its core - amplitude, SNR, template id: 12 bytes
+ * per cell, three grouped ncclSend - to `root` over RCCL; root receives all ranks
+ * at once, converts each record like sc_get_result (the id tables are the same on
+ * every rank) and places the four float64 planes in out = 4 x ny x nx doubles (host).
  *   cores   nranks x 4 ints: [cy0, cy1, cx0, cx1) of every rank, same on all ranks
  *   out     root only (ignored elsewhere)
  * Collective: all ranks of the communicator call it.  Without a communicator

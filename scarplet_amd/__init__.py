@@ -15,3 +15,4 @@ from scarplet_amd.WindowedTemplate import (Scarp, Ricker, Channel,  # noqa: F401
                                            LeftFacingUpperBreakScarp)
 from scarplet_amd.dem import DEMGrid  # noqa: F401
 from scarplet_amd.plotting import plot_results, Hillshade, hillshade  # noqa: F401
+from scarplet_amd._hostpool import release as release_host_buffers  # noqa: F401

@@ -11,14 +11,25 @@ Safety: a block is reused only when NOTHING outside this module references it.  
 numpy view of a block - the returned array, any slice or reshape of it - holds a
 reference to the owner block itself (numpy collapses view chains onto the owner), so
 ``sys.getrefcount`` of the block tells whether the caller still holds any of them.
+The check and the view that follows it run under one lock: two threads asking for a
+result block at once (one Matcher per device) are never handed the same block.
+
+Memory: the module pins at most MAX_BLOCKS blocks (one by default: a result the caller has
+dropped stays faulted in for the next call of the same size - 3.2 GB for a 10000 x 10000
+DEM).  ``scarplet_amd.release_host_buffers()`` gives unreferenced blocks back to the
+system, and ``SCARPLET_HOSTPOOL_BLOCKS=0`` in the environment switches the recycling off.
 """
+import os
 import sys
+import threading
 
 import numpy as np
 
 MIN_BYTES = 64 << 20          # smaller results: plain np.empty
-MAX_BLOCKS = 2                # blocks kept; beyond it unreferenced blocks are dropped first
+# blocks kept; beyond it unreferenced blocks are dropped first
+MAX_BLOCKS = max(0, int(os.environ.get("SCARPLET_HOSTPOOL_BLOCKS", "1")))
 _blocks = []
+_lock = threading.Lock()
 
 
 def _free_at(i):
@@ -30,23 +41,25 @@ def empty(shape, dtype=np.float64):
     """Like ``np.empty(shape, dtype)``; large arrays are views of recycled blocks."""
     dtype = np.dtype(dtype)
     n = int(np.prod(shape)) * dtype.itemsize
-    if n < MIN_BYTES:
+    if n < MIN_BYTES or MAX_BLOCKS == 0:
         return np.empty(shape, dtype=dtype)
-    for i in range(len(_blocks)):
-        if _blocks[i].nbytes == n and _free_at(i):
-            return _blocks[i].view(dtype).reshape(shape)
-    # none to reuse: drop blocks nobody holds (of other sizes), keep at most MAX_BLOCKS
-    for i in reversed(range(len(_blocks))):
-        if len(_blocks) >= MAX_BLOCKS and _free_at(i):
-            del _blocks[i]
-    blk = np.empty(n, dtype=np.uint8)
-    if len(_blocks) < MAX_BLOCKS:
-        _blocks.append(blk)
-    return blk.view(dtype).reshape(shape)
+    with _lock:
+        for i in range(len(_blocks)):
+            if _blocks[i].nbytes == n and _free_at(i):
+                return _blocks[i].view(dtype).reshape(shape)
+        # none to reuse: drop blocks nobody holds (of other sizes), keep at most MAX_BLOCKS
+        for i in reversed(range(len(_blocks))):
+            if len(_blocks) >= MAX_BLOCKS and _free_at(i):
+                del _blocks[i]
+        blk = np.empty(n, dtype=np.uint8)
+        if len(_blocks) < MAX_BLOCKS:
+            _blocks.append(blk)
+        return blk.view(dtype).reshape(shape)
 
 
 def release():
     """Drop every block no caller references (the memory goes back to the system)."""
-    for i in reversed(range(len(_blocks))):
-        if _free_at(i):
-            del _blocks[i]
+    with _lock:
+        for i in reversed(range(len(_blocks))):
+            if _free_at(i):
+                del _blocks[i]

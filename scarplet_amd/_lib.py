@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCARPLET_HIP_LIB") or os.path.join(_HERE, "libscarplet_hip.so")
 
 SC_OK = 0
-ABI_VERSION = 5
+ABI_VERSION = 6
 ID_NONE = 0xFFFFFFFF
 COMM_ID_BYTES = 128
 
@@ -69,6 +69,7 @@ _bp = C.POINTER(C.c_uint8)
 # every symbol include/scarplet_hip.h declares: (restype, argtypes)
 SIGNATURES = {
     "sc_abi_version": (C.c_int, []),
+    "sc_build_id": (C.c_char_p, []),
     "sc_device_count": (C.c_int, []),
     "sc_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "sc_destroy": (None, [_P]),
@@ -387,6 +388,10 @@ class Context(object):
         buf = C.create_string_buffer(bytes(uid), COMM_ID_BYTES)
         self._check(self.lib.sc_comm_init(self._h, buf, rank, nranks),
                     "sc_comm_init")
+
+    def comm_destroy(self):
+        """Drop this context's RCCL communicator (sc_comm_destroy); nothing to do without one."""
+        self._check(self.lib.sc_comm_destroy(self._h), "sc_comm_destroy")
 
     def resolution_stats(self):
         """(wins, wins near the float32 resolution floor) of the FFT searches since the last

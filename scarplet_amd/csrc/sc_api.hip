@@ -228,10 +228,34 @@ extern "C" size_t sc_device_bytes(sc_ctx* ctx) { return ctx ? sc_total_bytes(ctx
 // ---------------------------------------------------------------------------
 // DEM hand-over
 // ---------------------------------------------------------------------------
+static int set_dem_body(sc_ctx* ctx, int ly, int lx, int gy0, int gx0, int ny,
+                        int nx, int cy0, int cy1, int cx0, int cx1, double dx,
+                        double dy, int wrap, const double* xaxis,
+                        const double* yaxis);
+
+// A hand-over that fails part-way (an allocation, the digest, the curvature planes, the record's reset) leaves
+// NO DEM behind: the elevations and the geometry of the old one are overwritten by then, and a context that kept
+// have_dem and the new block's fingerprint would answer the same block handed over again with "unchanged" and
+// search on curvature planes and kept spectra of a half-installed state.
 static int set_dem_common(sc_ctx* ctx, int ly, int lx, int gy0, int gx0, int ny,
                           int nx, int cy0, int cy1, int cx0, int cx1, double dx,
                           double dy, int wrap, const double* xaxis,
                           const double* yaxis) {
+    const int rc = set_dem_body(ctx, ly, lx, gy0, gx0, ny, nx, cy0, cy1, cx0, cx1, dx, dy, wrap, xaxis, yaxis);
+    if (rc != SC_OK) {
+        ctx->have_dem = false;
+        ctx->dem_unchanged = false;
+        ctx->dem_hash[0] = ctx->dem_hash[1] = 0;
+        memset(ctx->dem_sig, 0, sizeof(ctx->dem_sig));
+        fft_spectra_forget(ctx);
+    }
+    return rc;
+}
+
+static int set_dem_body(sc_ctx* ctx, int ly, int lx, int gy0, int gx0, int ny,
+                        int nx, int cy0, int cy1, int cx0, int cx1, double dx,
+                        double dy, int wrap, const double* xaxis,
+                        const double* yaxis) {
     if (ly < 3 || lx < 3 || ny < 3 || nx < 3 || !xaxis || !yaxis)
         return sc_fail(ctx, SC_ERR_INVALID, "sc_set_dem: bad sizes or null axes");
     if (cy0 < 0 || cy1 > ny || cx0 < 0 || cx1 > nx || cy0 >= cy1 || cx0 >= cx1)
@@ -663,6 +687,11 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
         if ((rc = sc_ensure(ctx, ctx->dwin, sizeof(float2) * std::max<size_t>(max_dcells, 4)))) return rc;
         if ((rc = sc_ensure(ctx, ctx->spans, sizeof(int4) * std::max<size_t>(max_spans, 1)))) return rc;
     }
+    // from here on the context's host vectors are the source of copies in flight: whatever way this call ends
+    // (a launch failure or an allocation failing in a later chunk returns without draining the stream), the
+    // next call's prologue waits before it reuses them; sc_sync, at the end of every successful synchronous
+    // call, clears the flag
+    ctx->async_in_flight = true;
     SC_HIP(ctx, hipMemcpyAsync(ctx->templ.p, h.data(), sizeof(TemplDev) * n,
                                hipMemcpyHostToDevice, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(ctx->sums.p, sums.data(), sizeof(double) * 2 * n,
@@ -792,6 +821,16 @@ k_result(const float* __restrict__ amp, const float* __restrict__ snr,
     }
 }
 
+// k_result on any record of n cells (sc_gather_result converts the other ranks' records at the root)
+int sc_launch_result(sc_ctx* ctx, const float* amp, const float* snr, const uint32_t* id, const double* tab_par,
+                     const double* tab_ang, int n_ids, size_t n, double* planes) {
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(k_result, dim3(blocks), dim3(256), 0, ctx->stream, amp, snr, id, tab_par, tab_ang,
+                       (uint32_t)n_ids, n, planes);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
 // the record of this context's core as four float64 planes in ctx->res (device)
 int sc_result_planes(sc_ctx* ctx, const double* param_of_id, const double* angle_of_id, int n_ids,
                      double** planes_out, size_t* nc_out) {
@@ -804,11 +843,9 @@ int sc_result_planes(sc_ctx* ctx, const double* param_of_id, const double* angle
     double* tab = planes + 4 * nc;
     SC_HIP(ctx, hipMemcpyAsync(tab, param_of_id, sizeof(double) * n_ids, hipMemcpyHostToDevice, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(tab + n_ids, angle_of_id, sizeof(double) * n_ids, hipMemcpyHostToDevice, ctx->stream));
-    const unsigned blocks = (unsigned)std::min<size_t>((nc + 255) / 256, 256 * 64);
-    hipLaunchKernelGGL(k_result, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)ctx->best_amp.p,
-                       (const float*)ctx->best_snr.p, (const uint32_t*)ctx->best_id.p,
-                       (const double*)tab, (const double*)(tab + n_ids), (uint32_t)n_ids, nc, planes);
-    SC_HIP(ctx, hipGetLastError());
+    if ((rc = sc_launch_result(ctx, (const float*)ctx->best_amp.p, (const float*)ctx->best_snr.p,
+                               (const uint32_t*)ctx->best_id.p, tab, tab + n_ids, n_ids, nc, planes)))
+        return rc;
     *planes_out = planes;
     *nc_out = nc;
     return SC_OK;

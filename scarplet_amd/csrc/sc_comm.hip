@@ -152,47 +152,94 @@ extern "C" int sc_halo_exchange(sc_ctx* ctx, const double* core, int core_h, int
     return SC_OK;
 }
 
+// The final gather moves the float32 RECORD - amplitude, SNR, template id: 12 bytes per cell - and the root
+// converts it into the reference's four float64 planes (the id -> (age, orientation) tables are the same on
+// every rank): 2.7 x fewer bytes over xGMI than the converted planes (32 B per cell), and one conversion
+// kernel per rank at the root instead of one on every rank.  All receives are posted in ONE group - the
+// senders run in parallel over their own links - into one staging block per rank; the conversions and the
+// device-to-host placements follow on the stream, no host synchronisation between ranks.
 extern "C" int sc_gather_result(sc_ctx* ctx, int root, const int32_t* cores, int ny, int nx,
                                 const double* param_of_id, const double* angle_of_id, int n_ids,
                                 double* out) {
     if (!ctx || !cores || ny <= 0 || nx <= 0 || !param_of_id || !angle_of_id || n_ids <= 0)
         return SC_ERR_INVALID;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
     const int nranks = ctx->comm ? ctx->nranks : 1, rank = ctx->comm ? ctx->rank : 0;
     if (root < 0 || root >= nranks || (rank == root && !out)) return SC_ERR_INVALID;
     const int32_t* mine = cores + 4 * rank;
     if (mine[0] != ctx->g.cy0 || mine[1] != ctx->g.cy1 || mine[2] != ctx->g.cx0 || mine[3] != ctx->g.cx1)
         return sc_fail(ctx, SC_ERR_INVALID, "cores[%d] is not this context's core", rank);
-    double* planes = nullptr;
-    size_t nc = 0;
-    int rc = sc_result_planes(ctx, param_of_id, angle_of_id, n_ids, &planes, &nc);
-    if (rc) return rc;
-    const size_t full = (size_t)ny * nx;
-    // a core's planes (contiguous h x w each) into the full host planes
-    auto place = [&](const double* dev, const int32_t* c) -> int {
-        const int h = c[1] - c[0], w = c[3] - c[2];
-        for (int k = 0; k < 4; ++k)
-            SC_HIP(ctx, hipMemcpy2DAsync(out + k * full + (size_t)c[0] * nx + c[2], sizeof(double) * nx,
-                                         dev + (size_t)k * h * w, sizeof(double) * w,
-                                         sizeof(double) * w, h, hipMemcpyDeviceToHost, ctx->stream));
-        return SC_OK;
-    };
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nc = (size_t)(mine[1] - mine[0]) * (mine[3] - mine[2]);
     if (rank != root) {
-        SC_NCCL(ctx, ncclSend(planes, 4 * nc, ncclDouble, root, (ncclComm_t)ctx->comm, ctx->stream));
+        ncclComm_t comm = (ncclComm_t)ctx->comm;
+        SC_NCCL(ctx, ncclGroupStart());
+        SC_NCCL(ctx, ncclSend(ctx->best_amp.p, nc, ncclFloat, root, comm, ctx->stream));
+        SC_NCCL(ctx, ncclSend(ctx->best_snr.p, nc, ncclFloat, root, comm, ctx->stream));
+        SC_NCCL(ctx, ncclSend(ctx->best_id.p, nc, ncclUint32, root, comm, ctx->stream));
+        SC_NCCL(ctx, ncclGroupEnd());
         SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return SC_OK;
     }
-    if ((rc = place(planes, mine))) return rc;
+    // root: cells of every other rank, the largest core, the staging offsets (in cells)
+    size_t others = 0, max_nc = nc;
     for (int r = 0; r < nranks; ++r) {
-        if (r == root) continue;
         const int32_t* c = cores + 4 * r;
         const int h = c[1] - c[0], w = c[3] - c[2];
         if (h <= 0 || w <= 0 || c[0] < 0 || c[1] > ny || c[2] < 0 || c[3] > nx)
             return sc_fail(ctx, SC_ERR_INVALID, "cores[%d] outside the DEM", r);
-        const size_t n = (size_t)4 * h * w;
-        if ((rc = sc_ensure(ctx, ctx->halo_stage, sizeof(double) * n))) return rc;
-        SC_NCCL(ctx, ncclRecv(ctx->halo_stage.p, n, ncclDouble, r, (ncclComm_t)ctx->comm, ctx->stream));
-        if ((rc = place((const double*)ctx->halo_stage.p, c))) return rc;
-        SC_HIP(ctx, hipStreamSynchronize(ctx->stream));      // the staging buffer is reused
+        if (r != root) others += (size_t)h * w;
+        max_nc = std::max(max_nc, (size_t)h * w);
+    }
+    int rc;
+    if ((rc = sc_ensure(ctx, ctx->halo_stage, SC_RECORD_BYTES * std::max<size_t>(others, 1)))) return rc;
+    if ((rc = sc_ensure(ctx, ctx->res, sizeof(double) * (4 * max_nc + 2 * (size_t)n_ids)))) return rc;
+    double* planes = (double*)ctx->res.p;
+    double* tab = planes + 4 * max_nc;
+    SC_HIP(ctx, hipMemcpyAsync(tab, param_of_id, sizeof(double) * n_ids, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(tab + n_ids, angle_of_id, sizeof(double) * n_ids, hipMemcpyHostToDevice, ctx->stream));
+    char* stage = (char*)ctx->halo_stage.p;
+    if (nranks > 1) {
+        ncclComm_t comm = (ncclComm_t)ctx->comm;
+        SC_NCCL(ctx, ncclGroupStart());
+        size_t off = 0;
+        for (int r = 0; r < nranks; ++r) {
+            if (r == root) continue;
+            const int32_t* c = cores + 4 * r;
+            const size_t n = (size_t)(c[1] - c[0]) * (c[3] - c[2]);
+            // a rank's record in the staging block: amp[n] | snr[n] | id[n], the order of its three sends
+            SC_NCCL(ctx, ncclRecv(stage + off, n, ncclFloat, r, comm, ctx->stream));
+            SC_NCCL(ctx, ncclRecv(stage + off + 4 * n, n, ncclFloat, r, comm, ctx->stream));
+            SC_NCCL(ctx, ncclRecv(stage + off + 8 * n, n, ncclUint32, r, comm, ctx->stream));
+            off += SC_RECORD_BYTES * n;
+        }
+        SC_NCCL(ctx, ncclGroupEnd());
+    }
+    const size_t full = (size_t)ny * nx;
+    // one rank's record -> four float64 planes (device) -> its rectangle of the root's host planes; the
+    // planes buffer is reused rank after rank: kernel and copies are ordered by the stream
+    auto place = [&](const float* amp, const float* snr, const uint32_t* id, const int32_t* c) -> int {
+        const int h = c[1] - c[0], w = c[3] - c[2];
+        const size_t n = (size_t)h * w;
+        int rc_ = sc_launch_result(ctx, amp, snr, id, tab, tab + n_ids, n_ids, n, planes);
+        if (rc_) return rc_;
+        for (int k = 0; k < 4; ++k)
+            SC_HIP(ctx, hipMemcpy2DAsync(out + k * full + (size_t)c[0] * nx + c[2], sizeof(double) * nx,
+                                         planes + (size_t)k * n, sizeof(double) * w,
+                                         sizeof(double) * w, h, hipMemcpyDeviceToHost, ctx->stream));
+        return SC_OK;
+    };
+    if ((rc = place((const float*)ctx->best_amp.p, (const float*)ctx->best_snr.p, (const uint32_t*)ctx->best_id.p, mine)))
+        return rc;
+    size_t off = 0;
+    for (int r = 0; r < nranks; ++r) {
+        if (r == root) continue;
+        const int32_t* c = cores + 4 * r;
+        const size_t n = (size_t)(c[1] - c[0]) * (c[3] - c[2]);
+        if ((rc = place((const float*)(stage + off), (const float*)(stage + off + 4 * n),
+                        (const uint32_t*)(stage + off + 8 * n), c)))
+            return rc;
+        off += SC_RECORD_BYTES * n;
     }
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SC_OK;

@@ -2532,10 +2532,21 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         // argmax is the transform's rounding noise.  Recovered from the record at the write-back
         // (d = (T1 / snr - eps) n), not in the template loop.
         int n_won = 0, n_near = 0;
+        // one won cell into the statistic: template ix of the launch holds it with raw output b_xr[k], SNR b_snr[k]
+        auto count = [&](int k, const float* e) {
+            const float T1 = b_xr[k] * b_xr[k] * e[1], fl = fmaf(fabsf(b_xr[k]), e[2], e[3]);
+            const float d = (T1 / b_snr[k] - (float)SC_EPS) / e[4];
+            ++n_won;
+            n_near += (fl > 0.f && d < 256.f * fl) ? 1 : 0;
+        };
+        bool later_share = false;
         if constexpr (SPLITK) {
             if (blockIdx.z > 0) {
                 // a later share of the launch's transforms: its own record, EVERY valid cell written (zero where
-                // none of its templates scored), for k_merge_split to fold into the record in order
+                // none of its templates scored), for k_merge_split to fold into the record in order.  Its winners
+                // go into the statistic like the first share's (a cell counts once per share that scored on it:
+                // the statistic is a fraction of wins, and every share's wins are wins of this launch's templates)
+                later_share = true;
                 const size_t pl_ = (size_t)(blockIdx.z - 1) * ra.nc;
 #pragma unroll
                 for (int k = 0; k < NBEST; ++k) {
@@ -2545,13 +2556,15 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                     const uint32_t ix = (b_ix[k >> 2] >> (8 * (k & 3))) & 0xFFu;
                     const bool won = ix != 0xFFu;
                     const uint32_t o = 4u * (uint32_t)cj;
+                    const float* e = epi + EPI_FLOATS * (won ? ix : 0);
                     at_bytes(ra.s2 + pl_ + off_of(part), o) = won ? b_snr[k] : 0.f;
-                    at_bytes(ra.a2 + pl_ + off_of(part), o) = won ? b_xr[k] * epi[EPI_FLOATS * (won ? ix : 0)] : 0.f;
+                    at_bytes(ra.a2 + pl_ + off_of(part), o) = won ? b_xr[k] * e[0] : 0.f;
                     at_bytes(ra.i2 + pl_ + off_of(part), o) = won ? templ[ra.first + (won ? ix : 0)].id : SC_ID_NONE;
+                    if (won && b_snr[k] > 0.f) count(k, e);
                 }
-                return;
             }
         }
+        if (!later_share) {
 #pragma unroll
         for (int k = 0; k < NBEST; ++k) {
             const uint32_t ix = (b_ix[k >> 2] >> (8 * (k & 3))) & 0xFFu;
@@ -2562,11 +2575,9 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 at_bytes(best_snr + off_of(part), o) = b_snr[k];
                 at_bytes(best_amp + off_of(part), o) = b_xr[k] * e[0];
                 at_bytes(best_id + off_of(part), o) = templ[ra.first + ix].id;
-                const float T1 = b_xr[k] * b_xr[k] * e[1], fl = fmaf(fabsf(b_xr[k]), e[2], e[3]);
-                const float d = (T1 / b_snr[k] - (float)SC_EPS) / e[4];
-                ++n_won;
-                n_near += (fl > 0.f && d < 256.f * fl) ? 1 : 0;
+                count(k, e);
             }
+        }
         }
         if (ra.stats) {
             for (int sft = 32; sft > 0; sft >>= 1) {

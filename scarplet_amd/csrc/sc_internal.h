@@ -164,10 +164,14 @@ int sc_lds_attr(sc_ctx* ctx, const void* kernel, size_t bytes);
 
 // profiling brackets around kernel launches
 void sc_prof_begin(sc_ctx* ctx, int kernel);
-int sc_result_planes(sc_ctx* ctx, const double* param_of_id, const double* angle_of_id, int n_ids,
-                     double** planes_out, size_t* nc_out);
 void sc_prof_end(sc_ctx* ctx, int n = 1);
 void sc_prof_collect(sc_ctx* ctx);
+// bytes per cell of the running-best record as it travels between ranks: amp f32, snr f32, id u32
+#define SC_RECORD_BYTES 12
+int sc_launch_result(sc_ctx* ctx, const float* amp, const float* snr, const uint32_t* id, const double* tab_par,
+                     const double* tab_ang, int n_ids, size_t n, double* planes);
+int sc_result_planes(sc_ctx* ctx, const double* param_of_id, const double* angle_of_id, int n_ids,
+                     double** planes_out, size_t* nc_out);
 
 // ---- launchers implemented in sc_kernels.hip --------------------------------
 int launch_curv_planes(sc_ctx* ctx);

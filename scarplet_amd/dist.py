@@ -379,17 +379,37 @@ class DistMatcher(object):
                                       np.repeat(m.params, len(m.angles)),
                                       np.tile(m.angles, len(m.params)), self.rank == dst, out=out)
             return tuple(out) if self.rank == dst else None
-        if self.nranks == 1:
-            tiles = [(self.core(), self.result())]
-        else:
-            tiles = self.transport.gather((self.core(), self.result()), dst)
+        # host transport: the same layout as sc_gather_result - every rank ships the float32 RECORD of its
+        # core (amp, snr, id: 12 B per cell), the root turns each into the four float64 planes with the id
+        # tables every rank shares (record_planes) and places it
+        m = self.m
+        rec = m.ctx.get_best()
+        tiles = [(self.core(), rec)] if self.nranks == 1 else self.transport.gather((self.core(), rec), dst)
         if self.rank != dst:
             return None
+        par, ang = np.repeat(m.params, len(m.angles)), np.tile(m.angles, len(m.params))
         out = [np.zeros((self.ny, self.nx)) for _ in range(4)] if out is None else list(out)
-        for core, res in tiles:
+        for core, (amp, snr, idx) in tiles:
+            res = record_planes(amp, snr, idx, par, ang)
             for k in range(4):
                 out[k][core[0]:core[1], core[2]:core[3]] = res[k]
         return tuple(out)
+
+
+RECORD_BYTES = 12       # per cell between ranks: amp float32, snr float32, template id uint32 (sc_internal.h)
+
+
+def record_planes(amp, snr, idx, param_of_id, angle_of_id):
+    """The running-best record -> the reference's four float64 planes (amp, age, angle, snr;
+    core.py:190-195), as k_result does on the device: a cell no template has won (id beyond the
+    table, SC_ID_NONE) has age and angle 0."""
+    amp, snr, idx = np.asarray(amp), np.asarray(snr), np.asarray(idx)
+    par = np.asarray(param_of_id, dtype=np.float64)
+    ang = np.asarray(angle_of_id, dtype=np.float64)
+    won = idx < len(par)
+    safe = np.where(won, idx, 0)
+    return (amp.astype(np.float64), np.where(won, par[safe], 0.0), np.where(won, ang[safe], 0.0),
+            snr.astype(np.float64))
 
 
 # ---- orientation sharding -------------------------------------------------------------------

@@ -293,3 +293,96 @@ def test_orientation_chunks_and_host_fold():
                 continue
             want = max(range(4), key=lambda r: (col[r], -r))            # max SNR, then the earliest rank
             assert got[3, i, j] == col[want] and got[1, i, j] == want + 1 and got[0, i, j] == col[want] + 10 * (want + 1)
+
+
+# ---- the final gather ships the float32 record, the root converts it -------------------------
+def test_record_planes_is_the_device_conversion():
+    """dist.record_planes = k_result (sc_api.hip): amp and snr widened, age / angle looked up by id,
+    zero where no template has won (SC_ID_NONE)."""
+    rng = np.random.default_rng(2)
+    par, ang = np.array([1.0, 10.0, 100.0, 1.0, 10.0, 100.0]), np.array([-0.5, -0.5, -0.5, 0.5, 0.5, 0.5])
+    idx = rng.integers(0, 6, size=(5, 7)).astype(np.uint32)
+    idx[0, 0] = idx[4, 6] = 0xFFFFFFFF
+    amp = rng.standard_normal((5, 7)).astype(np.float32)
+    snr = rng.random((5, 7)).astype(np.float32)
+    a, g, o, s = sd.record_planes(amp, snr, idx, par, ang)
+    assert a.dtype == g.dtype == o.dtype == s.dtype == np.float64
+    assert np.array_equal(a, amp.astype(np.float64)) and np.array_equal(s, snr.astype(np.float64))
+    won = idx != 0xFFFFFFFF
+    assert np.array_equal(g[won], par[idx[won]]) and np.array_equal(o[won], ang[idx[won]])
+    assert (g[~won] == 0).all() and (o[~won] == 0).all()
+    assert sd.RECORD_BYTES == amp.itemsize + snr.itemsize + idx.itemsize
+
+
+class _RecordContext(object):
+    """Stands in for a rank's GPU context in the gather test: a record over the rank's core."""
+
+    def __init__(self, core, seed):
+        h, w = core[1] - core[0], core[3] - core[2]
+        rng = np.random.default_rng(seed)
+        self.rec = (rng.standard_normal((h, w)).astype(np.float32), rng.random((h, w)).astype(np.float32),
+                    rng.integers(0, 7, size=(h, w)).astype(np.uint32))     # id 6: beyond the 6-entry table
+
+    def get_best(self):
+        return self.rec
+
+
+def _gather_worker(rank, world, port, q):
+    try:
+        import types
+        import torch.distributed as dist
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from torch_transport import TorchTransport
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+        ny, nx = 37, 41
+        dm = object.__new__(sd.DistMatcher)                  # host side only: no device behind it
+        dm.rank, dm.nranks, dm.ny, dm.nx, dm.dx, dm.dy = rank, world, ny, nx, 1.0, 1.0
+        dm.backend, dm.transport, dm.cores = "host", TorchTransport(), None
+        dm.py, dm.px = sd.grid_dims(world, ny, nx)
+        params, angles = np.array([1.0, 10.0, 100.0]), np.array([-0.5, 0.5])
+        dm.m = types.SimpleNamespace(ctx=_RecordContext(dm.core(), 100 + rank), params=params, angles=angles)
+        sent = []
+        real_gather = dm.transport.gather
+
+        def spy(obj, dst):
+            sent.append(obj)
+            return real_gather(obj, dst)
+        dm.transport.gather = spy
+        got = dm.gather(0)
+        # what travelled: this rank's core and three 4-byte planes of exactly its cells - 12 B per cell
+        core, rec = sent[0]
+        cells = (core[1] - core[0]) * (core[3] - core[2])
+        ok = sum(a.nbytes for a in rec) == sd.RECORD_BYTES * cells and [a.dtype.itemsize for a in rec] == [4, 4, 4]
+        if rank == 0:
+            par, ang = np.repeat(params, len(angles)), np.tile(angles, len(params))
+            lay = sd.Layout(ny, nx, dm.py, dm.px, (0, 0, 0, 0))
+            want = np.zeros((4, ny, nx))
+            for r in range(world):
+                c = lay.core(r)
+                rec_r = _RecordContext(c, 100 + r).rec
+                want[:, c[0]:c[1], c[2]:c[3]] = np.stack(sd.record_planes(rec_r[0], rec_r[1], rec_r[2], par, ang))
+            ok = ok and np.array_equal(np.stack(got), want)
+        else:
+            ok = ok and got is None
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, bool(ok)))
+    except Exception:                            # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gather_ships_the_record_over_gloo(world):
+    """DistMatcher.gather on the host transport mirrors sc_gather_result's layout: 12 bytes per cell per
+    rank (amp f32, snr f32, id u32), converted to the four float64 planes at the root."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)], res

@@ -7,6 +7,7 @@ from scarplet_amd import _hostpool as hp
 def test_blocks_are_reused_only_when_unreferenced(monkeypatch):
     monkeypatch.setattr(hp, "MIN_BYTES", 1024)
     monkeypatch.setattr(hp, "_blocks", [])
+    monkeypatch.setattr(hp, "MAX_BLOCKS", 2)
     a = hp.empty((4, 16, 16))
     assert a.dtype == np.float64 and a.shape == (4, 16, 16) and a.flags.c_contiguous
     pa = a.ctypes.data
@@ -25,3 +26,27 @@ def test_blocks_are_reused_only_when_unreferenced(monkeypatch):
     del b, c, d
     hp.release()
     assert hp._blocks == []
+
+
+def test_one_block_is_pinned_by_default_and_threads_never_share_one(monkeypatch):
+    import threading
+    assert hp.MAX_BLOCKS == 1                  # (SCARPLET_HOSTPOOL_BLOCKS unset: 3.2 GB at 10000 x 10000, not 6.4)
+    monkeypatch.setattr(hp, "MIN_BYTES", 1024)
+    monkeypatch.setattr(hp, "_blocks", [])
+    got, go = [], threading.Barrier(8)
+
+    def worker():
+        go.wait()
+        for _ in range(50):
+            got.append(hp.empty((4, 16, 16)))
+
+    th = [threading.Thread(target=worker) for _ in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert len({a.ctypes.data for a in got}) == len(got)      # all alive: all distinct
+    assert len(hp._blocks) <= hp.MAX_BLOCKS
+    got.clear()
+    hp.release()
+    assert hp._blocks == []
+    monkeypatch.setattr(hp, "MAX_BLOCKS", 0)                  # the opt-out: plain numpy
+    assert hp.empty((4, 16, 16)).base is None

@@ -1,10 +1,14 @@
 """GeoTIFF reading without GDAL and the DEMGrid duck type (host side)."""
+import os
+
 import numpy as np
 import pytest
 
 import scarplet_amd as sl
 from scarplet_amd import tiff
 from conftest import golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_tiled_deflate_predictor_int16_geotiff():
@@ -235,3 +239,114 @@ def test_reading_a_dem_does_not_load_the_gpu_library():
             "g = sl.DEMGrid(%r); assert g._griddata.size > 0; assert L._lib is None, 'GPU library was loaded'"
             % os.path.join(root, "tests", "golden", "lzw_f32_strips.tif"))
     subprocess.check_call([sys.executable, "-c", code], cwd=root)
+
+
+# ---- untrusted input: the sanitizer leg -----------------------------------
+LZW_FIXTURES = ["lzw_i16_pred2.tif", "lzw_f32_pred3.tif", "lzw_f32_strips.tif", "bigtiff_f32_lzw.tif",
+                "lzw_f32_multistrip.tif"]
+
+
+def _raw_strips(path):
+    """The compressed strips / tiles of a TIFF fixture, byte for byte as stored."""
+    import struct
+    buf = open(path, "rb").read()
+    bo = "<" if buf[:2] == b"II" else ">"
+    (magic,) = struct.unpack_from(bo + "H", buf, 2)
+    if magic == 43:
+        (ifd,) = struct.unpack_from(bo + "Q", buf, 8)
+        t = tiff._read_ifd(buf, ifd, bo, big=True)
+    else:
+        (ifd,) = struct.unpack_from(bo + "I", buf, 4)
+        t = tiff._read_ifd(buf, ifd, bo)
+    offs, cnts = (t[324], t[325]) if 322 in t else (t[273], t[279])
+    return [buf[o:o + c] for o, c in zip(offs, cnts)]
+
+
+def test_lzw_decoder_under_address_sanitizer(tmp_path):
+    """`make asan`: sc_host.c built with -fsanitize=address,undefined (CPU only) and driven by
+    tools/lzw_fuzz.c - 10 000 mutated strips of the LZW fixtures decoded into heap blocks of exactly
+    the capacity handed to the decoder; any byte read or written out of bounds, any undefined
+    shift or overflow aborts the run."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    csrc = os.path.join(ROOT, "scarplet_amd", "csrc")
+    subprocess.check_call(["make", "-s", "-C", csrc, "asan"])
+    files = []
+    for name in LZW_FIXTURES:
+        for k, raw in enumerate(_raw_strips(golden(name))[:6]):
+            f = tmp_path / ("%s.%d.lzw" % (name, k))
+            f.write_bytes(raw)
+            files.append(str(f))
+    assert len(files) >= 6
+    exe = os.path.join(ROOT, "tools", "bin", "lzw_fuzz_asan")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([exe, "10000", "20261004"] + files, capture_output=True, text=True, env=env, timeout=600)
+    print(r.stdout.strip())
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "no sanitizer report" in r.stdout and "ERROR" not in r.stderr
+
+
+def test_geotiff_reader_answers_corrupt_files_with_valueerror(tmp_path):
+    """The Python reader over mutated copies of the fixtures (3 000 files: flipped bits, random
+    bytes in the header and directory, truncations): an array or a ValueError - no other exception
+    type, no allocation sized by a corrupt field, both LZW decoders in agreement."""
+    rng = np.random.default_rng(99)
+    seeds = [open(golden(n), "rb").read() for n in
+             ("lzw_i16_pred2.tif", "carrizo_crop.tif", "grandcanyon_crop.tif", "deflate_f32_pred3.tif",
+              "lzw_f32_pred3.tif", "bigtiff_f32_lzw.tif")]
+    path = str(tmp_path / "m.tif")
+    n_ok = n_err = 0
+    for case in range(3000):
+        b = bytearray(seeds[case % len(seeds)])
+        for _ in range(int(rng.integers(1, 6))):
+            kind = int(rng.integers(0, 4))
+            # the header and the directory (the first and last few hundred bytes) are hit most
+            if rng.random() < 0.6:
+                at = int(rng.integers(0, min(len(b), 600))) if rng.random() < 0.5 else len(b) - 1 - int(rng.integers(0, min(len(b), 600)))
+            else:
+                at = int(rng.integers(0, len(b)))
+            if kind == 0:
+                b[at] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:
+                b[at] = int(rng.integers(0, 256))
+            elif kind == 2:
+                b[at:at + 4] = bytes(rng.integers(0, 256, 4, dtype=np.uint8))
+            elif len(b) > 64:
+                del b[max(32, at):]
+        open(path, "wb").write(bytes(b))
+        try:
+            a, gt, nodata = tiff.read_geotiff(path)
+            assert a.ndim in (2, 3) and a.size <= 1 << 26
+            n_ok += 1
+        except ValueError:
+            n_err += 1
+    print("corrupt GeoTIFFs: %d read, %d refused with ValueError" % (n_ok, n_err))
+    assert n_ok + n_err == 3000 and n_err > 100
+
+
+def test_lzw_decoders_agree_on_mutated_strips():
+    """The C decoder and its Python stand-in return the same bytes or the same error code on
+    600 mutated strips."""
+    from scarplet_amd import _hostlib
+    lib = _hostlib.load()
+    if lib is None:
+        pytest.skip("libscarplet_host.so not built")
+    rng = np.random.default_rng(5)
+    strips = [s for n in LZW_FIXTURES[:3] for s in _raw_strips(golden(n))[:2]]
+    for case in range(600):
+        b = bytearray(strips[case % len(strips)][:4000])
+        for _ in range(int(rng.integers(1, 5))):
+            at = int(rng.integers(0, len(b)))
+            b[at] = int(rng.integers(0, 256)) if rng.random() < 0.7 else b[at] ^ (1 << int(rng.integers(0, 8)))
+        cap = int(rng.integers(0, 40000))
+        src = np.frombuffer(bytes(b), dtype=np.uint8)
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        n = lib.sch_tiff_lzw_decode(src.ctypes.data, src.size, out.ctypes.data, cap)
+        ref = _hostlib._lzw_decode_py(bytes(b), cap)
+        if isinstance(ref, int):
+            assert n == ref, (case, n, ref)
+        else:
+            assert n == len(ref) and out[:n].tobytes() == ref, (case, n, len(ref))
