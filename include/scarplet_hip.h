@@ -181,7 +181,9 @@ int sc_clear_windows(sc_ctx* ctx);
  *              that a template's window limits mask are skipped for that template), 15 the row
  *              pass of small grids folds a launch's transforms in ONE workgroup per row (default:
  *              dealt out over up to four, the shares merged in order), 16 the real-space kernel's
- *              256 x 16 patch also where the 512 x 16 patch would be taken
+ *              256 x 16 patch also where the 512 x 16 patch would be taken, 17 the orientation's
+ *              curvature plane written by a pass of its own and read back by the forward row pass
+ *              (default: mixed from the three stencil planes inside that pass - the same bits)
  *   "batch"    1 (default): searches whose single orientation does not fill the
  *              chip send several orientations through every launch; 0: one
  *              orientation per launch sequence.  Results are bit-identical.
@@ -191,6 +193,11 @@ int sc_clear_windows(sc_ctx* ctx);
  *   "i1_pairs" tile pairs per launch of the wave-per-column inverse pass (default 2; 1: one pair per
  *              launch), interleaved so that the workgroups which stream the same template
  *              coefficients run on one XCD at the same time.  Results are bit-identical.
+ *   "split_i1" 1 (default): a column pass whose workgroups do not fill the chip (a small DEM with many
+ *              templates per orientation) deals its transforms out over up to eight workgroups per column
+ *              block; 0: one workgroup per column block walks all of them.  Results are bit-identical.
+ *   "split_fill"  waves the dealt-out row pass of small grids may come to (0: the default, 4096 = four
+ *              per SIMD; round 4: 2048).  Results are bit-identical.
  *   "y_gb"     memory budget of the column -> row pass hand-off buffers in GB
  *              (0: a quarter of the free memory, at most 32)
  *   "sib"      sibling rendezvous (bit 0: row pass): the two workgroups that read the two

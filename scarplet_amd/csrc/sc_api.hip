@@ -167,6 +167,12 @@ extern "C" int sc_set_option(sc_ctx* ctx, const char* name, double value) {
     } else if (!strcmp(name, "i1_pairs")) {
         if (!(value >= 1.0 && value <= 64.0)) return sc_fail(ctx, SC_ERR_INVALID, "i1_pairs must be 1 .. 64");
         ctx->i1_pairs = (int)value;
+    } else if (!strcmp(name, "split_i1")) {
+        if (!(value >= 0.0 && value <= 64.0)) return sc_fail(ctx, SC_ERR_INVALID, "split_i1 must be 0 .. 64");
+        ctx->split_i1 = (int)value;
+    } else if (!strcmp(name, "split_fill")) {
+        if (!(value >= 0.0)) return sc_fail(ctx, SC_ERR_INVALID, "split_fill must be >= 0");
+        ctx->split_fill = (long long)value;
     } else if (!strcmp(name, "sib")) {
         ctx->sib = (int)value;
     } else if (!strcmp(name, "spectra_mb")) {
@@ -725,14 +731,20 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
                 const sc_template& sb = t[c.first + b * c.n];
                 coef[b][0] = (float)sb.cc; coef[b][1] = (float)sb.sc2; coef[b][2] = (float)sb.ss;
             }
-            if ((rc = launch_curv_alpha_batch(ctx, coef, c.nb))) return rc;
-            if (plan->method == SC_METHOD_FFT && (rc = fft_forward_curv(ctx, fg, c.nb))) return rc;
+            // FFT tiles: the orientations' curvature is mixed from the stencil planes inside the forward row
+            // kernel (no plane written and read back; option "variant" 17: the separate k_curv_alpha pass, for the
+            // cross-check - same bits); the real-space kernel reads the plane(s)
+            const bool fused = plan->method == SC_METHOD_FFT && ctx->variant != 17;
+            if (!fused && (rc = launch_curv_alpha_batch(ctx, coef, c.nb))) return rc;
+            if (plan->method == SC_METHOD_FFT && (rc = fft_forward_curv(ctx, fg, c.nb, fused ? coef : nullptr))) return rc;
             have_curv = false;                    // plane 0 no longer belongs to a single run
         } else {
             const sc_template& s0 = t[c.first];
             if (!have_curv || s0.cc != cur[0] || s0.sc2 != cur[1] || s0.ss != cur[2]) {
-                if ((rc = launch_curv_alpha(ctx, (float)s0.cc, (float)s0.sc2, (float)s0.ss))) return rc;
-                if (plan->method == SC_METHOD_FFT && (rc = fft_forward_curv(ctx, fg, 1))) return rc;
+                const bool fused = plan->method == SC_METHOD_FFT && ctx->variant != 17;
+                const float coef1[1][3] = {{(float)s0.cc, (float)s0.sc2, (float)s0.ss}};
+                if (!fused && (rc = launch_curv_alpha(ctx, coef1[0][0], coef1[0][1], coef1[0][2]))) return rc;
+                if (plan->method == SC_METHOD_FFT && (rc = fft_forward_curv(ctx, fg, 1, fused ? coef1 : nullptr))) return rc;
                 cur[0] = s0.cc; cur[1] = s0.sc2; cur[2] = s0.ss;
                 have_curv = true;
             }

@@ -643,15 +643,24 @@ __device__ __forceinline__ void fft4_lines(float2* s, const TW& twr) {
 // ---- F1c: curvature of a tile pair -> row FFT -> blocked ---------------------
 // grid = (Ty/4/FWD_ROWS_RBW, npairs); out plane index = pair*2 + {0: curv, 1: curv^2}
 constexpr int FWD_ROWS_RBW = 2;            // row blocks (of 4 tile rows) per workgroup
-template <int TX>
+// MIX: the orientation's curvature plane is not read but formed here, cell by cell, from the three
+// alpha-independent stencil planes: curv = cc A - sc2 B + ss C (dem.py:103-104) in float32, the very
+// expression and evaluation order of k_curv_alpha (no contraction: the file is built with
+// -ffp-contract=off) - the same bits.  k_curv_alpha wrote a plane per orientation that this kernel
+// read straight back (1.2 GB in, 0.4 GB out, 0.4 GB in again at 10000 x 10000); fused, the planes are
+// read once per tile cell and nothing is written.
+struct CurvMix { float c[SC_MAX_ORIENT][3]; };
+template <int TX, bool MIX>
 __global__ void __launch_bounds__(fft_threads(TX), 4)
-k_fwd_rows_curv(const float* __restrict__ curv, Geom g,
+k_fwd_rows_curv(const float* __restrict__ curv, const float* __restrict__ pB, const float* __restrict__ pC,
+                CurvMix mixc, Geom g,
                 const TileDev* __restrict__ tiles, int Ty,
                 const float2* __restrict__ tw, float2* __restrict__ blk,
                 double* __restrict__ norm_part, int dbg, int np, size_t curv_stride) {
     // blockIdx.y = b * np + p: tile pair p of the b-th orientation of the launch (its
-    // curvature plane lies curv_stride floats further on); small searches batch several
-    // orientations per launch (sc_api.hip, "orientation batching")
+    // curvature plane lies curv_stride floats further on; MIX: its coefficients are mixc.c[b],
+    // `curv` is plane A); small searches batch several orientations per launch (sc_api.hip,
+    // "orientation batching")
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     FftTw<TX> twr;
     twr.load(tw);
@@ -659,7 +668,12 @@ k_fwd_rows_curv(const float* __restrict__ curv, Geom g,
     constexpr int RBW = FWD_ROWS_RBW;
     const int rb0 = blockIdx.x * RBW, pair = blockIdx.y;
     const int ob = pair / np, ptile = pair - ob * np;
-    curv += (size_t)ob * curv_stride;
+    float m_cc = 0.f, m_sc2 = 0.f, m_ss = 0.f;
+    if constexpr (MIX) {
+        m_cc = mixc.c[ob][0]; m_sc2 = mixc.c[ob][1]; m_ss = mixc.c[ob][2];
+    } else {
+        curv += (size_t)ob * curv_stride;
+    }
     const TileDev ta = tiles[2 * ptile], tb = tiles[2 * ptile + 1];
     const size_t plane = (size_t)Ty * TX;
     constexpr int E = 4 * TX / NT;
@@ -704,10 +718,20 @@ k_fwd_rows_curv(const float* __restrict__ curv, Geom g,
             const int gi = t.gi0 + 4 * rb + rr;
             const int li = g.wrap ? wrap_index(gi, g.ny) : gi - g.gy0;
             const bool row_ok = g.wrap || (li >= 0 && li < g.ly);
-            const unsigned* row = cu + (size_t)(row_ok ? li : 0) * g.lx;
+            const size_t ro = (size_t)(row_ok ? li : 0) * g.lx;
+            const unsigned* row = cu + ro;
             const unsigned rmask = row_ok ? ~0u : 0u;
+            if constexpr (MIX) {
+                const float *rA = curv + ro, *rB = pB + ro, *rC = pC + ro;
 #pragma unroll
-            for (int k = 0; k < CPR; ++k) x[rr * CPR + k] = row[col[k]] & (rmask & cmask[k]);
+                for (int k = 0; k < CPR; ++k) {
+                    const float mixed = m_cc * rA[col[k]] - m_sc2 * rB[col[k]] + m_ss * rC[col[k]];
+                    x[rr * CPR + k] = __float_as_uint(mixed) & (rmask & cmask[k]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < CPR; ++k) x[rr * CPR + k] = row[col[k]] & (rmask & cmask[k]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < E; ++u) v[u] = __uint_as_float(x[u]);
@@ -1273,6 +1297,29 @@ k_inv_cols(const float2* __restrict__ uc, const float2* __restrict__ uc2,
 // product is the spectrum of a real plane, so the real part is orientation 2j's result and the
 // imaginary part orientation 2j+1's.  Two spectra are parked; `tstride` carries the batch's
 // orientation count, `ystride` is 1 (plane j of Y), one tile pair per launch.
+// A column-pass launch whose workgroups do not fill the chip (a small DEM with many templates per
+// orientation: 900 x 505 at 35 ages is 384 two-wave workgroups for 1 024 SIMDs, each a chain of 70
+// transforms) deals its transforms out along grid.z: part z of nz takes transforms
+// [NG z / nz, NG (z + 1) / nz) of the launch - its coefficient planes, its planes of Y.  Every part parks
+// the spectrum for itself; the transforms are the same instructions on the same operands: Y is
+// bit-identical whatever nz.
+struct TemplShare { int g0, g, t0; };      // first template, templates, first transform of this workgroup's part
+template <bool PT>
+__device__ __forceinline__ TemplShare template_share(int G) {
+    const int nz = gridDim.z;
+    if (nz <= 1) return {0, G, 0};
+    const int NG = PT ? (G + 1) / 2 : G;
+    const int t0 = (int)(((long long)NG * blockIdx.z) / nz), t1 = (int)(((long long)NG * (blockIdx.z + 1)) / nz);
+    const int g0 = PT ? 2 * t0 : t0, g1 = PT ? min(G, 2 * t1) : t1;
+    return {g0, g1 - g0, t0};
+}
+#define TAKE_TEMPLATE_SHARE(PTV, plane_)                                       \
+    {                                                                          \
+        const TemplShare sh_ = template_share<PTV>(G);                         \
+        vfirst += sh_.g0; G = sh_.g;                                           \
+        yw += (size_t)sh_.t0 * (plane_); ym += (size_t)sh_.t0 * (plane_);      \
+    }
+
 template <int TY, bool MIRROR, bool PT, bool XP = false>
 __device__ __forceinline__ void
 inv_cols_sym_body(const int cbx, const float2* __restrict__ uc, const float2* __restrict__ uc2,
@@ -1494,6 +1541,7 @@ k_inv_cols_symx(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                 float2* __restrict__ ym, int ystride, int dbg, int np, int pcj, int tstride,
                 const TileDev* __restrict__ tiles, int py_valid) {
     const int j = blockIdx.x, i = ((j >> 4) << 3) | (j & 7);
+    if constexpr (!XP) TAKE_TEMPLATE_SHARE(PT, (size_t)TY * Tx)
     if ((j >> 3) & 1)
         inv_cols_sym_body<TY, true, PT, XP>((Tx >> 2) - 1 - i, uc, uc2, wa, mb, Tx, 0, pair, vfirst, G, rp_lo, rp_hi, phx,
                                             parity, tw, yw, ym, ystride, dbg, np, pcj, tstride, tiles, py_valid);
@@ -1800,6 +1848,7 @@ k_inv_cols_w8(const float2* __restrict__ uc, const float2* __restrict__ uc2,
     // (grid.x = jil Tx/8, grid.y = jobs / jil).  jil = 1: one job per blockIdx.y as before.
     const int L = blockIdx.x, g16 = L / (16 * jil), r16 = L - g16 * 16 * jil, jq = r16 >> 4, j = r16 & 15;
     const int i = (g16 << 3) | (j & 7), jobx = (int)blockIdx.y * jil + jq;
+    TAKE_TEMPLATE_SHARE(PT, (size_t)TY * Tx)
     if ((j >> 3) & 1)
         inv_cols_w8_body<TY, true, PT, 8>((Tx >> 3) - 1 - i, jobx, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
                                    rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid, tl);
@@ -2828,24 +2877,36 @@ static int launch_fwd_cols(sc_ctx* ctx, const FftGeom& fg, int nplanes,
     return SC_OK;
 }
 
-int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg, int nb) {
+// coef: the nb orientations' (cc, sc2, ss) - the curvature is mixed from the stencil planes inside the
+// row kernel (k_fwd_rows_curv<.., true>); nullptr: the plane(s) k_curv_alpha left in ctx->curv are read
+int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg, int nb, const float (*coef)[3]) {
     int np = npairs_of(fg);
     size_t lds = fft_lds_bytes(fg.Tx);
     dim3 grid(fg.Ty / 4 / FWD_ROWS_RBW, np * nb);
+    CurvMix mixc;
+    memset(&mixc, 0, sizeof(mixc));
+    if (coef) {
+        if (nb > SC_MAX_ORIENT) return sc_fail(ctx, SC_ERR_INVALID, "curvature batch of %d planes", nb);
+        for (int b = 0; b < nb; ++b)
+            for (int j = 0; j < 3; ++j) mixc.c[b][j] = coef[b][j];
+    }
     sc_prof_begin(ctx, SC_K_FWD_ROWS);
-#define FN(T)                                                                  \
+#define FN2(T, MIXV)                                                           \
     {                                                                          \
-        int rc = set_lds(ctx, k_fwd_rows_curv<T>, lds);                        \
+        int rc = set_lds(ctx, k_fwd_rows_curv<T, MIXV>, lds);                  \
         if (rc) return rc;                                                     \
-        hipLaunchKernelGGL(k_fwd_rows_curv<T>, grid, dim3(fft_threads(T)),     \
-                           lds, ctx->stream, (const float*)ctx->curv.p,        \
+        hipLaunchKernelGGL((k_fwd_rows_curv<T, MIXV>), grid, dim3(fft_threads(T)), \
+                           lds, ctx->stream, (const float*)(MIXV ? ctx->A.p : ctx->curv.p), \
+                           (const float*)ctx->B.p, (const float*)ctx->C.p, mixc, \
                            ctx->g, (const TileDev*)ctx->tiles.p, fg.Ty,        \
                            (const float2*)ctx->tw_x.p, (float2*)ctx->blk.p,    \
                            (double*)ctx->norm_part.p, ctx->dbg, np,            \
                            (size_t)ctx->g.ly * ctx->g.lx);                     \
     }
+#define FN(T) { if (coef) FN2(T, true) else FN2(T, false) }
     DISPATCH_T(fg.Tx, FN)
 #undef FN
+#undef FN2
     hipLaunchKernelGGL(k_tile_norms, dim3(np * nb), dim3(64), 0, ctx->stream,
                        (const double*)ctx->norm_part.p, fg.Ty / 4, (double*)ctx->norms.p + ctx->norms_off);
     sc_prof_end(ctx);
@@ -2987,6 +3048,17 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             // kernels nor scored by the row pass (not with explicit per-cell masks or single-template
             // maps: those write every cell; option "variant" 13 switches it off for the cross-check)
             const bool row_skip = !full_masks && !to_maps && ctx->variant != 13;
+            // An under-filled column pass deals its transforms out along grid.z (take_template_share): nz parts
+            // so that the launch's workgroups come up to the chip's resident capacity for the kernel (the
+            // four-column kernels: 256 CUs x what LDS and 256 registers allow; wave-per-column: one or two
+            // 512-thread workgroups per CU), every part at least four transforms.  Option "split_i1" 0: off.
+            auto parts_for = [&](long long workgroups, long long capacity, int transforms) {
+                if (!ctx->split_i1 || workgroups <= 0) return 1;
+                if (ctx->split_i1 > 1) return std::max(1, std::min(ctx->split_i1, transforms));   // (lab: a given number of parts)
+                const long long by_fill = capacity / workgroups, by_len = transforms / 4;
+                return (int)std::max<long long>(1, std::min<long long>(std::min(by_fill, by_len), 8));
+            };
+            const int NGl = PTV ? (G + 1) / 2 : G;
             sc_prof_begin(ctx, SC_K_INV_COLS);
             int n_i1 = 0;
             for (int pl0 = 0; pl0 < pc; pl0 += pi1) {
@@ -3009,7 +3081,10 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     {                                                                          \
         int rc = set_lds(ctx, k_inv_cols_symx<T, PTV>, inv_cols_lds<T>());     \
         if (rc) return rc;                                                     \
-        hipLaunchKernelGGL((k_inv_cols_symx<T, PTV>), dim3(fg.Tx / 4, nb * pcc), dim3(fft_threads(T)), \
+        const int nz_ = parts_for((long long)(fg.Tx / 4) * nb * pcc,                                \
+                                  256LL * std::max<size_t>(1, std::min<size_t>((160 * 1024) / inv_cols_lds<T>(), \
+                                                                               2048 / fft_threads(T) / 2)), NGl); \
+        hipLaunchKernelGGL((k_inv_cols_symx<T, PTV>), dim3(fg.Tx / 4, nb * pcc, nz_), dim3(fft_threads(T)), \
                            inv_cols_lds<T>(), ctx->stream, (const float2*)ctx->uc.p + ctx->uc_off, (const float2*)ctx->uc2.p + ctx->uc_off, \
                            (const float*)ctx->wh.p, (const float*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo, rp_hi, \
                            (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group, \
@@ -3019,7 +3094,8 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     {                                                                          \
         int rc = set_lds(ctx, k_inv_cols_w8<T, PTV>, w8_lds<T>());             \
         if (rc) return rc;                                                     \
-        hipLaunchKernelGGL((k_inv_cols_w8<T, PTV>), dim3(fg.Tx / 8 * jilc, nb * pcc / jilc), dim3(512),  \
+        const int nz_ = parts_for((long long)(fg.Tx / 8) * nb * pcc, 256LL * ((T == 1024 && !PTV) ? 2 : 1), NGl); \
+        hipLaunchKernelGGL((k_inv_cols_w8<T, PTV>), dim3(fg.Tx / 8 * jilc, nb * pcc / jilc, nz_), dim3(512),  \
                            w8_lds<T>(), ctx->stream, (const float2*)ctx->uc.p + ctx->uc_off, (const float2*)ctx->uc2.p + ctx->uc_off, \
                            (const float*)ctx->wh.p, (const float*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo, rp_hi, \
                            (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, group, \
@@ -3126,7 +3202,11 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             if (fast && !to_maps && !full_masks && fg.Tx <= 1024 && ctx->variant != 15 && !(ctx->sib & 1)) {
                 const long long waves = (long long)rp_n * 2 * pc * (inv_rows_fast_threads<512>() * (fg.Tx / 512) / 64);
                 const int ngl = nb * (PTV ? (G + 1) / 2 : G);
-                while (nsplit < 4 && waves * nsplit * 2 <= 2048 && ngl / (nsplit * 2) >= 4) nsplit *= 2;
+                // (option "split_fill": the waves the dealt-out row pass may come to - 4 096 = the four waves per SIMD its
+                //  128 registers allow; round 4 stopped at two per SIMD, 2 048, and a 900 x 505 search at 35 ages -
+                //  1 044 single-wave rows - stayed one wave per SIMD by 40 waves)
+                const long long fill = ctx->split_fill > 0 ? ctx->split_fill : 4096;
+                while (nsplit < 4 && waves * nsplit * 2 <= fill && ngl / (nsplit * 2) >= 4) nsplit *= 2;
             }
             if (nsplit > 1) {
                 const size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);

@@ -117,6 +117,8 @@ struct sc_ctx {
     bool async_in_flight = false;        // an sc_match_async has not been followed by sc_sync yet
     int last_batch = 0;
     float kappa = 4.f;         // float32 resolution floor of the FFT path, in units of eps (sc_set_option "kappa")
+    int split_i1 = 1;          // sc_set_option "split_i1": under-filled column passes deal their transforms out along grid.z
+    long long split_fill = 0;  // sc_set_option "split_fill": waves a dealt-out row pass may come to (0: 4096)
     int variant = 0;           // sc_set_option "variant": alternative kernel paths kept for cross-checks
     int batch_off = 0;         // sc_set_option "batch" = 0: no orientation batching (cross-check in the tests)
     int i1_pairs = 2;          // sc_set_option "i1_pairs": tile pairs per launch of the wave-per-column pass, interleaved (1: one pair per launch)
@@ -190,7 +192,7 @@ int launch_compare_fold(sc_ctx* ctx, double age, double angle, bool planes);
 int fft_prepare(sc_ctx* ctx, const FftGeom& fg, int n_templ_chunk, int group, int nb, int n_slots);
 void fft_spectra_forget(sc_ctx* ctx);
 int fft_batch_orientations(const sc_ctx* ctx, const FftGeom& fg, int n_per, int group);
-int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg, int nb);
+int fft_forward_curv(sc_ctx* ctx, const FftGeom& fg, int nb, const float (*coef)[3] = nullptr);
 int fft_forward_templates(sc_ctx* ctx, const FftGeom& fg, int first, int n, int parity);
 int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                      int group, bool to_maps, bool full_masks, int parity, int nb);

@@ -528,3 +528,71 @@ def test_split_row_pass_is_bit_identical():
         for a, b, name in zip(b0, b1, ("amp", "snr", "id")):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (str(plan), name, int((a != b).sum()))
         assert (b0[1] > 0).any()
+
+
+def test_round5_launch_forms_are_bit_identical():
+    """Round 5: (a) the orientation's curvature mixed from the three stencil planes inside the forward row
+    pass (option variant=17: the separate k_curv_alpha pass writes the plane and the row pass reads it
+    back); (b) an under-filled column pass deals its transforms out along grid.z (split_i1=0: one
+    workgroup per column block walks them all); (c) the dealt-out row pass allowed four waves per SIMD
+    (split_fill=2048: round 4's two).  Each is the same arithmetic on the same operands, distributed
+    differently: the record must be equal in every bit - ties included - on tiled, paired-template,
+    batched and single-template searches."""
+    cz = dem_fixture("dem_carrizo.npz")
+    gc = dem_fixture("dem_grandcanyon.npz")
+    from scipy.special import erf
+    y, x = np.mgrid[-150:150, -160:160].astype(float)
+    flat = (-erf((-x * np.sin(1.1) + y * np.cos(1.1)) / (2 * np.sqrt(10.0))) + 0.01 * x).astype(np.float32)
+    lim = 17 * np.pi / 180
+    ages12 = list(_plan.age_grid()[::3])
+    cases = [(grid(cz[0], cz[1], cz[2]), sl.Scarp, 100.0, ages12, _plan.angle_grid()[::30]),      # C1F's plan: 3 x 2 tiles of 512, many ages
+             (grid(cz[0], cz[1], cz[2]), sl.Scarp, 100.0, [10.0], _plan.angle_grid(-lim, lim)),  # C1: batched orientations
+             (grid(gc[0], gc[1], gc[2]), sl.Channel, 10.0, [0.1], _plan.angle_grid()[::2]),      # C5: paired orientations
+             (synthetic.synthetic_scarp(1300, seed=5), sl.Scarp, 30.0, ages12[:9], _plan.angle_grid()[::45]),   # 1024 / 2048 tiles
+             (grid(flat, 1.0), sl.Scarp, 20.0, [3.0, 10.0, 30.0, 60.0, 90.0, 120.0, 200.0, 300.0], _plan.angle_grid()[::20])]   # exact ties
+    forms = [("default", {}), ("variant 17", {"variant": 17}), ("split_i1 0", {"split_i1": 0}),
+             ("split_fill 2048", {"split_fill": 2048}), ("all off", {"variant": 17, "split_i1": 0, "split_fill": 2048})]
+    for (g, cls, scale, params, angles) in cases:
+        ref = None
+        for name, opts in forms:
+            ctx = sl._lib.Context(0)
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            m = sl.Matcher(g, ctx=ctx)
+            ctx.profile(1)
+            m.search(cls, scale, params, angles, method="fft")
+            best, prof, plan = m.ctx.get_best(), ctx.profile_get(), m.plan
+            ctx.close()
+            if ref is None:
+                ref = best
+                print("round-5 launch forms:", plan, "launches", {k: v[0] for k, v in prof.items() if v[0]})
+                assert (best[1] > 0).any()
+                continue
+            for a, b, plane in zip(ref, best, ("amp", "snr", "id")):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (str(plan), name, plane, int((a != b).sum()))
+
+
+def test_c1f_carrizo_full_grid_is_the_reference_flagship(gpu_ctx, oracle_pool):
+    """The reference's own flagship call, docs/source/examples/scarps.ipynb cell 12:
+    `sl.match(load_carrizo(), Scarp, scale=100.)` - 35 ages x 181 orientations on the 900 x 505 lidar DEM
+    ("This can be slow on a laptop!").  Three windows of the folded result - interior, on the seam of four
+    FFT tiles, on the wrap corner - against EVERY one of the 6335 templates (oracle.snr_stack_window)."""
+    z, dx, dy = dem_fixture("dem_carrizo.npz")
+    res = sl.match(grid(z, dx, dy), sl.Scarp, scale=100.)
+    assert isinstance(res, tuple) and len(res) == 4 and res[0].shape == z.shape
+    ages, angles = _plan.age_grid(), _plan.angle_grid()
+    T = len(ages) * len(angles)
+    assert T == 6335
+    ny, nx = z.shape
+    # (crop and DEM sizes must have the same parity: 32 rows of the 900, 33 columns of the 505)
+    for name, win in (("interior", (420, 452, 230, 263)), ("tile seam", (332, 364, 240, 273)),
+                      ("wrap corner", (0, 32, nx - 33, nx))):
+        i0, i1, j0, j1 = win
+        a_st, s_st = orc.snr_stack_window(z, dx, dy, orc.SCARP, 100., ages, angles, win, 90, pool=oracle_pool)
+        sub = tuple(np.asarray(r)[i0:i1, j0:j1] for r in res)
+        chk = orc.check_fold(sub, a_st.reshape(T, i1 - i0, j1 - j0), s_st.reshape(T, i1 - i0, j1 - j0),
+                             np.repeat(ages, len(angles)), np.tile(angles, len(ages)),
+                             tie_rtol=orc.tie_window("fft", orc.SCARP), amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
+                             snr_tol=(SNR_RTOL, SNR_ATOL * np.max(s_st)))
+        report("C1F carrizo 35 x 181, window %s" % name, chk, "auto")
+        assert chk["n_bad"] == 0, (name, chk["n_bad"])

@@ -8,7 +8,8 @@
 // points k = (lane >> 4) + 4 s in register s) and its output (column n, points m = 4 (lane >> 4) + i):
 // the instruction moves the point index between register and lane-quad as a side effect.
 //
-// Legs (every leg: 256 x G workgroups, `iters` rounds, device time by HIP events, cycles by s_memtime):
+// Legs (every leg: ONE workgroup per CU - 96 KB of dynamic LDS each pins that -, `iters` rounds; device time by HIP
+// events, cycles by s_memtime, the clock held by s_memtime / s_memrealtime (100 MHz)):
 //   check     the DFT through the matrix pipe against a double-precision DFT on the host (layout + error)
 //   mfma      one wave per SIMD (256 threads) and two (512): 8 independent DFT groups per round
 //             (= stage 1 of one 2048-point column, one plane): 128 MFMAs per round and wave
@@ -134,22 +135,31 @@ __device__ __forceinline__ void valu_rounds(int iters, float seed, float* sink, 
     if ((threadIdx.x & 63) == 0) cyc[0] = t1 - t0;
 }
 
-__global__ void __launch_bounds__(512) k_mfma(int iters, float seed, float* sink, long long* cyc) {
+extern __shared__ float pin_lds[];          // 96 KB per workgroup: one workgroup per CU, so "waves per SIMD" is what it says
+__global__ void __launch_bounds__(512) k_mfma(int iters, float seed, float* sink, long long* cyc, long long* real) {
+    const long long r0 = __builtin_amdgcn_s_memrealtime();
     mfma_rounds(iters, seed, sink, cyc + (size_t)blockIdx.x * 8 + (threadIdx.x >> 6));
+    if (threadIdx.x == 0) real[blockIdx.x] = __builtin_amdgcn_s_memrealtime() - r0;
+    if (seed == 12345.f) pin_lds[threadIdx.x] = seed;
 }
-__global__ void __launch_bounds__(512) k_valu(int iters, float seed, float* sink, long long* cyc) {
+__global__ void __launch_bounds__(512) k_valu(int iters, float seed, float* sink, long long* cyc, long long* real) {
+    const long long r0 = __builtin_amdgcn_s_memrealtime();
     valu_rounds(iters, seed, sink, cyc + (size_t)blockIdx.x * 8 + (threadIdx.x >> 6));
+    if (threadIdx.x == 0) real[blockIdx.x] = __builtin_amdgcn_s_memrealtime() - r0;
+    if (seed == 12345.f) pin_lds[threadIdx.x] = seed;
 }
 // waves 0 - 3: matrix pipe, waves 4 - 7: vector pipe (one of each per SIMD)
-__global__ void __launch_bounds__(512) k_sibling(int it_m, int it_v, float seed, float* sink, long long* cyc) {
+__global__ void __launch_bounds__(512) k_sibling(int it_m, int it_v, float seed, float* sink, long long* cyc, long long* real) {
     long long* c = cyc + (size_t)blockIdx.x * 8 + (threadIdx.x >> 6);
     if ((threadIdx.x >> 6) < 4) mfma_rounds(it_m, seed, sink, c);
     else valu_rounds(it_v, seed, sink, c);
+    if (seed == 12345.f) pin_lds[threadIdx.x] = seed;
 }
 
 // one wave: an MFMA, then Q independent packed FMAs, 128 times per round
 template <int Q>
-__global__ void __launch_bounds__(512) k_mixed(int iters, float seed, float* sink, long long* cyc) {
+__global__ void __launch_bounds__(512) k_mixed(int iters, float seed, float* sink, long long* cyc, long long* real) {
+    if (seed == 12345.f) pin_lds[threadIdx.x] = seed;
     float fr[4], fi[4], nfi[4];
     dft_consts(fr, fi, 0.25f);
 #pragma unroll
@@ -199,29 +209,36 @@ __global__ void __launch_bounds__(512) k_mixed(int iters, float seed, float* sin
 }
 
 // ---- host --------------------------------------------------------------------------------------
-struct Timing { double ms; double cyc_a, cyc_b; };
+struct Timing { double ms; double cyc_a, cyc_b; double ghz; };
+constexpr size_t PIN_LDS = 96 * 1024;
 
-template <class L>
-static Timing run(L launch, int blocks, int waves, long long* d_cyc, int split = 0) {
+template <class K, class... A>
+static Timing run(K kernel, int blocks, int threads, long long* d_cyc, long long* d_real, int split, A... args) {
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIN_LDS));
     hipEvent_t e0, e1;
     HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
-    launch();                                                   // warm-up
+    HIPCHECK(hipMemset(d_real, 0, sizeof(long long) * blocks));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), PIN_LDS, 0, args..., d_cyc, d_real);      // warm-up
     HIPCHECK(hipDeviceSynchronize());
     HIPCHECK(hipEventRecord(e0));
-    launch();
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), PIN_LDS, 0, args..., d_cyc, d_real);
     HIPCHECK(hipEventRecord(e1));
     HIPCHECK(hipEventSynchronize(e1));
     float ms = 0;
     HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
-    std::vector<long long> h((size_t)blocks * 8);
+    const int waves = threads / 64;
+    std::vector<long long> h((size_t)blocks * 8), hr(blocks);
     HIPCHECK(hipMemcpy(h.data(), d_cyc, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
-    double a = 0, b = 0; long na = 0, nb = 0;
-    for (int bl = 0; bl < blocks; ++bl)
+    HIPCHECK(hipMemcpy(hr.data(), d_real, sizeof(long long) * blocks, hipMemcpyDeviceToHost));
+    double a = 0, b = 0, ratio = 0; long na = 0, nb = 0, nr = 0;
+    for (int bl = 0; bl < blocks; ++bl) {
         for (int w = 0; w < waves; ++w) {
             if (split && w >= split) { b += (double)h[(size_t)bl * 8 + w]; ++nb; }
             else { a += (double)h[(size_t)bl * 8 + w]; ++na; }
         }
-    return {ms, na ? a / na : 0, nb ? b / nb : 0};
+        if (hr[bl] > 0) { ratio += (double)h[(size_t)bl * 8] / (double)hr[bl]; ++nr; }     // shader ticks per 10 ns
+    }
+    return {ms, na ? a / na : 0, nb ? b / nb : 0, nr ? ratio / nr * 0.1 : 0.0};
 }
 
 int main(int argc, char** argv) {
@@ -229,7 +246,8 @@ int main(int argc, char** argv) {
     hipDeviceProp_t p;
     HIPCHECK(hipGetDeviceProperties(&p, 0));
     const int cus = p.multiProcessorCount;
-    printf("device %s, %d CUs; %d rounds per launch; s_memtime ticks = shader cycles\n", p.gcnArchName, cus, iters);
+    printf("device %s, %d CUs, one workgroup per CU (96 KB of LDS each); %d rounds per launch; cycles = s_memtime ticks of the "
+           "wave, GHz = s_memtime / s_memrealtime\n", p.gcnArchName, cus, iters);
 
     // ---- check
     {
@@ -258,39 +276,35 @@ int main(int argc, char** argv) {
     }
 
     float* sink;
-    long long* d_cyc;
-    const int blocks = cus * 4;
+    long long *d_cyc, *d_real;
+    const int blocks = cus;
     HIPCHECK(hipMalloc(&sink, 4));
     HIPCHECK(hipMalloc(&d_cyc, sizeof(long long) * (size_t)blocks * 8));
+    HIPCHECK(hipMalloc(&d_real, sizeof(long long) * (size_t)blocks));
     const double mf = 16.0 * GROUPS;                      // MFMAs per round and wave
 
     for (int waves : {4, 8}) {
-        Timing t = run([&] { hipLaunchKernelGGL(k_mfma, dim3(blocks), dim3(64 * waves), 0, 0, iters, 0.5f, sink, d_cyc); },
-                       blocks, waves, d_cyc);
-        printf("mfma     %d wave(s) per SIMD: %8.3f ms, %7.1f cycles per wave and DFT group (16 MFMAs), %5.1f per MFMA "
-               "(per SIMD: %5.1f cycles per MFMA)\n", waves / 4, t.ms, t.cyc_a / iters / GROUPS,
-               t.cyc_a / iters / mf, t.cyc_a / iters / mf / (waves / 4));
-        t = run([&] { hipLaunchKernelGGL(k_valu, dim3(blocks), dim3(64 * waves), 0, 0, iters, 0.5f, sink, d_cyc); },
-                blocks, waves, d_cyc);
-        printf("valu     %d wave(s) per SIMD: %8.3f ms, %7.2f cycles per wave and v_pk_fma_f32 (per SIMD: %5.2f)\n",
-               waves / 4, t.ms, t.cyc_a / iters / PKS, t.cyc_a / iters / PKS / (waves / 4));
+        const int wps = waves / 4;
+        Timing t = run(k_mfma, blocks, 64 * waves, d_cyc, d_real, 0, iters, 0.5f, sink);
+        printf("mfma     %d wave(s) per SIMD: %8.3f ms at %.2f GHz: %6.1f cycles per MFMA and wave = %5.1f per MFMA on the SIMD's matrix pipe; "
+               "a DFT group (16 MFMAs, 16 columns x 16 points) %6.0f cycles of the pipe\n", wps, t.ms, t.ghz,
+               t.cyc_a / iters / mf, t.cyc_a / iters / mf / wps, 16 * t.cyc_a / iters / mf / wps);
+        t = run(k_valu, blocks, 64 * waves, d_cyc, d_real, 0, iters, 0.5f, sink);
+        printf("valu     %d wave(s) per SIMD: %8.3f ms at %.2f GHz: %6.2f cycles per v_pk_fma_f32 and wave = %5.2f per instruction on the SIMD\n",
+               wps, t.ms, t.ghz, t.cyc_a / iters / PKS, t.cyc_a / iters / PKS / wps);
     }
-    // sibling: rounds chosen so that both halves take about the same time stand-alone (128 MFMAs x 32 cycles
-    // against 128 pk x ~4 cycles: eight valu rounds per mfma round)
-    for (int ratio : {4, 8, 12}) {
-        Timing t = run([&] { hipLaunchKernelGGL(k_sibling, dim3(blocks), dim3(512), 0, 0, iters, iters * ratio, 0.5f, sink, d_cyc); },
-                       blocks, 8, d_cyc, 4);
-        printf("sibling  mfma wave + valu wave per SIMD, %2d valu rounds per mfma round: %8.3f ms; mfma waves %5.1f cycles per MFMA, "
-               "valu waves %5.2f cycles per v_pk_fma_f32\n", ratio, t.ms, t.cyc_a / iters / mf, t.cyc_b / (iters * (double)ratio) / PKS);
+    // sibling: one mfma wave and one valu wave per SIMD; `ratio` valu rounds (128 pk each) per mfma round (128 MFMAs)
+    for (int ratio : {2, 4, 6, 8, 12}) {
+        Timing t = run(k_sibling, blocks, 512, d_cyc, d_real, 4, iters, iters * ratio, 0.5f, sink);
+        printf("sibling  mfma wave + valu wave per SIMD, %2d pk per MFMA offered: %8.3f ms; the mfma wave %5.1f cycles per MFMA, "
+               "the valu wave %5.2f cycles per v_pk_fma_f32 (= %4.1f pk issued per MFMA slot while both run)\n", ratio, t.ms,
+               t.cyc_a / iters / mf, t.cyc_b / (iters * (double)ratio) / PKS,
+               (t.cyc_a / iters / mf) / (t.cyc_b / (iters * (double)ratio) / PKS));
     }
-#define MIXED(Q) { Timing t = run([&] { hipLaunchKernelGGL(k_mixed<Q>, dim3(blocks), dim3(256), 0, 0, iters, 0.5f, sink, d_cyc); }, \
-                                  blocks, 4, d_cyc); \
-        printf("mixed    one wave per SIMD, %d v_pk_fma_f32 after every MFMA: %8.3f ms, %5.1f cycles per MFMA + its fillers\n", \
-               Q, t.ms, t.cyc_a / iters / mf); \
-        Timing u = run([&] { hipLaunchKernelGGL(k_mixed<Q>, dim3(blocks), dim3(512), 0, 0, iters, 0.5f, sink, d_cyc); }, \
-                       blocks, 8, d_cyc); \
-        printf("mixed    two waves per SIMD, %d v_pk_fma_f32 after every MFMA: %8.3f ms, %5.1f cycles per MFMA + its fillers per wave " \
-               "(%5.1f per SIMD)\n", Q, u.ms, u.cyc_a / iters / mf, u.cyc_a / iters / mf / 2); }
+#define MIXED(Q) { Timing t = run(k_mixed<Q>, blocks, 256, d_cyc, d_real, 0, iters, 0.5f, sink); \
+        Timing u = run(k_mixed<Q>, blocks, 512, d_cyc, d_real, 0, iters, 0.5f, sink); \
+        printf("mixed    %d v_pk_fma_f32 after every MFMA in ONE instruction stream: one wave per SIMD %5.1f cycles per MFMA + fillers; " \
+               "two waves per SIMD %5.1f per wave = %5.1f on the SIMD\n", Q, t.cyc_a / iters / mf, u.cyc_a / iters / mf, u.cyc_a / iters / mf / 2); }
     MIXED(0) MIXED(2) MIXED(4) MIXED(6) MIXED(8)
     return 0;
 }
