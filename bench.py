@@ -66,6 +66,8 @@ def parse():
                          "that would start beyond it are reported as skipped")
     ap.add_argument("--prof-stride", type=int, default=16)
     ap.add_argument("--opt", default="", help="engine options for lab runs: name=value[,name=value...] (sc_set_option)")
+    ap.add_argument("--tile-penalty", default="", help="lab: planner weights by tile size, e.g. 512=1.5,1024=1.0 "
+                                                       "(scarplet_amd._plan.TILE_PENALTY)")
     ap.add_argument("--shard", default="auto", choices=["auto", "orientations", "tiles"],
                     help="multi-rank sharding: 'orientations' = every rank the whole DEM and a chunk of the "
                          "orientation grid, records folded over RCCL (scarplet_amd.dist.OrientationMatcher); "
@@ -818,6 +820,14 @@ def main():
     from scarplet_amd import _lib
     from scarplet_amd import dist as sd
 
+    for kv in (a.tile_penalty or "").split(","):
+        if kv:
+            from scarplet_amd import _plan as _pl
+            k_, v_ = kv.split("=")
+            if k_.startswith("y"):                                  # y512=1.5: the column length's weights only
+                _pl.TILE_PENALTY_Y[int(k_[1:])] = float(v_)
+            else:
+                _pl.TILE_PENALTY[int(k_)] = _pl.TILE_PENALTY_Y[int(k_)] = float(v_)
     g, Template, scales, params, angles, label, kind = workload(a)     # same seed on every rank
     ny, nx = g._griddata.shape
     pool = None

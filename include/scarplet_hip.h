@@ -193,6 +193,9 @@ int sc_clear_windows(sc_ctx* ctx);
  *   "i1_pairs" tile pairs per launch of the wave-per-column inverse pass (default 2; 1: one pair per
  *              launch), interleaved so that the workgroups which stream the same template
  *              coefficients run on one XCD at the same time.  Results are bit-identical.
+ *   "near_window"  > 0: the FFT row pass flags near-ties within this relative window (sc_get_near_ties); needs
+ *              the fast row kernel (tile widths 512 / 1024 / 2048) and templates without per-cell masks, else
+ *              sc_match answers SC_ERR_UNSUPPORTED.  Default 0.
  *   "split_i1" 1 (default): a column pass whose workgroups do not fill the chip (a small DEM with many
  *              templates per orientation) deals its transforms out over up to eight workgroups per column
  *              block; 0: one workgroup per column block walks all of them.  Results are bit-identical.
@@ -311,6 +314,15 @@ int sc_curvature_f64(sc_ctx* ctx, double cos2, double sin_a, double cos_a, doubl
  * (lidar, the benchmark DEM), tens of per cent on synthetic surfaces stored without one; the
  * real-space path has no such limit.  scarplet_amd.match(method="auto") reads it to fall back. */
 int sc_get_resolution_stats(sc_ctx* ctx, long long* wins, long long* near_floor);
+
+/* Near-ties of the FFT searches since the last sc_reset_best, one byte per core cell, (cy1-cy0) x (cx1-cx0):
+ * 1 where some template scored within the relative window of option "near_window" of the cell's running best
+ * (either side of it) without equalling it.  A float32 FFT convolution carries an SNR error of up to half the
+ * path's tie window (scarplet_amd: oracle-measured): between two templates closer than
+ * that, which one the record holds is rounding noise.  scarplet_amd.match(..., exact=True) reads the flags and
+ * re-scores those cells on the real-space path (exact per cell): the argmax of every cell is then the float64
+ * reference's.  All zero when the option is 0 (the default: the flag costs the row pass ~10 %). */
+int sc_get_near_ties(sc_ctx* ctx, uint8_t* out);
 
 /* Per-template scalars of the last sc_match / sc_match_template call:
  * n = count(W != 0) + eps (core.py:350) and sum(W**2) (core.py:356). */

@@ -102,6 +102,7 @@ SIGNATURES = {
                                  C.POINTER(C.c_longlong)]),
     "sc_curvature": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, _fp]),
     "sc_curvature_f64": (C.c_int, [_P] + [C.c_double] * 4 + [_dp]),
+    "sc_get_near_ties": (C.c_int, [_P, _bp]),
     "sc_get_resolution_stats": (C.c_int, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "sc_get_template_sums": (C.c_int, [_P, C.c_int, _dp, _dp]),
     "sc_profile": (C.c_int, [_P, C.c_int]),
@@ -388,6 +389,13 @@ class Context(object):
         buf = C.create_string_buffer(bytes(uid), COMM_ID_BYTES)
         self._check(self.lib.sc_comm_init(self._h, buf, rank, nranks),
                     "sc_comm_init")
+
+    def near_ties(self):
+        """(h, w) uint8: 1 where an FFT search since the last reset saw a near-tie (option "near_window")."""
+        h, w = self.core_shape()
+        out = np.zeros((h, w), dtype=np.uint8)
+        self._check(self.lib.sc_get_near_ties(self._h, _as(out, _bp)), "sc_get_near_ties")
+        return out
 
     def comm_destroy(self):
         """Drop this context's RCCL communicator (sc_comm_destroy); nothing to do without one."""

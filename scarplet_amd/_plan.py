@@ -81,7 +81,13 @@ TILE_PENALTY = {64: 20.0, 128: 8.0, 256: 5.0, 512: 1.0, 1024: 1.0, 2048: 1.0,
                 4096: 2.3}
 
 
-def choose_tile(n_core, span, n_global, whole_axis, t_max=T_MAX):
+# The same along y (column length of the inverse column pass), where it differs: column length 512 runs the
+# four-column kernels (k_inv_cols_symx: seven workgroup barriers per transform), 1024 and 2048 the wave-per-column
+# kernels - per padded cell 512 costs the column pass ~2.5 x what 1024 does (profiles/r05_small_dems.txt)
+TILE_PENALTY_Y = dict(TILE_PENALTY)
+
+
+def choose_tile(n_core, span, n_global, whole_axis, t_max=T_MAX, penalty=None):
     """Pick the FFT length for one axis.
 
     n_core     -- output cells this device owns along the axis
@@ -95,8 +101,10 @@ def choose_tile(n_core, span, n_global, whole_axis, t_max=T_MAX):
     nothing is wasted."""
     best = None
 
+    penalty = TILE_PENALTY if penalty is None else penalty
+
     def cost(nt, t):
-        return nt * t * (math.log2(t) + 4.0) * TILE_PENALTY.get(t, 1.0)
+        return nt * t * (math.log2(t) + 4.0) * penalty.get(t, 1.0)
 
     if whole_axis and _is_pow2(n_global) and T_MIN <= n_global <= t_max \
             and span < n_global:
@@ -132,7 +140,7 @@ class Plan(object):
         self.Py, self.Qx = pmax, qmax
         if method == METHOD_FFT:
             self.Ty, self.Vy, self.nty, self.circ_y = choose_tile(
-                cy1 - cy0, pmax - pmin, ny, whole and (cy1 - cy0) == ny, t_max)
+                cy1 - cy0, pmax - pmin, ny, whole and (cy1 - cy0) == ny, t_max, TILE_PENALTY_Y)
             self.Tx, self.Vx, self.ntx, self.circ_x = choose_tile(
                 cx1 - cx0, qmax - qmin, nx, whole and (cx1 - cx0) == nx, t_max)
             # a circular axis has no halo to place: any origin with pmax <= P <= T + pmin serves.

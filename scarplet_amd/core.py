@@ -83,6 +83,7 @@ class Matcher(object):
         self.dx, self.dy = dx, dy
         self.core = (0, self.ny, 0, self.nx)
         self.whole = True
+        self._z = z                              # (a reference: exact=True cuts the blocks it re-scores out of it)
         self.ctx.set_dem(z, dx, dy, _WT.centred_axis(self.nx, dx),
                          _WT.centred_axis(self.ny, dx))
         # A NaN anywhere in the DEM turns every reference output into NaN: the
@@ -367,11 +368,28 @@ class Matcher(object):
         return p, sp
 
     # -- searches -------------------------------------------------------------------
+    # exact=True: relative window within which the FFT row pass flags near-ties (option "near_window"), by template
+    # family - twice the path's tie window, itself twice the largest SNR error measured on the path (DESIGN.md
+    # section 6): Scarp-like 1e-4, Ricker 7e-4 (a Ricker window's support is the float64 underflow of its
+    # exponential: tiles with far more energy, a larger float32 error)
+    EXACT_WINDOW = {_WT.KIND_SCARP: 2e-4, _WT.KIND_RICKER: 1.4e-3}
+    EXACT_PATCH = (8, 256)                       # rows x columns re-scored around a flagged cell: one real-space workgroup
+
     def search(self, Template, scale, params, angles, method="auto",
-               group=None, reset=True, sync=True, **kwargs):
-        """Fold every (param, angle) template into the running best."""
+               group=None, reset=True, sync=True, exact=False, **kwargs):
+        """Fold every (param, angle) template into the running best.
+
+        ``exact=True`` (with ``method`` 'auto' or 'fft'): the argmax of EVERY cell is the float64 reference's.
+        The FFT path is exact in (age, orientation) except where two templates score closer together than
+        its float32 convolution resolves - a handful of cells per million on a DEM with a noise floor (11 of
+        262 144 on the int16 Grand Canyon DEM).  With the flag on, the row pass marks the cells where some
+        template came within EXACT_WINDOW of the running best; each marked cell's 8 x 256 patch is searched
+        again on the real-space path (exact per cell, its own context, a halo block of the periodic DEM) for
+        all templates, and the marked cells of ``result()`` carry that answer.  Cost: ~10 % on the row pass
+        plus one small real-space search per patch; the device record itself keeps the FFT answer."""
         params = np.atleast_1d(np.asarray(params, dtype=float))
         angles = np.atleast_1d(np.asarray(angles, dtype=float))
+        self._patches = []
         if getattr(self, "nan_dem", False):
             self._nan_result = self._nan_fold(Template, scale, params, angles, **kwargs)
             self.params, self.angles = params, angles
@@ -387,7 +405,30 @@ class Matcher(object):
                                       n_params=len(params))
         if reset:
             self.ctx.reset_best()
-        self.ctx.match(arr, sp, sync=sync)
+        flagged = False
+        if exact:
+            self.exact_stats = {"flagged_cells": 0, "patches": 0, "changed_cells": 0}
+        if exact and sp.method == _plan.METHOD_FFT:
+            if not (reset and sync and self.whole):
+                raise ValueError("exact=True needs reset=True, sync=True and a whole-DEM matcher")
+            kinds = {int(t.kind) for t in arr[:1]} | {int(arr[len(arr) - 1].kind)}
+            win = max(self.EXACT_WINDOW.get(k, max(self.EXACT_WINDOW.values())) for k in kinds)
+            self.ctx.set_option("near_window", win)
+            try:
+                self.ctx.match(arr, sp, sync=True)
+                flagged = True
+            except _lib.ScarpletHipError as e:
+                # per-cell masks (generic plugins, UpperBreak error masks) or a tile size the flagging row
+                # kernel is not built for: the whole search on the exact path instead
+                if "near-tie flags" not in str(e):
+                    raise
+                self.plan, sp = self.plan_for(bbox, max_area, "direct", group, n_params=len(params))
+                self.ctx.reset_best()
+                self.ctx.match(arr, sp, sync=True)
+            finally:
+                self.ctx.set_option("near_window", 0.0)
+        else:
+            self.ctx.match(arr, sp, sync=sync)
         self.method_used = "direct" if sp.method == _plan.METHOD_DIRECT else "fft"
         if method == "auto" and reset and sync and self.method_used == "fft":
             self._exact_path_if_unresolved(arr, bbox, max_area, group, len(params))
@@ -406,7 +447,73 @@ class Matcher(object):
         self.n_templates = len(arr)
         self._id_par = np.concatenate([self._id_par, np.repeat(params, len(angles))])
         self._id_ang = np.concatenate([self._id_ang, np.tile(angles, len(params))])
+        if flagged and self.method_used == "fft":
+            self._rescore_near_ties(Template, scale, params, angles, kwargs)
         return self
+
+    def _rescore_near_ties(self, Template, scale, params, angles, kwargs):
+        """exact=True, second half: the cells the FFT row pass flagged, searched again on the real-space path."""
+        from scarplet_amd import dist as _dist
+        flags = self.ctx.near_ties()
+        cells = np.argwhere(flags)
+        self.exact_stats = {"flagged_cells": int(len(cells)), "patches": 0, "changed_cells": 0}
+        if not len(cells):
+            return
+        ph, pw = self.EXACT_PATCH
+        todo = sorted({(int(i) // ph, int(j) // pw) for i, j in cells})
+        if len(todo) * ph * pw > 0.5 * self.ny * self.nx:
+            # the flags cover half the DEM: a surface the FFT path does not resolve - what method="auto" answers
+            # with a whole real-space search; per-patch searches would cost more than that
+            import warnings
+            warnings.warn("exact=True: %d cells flagged (%d patches): searching the whole DEM on the real-space "
+                          "path instead" % (len(cells), len(todo)))
+            arr, bbox, max_area = self.describe(Template, scale, params, angles, **kwargs)
+            self.plan, sp = self.plan_for(bbox, max_area, "direct", None, n_params=len(params))
+            self.ctx.reset_best()
+            self.ctx.match(arr, sp, sync=True)
+            self.method_used = "direct"
+            return
+        aux = getattr(self, "_aux", None)
+        if aux is None:
+            aux = self._aux = Matcher(ctx=_lib.Context(self.ctx.device))
+        z = np.asarray(self._z)
+        ny, nx = self.ny, self.nx
+        arr = None
+        for (bi, bj) in todo:
+            i0, j0 = bi * ph, bj * pw
+            i1, j1 = min(i0 + ph, ny), min(j0 + pw, nx)
+            if arr is None:
+                aux.ny, aux.nx, aux.de = ny, nx, self.de
+                arr, bbox, max_area = aux.describe(Template, scale, params, angles, **kwargs)
+                halo = _dist.halo_for_search(bbox, ny, nx)
+            gi = np.arange(i0 - halo[0], i1 + halo[1]) % ny          # the DEM is a torus (the reference's circular convolution)
+            gj = np.arange(j0 - halo[2], j1 + halo[3]) % nx
+            blk = np.ascontiguousarray(z[np.ix_(gi, gj)], dtype=np.float64)
+            aux.set_block(blk, (i0 - halo[0], j0 - halo[2]), (ny, nx), (i0, i1, j0, j1), self.dx, self.dy)
+            _, sp = aux.plan_for(bbox, max_area, "direct", None, n_params=len(params))
+            aux.ctx.reset_best()
+            aux.ctx.match(arr, sp, sync=True)
+            amp, snr, idx = aux.ctx.get_best()
+            sel = flags[i0:i1, j0:j1] != 0
+            self._patches.append((i0, j0, sel, amp, snr, idx))
+            self.exact_stats["patches"] += 1
+        aux.ctx.clear_windows()
+
+    def _apply_patches(self, out):
+        """The re-scored cells of exact=True into a (4, h, w) result."""
+        par, ang = self._id_par, self._id_ang
+        for (i0, j0, sel, amp, snr, idx) in getattr(self, "_patches", ()):
+            won = sel & (idx < len(par))
+            safe = np.where(won, idx, 0)
+            h, w = sel.shape
+            view = out[:, i0:i0 + h, j0:j0 + w]
+            changed = won & ((view[1] != par[safe]) | (view[2] != ang[safe]))
+            self.exact_stats["changed_cells"] += int(changed.sum())
+            view[0][won] = amp[won]
+            view[1][won] = par[safe][won]
+            view[2][won] = ang[safe][won]
+            view[3][won] = snr[won]
+        return out
 
     # share of the cells an FFT search won whose residual lies near the transforms' float32
     # resolution floor (sc_get_resolution_stats) above which method="auto" takes the exact path
@@ -456,7 +563,12 @@ class Matcher(object):
             # descriptors were sent by hand (ctx.match): one grid, ids from 0
             return self.ctx.get_result(np.repeat(self.params, len(self.angles)),
                                        np.tile(self.angles, len(self.params)))
-        return self.ctx.get_result(self._id_par, self._id_ang)
+        out = self.ctx.get_result(self._id_par, self._id_ang)
+        if getattr(self, "_patches", None):
+            if hasattr(self, "exact_stats"):
+                self.exact_stats["changed_cells"] = 0
+            out = self._apply_patches(out)
+        return out
 
     def match_template(self, Template, scale, age, angle, method="auto",
                        **kwargs):
@@ -503,10 +615,11 @@ def calculate_best_fit_parameters(dem, Template, scale, age,
     are accepted but not forwarded to the template (core.py:145, 182)."""
     device = kwargs.pop("device", 0)
     method = kwargs.pop("method", "auto")
+    exact = kwargs.pop("exact", False)
     m = Matcher(dem, device=device)
     try:
         m.search(Template, scale, [age], _plan.angle_grid(ang_min, ang_max),
-                 method=method)
+                 method=method, exact=exact)
         return m.result_array()
     finally:
         m.ctx.clear_windows()
@@ -520,10 +633,11 @@ def calculate_best_fit_parameters_serial(dem, Template, scale,
     (best_amp, best_age, best_angle, best_snr)."""
     device = kwargs.pop("device", 0)
     method = kwargs.pop("method", "auto")
+    exact = kwargs.pop("exact", False)
     m = Matcher(dem, device=device)
     try:
         m.search(Template, scale, _plan.age_grid(),
-                 _plan.angle_grid(ang_min, ang_max), method=method, **kwargs)
+                 _plan.angle_grid(ang_min, ang_max), method=method, exact=exact, **kwargs)
         return m.result()
     finally:
         m.ctx.clear_windows()
@@ -550,7 +664,10 @@ def match(data, Template, **kwargs):
     grid 10**arange(0, 3.5, 0.1), returns the 4-tuple (amp, age, angle, snr).
     Keyword arguments: ``scale``, ``age``, ``ang_max``, ``ang_min`` as in the
     reference, plus ``device=`` (GPU ordinal), ``method=`` ('auto', 'fft',
-    'direct'), ``ages=`` (override the age grid) and ``fold=``:
+    'direct'), ``ages=`` (override the age grid), ``exact=`` (True: every cell's
+    (age, orientation) is the float64 reference's argmax - the cells where the
+    FFT path saw a near-tie are searched again on the real-space path,
+    Matcher.search) and ``fold=``:
 
     ``fold="fused"`` (default): ONE device search, the running best folded in
     the kernels - ties keep the incumbent, orientation-major order.
@@ -585,6 +702,7 @@ def match(data, Template, **kwargs):
         return calculate_best_fit_parameters(data, Template, **kwargs)
     device = kwargs.pop("device", 0)
     method = kwargs.pop("method", "auto")
+    exact = kwargs.pop("exact", False)
     ages = kwargs.pop("ages", None)
     scale = kwargs.pop("scale")
     ang_max = kwargs.pop("ang_max", np.pi / 2)
@@ -592,7 +710,7 @@ def match(data, Template, **kwargs):
     m = Matcher(data, device=device)
     try:
         m.search(Template, scale, _plan.age_grid() if ages is None else ages,
-                 _plan.angle_grid(ang_min, ang_max), method=method)
+                 _plan.angle_grid(ang_min, ang_max), method=method, exact=exact)
         return m.result()
     finally:
         m.ctx.clear_windows()

@@ -167,6 +167,12 @@ extern "C" int sc_set_option(sc_ctx* ctx, const char* name, double value) {
     } else if (!strcmp(name, "i1_pairs")) {
         if (!(value >= 1.0 && value <= 64.0)) return sc_fail(ctx, SC_ERR_INVALID, "i1_pairs must be 1 .. 64");
         ctx->i1_pairs = (int)value;
+    } else if (!strcmp(name, "near_window")) {
+        if (!(value >= 0.0 && value < 1.0)) return sc_fail(ctx, SC_ERR_INVALID, "near_window must be in [0, 1)");
+        ctx->near_w = (float)value;
+    } else if (!strcmp(name, "batch_templ")) {
+        if (!(value >= 0.0 && value <= (double)SC_MAX_BATCH)) return sc_fail(ctx, SC_ERR_INVALID, "batch_templ must be 0 .. %d", SC_MAX_BATCH);
+        ctx->batch_templ = (int)value;
     } else if (!strcmp(name, "split_i1")) {
         if (!(value >= 0.0 && value <= 64.0)) return sc_fail(ctx, SC_ERR_INVALID, "split_i1 must be 0 .. 64");
         ctx->split_i1 = (int)value;
@@ -461,7 +467,21 @@ extern "C" int sc_reset_best(sc_ctx* ctx) {
                        (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p, nc, (float*)ctx->split_s.p, n2,
                        (unsigned long long*)ctx->res_stats.p);
     SC_HIP(ctx, hipGetLastError());
+    if (ctx->near.p) SC_HIP(ctx, hipMemsetAsync(ctx->near.p, 0, ctx->near.cap, ctx->stream));
     return SC_OK;
+}
+
+extern "C" int sc_get_near_ties(sc_ctx* ctx, uint8_t* out) {
+    if (!ctx || !out) return SC_ERR_INVALID;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
+    if (!ctx->near.p || ctx->near.cap < nc) {        // no search has run with the option on: nothing flagged
+        memset(out, 0, nc);
+        return SC_OK;
+    }
+    SC_HIP(ctx, hipMemcpyAsync(out, ctx->near.p, nc, hipMemcpyDeviceToHost, ctx->stream));
+    return sc_sync(ctx);
 }
 
 extern "C" int sc_get_resolution_stats(sc_ctx* ctx, long long* wins, long long* near_floor) {
@@ -612,7 +632,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
     struct Chunk { int first, n, nb, wh, ww, parity; bool full, long_runs; size_t cells; int run0; };
     std::vector<Chunk> chunks;
     size_t max_cells = 0, max_dcells = 0, max_spans = 0;
-    int nb_max = 1;
+    int nb_max = 1, max_batch_templ = 1;
     for (size_t r = 0; r < runs.size();) {
         int nb = 1;
         if ((plan->method == SC_METHOD_FFT || (!ctx->batch_off && ctx->variant != 10)) && !to_maps) {
@@ -623,7 +643,9 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
             const int want = plan->method == SC_METHOD_FFT ? fft_batch_orientations(ctx, fg, runs[r].n, group)
                                                            : (wg1 <= 1024 ? 32 : 1);
             // compatible runs ahead, up to what one launch can hold (64 templates, 64 curvature planes)
-            const int hard = plan->method == SC_METHOD_FFT ? std::min(SC_MAX_ORIENT, SC_MAX_GROUP / std::max(1, runs[r].n)) : 32;
+            // (round 5: SC_MAX_BATCH templates per launch sequence - the row pass takes them in slices of whole
+            //  orientations, at most SC_MAX_GROUP templates each: fft_inverse_fold)
+            const int hard = plan->method == SC_METHOD_FFT ? std::min(SC_MAX_ORIENT, SC_MAX_BATCH / std::max(1, runs[r].n)) : 32;
             // (counted beyond what one launch can hold, up to two full batches: whether a remainder rides
             //  along or the rest is split evenly is decided on what is really left - capped at `hard`, 91
             //  orientations of ten templates went six at a time as 3 + 3 instead of 4 + 4 + ...)
@@ -662,6 +684,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
         chunks.push_back({runs[r].first, runs[r].n, nb, wh, ww, runs[r].parity, runs[r].full, runs[r].long_runs, off, (int)r});
         max_cells = std::max(max_cells, off);
         nb_max = std::max(nb_max, nb);
+        max_batch_templ = std::max(max_batch_templ, nb * runs[r].n);
         r += nb;
     }
     // Spectra kept across searches (option "spectra_mb"): slot of run r = its orientation's index among the
@@ -680,7 +703,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
                 if (slot_of[c.run0 + b] != slot_of[c.run0] + b) n_slots = 0;     // (an orientation twice in a batch)
     }
     if (plan->method == SC_METHOD_FFT &&
-        (rc = fft_prepare(ctx, fg, std::min(n, CHUNK), group, nb_max, n_slots)))
+        (rc = fft_prepare(ctx, fg, std::min(n, std::max(CHUNK, max_batch_templ)), group, nb_max, n_slots)))
         return rc;
     const bool keep = plan->method == SC_METHOD_FFT && ctx->spec_slots > 0;
     if ((rc = sc_ensure(ctx, ctx->templ, sizeof(TemplDev) * n))) return rc;

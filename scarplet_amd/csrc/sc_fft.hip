@@ -1912,6 +1912,11 @@ struct RowArgs {
     size_t nc;
     float *s2, *a2;
     uint32_t* i2;
+    // fast kernel, NEAR (the exact mode of the host layer): a byte per core cell, set where a template scored within
+    // near_w (relative) of the running best without equalling it - the cells whose argmax the float32 convolution
+    // cannot vouch for and that the host re-scores on the real-space path
+    float near_w;
+    uint8_t* near;
 };
 // One launch may serve several tile pairs (grid.y): pair = ra.pair + blockIdx.y,
 // its Y planes ystride planes further on.  More workgroups per launch fill the
@@ -2147,8 +2152,8 @@ __host__ __device__ constexpr size_t inv_rows_fast_lds() {
 #ifndef SC_I2_WAVES_FULL
 #define SC_I2_WAVES_FULL 3
 #endif
-template <int TX, bool FULL, bool MAPS, bool PT, bool SPLITK = false>
-__global__ void __launch_bounds__(inv_rows_fast_threads<TX>(), (FULL && !MAPS) ? SC_I2_WAVES_FULL : SC_I2_WAVES)
+template <int TX, bool FULL, bool MAPS, bool PT, bool SPLITK = false, bool NEAR = false>
+__global__ void __launch_bounds__(inv_rows_fast_threads<TX>(), ((FULL && !MAPS) || NEAR) ? SC_I2_WAVES_FULL : SC_I2_WAVES)
 k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 RowArgs ra, Geom g, const TileDev* __restrict__ tiles,
                 const TemplDev* __restrict__ templ, const double* __restrict__ sums,
@@ -2296,6 +2301,8 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     auto best_of = [](int c, int part) { return PT ? c : 2 * c + part; };
     float b_snr[NBEST], b_xr[NBEST];
     uint32_t b_ix[NBEST / 4];                  // one byte per cell (0xFF: unchanged)
+    uint32_t nearm = 0;                        // NEAR: bit k - some template came within near_w of cell k's running best
+    static_assert(!NEAR || (!SPLITK && !MAPS && !FULL), "near-tie flags: the plain fold only");
 #pragma unroll
     for (int c = 0; c < NBEST / 4; ++c) b_ix[c] = NONE;
 #pragma unroll
@@ -2477,7 +2484,8 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             pk::B<R3, true>::run(vm);
             // (RARE: rows of 1024 cells and more; the 512-cell kernels keep the selects - there the deferred form
             //  costs a scratch reload inside the template loop)
-            constexpr bool RARE = SC_I2_RAREWIN && TX >= 1024;
+            // (NEAR compares every score with the record as it stands: no deferred update)
+            constexpr bool RARE = SC_I2_RAREWIN && TX >= 1024 && !NEAR;
             // (GRP outputs pairs per branch: the fewer cells a branch stands for, the more rarely it is taken)
             constexpr int GRP = (RARE && SC_I2_GRP < R3) ? SC_I2_GRP : R3;
 #pragma unroll
@@ -2524,6 +2532,13 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                         // sc_fold: take if greater, ties keep the incumbent; a cell outside
                         // the range (lean variant) or masked to 0 never wins
                         const bool won = (FULL || in) && snr > b_snr[k];
+                        if constexpr (NEAR) {
+                            // a score within the window of the running best, either side of it, that does not EQUAL it
+                            // (an even or odd template at -pi/2 and +pi/2 is one template: bit-identical scores)
+                            const float top = fmaxf(snr, b_snr[k]);
+                            const bool nt = in && snr > 0.f && snr != b_snr[k] && fabsf(snr - b_snr[k]) <= ra.near_w * top;
+                            nearm |= nt ? (1u << k) : 0u;
+                        }
                         if constexpr (RARE) {
                             wonm[m - m0][part] = won;
                             snrs[m - m0][part] = snr;
@@ -2612,6 +2627,14 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                     if (won && b_snr[k] > 0.f) count(k, e);
                 }
             }
+        }
+        if constexpr (NEAR) {
+#pragma unroll
+            for (int k = 0; k < NBEST; ++k)
+                if (nearm & (1u << k)) {
+                    const int c = PT ? k : k >> 1, part = PT ? 0 : (k & 1);
+                    at_bytes(ra.near + off_of(part), (uint32_t)col_of(c)) = (uint8_t)1;
+                }
         }
         if (!later_share) {
 #pragma unroll
@@ -2814,7 +2837,13 @@ int fft_batch_orientations(const sc_ctx* ctx, const FftGeom& fg, int n_per, int 
     const bool fast = (fg.Tx == 512 || fg.Tx == 1024 || fg.Tx == 2048) && ctx->variant != 9;
     if (!fast) return 1;
     const int np = (fg.ntiles + 1) / 2;
-    const int by_table = SC_MAX_GROUP / n_per;
+    // What one launch sequence may carry.  The row pass folds at most SC_MAX_GROUP templates per launch: where three
+    // or more orientations fit that (C2: six of ten templates), the batch stops there and the row pass takes it in ONE
+    // launch (more, sliced over two row-pass launches, cost C2's row pass 14 %); where they do not (C1F: 35 ages, one
+    // orientation per row-pass launch either way) the forward passes and the column pass batch up to SC_MAX_BATCH
+    // templates - 181 five-kernel launch sequences of a few microseconds each were 15 of C1F's 52 ms, now 6
+    const int cap = ctx->batch_templ > 0 ? ctx->batch_templ : SC_MAX_BATCH;
+    const int by_table = (SC_MAX_GROUP / n_per >= 3 || cap <= SC_MAX_GROUP) ? std::min(cap, SC_MAX_GROUP) / n_per : cap / n_per;
     // (round 4: 4096 workgroups and up to SC_MAX_ORIENT orientations - BASELINE config C5, one template per
     //  orientation on a 512 x 512 tile, runs 64 orientations per launch sequence instead of 32: 5.95 -> 5.2 ms;
     //  C1 and C2 are where they were with either)
@@ -3014,7 +3043,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     // coefficient plane does not fit - 32 spilled values reloaded per transform wait for the stores in
     // flight, 1 455 us at C2 against k_inv_cols_symx's 1 000; k_inv_cols_w4: 915
     const bool w8 = symx && ctx->variant != 2 && (fg.Ty == 2048 || fg.Ty == 1024) && (fg.Tx / 16) % 8 == 0;
-    if (nb > 1 && (!fast || n > group || nb * n > SC_MAX_GROUP))
+    if (nb > 1 && (!fast || n > group || nb * n > SC_MAX_BATCH || n > SC_MAX_GROUP))
         return sc_fail(ctx, SC_ERR_INVALID, "orientation batching outside its conditions");
     // One chunk = pc tile pairs through I1 and I2, group by group.  PTV: the chunk is a
     // single pair whose second tile is empty; templates ride in pairs instead (see
@@ -3184,10 +3213,27 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             }
             sc_prof_end(ctx, n_i1);
             const int pair = pair0;
+            // The row pass folds at most SC_MAX_GROUP templates per launch (its scalar table, its 64-bit mask of
+            // transforms, the winner's byte): a batch of more - nb orientations of G templates each, round 5 -
+            // goes through it in slices of whole orientations, in order; the running best lives in the record
+            // between launches, so the fold is the one of a single launch (and of no batching at all).
+            // (slices of equal size: 8 orientations of 10 templates go 4 + 4, not 6 + 2 - a short last launch leaves the
+            //  chip part empty)
+            int nbs = nb;
+            if (nb > 1 && !xp) {
+                const int cap = std::max(1, SC_MAX_GROUP / std::max(1, G)), nsl = (nb + cap - 1) / cap;
+                nbs = (nb + nsl - 1) / nsl;
+            }
+            for (int b0 = 0; b0 < nb; b0 += nbs) {
+            const int nbc = std::min(nbs, nb - b0);
+            const size_t yoff = (size_t)b0 * pc * group * (size_t)fg.Ty * fg.Tx;        // job (b0, 0) of yw / ym
+            const float2* yw_s = (const float2*)ctx->yw.p + yoff;
+            const float2* ym_s = (const float2*)ctx->ym.p + yoff;
+            const double* norms_s = (const double*)ctx->norms.p + ctx->norms_off + (size_t)2 * np * b0;
             RowArgs ra{fg.Ty, fg.Py, fg.Qx, fg.circ_y, fg.circ_x, ctx->g.cy0, ctx->g.cx0,
-                       ctx->g.cx1 - ctx->g.cx0, pair, first + g0, G, rp_lo, rp_n, ctx->dbg, group,
-                       nb, np, pc, SibSync{nullptr, 0}, (unsigned long long*)ctx->res_stats.p, 0, row_skip ? 1 : 0,
-                       1, 0, nullptr, nullptr, nullptr};
+                       ctx->g.cx1 - ctx->g.cx0, pair, first + g0 + b0 * n, G, rp_lo, rp_n, ctx->dbg, group,
+                       nbc, np, pc, SibSync{nullptr, 0}, (unsigned long long*)ctx->res_stats.p, 0, row_skip ? 1 : 0,
+                       1, 0, nullptr, nullptr, nullptr, 0.f, nullptr};
             if (xp) {                            // to the row pass: ONE orientation of nb templates, in pairs
                 ra.G = nb; ra.nb = 1; ra.ystride = 1; ra.xp = 1;
             }
@@ -3198,10 +3244,23 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             // transforms are dealt out over nsplit workgroups per row, each folding its share in order into a
             // record of its own; k_merge_split folds the shares into the record in order.  Same winners, same
             // ties (option "variant" 15: off).
+            // Near-tie flags (option "near_window" > 0: the host layer's exact mode): the plain fast kernel only
+            const bool near = ctx->near_w > 0.f && !to_maps;
+            if (near) {
+                if (!fast || full_masks)
+                    return sc_fail(ctx, SC_ERR_UNSUPPORTED, "near-tie flags need the fast row kernel without per-cell masks");
+                const size_t nc_ = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
+                const bool fresh = ctx->near.cap < nc_;
+                int rc = sc_ensure(ctx, ctx->near, nc_);
+                if (rc) return rc;
+                if (fresh) SC_HIP(ctx, hipMemsetAsync(ctx->near.p, 0, nc_, ctx->stream));     // (sc_reset_best clears it from then on)
+                ra.near_w = ctx->near_w;
+                ra.near = (uint8_t*)ctx->near.p;
+            }
             int nsplit = 1;
-            if (fast && !to_maps && !full_masks && fg.Tx <= 1024 && ctx->variant != 15 && !(ctx->sib & 1)) {
+            if (fast && !near && !to_maps && !full_masks && fg.Tx <= 1024 && ctx->variant != 15 && !(ctx->sib & 1)) {
                 const long long waves = (long long)rp_n * 2 * pc * (inv_rows_fast_threads<512>() * (fg.Tx / 512) / 64);
-                const int ngl = nb * (PTV ? (G + 1) / 2 : G);
+                const int ngl = nbc * (PTV ? (G + 1) / 2 : G);
                 // (option "split_fill": the waves the dealt-out row pass may come to - 4 096 = the four waves per SIMD its
                 //  128 registers allow; round 4 stopped at two per SIMD, 2 048, and a 900 x 505 search at 35 ages -
                 //  1 044 single-wave rows - stayed one wave per SIMD by 40 waves)
@@ -3231,9 +3290,9 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             sc_prof_begin(ctx, SC_K_INV_ROWS);
 #define ROW_ARGS lds_r, FAST_ARGS
 #define FAST_ARGS                                                              \
-    ctx->stream, (const float2*)ctx->yw.p, (const float2*)ctx->ym.p, ra, ctx->g,     \
+    ctx->stream, yw_s, ym_s, ra, ctx->g,                                       \
         (const TileDev*)ctx->tiles.p, (const TemplDev*)ctx->templ.p, (const double*)ctx->sums.p, \
-        (const double*)ctx->wl1.p, (const double*)ctx->norms.p + ctx->norms_off, ctx->kappa,                 \
+        (const double*)ctx->wl1.p, norms_s, ctx->kappa,                        \
         (const double*)ctx->xaxis.p, (const double*)ctx->yaxis.p, (const float2*)ctx->tw_x.p, \
         (float*)ctx->best_snr.p, (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p,        \
         to_maps ? (float*)ctx->map_amp.p : nullptr, to_maps ? (float*)ctx->map_snr.p : nullptr
@@ -3263,7 +3322,20 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                            (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p, (const float*)ra.s2,   \
                            (const float*)ra.a2, (const uint32_t*)ra.i2, ra.nc, nsplit - 1);            \
     }
-            if (nsplit > 1) {
+#define LAUNCH_NEAR(T)                                                         \
+    {                                                                          \
+        int rc = set_lds(ctx, k_inv_rows_fast<T, false, false, PTV, false, true>, inv_rows_fast_lds<T>()); \
+        if (rc) return rc;                                                     \
+        hipLaunchKernelGGL((k_inv_rows_fast<T, false, false, PTV, false, true>), gridr,   \
+                           dim3(inv_rows_fast_threads<T>()), inv_rows_fast_lds<T>(), FAST_ARGS); \
+    }
+            if (near) {
+                switch (fg.Tx) {
+                    case 512: LAUNCH_NEAR(512) break;
+                    case 1024: LAUNCH_NEAR(1024) break;
+                    default: LAUNCH_NEAR(2048) break;
+                }
+            } else if (nsplit > 1) {
                 if (fg.Tx == 512) LAUNCH_SPLIT(512) else LAUNCH_SPLIT(1024)
             } else if (fast) {
                 switch (fg.Tx) {
@@ -3280,9 +3352,11 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
 #undef LAUNCH_FAST
 #undef LAUNCH_FAST2
 #undef LAUNCH_SPLIT
+#undef LAUNCH_NEAR
 #undef ROW_ARGS
 #undef FAST_ARGS
             sc_prof_end(ctx);
+            }                                    // (row-pass slices)
         }
         return SC_OK;
     };

@@ -66,6 +66,9 @@ struct WindowSlot {
 
 // templates per inverse launch (sc_match batches an orientation run in chunks)
 #define SC_MAX_GROUP 64
+// templates one batched launch SEQUENCE can carry (forward passes and column pass of nb orientations x n
+// templates each); the row pass folds them in launches of at most SC_MAX_GROUP, orientation slice after slice
+#define SC_MAX_BATCH 256
 #define SC_MAX_ORIENT 64         // orientations (curvature planes) one launch sequence can carry
 
 struct sc_ctx {
@@ -117,6 +120,9 @@ struct sc_ctx {
     bool async_in_flight = false;        // an sc_match_async has not been followed by sc_sync yet
     int last_batch = 0;
     float kappa = 4.f;         // float32 resolution floor of the FFT path, in units of eps (sc_set_option "kappa")
+    float near_w = 0.f;        // sc_set_option "near_window": the FFT row pass flags near-ties (sc_get_near_ties)
+    DevBuf near;               // one byte per core cell
+    int batch_templ = 0;       // sc_set_option "batch_templ": templates one batched launch sequence may carry (0: SC_MAX_BATCH)
     int split_i1 = 1;          // sc_set_option "split_i1": under-filled column passes deal their transforms out along grid.z
     long long split_fill = 0;  // sc_set_option "split_fill": waves a dealt-out row pass may come to (0: 4096)
     int variant = 0;           // sc_set_option "variant": alternative kernel paths kept for cross-checks

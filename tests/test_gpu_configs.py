@@ -56,6 +56,21 @@ def test_c5_grandcanyon_channel_readme_example(gpu_ctx):
     #  error on this int16 DEM is 2e-4; the real-space path is exact on it, "C5 scale ... direct" below)
     report("C5 grand canyon channel 1 x 181", chk, "auto", max_inexact=16)
     assert chk["n_bad"] == 0, chk
+    # exact=True: the cells where the FFT row pass saw a near-tie are searched again on the real-space path.  A
+    # Ricker wavelet's SNR varies slowly with the orientation: a QUARTER of this DEM's cells hold a second template
+    # within the window (68 000 flagged of 262 144) - the mode then answers with the real-space search of the whole
+    # DEM, whose own float32 resolution is what is left: 5 cells whose two best templates lie 1e-6 apart in the
+    # oracle's float64 SNRs (measured), against 10 cells up to 7e-5 apart on the FFT path
+    m = sl.Matcher(grid(z, dx, dy), ctx=gpu_ctx)
+    with pytest.warns(UserWarning, match="searching the whole DEM on the real-space path"):
+        res = m.search(sl.Channel, 10., [0.1], _plan.angle_grid(), method="fft", exact=True).result()
+    chk = fold_check(res, z, dx, dy, orc.RICKER, 10., [0.1], _plan.angle_grid(), "direct")
+    print("     exact=True:", m.exact_stats, m.method_used)
+    report("C5 grand canyon channel 1 x 181, exact=True", chk, "direct", max_inexact=8)
+    assert chk["n_bad"] == 0, chk
+    assert chk["inexact_gap"] <= 5e-6 and m.method_used == "direct" and m.exact_stats["flagged_cells"] > 0.1 * z.size
+    res2 = sl.match(grid(z, dx, dy), sl.Channel, scale=10., age=0.1, ang_min=-np.pi / 2, ang_max=np.pi / 2, exact=True)
+    assert np.array_equal(np.stack(res), res2)                   # (the public keyword reaches the same path)
 
 
 def test_c5_grandcanyon_channel_five_scales(gpu_ctx):
@@ -189,14 +204,26 @@ def test_odd_tile_count_and_odd_template_count(gpu_ctx):
         pytest.fail("no DEM size with an odd tile count found")
     sp = sl._lib.sc_plan(method=1, Ty=p.Ty, Tx=p.Tx, Vy=p.Vy, Vx=p.Vx, nty=p.nty, ntx=p.ntx,
                          circ_y=int(p.circ_y), circ_x=int(p.circ_x), Py=p.Py, Qx=p.Qx, group=len(ages))
-    m.ctx.reset_best()
-    m.ctx.match(arr, sp, sync=True)
-    m.params, m.angles, m.n_templates = np.asarray(ages), angles, len(arr)
-    res = m.result()
-    chk = fold_check(res, g._griddata, 1.0, 1.0, orc.SCARP, 30, ages, angles)
-    report("odd tile count, paired templates", chk, max_inexact=2)      # (measured: 1 of 748 000 cells)
-    assert chk["n_bad"] == 0, (p, chk)
-    assert chk["exact_frac"] >= EXACT_MIN, chk
+    for exact in (False, True):
+        # (exact: the row pass flags near-ties - option "near_window", what Matcher.search(exact=True) sets - and the
+        #  flagged cells are searched again on the real-space path; by hand here because the plan is)
+        m.ctx.reset_best()
+        m._patches = []
+        m.ctx.set_option("near_window", m.EXACT_WINDOW[WT.KIND_SCARP] if exact else 0.0)
+        m.ctx.match(arr, sp, sync=True)
+        m.ctx.set_option("near_window", 0.0)
+        m.params, m.angles, m.n_templates = np.asarray(ages), angles, len(arr)
+        m._id_par, m._id_ang = np.repeat(ages, len(angles)), np.tile(angles, len(ages))
+        if exact:
+            m._rescore_near_ties(WT.Scarp, 30, np.asarray(ages), angles, {})
+            print("     exact:", m.exact_stats)
+        res = m.result()
+        chk = fold_check(res, g._griddata, 1.0, 1.0, orc.SCARP, 30, ages, angles)
+        # (without the exact mode: 1 of 748 000 cells measured)
+        report("odd tile count, paired templates%s" % (", exact" if exact else ""), chk, max_inexact=0 if exact else 2)
+        assert chk["n_bad"] == 0, (p, chk)
+        assert chk["exact_frac"] >= EXACT_MIN, chk
+    m._id_par = None
 
 
 def test_paired_templates_agree_with_paired_tiles():
@@ -535,7 +562,9 @@ def test_round5_launch_forms_are_bit_identical():
     pass (option variant=17: the separate k_curv_alpha pass writes the plane and the row pass reads it
     back); (b) an under-filled column pass deals its transforms out along grid.z (split_i1=0: one
     workgroup per column block walks them all); (c) the dealt-out row pass allowed four waves per SIMD
-    (split_fill=2048: round 4's two).  Each is the same arithmetic on the same operands, distributed
+    (split_fill=2048: round 4's two); (d) up to 256 templates per batched launch sequence, the row pass
+    folding them in slices of whole orientations of at most 64 templates (batch_templ=64: round 4's 64 per
+    sequence; one orientation per sequence, batch=0, is test_orientation_batching_is_bit_identical's).  Each is the same arithmetic on the same operands, distributed
     differently: the record must be equal in every bit - ties included - on tiled, paired-template,
     batched and single-template searches."""
     cz = dem_fixture("dem_carrizo.npz")
@@ -551,7 +580,8 @@ def test_round5_launch_forms_are_bit_identical():
              (synthetic.synthetic_scarp(1300, seed=5), sl.Scarp, 30.0, ages12[:9], _plan.angle_grid()[::45]),   # 1024 / 2048 tiles
              (grid(flat, 1.0), sl.Scarp, 20.0, [3.0, 10.0, 30.0, 60.0, 90.0, 120.0, 200.0, 300.0], _plan.angle_grid()[::20])]   # exact ties
     forms = [("default", {}), ("variant 17", {"variant": 17}), ("split_i1 0", {"split_i1": 0}),
-             ("split_fill 2048", {"split_fill": 2048}), ("all off", {"variant": 17, "split_i1": 0, "split_fill": 2048})]
+             ("split_fill 2048", {"split_fill": 2048}), ("batch_templ 64", {"batch_templ": 64}),
+             ("all off", {"variant": 17, "split_i1": 0, "split_fill": 2048, "batch_templ": 64})]
     for (g, cls, scale, params, angles) in cases:
         ref = None
         for name, opts in forms:

@@ -1,0 +1,10 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r05e; mkdir -p $O
+python -m pytest tests/test_gpu_configs.py -m gpu -q -s -k "c5_grandcanyon_channel_readme or odd_tile or round5 or batching" > $O/gputest.txt 2>&1; echo "gpu tests rc=$?"; grep -E "exact|fold |passed|failed|Error" $O/gputest.txt | head -30
+L="--no-cpu-baseline --no-verify --no-e2e --no-other-configs"
+run() { cfg=$1; st=$2; shift 2; python bench.py --config $cfg --steps $st --warmup 3 $L "$@" 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg', '$*', d['ms_per_step'], d['config']['tiles'], d['kernels_ms_per_step'], d['gpu'].get('clock_mhz'))"; }
+{ run C1F 6; run C2 8; run C5 20; run C1 40; } | tee $O/ab.txt
+python -m pytest tests -m gpu -q > $O/gputest_all.txt 2>&1; echo "all gpu tests rc=$?"; tail -3 $O/gputest_all.txt

@@ -1,0 +1,10 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r05d; mkdir -p $O
+python -m pytest tests/test_gpu_configs.py -m gpu -x -q -s -k "round5 or batching or split_row or chunks" > $O/gputest.txt 2>&1; echo "gpu tests rc=$?"; tail -3 $O/gputest.txt
+L="--no-cpu-baseline --no-verify --no-e2e --no-other-configs"
+run() { cfg=$1; st=$2; shift 2; python bench.py --config $cfg --steps $st --warmup 3 $L "$@" 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg', '$*', d['ms_per_step'], d['config']['tiles'], d['kernels_ms_per_step'], d['gpu'].get('clock_mhz'))"; }
+{ run C1F 6; run C1F 6 --tile-penalty y512=1.3; run C1F 6 --tile-penalty y512=1.6; run C1F 6 --tile-penalty y512=2.5;
+  run C2 8; run C2 8 --opt batch_templ=64; run C5 20; run C1 40; run C1 40 --tile-penalty y1024=3; } | tee $O/ab.txt
