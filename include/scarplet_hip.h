@@ -183,7 +183,9 @@ int sc_clear_windows(sc_ctx* ctx);
  *              dealt out over up to four, the shares merged in order), 16 the real-space kernel's
  *              256 x 16 patch also where the 512 x 16 patch would be taken, 17 the orientation's
  *              curvature plane written by a pass of its own and read back by the forward row pass
- *              (default: mixed from the three stencil planes inside that pass - the same bits)
+ *              (default: mixed from the three stencil planes inside that pass - the same bits), 18 the
+ *              inverse column pass at column length 512 by the four-column kernels (default: half a wave
+ *              per column, k_inv_cols_h2 - the same bits), 19 paired orientations on k_inv_cols_h2 too
  *   "batch"    1 (default): searches whose single orientation does not fill the
  *              chip send several orientations through every launch; 0: one
  *              orientation per launch sequence.  Results are bit-identical.

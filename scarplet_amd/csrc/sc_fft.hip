@@ -1879,6 +1879,221 @@ k_inv_cols_w4(const float2* __restrict__ uc, const float2* __restrict__ uc2,
                                            rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid, tl);
 }
 
+// ---- I1 at column length 512: HALF a wave per column (round 5) --------------------------------------
+// Every DEM the reference ships (carrizo 900 x 505, grandcanyon 512 x 512, synthetic 200 x 200 ...) plans tiles of
+// column length 512, and there the column pass ran the four-column kernels: 128 threads, seven workgroup barriers
+// per transform, 1.7 - 2.7 TB/s (C1F: 19 of 43 ms; C5: a third of the search).  The wave-per-column idea needs one
+// 16-point set per lane and stage: a 512-point column has 32 sets - half a wave.  So a wave takes TWO adjacent
+// columns, lanes 0 - 31 one and lanes 32 - 63 the other, one set per lane and stage (cells fy = hl + 32 k of its
+// column, k = 0 .. 15: exactly the inputs of stage-1 set hl), and a workgroup of eight waves takes SIXTEEN columns:
+//  * no barrier inside a transform (a wave's LDS instructions execute in order; the two halves of a wave never
+//    touch each other's line), two per template and plane around the store pass, as in k_inv_cols_w8;
+//  * the store pass writes 16 columns x 2 rows = two whole 128-byte rows2 blocks per row pair, 1 KB per instruction;
+//  * 16 cells per lane: the parked spectrum is 32 registers (64 with a second orientation, XP), the coefficient
+//    prefetch 16 (32 with paired templates): two workgroups per CU, four waves per SIMD.
+// Same products, butterflies, twiddle bases and operand order as inv_cols_sym_body / fft4_lines<512>: Y is
+// bit-identical (option "variant" 18 keeps the four-column kernels at 512 for the cross-check).
+// PT: templates 2k, 2k+1 of the orientation in one transform (x (a + i a2)); XP: the job is a PAIR of orientations
+// with one template each (x a + i xb a2), see inv_cols_sym_body.
+constexpr int H2_TY = 512, H2_COLS = 16;
+__host__ __device__ constexpr size_t h2_lds() {
+    return ((size_t)H2_COLS * w8_line<H2_TY>() + 4 * (H2_TY / 16 + H2_TY / 256) + SC_MAX_GROUP) * sizeof(float2);
+}
+template <bool MIRROR, bool PT, bool XP>
+__device__ __forceinline__ void
+inv_cols_h2_body(const int B, const int jobx, const float2* __restrict__ uc, const float2* __restrict__ uc2,
+                 const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
+                 int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
+                 int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
+                 float2* __restrict__ ym, int ystride, int np, int pcj, int tstride,
+                 const TileDev* __restrict__ tiles, int py_valid, const TemplDev* __restrict__ tl) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    constexpr int TY = H2_TY, S = TY / 16, NK = 16, NC = H2_COLS;
+    constexpr int LINE = w8_line<TY>();
+    static_assert(S == 32 && !(XP && !PT), "half a wave per column; paired orientations are a paired-template mode");
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int hl = lane & 31, cw = 2 * w + (lane >> 5);          // set / cell index within the column; column of the workgroup
+    float2* line = sm + cw * LINE;
+    int i0A = 0, i0B = 0, vyA = 0, vyB = 0, pairB = 0;
+    if constexpr (XP) {
+        const int oA = 2 * jobx;                                 // the job's first orientation
+        G = min(2, tstride - oA);                                // templates of the job (1: no partner)
+        if (py_valid >= 0) {
+            const int vy = max(tiles[2 * pair].vy, tiles[2 * pair + 1].vy);
+            rp_hi = min(rp_hi, (py_valid + vy - 1) >> 1);
+        }
+        pair += oA * np;
+        pairB = pair + (G > 1 ? np : 0);
+        vfirst += oA;
+    } else {
+        const int ob = jobx / pcj, q = jobx - ob * pcj;
+        const TileDev tA_ = tiles[2 * (pair + q)], tB_ = tiles[2 * (pair + q) + 1];
+        i0A = tA_.i0; i0B = tB_.i0; vyA = tA_.vy; vyB = tB_.vy;
+        if (py_valid >= 0) {
+            const int vy = max(tA_.vy, tB_.vy);
+            rp_hi = min(rp_hi, (py_valid + vy - 1) >> 1);
+        }
+        pair += ob * np + q;
+        vfirst += ob * tstride;
+    }
+    // rows to store per transform (see inv_cols_w8_body): worked out once, parked in LDS behind the tables
+    int2* const rng = reinterpret_cast<int2*>(sm + NC * LINE + 4 * (S + S / 16));
+    const int NG = (PT && !XP) ? (G + 1) / 2 : (XP ? 1 : G);    // inverse transforms per plane
+    {
+        const int gi_ = threadIdx.x;
+        if (gi_ < NG) {
+            int lo = rp_lo, hi = rp_hi;
+            if (!XP && tl && py_valid >= 0) {
+                int klo = INT_MAX, khi = INT_MIN;
+#pragma unroll
+                for (int k = 0; k < (PT ? 2 : 1); ++k) {
+                    const int ti = vfirst + (PT ? 2 * gi_ + k : gi_);
+                    if (PT && k == 1 && 2 * gi_ + 1 >= G) break;
+                    const int ilo = tl[ti].ilo, ihi = tl[ti].ihi;
+                    if (vyA > 0) { klo = min(klo, ilo - i0A); khi = max(khi, ihi - i0A); }
+                    if (vyB > 0) { klo = min(klo, ilo - i0B); khi = max(khi, ihi - i0B); }
+                }
+                if (khi < klo) { lo = 1; hi = 0; }
+                else {
+                    lo = max(lo, (max(klo, 0) + py_valid) >> 1);
+                    hi = min(hi, (min(khi, TY) + py_valid) >> 1);
+                }
+            }
+            rng[gi_] = make_int2(lo, hi);
+        }
+    }
+    const size_t plane = (size_t)TY * Tx, hplane = half_plane(TY, Tx);
+    yw += (size_t)jobx * ystride * plane;
+    ym += (size_t)jobx * ystride * plane;
+    const int ft = NC * B + cw;                // this half-wave's column of Y
+    const int fs = MIRROR ? Tx - ft : ft;      // the coefficient column it pairs with
+    float2* t1 = sm + NC * LINE;
+    float2* t2 = t1 + 4 * S;
+    for (int i = threadIdx.x; i < 4 * S; i += 512) t1[i] = tw[(i % S) << (i / S)];
+    for (int i = threadIdx.x; i < 4 * (S / 16); i += 512) t2[i] = tw[((i % (S / 16)) << 4) << (i / (S / 16))];
+    auto tw_of = [&](const float2* t, int n, int idx, float2 (&wq)[4]) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) wq[m] = lds_cell<true>(t + m * n + idx);
+    };
+    float c[NK], c2[PT ? NK : 1];
+    for (int pl = 0; pl < 2; ++pl) {
+        const float2* xcol = (pl ? uc2 : uc) + (size_t)pair * plane + (size_t)ft * TY;
+        const float2* xcolB = (pl ? uc2 : uc) + (size_t)pairB * plane + (size_t)ft * TY;
+        const float* hsrc = (pl ? mb : wa) + (size_t)vfirst * hplane + (size_t)fs * TY;
+        const bool rot = pl == 0 && parity == 1;          // odd W: factor i (own columns) / -i (mirrors)
+        // ---- park X P {i} of the lane's cells (the arithmetic of inv_cols_sym_body, cell for cell): the phase
+        // factors first (table entries, back quickly), then the spectrum
+        float2 pvv[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int fy = hl + 32 * k;
+            if (!MIRROR) {
+                pvv[k] = phase_tab(tw + TY, phx, fy, ft);
+            } else {
+                pvv[k] = phase_tab(tw + TY, phx, (TY - fy) & (TY - 1), (Tx - ft) & (Tx - 1));
+                pvv[k].y = -pvv[k].y;
+            }
+        }
+        asm volatile("" ::: "memory");
+        float2 xp[NK], xpB[XP ? NK : 1];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) xp[k] = xcol[hl + 32 * k];
+        if constexpr (XP) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) xpB[k] = xcolB[hl + 32 * k];
+        }
+        auto park = [&](float2 x, float2 pv) {
+            float2 v = cmul(x, pv);
+            if (rot) v = MIRROR ? make_float2(v.y, -v.x) : make_float2(-v.y, v.x);
+            return v;
+        };
+#pragma unroll
+        for (int k = 0; k < NK; ++k) xp[k] = park(xp[k], pvv[k]);
+        if constexpr (XP) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) xpB[k] = park(xpB[k], pvv[k]);
+        }
+        // coefficient of cell fy: a[fs][fy], mirrors a[fs][-fy mod TY] = a[fs][TY - hl - 32 k] but for fy = 0
+        const float* cbase = hsrc + (MIRROR ? TY - hl : hl);
+        const int c0off = (MIRROR && hl == 0) ? -TY : 0;
+        auto fetch = [&](int gi_) {
+            const float* p = cbase + (size_t)((PT && !XP) ? 2 * gi_ : gi_) * hplane;
+            const bool has2 = PT && (XP ? G > 1 : 2 * gi_ + 1 < G);
+            const float* p2 = has2 ? p + hplane : p;
+            const unsigned keep2 = has2 ? ~0u : 0u;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int off = k ? (MIRROR ? -32 * k : 32 * k) : c0off;
+                c[k] = p[off];
+                if constexpr (PT) c2[k] = __uint_as_float(__float_as_uint(p2[off]) & keep2);
+            }
+        };
+        fetch(0);
+        for (int gi_ = 0; gi_ < NG; ++gi_) {
+            lds_barrier();                                   // the store pass of the previous transform is done with the lines
+            float2 wq[4];
+            int lt = hl;                                     // (LDS addresses rebuilt from the lane id in every transform)
+            asm volatile("" : "+v"(lt));
+            {
+                float2 a1[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float2 x = xp[j];
+                    if constexpr (XP) a1[j] = make_float2(x.x * c[j] - xpB[j].y * c2[j], x.y * c[j] + xpB[j].x * c2[j]);
+                    else a1[j] = PT ? make_float2(x.x * c[j] - x.y * c2[j], x.x * c2[j] + x.y * c[j])
+                                    : make_float2(c[j] * x.x, c[j] * x.y);
+                }
+                tw_of(t1, S, lt, wq);
+                set_compute_store<TY, 16, 0, true, false, true>(line, lt, a1, wq);
+            }
+            if (gi_ + 1 < NG) fetch(gi_ + 1);
+            asm volatile("" ::: "memory");
+            float2 a[16];
+            set_load<TY, true>(line, lt, a);
+            tw_of(t2, S / 16, lt >> 4, wq);
+            set_compute_store<TY, 16, 4, true, false, true>(line, lt, a, wq);
+            asm volatile("" ::: "memory");
+            set_load<TY, true>(line, lt, a);
+            set_compute_store<TY, 2, 8, true, false, true>(line, lt, a, wq);
+            lds_barrier();                                   // all sixteen lines are complete
+            // ---- store: lane (q, c) of wave w takes column c of row pair s_lo + 4 w + 32 it + q: sixteen lanes write
+            // the two 128-byte rows2 blocks of a row pair
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            float2* o = (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)B * 32 + 2 * (ln & 15);
+            const float2* lc = sm + (ln & 15) * LINE;
+            const int2 sr = rng[gi_];
+            const int s_lo = __builtin_amdgcn_readfirstlane(sr.x), s_hi = __builtin_amdgcn_readfirstlane(sr.y);
+#pragma unroll 2
+            for (int rp = s_lo + 4 * w + (ln >> 4); rp <= s_hi; rp += 32)
+                store_stream(o + (size_t)rp * (Tx >> 3) * 16, lds_cell<true>(lc + ph(2 * rp)), lds_cell<true>(lc + ph(2 * rp + 1)));
+        }
+        lds_barrier();
+    }
+}
+
+// grid.x = Tx/16 workgroups j: group j / 16, kind (j / 8) & 1, index i = 8 (j / 16) + j % 8: kind 0 is column block i
+// (columns 16 i .. 16 i + 15), kind 1 the mirror block Tx/16 - 1 - i whose coefficient columns are 16 i + 1 .. 16 i + 16 -
+// eight workgroup ids from the block that streams (all but one of) the same lines, on the same XCD.  grid.y: jobs
+// (tile pairs x batched orientations; XP: pairs of orientations); grid.z: parts of the template loop (template_share).
+template <bool PT, bool XP>
+__global__ void __launch_bounds__(512, 4)
+k_inv_cols_h2(const float2* __restrict__ uc, const float2* __restrict__ uc2,
+              const float* __restrict__ wa, const float* __restrict__ mb, int Tx,
+              int pair, int vfirst, int G, int rp_lo, int rp_hi, const float2* __restrict__ phx,
+              int parity, const float2* __restrict__ tw, float2* __restrict__ yw,
+              float2* __restrict__ ym, int ystride, int np, int pcj, int tstride,
+              const TileDev* __restrict__ tiles, int py_valid, const TemplDev* __restrict__ tl) {
+    const int j = blockIdx.x, i = ((j >> 4) << 3) | (j & 7);
+    if constexpr (!XP) TAKE_TEMPLATE_SHARE(PT, (size_t)H2_TY * Tx)
+    if ((j >> 3) & 1)
+        inv_cols_h2_body<true, PT, XP>((Tx >> 4) - 1 - i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
+                                       rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid, tl);
+    else
+        inv_cols_h2_body<false, PT, XP>(i, (int)blockIdx.y, uc, uc2, wa, mb, Tx, pair, vfirst, G, rp_lo,
+                                        rp_hi, phx, parity, tw, yw, ym, ystride, np, pcj, tstride, tiles, py_valid, tl);
+}
+
 // ---- I2: inverse row FFT -> epilogue -> fold ---------------------------------
 // grid = (valid row blocks): one workgroup per block of 4 tile rows.  The rows
 // are done as two sub-batches of 2 rows x {W plane, M plane} = 4 LDS lines, so
@@ -3170,7 +3385,28 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             hipLaunchKernelGGL((k_inv_cols<T, true>), dim3(nhi, nb * pcc), dim3(fft_threads(T)), \
                                inv_cols_lds<T>(), COL_ARGS(nlo));              \
     }
-            if (xp) {
+            // column length 512: half a wave per column (k_inv_cols_h2), where the grid pairs up per XCD - sixteen
+            // workgroup ids = eight column blocks and their mirrors: (Tx / 32) % 8 == 0; "variant" 18: the four-column kernels
+            const bool h2 = sym && symx && fg.Ty == 512 && (fg.Tx / 32) % 8 == 0 && ctx->variant != 18 && ctx->variant != 1 &&
+                            ctx->variant != 2;
+#define FN_H2(XPV, GY, YSTR, PCJ, TSTR, TLP)                                   \
+    {                                                                          \
+        int rc = set_lds(ctx, k_inv_cols_h2<PTV, XPV>, h2_lds());              \
+        if (rc) return rc;                                                     \
+        const int nz_ = XPV ? 1 : parts_for((long long)(fg.Tx / 16) * (GY), 512, NGl); \
+        hipLaunchKernelGGL((k_inv_cols_h2<PTV, XPV>), dim3(fg.Tx / 16, (GY), nz_), dim3(512), h2_lds(), ctx->stream, \
+                           (const float2*)ctx->uc.p + ctx->uc_off, (const float2*)ctx->uc2.p + ctx->uc_off, \
+                           (const float*)ctx->wh.p, (const float*)ctx->mh.p, fg.Tx, pair, g0, G, rp_lo, rp_hi, \
+                           (const float2*)ctx->tw_x.p + fg.Tx, parity, (const float2*)ctx->tw_y.p, ywp, ymp, (YSTR), \
+                           np, (PCJ), (TSTR), (const TileDev*)ctx->tiles.p, fg.circ_y ? -1 : fg.Py, (TLP)); \
+    }
+            // (paired orientations - ONE transform per plane and job, all prologue - stay on the four-column kernel: on the
+            //  sixteen-column workgroups C5's column pass took 2.07 ms against 1.62; option "variant" 19 takes them anyway)
+            if (xp && h2 && ctx->variant == 19) {
+                if constexpr (PTV) FN_H2(true, (nb + 1) / 2, 1, 1, nb, (const TemplDev*)nullptr)
+            } else if (h2 && !xp) {
+                FN_H2(false, nb * pcc, group, pcc, n, row_skip ? (const TemplDev*)ctx->templ.p + first : (const TemplDev*)nullptr)
+            } else if (xp) {
                 // paired orientations: job j = orientations 2j, 2j+1; plane j of Y; tstride carries nb
                 const size_t ldsx = inv_cols_lds<512>() + (size_t)4 * 512 * sizeof(float2);
                 int rc = set_lds(ctx, k_inv_cols_symx<512, PTV, PTV>, ldsx);
@@ -3207,6 +3443,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
 #undef FN_SYMX
 #undef FN_W8
 #undef FN_W4
+#undef FN_H2
 #undef SYM_ARGS_D
 #undef SYM_ARGS
 #undef COL_ARGS

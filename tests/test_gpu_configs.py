@@ -564,7 +564,9 @@ def test_round5_launch_forms_are_bit_identical():
     workgroup per column block walks them all); (c) the dealt-out row pass allowed four waves per SIMD
     (split_fill=2048: round 4's two); (d) up to 256 templates per batched launch sequence, the row pass
     folding them in slices of whole orientations of at most 64 templates (batch_templ=64: round 4's 64 per
-    sequence; one orientation per sequence, batch=0, is test_orientation_batching_is_bit_identical's).  Each is the same arithmetic on the same operands, distributed
+    sequence; one orientation per sequence, batch=0, is test_orientation_batching_is_bit_identical's); (e) column length
+    512 by the half-wave-per-column kernel k_inv_cols_h2 (variant=18: the four-column kernels), with one template, paired
+    templates and paired orientations.  Each is the same arithmetic on the same operands, distributed
     differently: the record must be equal in every bit - ties included - on tiled, paired-template,
     batched and single-template searches."""
     cz = dem_fixture("dem_carrizo.npz")
@@ -578,10 +580,13 @@ def test_round5_launch_forms_are_bit_identical():
              (grid(cz[0], cz[1], cz[2]), sl.Scarp, 100.0, [10.0], _plan.angle_grid(-lim, lim)),  # C1: batched orientations
              (grid(gc[0], gc[1], gc[2]), sl.Channel, 10.0, [0.1], _plan.angle_grid()[::2]),      # C5: paired orientations
              (synthetic.synthetic_scarp(1300, seed=5), sl.Scarp, 30.0, ages12[:9], _plan.angle_grid()[::45]),   # 1024 / 2048 tiles
-             (grid(flat, 1.0), sl.Scarp, 20.0, [3.0, 10.0, 30.0, 60.0, 90.0, 120.0, 200.0, 300.0], _plan.angle_grid()[::20])]   # exact ties
+             (grid(flat, 1.0), sl.Scarp, 20.0, [3.0, 10.0, 30.0, 60.0, 90.0, 120.0, 200.0, 300.0], _plan.angle_grid()[::20]),   # exact ties
+             (synthetic.synthetic_scarp(700, ny=1100, seed=9), sl.Scarp, 40.0, ages12[:7], _plan.angle_grid()[::25]),   # 512 tiles, odd count: paired templates
+             (grid(gc[0], gc[1], gc[2]), sl.Channel, 20.0, [0.05, 0.1, 0.2], _plan.angle_grid()[::9])]                  # one 512 tile, paired templates
     forms = [("default", {}), ("variant 17", {"variant": 17}), ("split_i1 0", {"split_i1": 0}),
-             ("split_fill 2048", {"split_fill": 2048}), ("batch_templ 64", {"batch_templ": 64}),
-             ("all off", {"variant": 17, "split_i1": 0, "split_fill": 2048, "batch_templ": 64})]
+             ("split_fill 2048", {"split_fill": 2048}), ("batch_templ 64", {"batch_templ": 64}), ("variant 18", {"variant": 18}),
+             ("all off", {"variant": 17, "split_i1": 0, "split_fill": 2048, "batch_templ": 64}),
+             ("variant 18, no split", {"variant": 18, "split_i1": 0})]
     for (g, cls, scale, params, angles) in cases:
         ref = None
         for name, opts in forms:
