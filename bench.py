@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_UNIT = 28.0        # bytes per px.template
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
 # profiling slot of the library -> kernel symbols as rocprofv3 lists them
-KERNEL_SYMBOLS = {"k_inv_cols": "k_inv_cols_w8<T> (paired-template chunks: k_inv_cols_symx<T,true>)", "k_inv_rows": "k_inv_rows_fast<T,false,false,false,false>"}
+KERNEL_SYMBOLS = {"k_inv_cols": "k_inv_cols_w8<T> (column length 512: k_inv_cols_h2; paired templates at 2048: k_inv_cols_w4)", "k_inv_rows": "k_inv_rows_fast<T,false,false,false,false,false>"}
 
 
 def parse():

@@ -48,8 +48,15 @@ def test_real_space_kernel_has_no_scratch():
 @pytest.mark.slow
 def test_fft_kernels_fit_their_occupancy():
     t = kernel_table("sc_fft.hip")
-    row = t["k_inv_rows_fast<2048, false, false, false, false>"]
+    row = t["k_inv_rows_fast<2048, false, false, false, false, false>"]
     assert row["scratch"] == 0 and row["vgpr"] <= 128, row             # four waves per SIMD, nothing spilled
+    # round 5: column length 512, half a wave per column: two 512-thread workgroups per CU (its scratch - the
+    # phase factors of the parking prologue - lies outside the template loop)
+    for name in ("k_inv_cols_h2<false, false>", "k_inv_cols_h2<true, false>"):
+        assert t[name]["vgpr"] + t[name]["agpr"] <= 128, (name, t[name])
+    # ... and the forward row pass that mixes the curvature itself still fits four waves per SIMD without scratch
+    mix = t["k_fwd_rows_curv<2048, true>"]
+    assert mix["scratch"] == 0 and mix["vgpr"] <= 128, mix
     col = t["k_inv_cols_w8<2048, false>"]
     assert col["vgpr"] + col["agpr"] <= 256, col                       # two waves per SIMD (its scratch lies outside the template loop)
     c1024 = t["k_inv_cols_w8<1024, false>"]

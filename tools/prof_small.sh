@@ -5,11 +5,11 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/small_$TAG
 rm -rf $OUT; mkdir -p $OUT; cd $GRAFT_REPO_ROOT
-for C in C1 C2 C5; do
-  python3 bench.py --config $C --steps 20 --warmup 3 "$@" > $OUT/bench_$C.json 2> $OUT/bench_$C.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$C -- python3 bench.py --config $C --steps 20 --warmup 3 --no-cpu-baseline --no-verify --no-e2e > $OUT/trace_$C.log 2>&1
+for C in C1 C2 C5 C1F; do
+  python3 bench.py --config $C --steps $([ $C = C1F ] && echo 6 || echo 20) --warmup 3 "$@" > $OUT/bench_$C.json 2> $OUT/bench_$C.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$C -- python3 bench.py --config $C --steps $([ $C = C1F ] && echo 6 || echo 20) --warmup 3 --no-cpu-baseline --no-verify --no-e2e > $OUT/trace_$C.log 2>&1
   cp $OUT/trace_$C/*/*kernel_stats.csv $OUT/kernel_stats_$C.csv 2>/dev/null
-  python3 - $OUT/kernel_stats_$C.csv 23 > $OUT/summary_$C.txt <<'PY'
+  python3 - $OUT/kernel_stats_$C.csv $([ $C = C1F ] && echo 9 || echo 23) > $OUT/summary_$C.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2])
