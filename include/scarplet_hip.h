@@ -185,7 +185,9 @@ int sc_clear_windows(sc_ctx* ctx);
  *              curvature plane written by a pass of its own and read back by the forward row pass
  *              (default: mixed from the three stencil planes inside that pass - the same bits), 18 the
  *              inverse column pass at column length 512 by the four-column kernels (default: half a wave
- *              per column, k_inv_cols_h2 - the same bits), 19 paired orientations on k_inv_cols_h2 too
+ *              per column, k_inv_cols_h2 - the same bits), 19 paired orientations on k_inv_cols_h2 too,
+ *              20 at most 64 templates per row-pass launch (default: the dealt-out row pass of small grids
+ *              takes up to 255 in shares of at most 64 transforms - the same bits)
  *   "batch"    1 (default): searches whose single orientation does not fill the
  *              chip send several orientations through every launch; 0: one
  *              orientation per launch sequence.  Results are bit-identical.

@@ -2362,6 +2362,13 @@ __host__ __device__ constexpr size_t inv_rows_fast_lds() {
            sizeof(unsigned long long);                  // + the mask of the transforms this row takes part in
 }
 
+// SPLITK (round 5): a launch may carry up to 255 templates, every share of it at most SC_MAX_GROUP TRANSFORMS (the
+// 64-bit mask of a workgroup's transforms is relative to its share) - with paired templates twice that many scalar sets
+template <int TX>
+__host__ __device__ constexpr size_t inv_rows_fast_lds_split() {
+    return inv_rows_fast_lds<TX>() + (size_t)SC_MAX_GROUP * EPI_FLOATS * sizeof(float);
+}
+
 // (FULL - error masks, per-cell masks of generic plugins - carries the mask test's float64 coordinates: at four
 //  waves per SIMD it spilled 76 - 92 B per lane inside the template loop; SC_I2_WAVES_FULL waves, 168 registers)
 #ifndef SC_I2_WAVES_FULL
@@ -2408,23 +2415,40 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     const int GT = ra.nb * ra.G;               // templates folded by this launch, first + 0 .. GT-1
     const TileDev tA = tiles[2 * ra.pair], tB = tiles[2 * ra.pair + 1];
     const float scale = 1.0f / ((float)ra.Ty * (float)TX);
+    const int NGO = PT ? (ra.G + 1) / 2 : ra.G;                  // transforms per orientation
+    // SPLITK: this workgroup's share [k0, k1) of the launch's transforms - at most SC_MAX_GROUP of them (the host
+    // sees to it) - and the templates [tlo, thi] they carry.  Everything per template below - the scalar table, the
+    // mask of transforms - is relative to the share, so that the LAUNCH may carry up to 255 templates (round 5)
+    int k0 = 0, k1 = ra.nb * NGO;
+    if constexpr (SPLITK) {
+        const int ng = k1;
+        k0 = (int)(((long long)ng * blockIdx.z) / ra.nsplit);
+        k1 = (int)(((long long)ng * (blockIdx.z + 1)) / ra.nsplit);
+    }
+    auto templ_of = [&](int k, int part) {                       // template of the launch in transform k (PT: part 0 / 1)
+        const int ob_ = k / NGO, ok__ = k - ob_ * NGO;
+        return ob_ * ra.G + (PT ? min(2 * ok__ + part, ra.G - 1) : ok__);
+    };
+    const int tlo = SPLITK ? (k1 > k0 ? templ_of(k0, 0) : 0) : 0;
+    const int thi = SPLITK ? (k1 > k0 ? templ_of(k1 - 1, 1) : -1) : GT - 1;
 
-    float* epi = reinterpret_cast<float*>(sm + 2 * LINE);
-    v2* tw1 = reinterpret_cast<v2*>(epi + SC_MAX_GROUP * EPI_FLOATS);
+    float* epi_ = reinterpret_cast<float*>(sm + 2 * LINE);
+    v2* tw1 = reinterpret_cast<v2*>(epi_ + (SPLITK ? 2 : 1) * SC_MAX_GROUP * EPI_FLOATS);
     v2* tw2 = tw1 + 2 * S;
+    float* const epi = epi_ - EPI_FLOATS * tlo;                  // indexed by the template of the LAUNCH, tlo .. thi
     // per-template scalars of the epilogue (float64 arithmetic on the template
     // sums) are the same for every cell: thread t prepares template t once and
     // parks the five floats in LDS.  xcorr = xr*scale_w, T3 = tr*scale
     //   =>  amp = xr*ka, T1 = xr^2*kt, floor = |xr|*kx2 + fl0
-    if (id < GT) {
-        const int it = ra.first + id;
-        const int nrm = (ra.xp ? id : id / ra.G) * ra.np + ra.pair;      // tile-pair norms of the template's orientation
+    for (int tl_ = tlo + id; tl_ <= thi; tl_ += NT) {
+        const int it = ra.first + tl_;
+        const int nrm = (ra.xp ? tl_ : tl_ / ra.G) * ra.np + ra.pair;    // tile-pair norms of the template's orientation
         EpiScal es = sc_epi_scalars(sums, it);
         sc_epi_floor(es, sums[2 * it], sums[2 * it + 1], wl1[it], norms[2 * nrm],
                      norms[2 * nrm + 1], (double)ra.Ty * TX, kappa);
         const float scale_w = scale / sc_fft_alpha(sums, it);
         const float ka = scale_w * es.inv_ts;
-        float* e = epi + EPI_FLOATS * id;
+        float* e = epi + EPI_FLOATS * tl_;
         e[0] = ka;
         e[1] = scale_w * ka;
         e[2] = scale_w * es.dx2;
@@ -2477,10 +2501,10 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     unsigned long long* const actm = reinterpret_cast<unsigned long long*>(tw2 + S);
     const bool skip_ok = !PT && !FULL && !MAPS && ra.skip && ra.nb == 1 && !ra.xp && ra.sib.slots == nullptr;
     // (a row no tile of the pair holds has returned above; with PT / FULL / MAPS the mask is all ones)
-    if (id < 64) {                                               // the first wave, whole
-        bool act = id < (PT ? ra.nb * ((ra.G + 1) / 2) : GT);
+    if (id < 64) {                                               // the first wave, whole: bit id = transform k0 + id
+        bool act = k0 + id < k1;
         if (skip_ok && act) {
-            const TemplDev* tp = templ + ra.first + id;
+            const TemplDev* tp = templ + ra.first + k0 + id;
             const int ilo = tp->ilo, ihi = tp->ihi, jlo = tp->jlo, jhi = tp->jhi;
             const bool a0 = rowA && ri >= ilo - tA.i0 && ri <= ihi - tA.i0 && min(tA.vx - 1, jhi - tA.j0) >= max(0, jlo - tA.j0);
             const bool a1 = rowB && ri >= ilo - tB.i0 && ri <= ihi - tB.i0 && min(tB.vx - 1, jhi - tB.j0) >= max(0, jlo - tB.j0);
@@ -2535,7 +2559,6 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         }
     }
 
-    const int NGO = PT ? (ra.G + 1) / 2 : ra.G;                  // transforms per orientation
     const size_t ostep = ((size_t)ra.pcj * ra.ystride - NGO) * plane * sizeof(float2);   // last plane of a job -> first of the next
     v2 a[16];
     // transforms are fetched in order: fp walks the planes of a job, then steps to the same
@@ -2556,13 +2579,6 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         ob = k / NGO; ok_ = k - ob * NGO; fk = ok_;
         fp = src1 + ((size_t)ob * ra.pcj * ra.ystride + ok_) * plane * sizeof(float2);
     };
-    // SPLITK: this workgroup's share [k0, k1) of the launch's transforms
-    int k0 = 0, k1 = ra.nb * NGO;
-    if constexpr (SPLITK) {
-        const int ng = k1;
-        k0 = (int)(((long long)ng * blockIdx.z) / ra.nsplit);
-        k1 = (int)(((long long)ng * (blockIdx.z + 1)) / ra.nsplit);
-    }
     if constexpr (!CAN_SKIP) {
         if constexpr (SPLITK) seek(k0);
         fetch();
@@ -2573,15 +2589,11 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         const uint32_t* mp = reinterpret_cast<const uint32_t*>(actm);
         am = ((unsigned long long)__builtin_amdgcn_readfirstlane(mp[1]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(mp[0]);
     }
-    if constexpr (SPLITK) {
-        const unsigned long long hi_ = k1 >= 64 ? ~0ull : ((1ull << k1) - 1), lo_ = (1ull << k0) - 1;
-        am &= hi_ & ~lo_;
-    }
     if (am == 0 && !(SPLITK && blockIdx.z > 0)) {                // every template masks this row
         if (sib_mine && id == 0) sib_publish(sib_mine, ra.sib.base + SIB_DONE);
         return;
     }
-    int cur = am ? __builtin_ctzll(am) : -1;                     // the transform in hand (the first one unless transforms are skipped)
+    int cur = am ? k0 + (int)__builtin_ctzll(am) : -1;           // the transform in hand (the first one unless transforms are skipped)
     am &= am - 1;
     if constexpr (CAN_SKIP) {
         if constexpr (SPLITK) {
@@ -2598,7 +2610,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     bool sib_on = sib_mine != nullptr;
     uint32_t sib_seen = 0;
     for (int gi_ = 0; !SPLITK || cur >= 0; ++gi_) {              // gi_: transforms done so far
-        const int nxt = am ? __builtin_ctzll(am) : -1;           // the next one this row takes part in
+        const int nxt = am ? k0 + (int)__builtin_ctzll(am) : -1; // the next one this row takes part in
         am &= am - 1;
         const bool more = nxt >= 0;
         if (skip_ok) ok_ = cur;                                  // (one orientation, one template per transform)
@@ -2835,7 +2847,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                     const uint32_t ix = (b_ix[k >> 2] >> (8 * (k & 3))) & 0xFFu;
                     const bool won = ix != 0xFFu;
                     const uint32_t o = 4u * (uint32_t)cj;
-                    const float* e = epi + EPI_FLOATS * (won ? ix : 0);
+                    const float* e = epi + EPI_FLOATS * (won ? ix : (uint32_t)tlo);
                     at_bytes(ra.s2 + pl_ + off_of(part), o) = won ? b_snr[k] : 0.f;
                     at_bytes(ra.a2 + pl_ + off_of(part), o) = won ? b_xr[k] * e[0] : 0.f;
                     at_bytes(ra.i2 + pl_ + off_of(part), o) = won ? templ[ra.first + (won ? ix : 0)].id : SC_ID_NONE;
@@ -3456,9 +3468,21 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             // between launches, so the fold is the one of a single launch (and of no batching at all).
             // (slices of equal size: 8 orientations of 10 templates go 4 + 4, not 6 + 2 - a short last launch leaves the
             //  chip part empty)
+            // Round 5, second step: where the dealt-out row pass applies (small grids: SPLITK) a launch carries up to
+            // 255 templates - the winner's byte - in shares of at most SC_MAX_GROUP transforms each; C1F's 7 batched
+            // orientations of 35 ages are then ONE row-pass launch of four shares at four waves per SIMD instead of
+            // seven launches of two
+            const bool can_split = fast && !(ctx->near_w > 0.f) && !to_maps && !full_masks && fg.Tx <= 1024 && ctx->variant != 15 &&
+                                   !(ctx->sib & 1) && ctx->variant != 20;
+            const long long row_waves = (long long)rp_n * 2 * pc * (inv_rows_fast_threads<512>() * (fg.Tx / 512) / 64);
+            const long long fill_ = ctx->split_fill > 0 ? ctx->split_fill : 4300;       // (4096 + 5 %: 1 044 rows x 4 shares)
+            int nsplit_max = 1;
+            while (can_split && nsplit_max < 4 && row_waves * nsplit_max * 2 <= fill_) nsplit_max *= 2;
+            const int tper = PTV ? 2 : 1;                      // templates per transform
             int nbs = nb;
             if (nb > 1 && !xp) {
-                const int cap = std::max(1, SC_MAX_GROUP / std::max(1, G)), nsl = (nb + cap - 1) / cap;
+                const int cap_t = nsplit_max > 1 ? std::min(255, SC_MAX_GROUP * nsplit_max * tper) : SC_MAX_GROUP;
+                const int cap = std::max(1, cap_t / std::max(1, G)), nsl = (nb + cap - 1) / cap;
                 nbs = (nb + nsl - 1) / nsl;
             }
             for (int b0 = 0; b0 < nb; b0 += nbs) {
@@ -3501,8 +3525,11 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                 // (option "split_fill": the waves the dealt-out row pass may come to - 4 096 = the four waves per SIMD its
                 //  128 registers allow; round 4 stopped at two per SIMD, 2 048, and a 900 x 505 search at 35 ages -
                 //  1 044 single-wave rows - stayed one wave per SIMD by 40 waves)
-                const long long fill = ctx->split_fill > 0 ? ctx->split_fill : 4096;
+                const long long fill = fill_;
                 while (nsplit < 4 && waves * nsplit * 2 <= fill && ngl / (nsplit * 2) >= 4) nsplit *= 2;
+                while (nsplit < 4 && (ngl + nsplit - 1) / nsplit > SC_MAX_GROUP) nsplit *= 2;      // a share's 64-bit mask
+                if ((ngl + nsplit - 1) / nsplit > SC_MAX_GROUP)
+                    return sc_fail(ctx, SC_ERR_INVALID, "row pass: %d transforms in %d shares", ngl, nsplit);
             }
             if (nsplit > 1) {
                 const size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
@@ -3550,10 +3577,10 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     { if (to_maps) LAUNCH_FAST2(T, FULLV, true) else LAUNCH_FAST2(T, FULLV, false) }
 #define LAUNCH_SPLIT(T)                                                        \
     {                                                                          \
-        int rc = set_lds(ctx, k_inv_rows_fast<T, false, false, PTV, true>, inv_rows_fast_lds<T>()); \
+        int rc = set_lds(ctx, k_inv_rows_fast<T, false, false, PTV, true>, inv_rows_fast_lds_split<T>()); \
         if (rc) return rc;                                                     \
         hipLaunchKernelGGL((k_inv_rows_fast<T, false, false, PTV, true>), gridr,   \
-                           dim3(inv_rows_fast_threads<T>()), inv_rows_fast_lds<T>(), FAST_ARGS); \
+                           dim3(inv_rows_fast_threads<T>()), inv_rows_fast_lds_split<T>(), FAST_ARGS); \
         const unsigned mb_ = (unsigned)std::min<size_t>((ra.nc + 255) / 256, 2048); \
         hipLaunchKernelGGL(k_merge_split, dim3(mb_), dim3(256), 0, ctx->stream, (float*)ctx->best_snr.p, \
                            (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p, (const float*)ra.s2,   \

@@ -566,7 +566,8 @@ def test_round5_launch_forms_are_bit_identical():
     folding them in slices of whole orientations of at most 64 templates (batch_templ=64: round 4's 64 per
     sequence; one orientation per sequence, batch=0, is test_orientation_batching_is_bit_identical's); (e) column length
     512 by the half-wave-per-column kernel k_inv_cols_h2 (variant=18: the four-column kernels), with one template, paired
-    templates and paired orientations.  Each is the same arithmetic on the same operands, distributed
+    templates and paired orientations; (f) row-pass launches of up to 255 templates in shares of at most 64 transforms
+    (variant=20: at most 64 templates per row-pass launch).  Each is the same arithmetic on the same operands, distributed
     differently: the record must be equal in every bit - ties included - on tiled, paired-template,
     batched and single-template searches."""
     cz = dem_fixture("dem_carrizo.npz")
@@ -584,7 +585,7 @@ def test_round5_launch_forms_are_bit_identical():
              (synthetic.synthetic_scarp(700, ny=1100, seed=9), sl.Scarp, 40.0, ages12[:7], _plan.angle_grid()[::25]),   # 512 tiles, odd count: paired templates
              (grid(gc[0], gc[1], gc[2]), sl.Channel, 20.0, [0.05, 0.1, 0.2], _plan.angle_grid()[::9])]                  # one 512 tile, paired templates
     forms = [("default", {}), ("variant 17", {"variant": 17}), ("split_i1 0", {"split_i1": 0}),
-             ("split_fill 2048", {"split_fill": 2048}), ("batch_templ 64", {"batch_templ": 64}), ("variant 18", {"variant": 18}),
+             ("split_fill 2048", {"split_fill": 2048}), ("batch_templ 64", {"batch_templ": 64}), ("variant 18", {"variant": 18}), ("variant 20", {"variant": 20}),
              ("all off", {"variant": 17, "split_i1": 0, "split_fill": 2048, "batch_templ": 64}),
              ("variant 18, no split", {"variant": 18, "split_i1": 0})]
     for (g, cls, scale, params, angles) in cases:
