@@ -50,3 +50,21 @@ def test_one_block_is_pinned_by_default_and_threads_never_share_one(monkeypatch)
     assert hp._blocks == []
     monkeypatch.setattr(hp, "MAX_BLOCKS", 0)                  # the opt-out: plain numpy
     assert hp.empty((4, 16, 16)).base is None
+
+
+def test_prefault_hands_the_touched_block_to_the_next_request(monkeypatch):
+    """Matcher.search faults the result block in while the device works: the block the prefault thread touched is
+    the one the next empty() of that size returns; a second prefault with that block waiting does nothing."""
+    monkeypatch.setattr(hp, "MIN_BYTES", 1024)
+    monkeypatch.setattr(hp, "_blocks", [])
+    monkeypatch.setattr(hp, "MAX_BLOCKS", 1)
+    t = hp.prefault((4, 32, 32))
+    assert t is not None
+    t.join()
+    assert len(hp._blocks) == 1 and hp._free_at(0) and not hp._blocks[0].any()
+    assert hp.prefault((4, 32, 32)) is None                  # one is waiting
+    a = hp.empty((4, 32, 32))
+    assert a.ctypes.data == hp._blocks[0].ctypes.data
+    assert hp.prefault((2, 4)) is None                       # small results: plain numpy
+    del a
+    hp.release()
