@@ -58,6 +58,9 @@ struct TileDev {
 #ifndef SC_LDS_RD1
 #define SC_LDS_RD1 1      // LDS cells read one ds_read_b64 each (0: the compiler's ds_read2_b64 pairs)
 #endif
+#ifndef SC_H2_XLANE
+#define SC_H2_XLANE 1      // k_inv_cols_h2: the last stage (radix 2) across lanes with v_permlane16_swap instead of through the LDS
+#endif
 #ifndef SC_I1_TWTAB
 #define SC_I1_TWTAB 0      // 1: the wave-per-column kernels read all fifteen twiddles of a set from LDS tables
 #endif
@@ -2051,10 +2054,33 @@ inv_cols_h2_body(const int B, const int jobx, const float2* __restrict__ uc, con
             float2 a[16];
             set_load<TY, true>(line, lt, a);
             tw_of(t2, S / 16, lt >> 4, wq);
+#if SC_H2_XLANE
+            // Stage 2 into registers; stage 3 - radix 2 at stride 256 - across lanes.  Output m of lane hl's stage-2 set
+            // is element (hl & 15) + 16 m + 256 (hl >> 4) of its column: the butterfly partner of every one of them sits
+            // in the lane 16 further on (the other 16-lane row of the half-wave), same m.  v_permlane16_swap of a value
+            // with its own copy leaves the even row's value in one register and the odd row's in the other, in both
+            // rows; the even row keeps the sum (element e), the odd row the difference (element e + 256) - where their
+            // stage-2 outputs were.  One LDS round trip (16 cells written, 16 read back per lane) less per transform;
+            // x + y and x - y as fma(+-1, y, x): the same bits.
+            {
+                float2 o2[16];
+                set_compute_regs<true>(a, wq, o2);
+                const float sgn = (lt & 16) ? -1.f : 1.f;
+                float2* const wb = line + ph((lt & 15) + ((lt >> 4) << 8));
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    float lo_x = o2[m].x, hi_x = o2[m].x, lo_y = o2[m].y, hi_y = o2[m].y;
+                    xlane_swap16(lo_x, hi_x);                // lo: the even row's value, hi: the odd row's - in both rows
+                    xlane_swap16(lo_y, hi_y);
+                    wb[17 * m] = make_float2(fmaf(sgn, hi_x, lo_x), fmaf(sgn, hi_y, lo_y));
+                }
+            }
+#else
             set_compute_store<TY, 16, 4, true, false, true>(line, lt, a, wq);
             asm volatile("" ::: "memory");
             set_load<TY, true>(line, lt, a);
             set_compute_store<TY, 2, 8, true, false, true>(line, lt, a, wq);
+#endif
             lds_barrier();                                   // all sixteen lines are complete
             // ---- store: lane (q, c) of wave w takes column c of row pair s_lo + 4 w + 32 it + q: sixteen lanes write
             // the two 128-byte rows2 blocks of a row pair
