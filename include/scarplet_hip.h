@@ -203,8 +203,8 @@ int sc_clear_windows(sc_ctx* ctx);
  *   "split_i1" 1 (default): a column pass whose workgroups do not fill the chip (a small DEM with many
  *              templates per orientation) deals its transforms out over up to eight workgroups per column
  *              block; 0: one workgroup per column block walks all of them.  Results are bit-identical.
- *   "split_fill"  waves the dealt-out row pass of small grids may come to (0: the default, 4096 = four
- *              per SIMD; round 4: 2048).  Results are bit-identical.
+ *   "split_fill"  waves the dealt-out row pass of small grids may come to (0: the default, 4300 - four
+ *              per SIMD and 5 %; round 4: 2048).  Results are bit-identical.
  *   "y_gb"     memory budget of the column -> row pass hand-off buffers in GB
  *              (0: a quarter of the free memory, at most 32)
  *   "sib"      sibling rendezvous (bit 0: row pass): the two workgroups that read the two

@@ -3500,10 +3500,13 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             // seven launches of two
             const bool can_split = fast && !(ctx->near_w > 0.f) && !to_maps && !full_masks && fg.Tx <= 1024 && ctx->variant != 15 &&
                                    !(ctx->sib & 1) && ctx->variant != 20;
-            const long long row_waves = (long long)rp_n * 2 * pc * (inv_rows_fast_threads<512>() * (fg.Tx / 512) / 64);
-            const long long fill_ = ctx->split_fill > 0 ? ctx->split_fill : 4300;       // (4096 + 5 %: 1 044 rows x 4 shares)
-            int nsplit_max = 1;
-            while (can_split && nsplit_max < 4 && row_waves * nsplit_max * 2 <= fill_) nsplit_max *= 2;
+            // How many shares: up to four (any number, not only powers of two) while the launch stays within ~4 300 waves -
+            // the four per SIMD the kernel's 128 registers allow and 5 % (measured at C1F, 1 044 single-wave rows: two
+            // shares 19.0 ms, three 13.8, four 13.5; option "split_fill" sets another bound)
+            const int wpw = inv_rows_fast_threads<512>() * (fg.Tx / 512) / 64;          // waves per row workgroup
+            const long long row_wgs = (long long)rp_n * 2 * pc;
+            const long long cap_wg = (ctx->split_fill > 0 ? ctx->split_fill : 4300) / wpw;
+            const int nsplit_max = can_split ? (int)std::max<long long>(1, std::min<long long>(4, cap_wg / std::max<long long>(1, row_wgs))) : 1;
             const int tper = PTV ? 2 : 1;                      // templates per transform
             int nbs = nb;
             if (nb > 1 && !xp) {
@@ -3546,15 +3549,12 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             }
             int nsplit = 1;
             if (fast && !near && !to_maps && !full_masks && fg.Tx <= 1024 && ctx->variant != 15 && !(ctx->sib & 1)) {
-                const long long waves = (long long)rp_n * 2 * pc * (inv_rows_fast_threads<512>() * (fg.Tx / 512) / 64);
                 const int ngl = nbc * (PTV ? (G + 1) / 2 : G);
-                // (option "split_fill": the waves the dealt-out row pass may come to - 4 096 = the four waves per SIMD its
-                //  128 registers allow; round 4 stopped at two per SIMD, 2 048, and a 900 x 505 search at 35 ages -
-                //  1 044 single-wave rows - stayed one wave per SIMD by 40 waves)
-                const long long fill = fill_;
-                while (nsplit < 4 && waves * nsplit * 2 <= fill && ngl / (nsplit * 2) >= 4) nsplit *= 2;
-                while (nsplit < 4 && (ngl + nsplit - 1) / nsplit > SC_MAX_GROUP) nsplit *= 2;      // a share's 64-bit mask
-                if ((ngl + nsplit - 1) / nsplit > SC_MAX_GROUP)
+                // (option "split_fill": the waves the dealt-out row pass may come to instead of the chip's resident
+                //  capacity for the kernel; every share at least four transforms, at most SC_MAX_GROUP - its 64-bit mask)
+                nsplit = std::max(1, std::min(nsplit_max, ngl / 4));
+                nsplit = std::max(nsplit, (ngl + SC_MAX_GROUP - 1) / SC_MAX_GROUP);
+                if (nsplit > 4 || (ngl + nsplit - 1) / nsplit > SC_MAX_GROUP)
                     return sc_fail(ctx, SC_ERR_INVALID, "row pass: %d transforms in %d shares", ngl, nsplit);
             }
             if (nsplit > 1) {
