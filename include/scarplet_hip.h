@@ -323,10 +323,19 @@ int sc_get_resolution_stats(sc_ctx* ctx, long long* wins, long long* near_floor)
  * 1 where some template scored within the relative window of option "near_window" of the cell's running best
  * (either side of it) without equalling it.  A float32 FFT convolution carries an SNR error of up to half the
  * path's tie window (scarplet_amd: oracle-measured): between two templates closer than
- * that, which one the record holds is rounding noise.  scarplet_amd.match(..., exact=True) reads the flags and
+ * that, which one the record holds is rounding noise.  The real-space path flags the same way with the option on.  scarplet_amd.match(..., exact=True) reads the flags and
  * re-scores those cells on the real-space path (exact per cell): the argmax of every cell is then the float64
  * reference's.  All zero when the option is 0 (the default: the flag costs the row pass ~10 %). */
 int sc_get_near_ties(sc_ctx* ctx, uint8_t* out);
+
+/* match_template() at single cells in FLOAT64 - core.py:297-377 as the real-space closed form, the template
+ * evaluated with the reference's float64 expressions, the curvature from the float64 elevations (dem.py:88-104) -
+ * for the m cells given (global row, column pairs) and EVERY template of the last sc_match in this context, in
+ * the order they were handed over: amp, snr = m x n doubles each, masks applied (core.py:369-375).  The last step
+ * of scarplet_amd.match(..., exact=True): the cells where two templates lie inside the float32 paths' own rounding
+ * are settled the way the reference settles them.  Built-in templates only (SC_ERR_UNSUPPORTED otherwise); the
+ * context must hold the cells' neighbourhoods (a whole DEM does). */
+int sc_score_cells_f64(sc_ctx* ctx, const int32_t* cells, int m, double* amp, double* snr);
 
 /* Per-template scalars of the last sc_match / sc_match_template call:
  * n = count(W != 0) + eps (core.py:350) and sum(W**2) (core.py:356). */

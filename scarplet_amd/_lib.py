@@ -103,6 +103,7 @@ SIGNATURES = {
     "sc_curvature": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, _fp]),
     "sc_curvature_f64": (C.c_int, [_P] + [C.c_double] * 4 + [_dp]),
     "sc_get_near_ties": (C.c_int, [_P, _bp]),
+    "sc_score_cells_f64": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, _dp, _dp]),
     "sc_get_resolution_stats": (C.c_int, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "sc_get_template_sums": (C.c_int, [_P, C.c_int, _dp, _dp]),
     "sc_profile": (C.c_int, [_P, C.c_int]),
@@ -396,6 +397,17 @@ class Context(object):
         out = np.zeros((h, w), dtype=np.uint8)
         self._check(self.lib.sc_get_near_ties(self._h, _as(out, _bp)), "sc_get_near_ties")
         return out
+
+    def score_cells_f64(self, cells, n_templates):
+        """(amp, snr) float64, each (m, n_templates): match_template() in float64 at the m global cells (rows of
+        (i, j)) for every template of the last match in this context, in hand-over order (sc_score_cells_f64)."""
+        cells = np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, 2)
+        m = len(cells)
+        amp = np.empty((m, int(n_templates)), dtype=np.float64)
+        snr = np.empty((m, int(n_templates)), dtype=np.float64)
+        self._check(self.lib.sc_score_cells_f64(self._h, cells.ctypes.data_as(C.POINTER(C.c_int32)), m,
+                                                _as(amp, _dp), _as(snr, _dp)), "sc_score_cells_f64")
+        return amp, snr
 
     def comm_destroy(self):
         """Drop this context's RCCL communicator (sc_comm_destroy); nothing to do without one."""

@@ -373,6 +373,7 @@ class Matcher(object):
     # section 6): Scarp-like 1e-4, Ricker 7e-4 (a Ricker window's support is the float64 underflow of its
     # exponential: tiles with far more energy, a larger float32 error)
     EXACT_WINDOW = {_WT.KIND_SCARP: 2e-4, _WT.KIND_RICKER: 1.4e-3}
+    EXACT_MAX_COST = 50.0                        # re-scoring is not started beyond this many times the search's own cost
     EXACT_PATCH = (8, 256)                       # rows x columns re-scored around a flagged cell: one real-space workgroup
 
     def search(self, Template, scale, params, angles, method="auto",
@@ -390,6 +391,7 @@ class Matcher(object):
         params = np.atleast_1d(np.asarray(params, dtype=float))
         angles = np.atleast_1d(np.asarray(angles, dtype=float))
         self._patches = []
+        self._cells64 = None
         if getattr(self, "nan_dem", False):
             self._nan_result = self._nan_fold(Template, scale, params, angles, **kwargs)
             self.params, self.angles = params, angles
@@ -413,7 +415,7 @@ class Matcher(object):
             pre = _hostpool.prefault((4, self.core[1] - self.core[0], self.core[3] - self.core[2]))
         flagged = False
         if exact:
-            self.exact_stats = {"flagged_cells": 0, "patches": 0, "changed_cells": 0}
+            self.exact_stats = {"flagged_cells": 0, "patches": 0, "changed_cells": 0, "float64_cells": 0}
         if exact and sp.method == _plan.METHOD_FFT:
             if not (reset and sync and self.whole):
                 raise ValueError("exact=True needs reset=True, sync=True and a whole-DEM matcher")
@@ -461,52 +463,119 @@ class Matcher(object):
         return self
 
     def _rescore_near_ties(self, Template, scale, params, angles, kwargs):
-        """exact=True, second half: the cells the FFT row pass flagged, searched again on the real-space path."""
+        """exact=True, second and third step: the cells the FFT row pass flagged are searched again on the
+        real-space path - which flags, in turn, the cells it decides inside ITS float32 rounding
+        (EXACT_WINDOW_DIRECT) - and those last cells are scored in float64 (sc_score_cells_f64: every template,
+        the reference's own arithmetic) and take the float64 argmax."""
         from scarplet_amd import dist as _dist
         flags = self.ctx.near_ties()
         cells = np.argwhere(flags)
-        self.exact_stats = {"flagged_cells": int(len(cells)), "patches": 0, "changed_cells": 0}
+        self.exact_stats = {"flagged_cells": int(len(cells)), "patches": 0, "changed_cells": 0, "float64_cells": 0}
+        self._cells64 = None
         if not len(cells):
             return
         ph, pw = self.EXACT_PATCH
         todo = sorted({(int(i) // ph, int(j) // pw) for i, j in cells})
+        # what the second pass would cost against the search it follows (the planner's per-cell figures): a large DEM
+        # with thousands of flagged cells and templates of tens of thousands of taps is hours of real-space work -
+        # said, not started
+        n_t = len(params) * len(angles)
+        _, bbox0, area0 = self.describe(Template, scale, params[:1], angles[:1], **kwargs)
+        area = max(area0, int((2 * float(np.max(np.abs(self.plan.bbox))) + 1) ** 2 * 0.15))
+        n_cells = self.ny * self.nx
+        cost_fft = _plan.fft_cost(self.plan, n_cells, len(params)) * n_cells * n_t
+        cost_patches = _plan.direct_cost(area) * min(len(todo) * ph * pw, n_cells) * n_t
+        if cost_patches > self.EXACT_MAX_COST * cost_fft:
+            import warnings
+            warnings.warn("exact=True: %d cells flagged in %d patches; searching them again on the real-space path would "
+                          "take about %.0f times the search itself - not done, the FFT result stands (Matcher.ctx.near_ties() "
+                          "has the flags)" % (len(cells), len(todo), cost_patches / cost_fft))
+            self.exact_stats["skipped"] = True
+            return
+        arr_main, bbox, max_area = self.describe(Template, scale, params, angles, **kwargs)
+        last = []                                        # global (i, j) of the cells the real-space path leaves undecided
         if len(todo) * ph * pw > 0.5 * self.ny * self.nx:
-            # the flags cover half the DEM: a surface the FFT path does not resolve - what method="auto" answers
-            # with a whole real-space search; per-patch searches would cost more than that
+            # the flags cover half the DEM: a surface the FFT path does not resolve (or a template family whose SNR
+            # varies slowly with the orientation: a Ricker) - what method="auto" answers with a whole real-space
+            # search; per-patch searches would cost more than that
             import warnings
             warnings.warn("exact=True: %d cells flagged (%d patches): searching the whole DEM on the real-space "
                           "path instead" % (len(cells), len(todo)))
-            arr, bbox, max_area = self.describe(Template, scale, params, angles, **kwargs)
             self.plan, sp = self.plan_for(bbox, max_area, "direct", None, n_params=len(params))
-            self.ctx.reset_best()
-            self.ctx.match(arr, sp, sync=True)
+            self.ctx.set_option("near_window", self.EXACT_WINDOW_DIRECT)
+            try:
+                self.ctx.reset_best()
+                self.ctx.match(arr_main, sp, sync=True)
+                last = [tuple(c) for c in np.argwhere(self.ctx.near_ties())]
+            finally:
+                self.ctx.set_option("near_window", 0.0)
             self.method_used = "direct"
+        else:
+            aux = getattr(self, "_aux", None)
+            if aux is None:
+                aux = self._aux = Matcher(ctx=_lib.Context(self.ctx.device))
+            z = np.asarray(self._z)
+            ny, nx = self.ny, self.nx
+            aux.ny, aux.nx, aux.de = ny, nx, self.de
+            arr, _, _ = aux.describe(Template, scale, params, angles, **kwargs)
+            halo = _dist.halo_for_search(bbox, ny, nx)
+            aux.ctx.set_option("near_window", self.EXACT_WINDOW_DIRECT)
+            try:
+                for (bi, bj) in todo:
+                    i0, j0 = bi * ph, bj * pw
+                    i1, j1 = min(i0 + ph, ny), min(j0 + pw, nx)
+                    gi = np.arange(i0 - halo[0], i1 + halo[1]) % ny      # the DEM is a torus (the reference's circular convolution)
+                    gj = np.arange(j0 - halo[2], j1 + halo[3]) % nx
+                    blk = np.ascontiguousarray(z[np.ix_(gi, gj)], dtype=np.float64)
+                    aux.set_block(blk, (i0 - halo[0], j0 - halo[2]), (ny, nx), (i0, i1, j0, j1), self.dx, self.dy)
+                    _, sp = aux.plan_for(bbox, max_area, "direct", None, n_params=len(params))
+                    aux.ctx.reset_best()
+                    aux.ctx.match(arr, sp, sync=True)
+                    amp, snr, idx = aux.ctx.get_best()
+                    sel = flags[i0:i1, j0:j1] != 0
+                    self._patches.append((i0, j0, sel, amp, snr, idx))
+                    self.exact_stats["patches"] += 1
+                    last += [(i0 + int(a), j0 + int(b)) for a, b in np.argwhere(sel & (aux.ctx.near_ties() != 0))]
+            finally:
+                aux.ctx.set_option("near_window", 0.0)
+                aux.ctx.clear_windows()
+        self._score_float64(last, arr_main, bbox)
+
+    # exact=True, third step: window of the real-space path's near-tie flags (twice its tie window's half, i.e. the
+    # window itself: 1e-4 - its largest measured SNR error is 4e-5), and how much float64 work is started at most
+    EXACT_WINDOW_DIRECT = 1e-4
+    EXACT_MAX_F64 = 4e11                         # cells x templates x support-box cells
+
+    def _score_float64(self, last, arr_main, bbox):
+        """The cells the real-space path decided inside its own rounding: match_template() in float64 for every
+        template (the MAIN context holds the whole DEM and the search's descriptors and sums), the argmax in fold
+        order - ties to the earlier template, as the device folds."""
+        if not last:
             return
-        aux = getattr(self, "_aux", None)
-        if aux is None:
-            aux = self._aux = Matcher(ctx=_lib.Context(self.ctx.device))
-        z = np.asarray(self._z)
-        ny, nx = self.ny, self.nx
-        arr = None
-        for (bi, bj) in todo:
-            i0, j0 = bi * ph, bj * pw
-            i1, j1 = min(i0 + ph, ny), min(j0 + pw, nx)
-            if arr is None:
-                aux.ny, aux.nx, aux.de = ny, nx, self.de
-                arr, bbox, max_area = aux.describe(Template, scale, params, angles, **kwargs)
-                halo = _dist.halo_for_search(bbox, ny, nx)
-            gi = np.arange(i0 - halo[0], i1 + halo[1]) % ny          # the DEM is a torus (the reference's circular convolution)
-            gj = np.arange(j0 - halo[2], j1 + halo[3]) % nx
-            blk = np.ascontiguousarray(z[np.ix_(gi, gj)], dtype=np.float64)
-            aux.set_block(blk, (i0 - halo[0], j0 - halo[2]), (ny, nx), (i0, i1, j0, j1), self.dx, self.dy)
-            _, sp = aux.plan_for(bbox, max_area, "direct", None, n_params=len(params))
-            aux.ctx.reset_best()
-            aux.ctx.match(arr, sp, sync=True)
-            amp, snr, idx = aux.ctx.get_best()
-            sel = flags[i0:i1, j0:j1] != 0
-            self._patches.append((i0, j0, sel, amp, snr, idx))
-            self.exact_stats["patches"] += 1
-        aux.ctx.clear_windows()
+        n_t = len(arr_main)
+        box = (bbox[1] - bbox[0] + 1) * (bbox[3] - bbox[2] + 1)
+        if float(len(last)) * n_t * box > self.EXACT_MAX_F64:
+            import warnings
+            warnings.warn("exact=True: %d cells are left to float64 by the real-space path; scoring them for %d templates is "
+                          "not started (%.1e support cells) - they keep the real-space answer" % (len(last), n_t, float(len(last)) * n_t * box))
+            return
+        if self.method_used != "direct":
+            # the main context's last search must be THIS search (descriptors, template sums): it is - the patches ran
+            # in the auxiliary context
+            pass
+        cells = np.asarray(sorted(set(last)), dtype=np.int32).reshape(-1, 2)
+        try:
+            amp, snr = self.ctx.score_cells_f64(cells, n_t)
+        except _lib.ScarpletHipError as e:
+            if "built-in templates only" in str(e):
+                return
+            raise
+        k = np.argmax(snr, axis=1)                       # (first maximum: the fold order is the order of arr_main)
+        rows = np.arange(len(cells))
+        ids = np.array([arr_main[int(v)].id for v in k], dtype=np.int64)
+        best_snr, best_amp = snr[rows, k], amp[rows, k]
+        self._cells64 = (cells[:, 0].astype(np.int64), cells[:, 1].astype(np.int64), best_amp, best_snr, ids)
+        self.exact_stats["float64_cells"] = int(len(cells))
 
     def _apply_patches(self, out):
         """The re-scored cells of exact=True into a (4, h, w) result."""
@@ -522,6 +591,16 @@ class Matcher(object):
             view[1][won] = par[safe][won]
             view[2][won] = ang[safe][won]
             view[3][won] = snr[won]
+        c64 = getattr(self, "_cells64", None)
+        if c64 is not None:
+            ii, jj, amp, snr, ids = c64
+            won = snr > 0
+            changed = won & ((out[1][ii, jj] != par[ids]) | (out[2][ii, jj] != ang[ids]))
+            self.exact_stats["changed_cells"] += int(changed.sum())
+            out[0][ii[won], jj[won]] = amp[won]
+            out[1][ii[won], jj[won]] = par[ids[won]]
+            out[2][ii[won], jj[won]] = ang[ids[won]]
+            out[3][ii[won], jj[won]] = snr[won]
         return out
 
     # share of the cells an FFT search won whose residual lies near the transforms' float32
@@ -573,7 +652,7 @@ class Matcher(object):
             return self.ctx.get_result(np.repeat(self.params, len(self.angles)),
                                        np.tile(self.angles, len(self.params)))
         out = self.ctx.get_result(self._id_par, self._id_ang)
-        if getattr(self, "_patches", None):
+        if getattr(self, "_patches", None) or getattr(self, "_cells64", None) is not None:
             if hasattr(self, "exact_stats"):
                 self.exact_stats["changed_cells"] = 0
             out = self._apply_patches(out)

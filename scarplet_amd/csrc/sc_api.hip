@@ -484,6 +484,32 @@ extern "C" int sc_get_near_ties(sc_ctx* ctx, uint8_t* out) {
     return sc_sync(ctx);
 }
 
+extern "C" int sc_score_cells_f64(sc_ctx* ctx, const int32_t* cells, int m, double* amp, double* snr) {
+    if (!ctx || !cells || m <= 0 || !amp || !snr) return SC_ERR_INVALID;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    const int n = ctx->last_batch;
+    if (n <= 0) return sc_fail(ctx, SC_ERR_INVALID, "sc_score_cells_f64: no search has run in this context");
+    if (ctx->templ_windows)
+        return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_score_cells_f64: built-in templates only (a plugin's window is float32 on the device)");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    for (int k = 0; k < m; ++k)
+        if (cells[2 * k] < 0 || cells[2 * k] >= ctx->g.ny || cells[2 * k + 1] < 0 || cells[2 * k + 1] >= ctx->g.nx)
+            return sc_fail(ctx, SC_ERR_INVALID, "sc_score_cells_f64: cell %d outside the DEM", k);
+    const size_t nout = (size_t)m * n;
+    int rc = sc_ensure(ctx, ctx->score, sizeof(int32_t) * 2 * (size_t)m + 16 + sizeof(double) * 2 * nout);
+    if (rc) return rc;
+    double* d_amp = (double*)ctx->score.p;
+    double* d_snr = d_amp + nout;
+    int* d_cells = (int*)(d_snr + nout);
+    SC_HIP(ctx, hipMemcpyAsync(d_cells, cells, sizeof(int32_t) * 2 * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
+    // (grid.y is limited to 65535: the templates of a search are at most a few thousand)
+    if (n > 65535) return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_score_cells_f64: %d templates", n);
+    if ((rc = launch_score_f64(ctx, d_cells, m, n, d_amp, d_snr))) return rc;
+    SC_HIP(ctx, hipMemcpyAsync(amp, d_amp, sizeof(double) * nout, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(snr, d_snr, sizeof(double) * nout, hipMemcpyDeviceToHost, ctx->stream));
+    return sc_sync(ctx);
+}
+
 extern "C" int sc_get_resolution_stats(sc_ctx* ctx, long long* wins, long long* near_floor) {
     if (!ctx || !wins || !near_floor) return SC_ERR_INVALID;
     *wins = *near_floor = 0;
@@ -728,6 +754,8 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
     SC_HIP(ctx, hipMemcpyAsync(ctx->wl1.p, wl1.data(), sizeof(double) * n,
                                hipMemcpyHostToDevice, ctx->stream));
     ctx->last_batch = n;
+    ctx->templ_windows = false;
+    for (int k = 0; k < n; ++k) ctx->templ_windows = ctx->templ_windows || t[k].kind == SC_KIND_WINDOW;
 
     double cur[3] = {0, 0, 0};
     bool have_curv = false;

@@ -3337,8 +3337,18 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             auto parts_for = [&](long long workgroups, long long capacity, int transforms) {
                 if (!ctx->split_i1 || workgroups <= 0) return 1;
                 if (ctx->split_i1 > 1) return std::max(1, std::min(ctx->split_i1, transforms));   // (lab: a given number of parts)
-                const long long by_fill = capacity / workgroups, by_len = transforms / 4;
-                return (int)std::max<long long>(1, std::min<long long>(std::min(by_fill, by_len), 8));
+                // the number of parts (1 .. 8, every part at least four transforms) that fills the launch's rounds of
+                // resident workgroups best: 672 workgroups on 512 slots are 1.31 rounds - a third of the chip idles through
+                // the second -, in three parts 2 016 workgroups are 3.94 rounds of a third the length (C1F: seven batched
+                // orientations x three tile pairs x 32 column blocks).  Fewer parts win ties: every part parks the spectrum.
+                int best = 1;
+                double best_u = 0.0;
+                for (int nz = 1; nz <= 8 && transforms / nz >= 4; ++nz) {
+                    const long long w = workgroups * nz, rounds = (w + capacity - 1) / capacity;
+                    const double u = (double)w / (double)(rounds * capacity);
+                    if (u > best_u + 0.03) { best_u = u; best = nz; }
+                }
+                return best;
             };
             const int NGl = PTV ? (G + 1) / 2 : G;
             sc_prof_begin(ctx, SC_K_INV_COLS);

@@ -122,6 +122,8 @@ struct sc_ctx {
     float kappa = 4.f;         // float32 resolution floor of the FFT path, in units of eps (sc_set_option "kappa")
     float near_w = 0.f;        // sc_set_option "near_window": the FFT row pass flags near-ties (sc_get_near_ties)
     DevBuf near;               // one byte per core cell
+    DevBuf score;              // sc_score_cells_f64: the cell list and the two float64 outputs
+    bool templ_windows = false;   // the last sc_match carried host-uploaded windows (no float64 form on the device)
     int batch_templ = 0;       // sc_set_option "batch_templ": templates one batched launch sequence may carry (0: SC_MAX_BATCH)
     int split_i1 = 1;          // sc_set_option "split_i1": under-filled column passes deal their transforms out along grid.z
     long long split_fill = 0;  // sc_set_option "split_fill": waves a dealt-out row pass may come to (0: 4096)
@@ -187,6 +189,7 @@ int launch_dem_digest(sc_ctx* ctx, unsigned long long* out_dev);
 int launch_curv_alpha(sc_ctx* ctx, float cc, float sc2, float ss, int plane = 0);
 int launch_curv_f64(sc_ctx* ctx, double c2, double sn, double cs, double s2, double* out_dev);
 int launch_curv_alpha_batch(sc_ctx* ctx, const float (*coef)[3], int nb);
+int launch_score_f64(sc_ctx* ctx, const int* cells_dev, int m, int n_templ, double* amp_dev, double* snr_dev);
 int launch_windows(sc_ctx* ctx, int first, int n, int wh_max, int ww_max);
 int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_max, int ww_max, bool long_runs);
 bool direct_window_fits(int ww);

@@ -82,6 +82,114 @@ k_curv_f64(const double* __restrict__ z, Geom g, double dx, double dy, double c2
     out[(size_t)i * g.lx + j] = __dadd_rn(__dsub_rn(t1, t2), t3);
 }
 
+// ---------------------------------------------------------------------------
+// match_template() at single cells in FLOAT64 (core.py:297-377 as the real-space closed form): the last step of
+// the host layer's exact mode.  The float32 paths decide a cell's argmax to within their own rounding - 2e-4
+// (FFT tiles), 1e-5 (real space) of the SNR; where two templates lie closer than that the answer is settled here
+// the way the reference settles it, in float64: for every (cell, template) of the list
+//   xcorr = sum W[p, q] curv[(i - p + oy) % ny, (j - q + ox) % nx],  T3 likewise with (W != 0), curv**2
+// over the template's support box, W evaluated with k_windows' float64 expressions, the curvature with
+// k_curv_f64's (stencils of dem.py:88-101 on the float64 elevations, global borders zero), then core.py:360-375.
+// grid = (cells, templates), one workgroup each; the support box is dealt out over the threads.
+// Built-in templates only (a generic plugin's window exists in float32 on the device).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_score_f64(const double* __restrict__ z, Geom g, double dx, double dy,
+            const TemplDev* __restrict__ templ, int n_templ, const double* __restrict__ sums,
+            const double* __restrict__ xaxis, const double* __restrict__ yaxis,
+            const int* __restrict__ cells, double* __restrict__ amp_out, double* __restrict__ snr_out) {
+    const int ci = blockIdx.x, it = blockIdx.y;
+    const int i = cells[2 * ci], j = cells[2 * ci + 1];                  // global cell
+    const TemplDev t = templ[it];
+    // curvature mix of this template's orientation: cc, sc2, ss are not in TemplDev - the same expression as the
+    // reference's from its alpha = -orientation: cos(a)^2, 2 sin(a) cos(a), sin(a)^2 with a = -alpha, i.e. the
+    // orientation; cos_a / sin_a of the descriptor are those of alpha
+    const double ca = t.cos_a, sa = -t.sin_a;                             // cos / sin of the ORIENTATION
+    const double k_cc = __dmul_rn(ca, ca), k_ss = __dmul_rn(sa, sa);
+    double xc = 0.0, t3 = 0.0;
+    const int box = t.wh * t.ww;
+    for (int e = threadIdx.x; e < box; e += 256) {
+        const int a = e / t.ww, b = e - a * t.ww;
+        const int p = t.pmin + a, q = t.qmin + b;
+        const int k = g.ny / 2 + p, l = g.nx / 2 + q;
+        if (k < 0 || k >= g.ny || l < 0 || l >= g.nx) continue;
+        const double x = xaxis[l], y = yaxis[k];
+        const double xr = __dadd_rn(__dmul_rn(x, t.cos_a), __dmul_rn(y, t.sin_a));
+        const double yr = __dadd_rn(__dmul_rn(-x, t.sin_a), __dmul_rn(y, t.cos_a));
+        if (!((fabs(xr) < t.c) && (fabs(yr) < t.d))) continue;
+        double w;
+        bool m;
+        if (t.kind == SC_KIND_SCARP) {
+            w = __dmul_rn(__ddiv_rn(-xr, t.p0), exp(__ddiv_rn(-__dmul_rn(xr, xr), t.p1)));
+            m = (xr != 0.0);
+        } else {
+            const double u = __dmul_rn(t.p0, xr), u2 = __dmul_rn(u, u);
+            const double poly = __dsub_rn(1.0, __dmul_rn(2.0, u2));
+            m = (u2 < SC_EXP_UNDERFLOW) && (poly != 0.0);
+            w = m ? __dmul_rn(poly, exp(-u2)) : 0.0;
+        }
+        if (!m) continue;
+        if (t.flags & SC_FLAG_NEGATE) w = -w;
+        // curvature at global ((i - p + oy) mod ny, (j - q + ox) mod nx): its local position in the block
+        int gi = i - p + g.oy, gj = j - q + g.ox;
+        int li, lj;
+        if (g.wrap) { gi = wrap_index(gi, g.ny); gj = wrap_index(gj, g.nx); li = gi; lj = gj; }
+        else { li = gi - g.gy0; lj = gj - g.gx0; gi = wrap_index(gi, g.ny); gj = wrap_index(gj, g.nx); }
+        if (li < 0 || li >= g.ly || lj < 0 || lj >= g.lx) continue;       // (outside the block: the host sized the halo)
+        const int im = max(li - 1, 0), ip = min(li + 1, g.ly - 1), jm = max(lj - 1, 0), jp = min(lj + 1, g.lx - 1);
+        const double* r0 = z + (size_t)im * g.lx;
+        const double* r1 = z + (size_t)li * g.lx;
+        const double* r2 = z + (size_t)ip * g.lx;
+        const double z11 = r1[lj];
+        double A = 0.0, Bc = 0.0, C = 0.0;
+        if (gj >= 1 && gj <= g.nx - 2)
+            A = __ddiv_rn(__dsub_rn(__dsub_rn(r1[jp], z11), __dsub_rn(z11, r1[jm])), __dmul_rn(dx, dx));
+        if (gi >= 1 && gj >= 1) {
+            const double d1 = __ddiv_rn(__dsub_rn(z11, r1[jm]), dx);
+            const double d0 = __ddiv_rn(__dsub_rn(r0[lj], r0[jm]), dx);
+            Bc = __ddiv_rn(__dsub_rn(d1, d0), dx);
+        }
+        if (gi >= 1 && gi <= g.ny - 2)
+            C = __ddiv_rn(__dsub_rn(__dsub_rn(r2[lj], z11), __dsub_rn(z11, r0[lj])), __dmul_rn(dy, dy));
+        // dem.py:103-104: d2z_dx2 cos^2 - 2 d2z_dxdy sin cos + d2z_dy2 sin^2 (numpy's order)
+        const double cv = __dadd_rn(__dsub_rn(__dmul_rn(A, k_cc), __dmul_rn(__dmul_rn(__dmul_rn(2.0, Bc), sa), ca)),
+                                    __dmul_rn(C, k_ss));
+        xc = fma(w, cv, xc);
+        t3 = fma(cv, cv, t3);
+    }
+    __shared__ double red[2][4];
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        xc += __shfl_down(xc, sft, 64);
+        t3 += __shfl_down(t3, sft, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = xc; red[1][threadIdx.x >> 6] = t3; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        xc = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        t3 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const double n = sums[2 * it] + SC_EPS, ts = sums[2 * it + 1];
+        double amp = xc / ts;
+        const double T1 = ts * (amp * amp);
+        const double err = (1.0 / n) * (T1 - 2.0 * amp * xc + t3) + SC_EPS;
+        double snr = fabs(T1 / err);
+        if (t.flags & (SC_FLAG_ERR_XR_LE0 | SC_FLAG_ERR_XR_GE0)) {
+            const double xr = __dadd_rn(__dmul_rn(xaxis[j], t.cos_a), __dmul_rn(yaxis[i], t.sin_a));
+            if ((t.flags & SC_FLAG_ERR_XR_LE0) ? (xr <= 0.0) : (xr >= 0.0)) snr = 0.0;
+        }
+        if (!(i >= t.ilo && i <= t.ihi && j >= t.jlo && j <= t.jhi)) { amp = 0.0; snr = 0.0; }
+        amp_out[(size_t)ci * n_templ + it] = amp;
+        snr_out[(size_t)ci * n_templ + it] = snr;
+    }
+}
+
+int launch_score_f64(sc_ctx* ctx, const int* cells_dev, int m, int n_templ, double* amp_dev, double* snr_dev) {
+    hipLaunchKernelGGL(k_score_f64, dim3(m, n_templ), dim3(256), 0, ctx->stream, ctx->z_dev, ctx->g, ctx->dx, ctx->dy,
+                       (const TemplDev*)ctx->templ.p, n_templ, (const double*)ctx->sums.p, (const double*)ctx->xaxis.p,
+                       (const double*)ctx->yaxis.p, cells_dev, amp_dev, snr_dev);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
 // Digest of the elevation block as it sits in HBM: the number of NaN cells (one NaN turns every reference
 // output NaN, core.py:349-363 - the host answers such a DEM without a search) and a 128-bit fingerprint of
 // the float64 bit patterns, position-dependent and summed (order-free, so plain atomics do).  The host used
@@ -449,7 +557,11 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
           const double* __restrict__ sums, const double* __restrict__ xaxis,
           const double* __restrict__ yaxis, float* __restrict__ best_snr,
           float* __restrict__ best_amp, uint32_t* __restrict__ best_id,
-          float* __restrict__ map_amp, float* __restrict__ map_snr) {
+          float* __restrict__ map_amp, float* __restrict__ map_snr,
+          float near_w, uint8_t* __restrict__ near) {
+    // near_w > 0 (the host layer's exact mode): a byte per core cell, set where a template scored within near_w
+    // (relative) of the cell's running best without equalling it - the cells whose argmax is decided inside THIS path's
+    // own float32 error and that sc_score_cells_f64 settles (see k_inv_rows_fast, NEAR)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TXW = 256 * NB, TY = DR2_WAVES * RW;
     const int lane = threadIdx.x & 63;
@@ -845,6 +957,11 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                     } else {
                         float w_amp = 0.f;
                         uint32_t w_id = SC_ID_NONE;
+                        if (near_w > 0.f) {                  // (wave-uniform)
+                            const float bs = b_snr[rr][n][u];
+                            if (snr > 0.f && snr != bs && fabsf(snr - bs) <= near_w * fmaxf(snr, bs))
+                                near[(size_t)(gi - g.cy0 + zt) * cw + (gj - g.cx0)] = (uint8_t)1;
+                        }
                         if (sc_fold(b_snr[rr][n][u], w_amp, w_id, snr, amp, t.id)) {
                             // (zt: the cells' offsets are worked out here, at a win - hoisted out of the template loop
                             //  they are 32 registers that live through every row of every template)
@@ -1189,6 +1306,15 @@ int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_ma
                        (const uint8_t*)ctx->win_m.p, (float2*)ctx->dwin.p, (int4*)ctx->spans.p);
     sc_prof_end(ctx);
     SC_HIP(ctx, hipGetLastError());
+    // near-tie flags of the exact mode (option "near_window"): the byte plane of sc_get_near_ties
+    const bool near_on = ctx->near_w > 0.f && !to_maps;
+    if (near_on) {
+        const size_t nc_ = (size_t)ch * cw;
+        const bool fresh = ctx->near.cap < nc_;
+        int rc = sc_ensure(ctx, ctx->near, nc_);
+        if (rc) return rc;
+        if (fresh) SC_HIP(ctx, hipMemsetAsync(ctx->near.p, 0, nc_, ctx->stream));
+    }
     // patch: 512 x 16 cells where that still gives every CU a workgroup, else 256 x 16, else 256 x 8
     const size_t lds = (size_t)DR2_LDS_FLOATS * sizeof(float);
     const size_t plane = (size_t)g.ly * g.lx;
@@ -1206,7 +1332,8 @@ int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_ma
                            (const double*)ctx->yaxis.p, (float*)ctx->best_snr.p,                   \
                            (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p,                     \
                            to_maps ? (float*)ctx->map_amp.p : nullptr,                             \
-                           to_maps ? (float*)ctx->map_snr.p : nullptr);                            \
+                           to_maps ? (float*)ctx->map_snr.p : nullptr,                             \
+                           near_on ? ctx->near_w : 0.f, near_on ? (uint8_t*)ctx->near.p : nullptr); \
         sc_prof_end(ctx);                                                                          \
     }
     // (variant 11: T3 in the weighted form on every row; long_runs: some template of the launch has

@@ -730,3 +730,30 @@ def test_async_searches_back_to_back_equal_the_synchronous_ones(gpu_ctx):
     for a, b, name in zip(out[0], out[1], ("amp", "snr", "id")):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
     assert (out[0][1] > 0).any()
+
+
+def test_float64_scoring_of_single_cells(gpu_ctx):
+    """sc_score_cells_f64 - match_template() at single cells in float64 on the device, the last step of exact=True -
+    against the oracle's float64 maps: Scarp (odd and even grid sizes, dy < 0, an UpperBreak's error mask, cells at the
+    window-limit border and on the DEM's edge) and Ricker, to 1e-9 of the map's largest value."""
+    rng = np.random.default_rng(33)
+    for (kind, cls, ny, nx, de, dy, scale, params, angles) in [
+            (orc.SCARP, WT.Scarp, 90, 101, 1.0, 1.0, 8, [1.0, 6.0, 40.0], [-1.3, -0.2, 0.0, 0.9, np.pi / 2]),
+            (orc.SCARP, WT.Scarp, 80, 64, 2.0, -2.0, 14, [3.0, 25.0], [-np.pi / 2, 0.4]),
+            ("left_upper_break", WT.LeftFacingUpperBreakScarp, 72, 76, 1.0, 1.0, 9, [5.0], [-0.6, 0.7]),
+            (orc.RICKER, WT.Ricker, 64, 72, 1.0, -1.0, 6, [0.1, 0.25], [-0.8, 0.0, 1.1])]:
+        z = (np.cumsum(np.cumsum(rng.standard_normal((ny, nx)), 0), 1) * 0.01 + rng.standard_normal((ny, nx)) * 0.05).astype(np.float32)
+        m = sl.Matcher(grid(z, de, dy), ctx=gpu_ctx)
+        m.search(cls, scale, params, angles, method="direct")
+        cells = np.column_stack([rng.integers(0, ny, 40), rng.integers(0, nx, 40)])
+        cells[:4] = [[0, 0], [ny - 1, nx - 1], [ny // 2, 0], [0, nx // 2]]
+        n_t = len(params) * len(angles)
+        amp, snr = m.ctx.score_cells_f64(cells, n_t)
+        k = 0
+        for ang in angles:                                  # hand-over order: orientation-major
+            for par in params:
+                o_amp, _, _, o_snr = orc.match_template(z, de, dy, kind, scale, par, ang)
+                ea = np.abs(amp[:, k] - o_amp[cells[:, 0], cells[:, 1]]).max() / max(np.abs(o_amp).max(), 1e-300)
+                es = np.abs(snr[:, k] - o_snr[cells[:, 0], cells[:, 1]]).max() / max(o_snr.max(), 1e-300)
+                assert ea <= 1e-9 and es <= 1e-9, (str(kind), par, ang, ea, es)
+                k += 1

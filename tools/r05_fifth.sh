@@ -1,7 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r05e; mkdir -p $O
-python -m pytest tests/test_gpu_configs.py -m gpu -q -s -k "c5_grandcanyon_channel_readme or odd_tile or round5 or batching" > $O/gputest.txt 2>&1; echo "gpu tests rc=$?"; grep -E "exact|fold |passed|failed|Error" $O/gputest.txt | head -30
+python -m pytest tests/test_gpu_configs.py -m gpu -q -s -k "c5_grandcanyon_channel_readme or odd_tile or round5" > $O/gputest.txt 2>&1; echo "gpu tests rc=$?"; grep -E "exact|fold |passed|failed|Error" $O/gputest.txt | head -30
 L="--no-cpu-baseline --no-verify --no-e2e --no-other-configs"
 run() { cfg=$1; st=$2; shift 2; python bench.py --config $cfg --steps $st --warmup 3 $L "$@" 2>/dev/null | python -c "
 import json,sys

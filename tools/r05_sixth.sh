@@ -6,4 +6,4 @@ L="--no-cpu-baseline --no-verify --no-e2e --no-other-configs"
 run() { cfg=$1; st=$2; shift 2; python bench.py --config $cfg --steps $st --warmup 3 $L "$@" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg', '$*', d['ms_per_step'], d['config']['tiles'], d['kernels_ms_per_step'], d['gpu'].get('clock_mhz'))"; }
-{ run C1F 6; run C1F 6 --opt split_fill=2048; run C1F 6 --opt split_fill=4300; run C5 20; run C1 40; run C2 8; run C1F 6; } | tee $O/ab.txt
+{ run C1F 6; run C1F 6 --opt split_i1=0; run C5 20; run C1 40; run C2 8; run C1F 6; } | tee $O/ab.txt
