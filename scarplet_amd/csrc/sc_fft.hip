@@ -61,6 +61,9 @@ struct TileDev {
 #ifndef SC_H2_XLANE
 #define SC_H2_XLANE 1      // k_inv_cols_h2: the last stage (radix 2) across lanes with v_permlane16_swap instead of through the LDS
 #endif
+#ifndef SC_F1C_HOLD
+#define SC_F1C_HOLD 1      // k_fwd_rows_curv<.., MIX>: the mixed curvature held in registers for the second plane
+#endif
 #ifndef SC_I1_TWTAB
 #define SC_I1_TWTAB 0      // 1: the wave-per-column kernels read all fifteen twiddles of a set from LDS tables
 #endif
@@ -803,7 +806,14 @@ k_fwd_rows_curv(const float* __restrict__ curv, const float* __restrict__ pB, co
         }
         lds_barrier();
         if (!SC_DBGBIT(dbg, 2)) fft4_lines<TX, false, true>(sm, twr);
+#if SC_F1C_HOLD
+        // MIX: the second plane (curv^2) is filled from the SAME values - held across the first plane's transform - instead
+        // of mixing the three stencil planes again: fetched twice, the 12 B per cell came from memory twice (the workgroups
+        // of an XCD have more rows in flight than its L2 holds: FETCH_SIZE 3.5 GB per launch for 1.8 GB of planes)
+        if (step + 1 < 2 * RBW && (!MIX || ((step + 1) & 1) == 0)) fetch(rb0 + ((step + 1) >> 1));
+#else
         if (step + 1 < 2 * RBW) fetch(rb0 + ((step + 1) >> 1));
+#endif
         float2* out = blk + (size_t)(pair * 2 + pl) * plane + (size_t)rb * 4 * TX;
         if (!SC_DBGBIT(dbg, 4))
 #pragma unroll 4
