@@ -1,0 +1,8 @@
+#!/bin/bash
+# Round-5 closing run (on the GPU box): the whole GPU suite, the headline bench with its rocprofv3 passes, the small configs.
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r05_final; mkdir -p $O
+sha256sum scarplet_amd/libscarplet_hip.so > $O/library.txt
+python -m pytest tests -m gpu -q > $O/gputest.txt 2>&1; echo "gpu tests rc=$?"; tail -3 $O/gputest.txt
+bash tools/prof_run.sh r05 > $O/prof_run.txt 2>&1; tail -40 $O/prof_run.txt
+bash tools/prof_small.sh r05 > $O/prof_small.txt 2>&1; grep -E "^C[0-9]" $O/prof_small.txt
