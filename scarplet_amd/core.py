@@ -414,6 +414,7 @@ class Matcher(object):
             from scarplet_amd import _hostpool
             pre = _hostpool.prefault((4, self.core[1] - self.core[0], self.core[3] - self.core[2]))
         flagged = False
+        direct_last = None
         if exact:
             self.exact_stats = {"flagged_cells": 0, "patches": 0, "changed_cells": 0, "float64_cells": 0}
         if exact and sp.method == _plan.METHOD_FFT:
@@ -430,11 +431,15 @@ class Matcher(object):
                 # kernel is not built for: the whole search on the exact path instead
                 if "near-tie flags" not in str(e):
                     raise
+                self.ctx.set_option("near_window", 0.0)
                 self.plan, sp = self.plan_for(bbox, max_area, "direct", group, n_params=len(params))
-                self.ctx.reset_best()
-                self.ctx.match(arr, sp, sync=True)
+                direct_last = self._direct_exact(arr, sp)
             finally:
                 self.ctx.set_option("near_window", 0.0)
+        elif exact and reset and sync and self.whole:
+            # the real-space path was chosen (by name, or by `auto` for a small support): exact per cell up to ITS float32
+            # rounding - the cells it decides inside that are settled in float64 like the third step of the FFT route
+            direct_last = self._direct_exact(arr, sp)
         else:
             self.ctx.match(arr, sp, sync=sync)
         # (not joined: a search shorter than the touching finds the block still referenced by the thread and takes a
@@ -460,7 +465,20 @@ class Matcher(object):
         self._id_ang = np.concatenate([self._id_ang, np.tile(angles, len(params))])
         if flagged and self.method_used == "fft":
             self._rescore_near_ties(Template, scale, params, angles, kwargs)
+        elif direct_last is not None:
+            self._score_float64(direct_last, arr, bbox)
         return self
+
+    def _direct_exact(self, arr, sp):
+        """exact=True on the real-space path: the search with its own near-tie flags on (EXACT_WINDOW_DIRECT: the cells
+        it decides inside its float32 rounding); returns those cells for _score_float64."""
+        self.ctx.set_option("near_window", self.EXACT_WINDOW_DIRECT)
+        try:
+            self.ctx.reset_best()
+            self.ctx.match(arr, sp, sync=True)
+            return [tuple(c) for c in np.argwhere(self.ctx.near_ties())]
+        finally:
+            self.ctx.set_option("near_window", 0.0)
 
     def _rescore_near_ties(self, Template, scale, params, angles, kwargs):
         """exact=True, second and third step: the cells the FFT row pass flagged are searched again on the
@@ -502,13 +520,7 @@ class Matcher(object):
             warnings.warn("exact=True: %d cells flagged (%d patches): searching the whole DEM on the real-space "
                           "path instead" % (len(cells), len(todo)))
             self.plan, sp = self.plan_for(bbox, max_area, "direct", None, n_params=len(params))
-            self.ctx.set_option("near_window", self.EXACT_WINDOW_DIRECT)
-            try:
-                self.ctx.reset_best()
-                self.ctx.match(arr_main, sp, sync=True)
-                last = [tuple(c) for c in np.argwhere(self.ctx.near_ties())]
-            finally:
-                self.ctx.set_option("near_window", 0.0)
+            last = self._direct_exact(arr_main, sp)
             self.method_used = "direct"
         else:
             aux = getattr(self, "_aux", None)

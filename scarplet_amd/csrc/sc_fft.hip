@@ -65,6 +65,9 @@ struct TileDev {
 #define SC_F1C_HOLD 1      // k_fwd_rows_curv<.., MIX>: the mixed curvature held in registers for the second plane
 #endif
 #ifndef SC_I1_TWTAB
+#ifndef SC_Y_ROWMAJOR
+#define SC_Y_ROWMAJOR 0    // lab (k_inv_cols_w8 + k_inv_rows_fast only): the I1 -> I2 hand-off row-major instead of rows2 blocks
+#endif
 #define SC_I1_TWTAB 0      // 1: the wave-per-column kernels read all fifteen twiddles of a set from LDS tables
 #endif
 
@@ -1830,6 +1833,19 @@ inv_cols_w8_body(const int B, const int jobx, const float2* __restrict__ uc, con
 #ifdef SC_I1_PRIO
             __builtin_amdgcn_s_setprio(3);                   // (experiment: the store pass ahead of other waves' butterflies)
 #endif
+#if SC_Y_ROWMAJOR
+            if constexpr (NC == 8) {                         // (lab: the eight-column kernel only)
+                float2* orow = (pl ? ym : yw) + (size_t)gi_ * plane + (size_t)B * 8 + (ln & 7);
+#pragma unroll 2
+                for (int rp = s_lo + RQ * w + ln / NC; rp <= s_hi; rp += RQ * NC) {
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const float2 c0 = lds_cell<true>(lc + ph(2 * rp)), c1 = lds_cell<true>(lc + ph(2 * rp + 1));
+                    float2* p = orow + (size_t)(2 * rp) * Tx;
+                    __builtin_nontemporal_store(f2{c0.x, c0.y}, reinterpret_cast<f2*>(p));
+                    __builtin_nontemporal_store(f2{c1.x, c1.y}, reinterpret_cast<f2*>(p + Tx));
+                }
+            } else
+#endif
 #pragma unroll 2
             for (int rp = s_lo + RQ * w + ln / NC; rp <= s_hi; rp += RQ * NC)
                 store_stream(o + (size_t)rp * (Tx >> 3) * 16, lds_cell<true>(lc + ph(2 * rp)), lds_cell<true>(lc + ph(2 * rp + 1)));
@@ -2508,8 +2524,16 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     const int pl1 = (S % 64 == 0) ? __builtin_amdgcn_readfirstlane(id / S) : id / S;
     const int tt1 = id % S;
     v2* line1 = sm + pl1 * LINE + 17 * tt1;
+#if SC_Y_ROWMAJOR
+    // lab: the hand-off row-major, Y[row][column] - the row reads whole 128-byte lines of its own
+    const char* src1 = reinterpret_cast<const char*>((pl1 ? ym : yw) + (size_t)(2 * rp + rh) * TX);
+    const uint32_t voff1 = (uint32_t)(tt1 * sizeof(float2));
+    constexpr size_t JSTRIDE1 = (size_t)S * sizeof(float2);
+#else
     const char* src1 = reinterpret_cast<const char*>((pl1 ? ym : yw) + (size_t)rp * 2 * TX);
     const uint32_t voff1 = (uint32_t)(((tt1 >> 3) * 16 + (tt1 & 7) * 2 + rh) * sizeof(float2));
+    constexpr size_t JSTRIDE1 = (size_t)2 * S * sizeof(float2);
+#endif
     // stage-2 mapping (standard): line id / S, set tt2
     const int tt2 = id % S;
     v2* line2 = sm + (id / S) * LINE;
@@ -2604,7 +2628,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     auto fetch = [&]() {
 #pragma unroll
         for (int j = 0; j < 16; ++j)                             // column tt1 + j*S
-            a[j] = *reinterpret_cast<const v2*>(fp + (size_t)j * 2 * S * sizeof(float2) + voff1);
+            a[j] = *reinterpret_cast<const v2*>(fp + (size_t)j * JSTRIDE1 + voff1);
         fp += plane * sizeof(float2);
         if (++fk == NGO) { fk = 0; fp += ostep; }
     };

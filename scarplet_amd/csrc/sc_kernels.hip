@@ -560,7 +560,7 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
           float* __restrict__ map_amp, float* __restrict__ map_snr,
           float near_w, uint8_t* __restrict__ near) {
     // near_w > 0 (the host layer's exact mode): a byte per core cell, set where a template scored within near_w
-    // (relative) of the cell's running best without equalling it - the cells whose argmax is decided inside THIS path's
+    // (relative) of the cell's running best, equal scores included - the cells whose argmax is decided inside THIS path's
     // own float32 error and that sc_score_cells_f64 settles (see k_inv_rows_fast, NEAR)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TXW = 256 * NB, TY = DR2_WAVES * RW;
@@ -959,7 +959,9 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                         uint32_t w_id = SC_ID_NONE;
                         if (near_w > 0.f) {                  // (wave-uniform)
                             const float bs = b_snr[rr][n][u];
-                            if (snr > 0.f && snr != bs && fabsf(snr - bs) <= near_w * fmaxf(snr, bs))
+                            // (EQUAL float32 scores are flagged too: two templates a rounding apart can score the same bits here
+                            //  and differ in float64 - exact twins, Scarp at -pi/2 and +pi/2, cost the float64 pass their cells)
+                            if (snr > 0.f && fabsf(snr - bs) <= near_w * fmaxf(snr, bs))
                                 near[(size_t)(gi - g.cy0 + zt) * cw + (gj - g.cx0)] = (uint8_t)1;
                         }
                         if (sc_fold(b_snr[rr][n][u], w_amp, w_id, snr, amp, t.id)) {

@@ -732,6 +732,39 @@ def test_async_searches_back_to_back_equal_the_synchronous_ones(gpu_ctx):
     assert (out[0][1] > 0).any()
 
 
+def test_exact_mode_on_the_real_space_path(gpu_ctx):
+    """exact=True where the search runs on the real-space path - asked for by name, chosen by `auto`, or taken because
+    the flagging row kernel does not serve the templates (an UpperBreak's error masks): the path flags the cells it
+    decides inside its own float32 rounding and those take the float64 argmax (sc_score_cells_f64).  The searches here
+    hold two orientations 2e-6 rad apart - SNRs 1e-6 apart in float64, nothing float32 resolves: without the mode
+    about half the cells carry the other one (allowed: a near-tie inside the window), with it none does."""
+    rng = np.random.default_rng(77)
+    for (kind, cls, ny, nx, de, dy, scale, params, method) in [
+            (orc.SCARP, WT.Scarp, 96, 90, 1.0, 1.0, 10, [4.0, 30.0], "direct"),
+            (orc.SCARP, WT.Scarp, 70, 101, 2.0, -2.0, 16, [12.0], "auto"),
+            ("left_upper_break", WT.LeftFacingUpperBreakScarp, 88, 84, 1.0, 1.0, 9, [5.0, 20.0], "fft")]:
+        angles = np.array([-0.7, 0.3, 0.3 + 2e-6])
+        z = (np.cumsum(np.cumsum(rng.standard_normal((ny, nx)), 0), 1) * 0.01 + rng.standard_normal((ny, nx)) * 0.05).astype(np.float32)
+        a_st, s_st = orc.snr_stack(z, de, dy, kind, scale, params, angles)
+        T = len(params) * len(angles)
+        ages, angs = np.repeat(np.asarray(params, float), len(angles)), np.tile(angles, len(params))
+        A, S = a_st.reshape(T, ny, nx), s_st.reshape(T, ny, nx)
+        tol = dict(amp_tol=(AMP_RTOL, AMP_ATOL * float(np.max(np.abs(A)))), snr_tol=(SNR_RTOL, SNR_ATOL * float(np.max(S))))
+        off = {}
+        for exact in (False, True):
+            m = sl.Matcher(grid(z, de, dy), ctx=gpu_ctx)
+            res = m.search(cls, scale, params, angles, method=method, exact=exact).result()
+            chk = orc.check_fold(res, A, S, ages, angs, tie_rtol=orc.tie_window(m.method_used, kind), **tol)
+            assert chk["n_bad"] == 0, (str(kind), method, exact, chk["n_bad"], m.method_used)
+            assert m.method_used == "direct" or not exact, (str(kind), method, m.method_used)
+            off[exact] = chk["n_inexact"]
+            if exact:
+                assert m.exact_stats["float64_cells"] > 0, m.exact_stats
+        print("     exact on the real-space path, %s / %s: cells off the oracle's argmax %d -> %d (float64 cells %d of %d)" % (
+            cls.__name__, method, off[False], off[True], m.exact_stats["float64_cells"], ny * nx))
+        assert off[False] > 0 and off[True] == 0, (str(kind), method, off)
+
+
 def test_float64_scoring_of_single_cells(gpu_ctx):
     """sc_score_cells_f64 - match_template() at single cells in float64 on the device, the last step of exact=True -
     against the oracle's float64 maps: Scarp (odd and even grid sizes, dy < 0, an UpperBreak's error mask, cells at the
