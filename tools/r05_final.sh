@@ -6,3 +6,4 @@ sha256sum scarplet_amd/libscarplet_hip.so > $O/library.txt
 python -m pytest tests -m gpu -q > $O/gputest.txt 2>&1; echo "gpu tests rc=$?"; tail -3 $O/gputest.txt
 bash tools/prof_run.sh r05 > $O/prof_run.txt 2>&1; tail -40 $O/prof_run.txt
 bash tools/prof_small.sh r05 > $O/prof_small.txt 2>&1; grep -E "^C[0-9]" $O/prof_small.txt
+timeout 900 python tools/fuzz_oracle.py 150 11 > $O/fuzz_oracle.txt 2>&1; echo "fuzz rc=$?"; grep -v arn $O/fuzz_oracle.txt | tail -6
