@@ -562,7 +562,13 @@ def snr_stack_window(z, dx, dy, kind, scale, ages, angles, win, margin,
 #         a noise floor (profiles/r04_gputest_log.txt) -> window 1e-4; the 7e-4 window is the Ricker
 #         / Channel one (2.2e-4 on the int16 Grand Canyon DEM) and the fallback where the kind is not
 #         known (mixed or generic templates).
-PARITY = dict(amp=(2e-4, 2e-6), snr=(2e-3, 2e-6), tie_rtol=7e-4, tie_rtol_direct=1e-4, tie_rtol_fft_scarp=1e-4)
+#         Round 5, tools/fuzz_oracle.py (250 random searches on random-walk surfaces, 12.2 M cells, profiles/r05_fuzz_oracle.txt):
+#         no cell outside these windows on any path; the largest single-cell SNR errors there are 1.6e-4 (FFT, Scarp family)
+#         and 1.0e-4 (real space, supports of thousands of taps: float32 sums) - above half their windows in 7 of the 250
+#         searches, which is why exact=True flags inside WIDER windows than these (core.py EXACT_WINDOW*).  amp: one cell of
+#         the 12.2 M sat 2.4e-6 x max|amp| off (a cell at 0.2 % of the map's largest amplitude: the float32 FFT's absolute
+#         resolution) - the absolute term of the amp tolerance is 4e-6 since (2e-6 before).
+PARITY = dict(amp=(2e-4, 4e-6), snr=(2e-3, 2e-6), tie_rtol=7e-4, tie_rtol_direct=1e-4, tie_rtol_fft_scarp=1e-4)
 
 
 def tie_window(method, kind=None):

@@ -372,7 +372,7 @@ class Matcher(object):
     # family - twice the path's tie window, itself twice the largest SNR error measured on the path (DESIGN.md
     # section 6): Scarp-like 1e-4, Ricker 7e-4 (a Ricker window's support is the float64 underflow of its
     # exponential: tiles with far more energy, a larger float32 error)
-    EXACT_WINDOW = {_WT.KIND_SCARP: 2e-4, _WT.KIND_RICKER: 1.4e-3}
+    EXACT_WINDOW = {_WT.KIND_SCARP: 3.5e-4, _WT.KIND_RICKER: 1.4e-3}     # (round 5's fuzz: single cells of the Scarp family 1.6e-4 off)
     EXACT_MAX_COST = 50.0                        # re-scoring is not started beyond this many times the search's own cost
     EXACT_PATCH = (8, 256)                       # rows x columns re-scored around a flagged cell: one real-space workgroup
 
@@ -433,12 +433,14 @@ class Matcher(object):
                     raise
                 self.ctx.set_option("near_window", 0.0)
                 self.plan, sp = self.plan_for(bbox, max_area, "direct", group, n_params=len(params))
+                arr = self._without_end_twin(arr, len(params), angles)
                 direct_last = self._direct_exact(arr, sp)
             finally:
                 self.ctx.set_option("near_window", 0.0)
         elif exact and reset and sync and self.whole:
             # the real-space path was chosen (by name, or by `auto` for a small support): exact per cell up to ITS float32
             # rounding - the cells it decides inside that are settled in float64 like the third step of the FFT route
+            arr = self._without_end_twin(arr, len(params), angles)
             direct_last = self._direct_exact(arr, sp)
         else:
             self.ctx.match(arr, sp, sync=sync)
@@ -468,6 +470,26 @@ class Matcher(object):
         elif direct_last is not None:
             self._score_float64(direct_last, arr, bbox)
         return self
+
+    @staticmethod
+    def _without_end_twin(arr, n_params, angles):
+        """The descriptors (orientation-major) without the LAST orientation where that is +pi/2 and the first is -pi/2
+        and the templates are the symmetric built-ins (Scarp: W(alpha + pi) = -W(alpha); Ricker / Channel: the same
+        template): the two ends of the reference's grid (core.py:173-175) are one template, their float64 SNRs differ
+        by rounding noise (1e-13: one maximum by the parity policy) and their float32 real-space scores are the same
+        bits - which the real-space path's own flags (equal scores included) would hand to float64 cell by cell for
+        nothing.  The real-space steps of exact=True search one of the two."""
+        from scarplet_amd import WindowedTemplate as _WT
+        n = len(arr) - n_params
+        if len(angles) < 2 or n <= 0 or abs(angles[0] + np.pi / 2) > 1e-12 or abs(angles[-1] - np.pi / 2) > 1e-12:
+            return arr
+        err = _WT.FLAG_ERR_XR_LE0 | _WT.FLAG_ERR_XR_GE0
+        if any(int(arr[k].window) >= 0 or (int(arr[k].flags) & err) for k in (0, len(arr) - 1)):
+            return arr
+        out = (_lib.sc_template * n)()
+        for k in range(n):
+            out[k] = arr[k]
+        return out
 
     def _direct_exact(self, arr, sp):
         """exact=True on the real-space path: the search with its own near-tie flags on (EXACT_WINDOW_DIRECT: the cells
@@ -520,6 +542,7 @@ class Matcher(object):
             warnings.warn("exact=True: %d cells flagged (%d patches): searching the whole DEM on the real-space "
                           "path instead" % (len(cells), len(todo)))
             self.plan, sp = self.plan_for(bbox, max_area, "direct", None, n_params=len(params))
+            arr_main = self._without_end_twin(arr_main, len(params), angles)
             last = self._direct_exact(arr_main, sp)
             self.method_used = "direct"
         else:
@@ -530,6 +553,7 @@ class Matcher(object):
             ny, nx = self.ny, self.nx
             aux.ny, aux.nx, aux.de = ny, nx, self.de
             arr, _, _ = aux.describe(Template, scale, params, angles, **kwargs)
+            arr = self._without_end_twin(arr, len(params), angles)
             halo = _dist.halo_for_search(bbox, ny, nx)
             aux.ctx.set_option("near_window", self.EXACT_WINDOW_DIRECT)
             try:
@@ -553,9 +577,10 @@ class Matcher(object):
                 aux.ctx.clear_windows()
         self._score_float64(last, arr_main, bbox)
 
-    # exact=True, third step: window of the real-space path's near-tie flags (twice its tie window's half, i.e. the
-    # window itself: 1e-4 - its largest measured SNR error is 4e-5), and how much float64 work is started at most
-    EXACT_WINDOW_DIRECT = 1e-4
+    # exact=True, third step: window of the real-space path's near-tie flags - twice its largest measured SNR error (1.0e-4
+    # in single cells of round 5's fuzz on supports of thousands of taps; 4e-5 on the tests' DEMs) - and how much float64
+    # work is started at most
+    EXACT_WINDOW_DIRECT = 2e-4
     EXACT_MAX_F64 = 4e11                         # cells x templates x support-box cells
 
     def _score_float64(self, last, arr_main, bbox):

@@ -10,6 +10,10 @@ sys.path.insert(0, ROOT)
 import scarplet_amd as sl
 from scarplet_amd import _plan, synthetic
 warnings.simplefilter("ignore")
+if os.environ.get("EXACT_WINDOW_DIRECT"):                      # lab: another window for the real-space path's own flags
+    sl.Matcher.EXACT_WINDOW_DIRECT = float(os.environ["EXACT_WINDOW_DIRECT"])
+if os.environ.get("EXACT_MAX_F64"):
+    sl.Matcher.EXACT_MAX_F64 = float(os.environ["EXACT_MAX_F64"])
 f = np.load(os.path.join(ROOT, "tests", "golden", "dem_grandcanyon.npz"))
 cases = [("grandcanyon 512 x 512, Channel f=0.1 scale 10, 1 x 181", sl.DEMGrid.from_array(f["z"].astype(float), float(f["dx"]), float(f["dy"])),
           sl.Channel, 10.0, [0.1], _plan.angle_grid()),

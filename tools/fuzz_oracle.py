@@ -78,6 +78,14 @@ for case in range(n_cases):
             t["snr_err"], t["worst"] = chk["snr_err"], case
         t["amp_err"] = max(t["amp_err"], chk["amp_err"])
         line += "  | %s bad %d off-argmax %d err %.1e" % (name, chk["n_bad"], chk["n_inexact"], chk["snr_err"])
+        if ONLY and chk["n_bad"]:
+            for (i, j) in np.argwhere(~chk["ok"])[:6]:
+                hit = np.nonzero((ages == res[1][i, j]) & (angs == res[2][i, j]))[0]
+                srt = np.argsort(S[:, i, j])[::-1][:3]
+                line += "\n      %s BAD cell (%d,%d): carries amp %.9g age %g ang %.4f snr %.9g | oracle at the carried one %s | oracle top3 %s | max|A| %.4g max S %.4g" % (
+                    name, i, j, res[0][i, j], res[1][i, j], res[2][i, j], res[3][i, j],
+                    [(int(t_), "amp %.9g snr %.9g" % (A[t_, i, j], S[t_, i, j])) for t_ in hit],
+                    [(int(t_), "%.9g" % S[t_, i, j]) for t_ in srt], float(np.max(np.abs(A))), float(np.max(S)))
         if ONLY and chk["n_inexact"]:
             smax = S.max(axis=0)
             carried = np.zeros((ny, nx), bool)
