@@ -332,6 +332,26 @@ def other_config_line(a, cfg, steps, warmup, device, pool):
             "tiles": "%dx%d of %dx%d" % (plan.nty, plan.ntx, plan.Ty, plan.Tx),
             "roofline_frac": round(value * 1e6 * ALGO_BYTES_PER_UNIT / 1e9 / HBM_PEAK_GBS, 4),
             "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in prof.items() if v[0]}}
+    if not a.no_e2e and len(scales) == 1:
+        # the call a user makes (C1F: the reference's flagship example, sl.match(load_carrizo(), Scarp, scale=100.)): upload,
+        # curvature planes, descriptors, search, float64 result planes, D2H - the first call and the same call again
+        def call():
+            if len(params) == 1:
+                return sl.match(g, Template, scale=scales[0], age=float(params[0]), ang_min=float(angles[0]),
+                                ang_max=float(angles[-1]), device=device, method=b.method)
+            if len(params) == 35 and len(angles) == 181:
+                return sl.match(g, Template, scale=scales[0], device=device, method=b.method)
+            return sl.Matcher(g, device=device).search(Template, scales[0], params, angles, method=b.method).result()
+        secs = []
+        for _ in range(2):
+            m.ctx.sync()
+            t1 = time.perf_counter()
+            r_ = call()
+            secs.append(time.perf_counter() - t1)
+            del r_
+        line["end_to_end_ms"] = {"first_call": round(1e3 * secs[0], 2), "repeat_call": round(1e3 * secs[1], 2),
+                                 "call": "sl.match(data, Template, scale=...)" if (len(params) == 1 or len(params) == 35)
+                                         else "Matcher(data).search(...).result()"}
     if pool is not None and not a.no_verify:
         res = m.ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
         ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan, b.method)
