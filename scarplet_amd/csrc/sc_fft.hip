@@ -2387,6 +2387,9 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
 #define SC_I2_GRP 8         // output pairs per record branch of the row pass (SC_I2_RAREWIN); 4, 2, 1: the 2048 kernel spills 44 - 92 B
 #endif
 #ifndef SC_I2_RAREWIN
+#ifndef SC_I2_RARE512
+#define SC_I2_RARE512 1     // the deferred record update in the 512-cell row kernels too (round 5, end: row pass of the small grids -4.5 %; 0: selects)
+#endif
 #define SC_I2_RAREWIN 1     // the row pass records a winner's output and index under a rarely taken branch (0: selects per output)
 #endif
 #ifndef SC_I2_STATIC
@@ -2769,10 +2772,11 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             }
             pk::B<R3, true>::run(vw);
             pk::B<R3, true>::run(vm);
-            // (RARE: rows of 1024 cells and more; the 512-cell kernels keep the selects - there the deferred form
-            //  costs a scratch reload inside the template loop)
+            // (RARE: every row length since the end of round 5.  The 512-cell kernels kept the selects while the deferred form
+            //  cost them a scratch reload inside the template loop; it no longer does - 16 B outside the loop in the dealt-out
+            //  form - and their row pass is 4.5 % faster with it: C1F 35.2 -> 34.9 ms, profiles/r05_launch_forms.txt)
             // (NEAR compares every score with the record as it stands: no deferred update)
-            constexpr bool RARE = SC_I2_RAREWIN && TX >= 1024 && !NEAR;
+            constexpr bool RARE = SC_I2_RAREWIN && (TX >= 1024 || SC_I2_RARE512) && !NEAR;
             // (GRP outputs pairs per branch: the fewer cells a branch stands for, the more rarely it is taken)
             constexpr int GRP = (RARE && SC_I2_GRP < R3) ? SC_I2_GRP : R3;
 #pragma unroll
