@@ -13,6 +13,8 @@ Stated tolerances (float32 device arithmetic vs the float64 reference):
   cells that carry exactly the oracle's argmax (EXACT_MIN) and that its own
   measured SNR error is at most HALF the window (report()).
 """
+import warnings
+
 import numpy as np
 import pytest
 
@@ -730,6 +732,57 @@ def test_async_searches_back_to_back_equal_the_synchronous_ones(gpu_ctx):
     for a, b, name in zip(out[0], out[1], ("amp", "snr", "id")):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
     assert (out[0][1] > 0).any()
+
+
+def test_random_searches_against_the_oracle(gpu_ctx):
+    """The wide net of tools/fuzz_oracle.py in the driver-run suite: 40 random searches (DEM size and parity, power-of-two
+    periodic DEMs, cell size, sign of dy, float and int16 surfaces, the five built-in template classes, 1 - 6 parameters
+    x 1 - 7 orientations incl. the -pi/2, 0, +pi/2 windows) through the FFT path, the real-space path, method="auto" and
+    exact=True against the oracle: NO cell outside oracle.PARITY on any path, and with exact=True no cell whose
+    (age, angle) is not the oracle's own argmax.  (250 searches of the same generator: profiles/r05_fuzz_oracle.txt.)"""
+    kinds = {WT.Scarp: orc.SCARP, WT.Ricker: orc.RICKER, WT.Channel: orc.RICKER,
+             WT.RightFacingUpperBreakScarp: "right_upper_break", WT.LeftFacingUpperBreakScarp: "left_upper_break"}
+    classes = [WT.Scarp, WT.Scarp, WT.Channel, WT.Ricker, WT.LeftFacingUpperBreakScarp, WT.RightFacingUpperBreakScarp]
+    rng = np.random.default_rng(41)
+    off = {"fft": 0, "direct": 0, "auto": 0, "exact": 0}
+    cells = 0
+    for case in range(40):
+        ny, nx = (int(v) for v in rng.integers(48, 300, size=2))
+        if case % 7 == 0:
+            ny, nx = int(2 ** rng.integers(6, 9)), int(2 ** rng.integers(6, 9))
+        cls = classes[int(rng.integers(0, len(classes)))]
+        de = float(rng.choice([1.0, 1.0, 2.0, 0.5]))
+        scale = float(rng.uniform(4, min(ny, nx) / 4.5)) * de
+        if cls in (WT.Channel, WT.Ricker):
+            params = list(np.round(rng.uniform(0.05, 0.4, size=int(rng.integers(1, 4))) / de, 4))
+        else:
+            params = list(np.round(10 ** rng.uniform(0, 2.6, size=int(rng.integers(1, 7))) * de * de, 3))
+        angles = np.sort(rng.uniform(-np.pi / 2, np.pi / 2, size=int(rng.integers(1, 8))))
+        if case % 5 == 0:
+            angles = np.array([-np.pi / 2, 0.0, np.pi / 2])
+        z = np.cumsum(np.cumsum(rng.standard_normal((ny, nx)), 0), 1) * 0.01 + rng.standard_normal((ny, nx)) * 0.05
+        if case % 4 == 1:
+            z = np.round(z * 20.0).astype(np.int16)
+        z = z.astype(np.float32)
+        dy = -de if case % 3 == 0 else de
+        kind = kinds[cls]
+        a_st, s_st = orc.snr_stack(z, de, dy, kind, scale, params, angles)
+        T = len(params) * len(angles)
+        ages, angs = np.repeat(np.asarray(params, float), len(angles)), np.tile(angles, len(params))
+        A, S = a_st.reshape(T, ny, nx), s_st.reshape(T, ny, nx)
+        tol = dict(amp_tol=(AMP_RTOL, AMP_ATOL * float(np.max(np.abs(A)))), snr_tol=(SNR_RTOL, SNR_ATOL * float(np.max(S))))
+        cells += ny * nx
+        for name, kw in (("fft", dict(method="fft")), ("direct", dict(method="direct")), ("auto", dict(method="auto")),
+                         ("exact", dict(method="fft", exact=True))):
+            m = sl.Matcher(grid(z, de, dy), ctx=gpu_ctx)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")                   # (exact=True says when it searches the whole DEM again)
+                res = m.search(cls, scale, params, angles, **kw).result()
+            chk = orc.check_fold(res, A, S, ages, angs, tie_rtol=orc.tie_window(m.method_used, kind), **tol)
+            assert chk["n_bad"] == 0, (case, cls.__name__, (ny, nx), de, dy, scale, name, chk["n_bad"])
+            off[name] += chk["n_inexact"]
+    print("     40 random searches, %d cells: off the oracle's argmax (near-ties inside the window) %s" % (cells, off))
+    assert off["exact"] == 0, off
 
 
 def test_exact_mode_on_the_real_space_path(gpu_ctx):
