@@ -123,6 +123,8 @@ struct sc_ctx {
     float near_w = 0.f;        // sc_set_option "near_window": the FFT row pass flags near-ties (sc_get_near_ties)
     DevBuf near;               // one byte per core cell
     DevBuf score;              // sc_score_cells_f64: the cell list and the two float64 outputs
+    DevBuf score_w;            // ... and the templates' float64 windows (offsets, then the windows)
+    DevBuf score_abc;          // ... and the three stencil planes of the block in float64 (rebuilt at every call)
     bool templ_windows = false;   // the last sc_match carried host-uploaded windows (no float64 form on the device)
     int batch_templ = 0;       // sc_set_option "batch_templ": templates one batched launch sequence may carry (0: SC_MAX_BATCH)
     int split_i1 = 1;          // sc_set_option "split_i1": under-filled column passes deal their transforms out along grid.z

@@ -10,10 +10,11 @@
 // DEM column, d2z/dxdy in the first row/column, d2z/dy2 in the first and last
 // row.  One thread per cell, rows of the block are read as coalesced float64.
 // ---------------------------------------------------------------------------
+template <typename OUT>          // float: the matcher's planes; double: the float64 scorer's (sc_score_cells_f64)
 __global__ void __launch_bounds__(256)
 k_curv_planes(const double* __restrict__ z, Geom g, double dx, double dy,
-              float* __restrict__ A, float* __restrict__ B,
-              float* __restrict__ C) {
+              OUT* __restrict__ A, OUT* __restrict__ B,
+              OUT* __restrict__ C) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     int i = blockIdx.y;
     if (j >= g.lx) return;
@@ -40,9 +41,9 @@ k_curv_planes(const double* __restrict__ z, Geom g, double dx, double dy,
         c = __ddiv_rn(__dsub_rn(__dsub_rn(r2[j], z11), __dsub_rn(z11, r0[j])),
                       __dmul_rn(dy, dy));
     size_t o = (size_t)i * g.lx + j;
-    A[o] = (float)a;
-    B[o] = (float)b;
-    C[o] = (float)c;
+    A[o] = (OUT)a;
+    B[o] = (OUT)b;
+    C[o] = (OUT)c;
 }
 
 // The reference's curvature as its data object returns it (dem.py:68-107), float64 out: the three
@@ -93,10 +94,41 @@ k_curv_f64(const double* __restrict__ z, Geom g, double dx, double dy, double c2
 // grid = (cells, templates), one workgroup each; the support box is dealt out over the threads.
 // Built-in templates only (a generic plugin's window exists in float32 on the device).
 // ---------------------------------------------------------------------------
+// The float64 windows of the scorer, once per template instead of once per (cell, template): W over the template's support
+// box, 0 where the reference's W is 0 (outside the grid, outside |xr| < c & |yr| < d, at xr = 0, beyond the float64
+// underflow of a Ricker's exponential - core.py:348's M is literally W != 0).  grid = (ceil(largest box / 256), templates).
 __global__ void __launch_bounds__(256)
-k_score_f64(const double* __restrict__ z, Geom g, double dx, double dy,
+k_window_f64(const TemplDev* __restrict__ templ, Geom g, const double* __restrict__ xaxis, const double* __restrict__ yaxis,
+             const unsigned long long* __restrict__ woff, double* __restrict__ wbuf) {
+    const TemplDev t = templ[blockIdx.y];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= t.wh * t.ww) return;
+    const int a = e / t.ww, b = e - a * t.ww;
+    const int k = g.ny / 2 + t.pmin + a, l = g.nx / 2 + t.qmin + b;
+    double w = 0.0;
+    if (k >= 0 && k < g.ny && l >= 0 && l < g.nx) {
+        const double x = xaxis[l], y = yaxis[k];
+        const double xr = __dadd_rn(__dmul_rn(x, t.cos_a), __dmul_rn(y, t.sin_a));
+        const double yr = __dadd_rn(__dmul_rn(-x, t.sin_a), __dmul_rn(y, t.cos_a));
+        if ((fabs(xr) < t.c) && (fabs(yr) < t.d)) {
+            if (t.kind == SC_KIND_SCARP) {
+                if (xr != 0.0) w = __dmul_rn(__ddiv_rn(-xr, t.p0), exp(__ddiv_rn(-__dmul_rn(xr, xr), t.p1)));
+            } else {
+                const double u = __dmul_rn(t.p0, xr), u2 = __dmul_rn(u, u);
+                const double poly = __dsub_rn(1.0, __dmul_rn(2.0, u2));
+                if ((u2 < SC_EXP_UNDERFLOW) && (poly != 0.0)) w = __dmul_rn(poly, exp(-u2));
+            }
+            if (t.flags & SC_FLAG_NEGATE) w = -w;
+        }
+    }
+    wbuf[woff[blockIdx.y] + e] = w;
+}
+
+__global__ void __launch_bounds__(256)
+k_score_f64(const double* __restrict__ pa, const double* __restrict__ pb, const double* __restrict__ pc, Geom g,
             const TemplDev* __restrict__ templ, int n_templ, const double* __restrict__ sums,
             const double* __restrict__ xaxis, const double* __restrict__ yaxis,
+            const unsigned long long* __restrict__ woff, const double* __restrict__ wbuf,
             const int* __restrict__ cells, double* __restrict__ amp_out, double* __restrict__ snr_out) {
     const int ci = blockIdx.x, it = blockIdx.y;
     const int i = cells[2 * ci], j = cells[2 * ci + 1];                  // global cell
@@ -106,51 +138,24 @@ k_score_f64(const double* __restrict__ z, Geom g, double dx, double dy,
     // orientation; cos_a / sin_a of the descriptor are those of alpha
     const double ca = t.cos_a, sa = -t.sin_a;                             // cos / sin of the ORIENTATION
     const double k_cc = __dmul_rn(ca, ca), k_ss = __dmul_rn(sa, sa);
+    const double* __restrict__ wt = wbuf + woff[it];
     double xc = 0.0, t3 = 0.0;
     const int box = t.wh * t.ww;
     for (int e = threadIdx.x; e < box; e += 256) {
+        const double w = wt[e];
+        if (w == 0.0) continue;                                           // (outside the support: W != 0 is the mask M)
         const int a = e / t.ww, b = e - a * t.ww;
         const int p = t.pmin + a, q = t.qmin + b;
-        const int k = g.ny / 2 + p, l = g.nx / 2 + q;
-        if (k < 0 || k >= g.ny || l < 0 || l >= g.nx) continue;
-        const double x = xaxis[l], y = yaxis[k];
-        const double xr = __dadd_rn(__dmul_rn(x, t.cos_a), __dmul_rn(y, t.sin_a));
-        const double yr = __dadd_rn(__dmul_rn(-x, t.sin_a), __dmul_rn(y, t.cos_a));
-        if (!((fabs(xr) < t.c) && (fabs(yr) < t.d))) continue;
-        double w;
-        bool m;
-        if (t.kind == SC_KIND_SCARP) {
-            w = __dmul_rn(__ddiv_rn(-xr, t.p0), exp(__ddiv_rn(-__dmul_rn(xr, xr), t.p1)));
-            m = (xr != 0.0);
-        } else {
-            const double u = __dmul_rn(t.p0, xr), u2 = __dmul_rn(u, u);
-            const double poly = __dsub_rn(1.0, __dmul_rn(2.0, u2));
-            m = (u2 < SC_EXP_UNDERFLOW) && (poly != 0.0);
-            w = m ? __dmul_rn(poly, exp(-u2)) : 0.0;
-        }
-        if (!m) continue;
-        if (t.flags & SC_FLAG_NEGATE) w = -w;
         // curvature at global ((i - p + oy) mod ny, (j - q + ox) mod nx): its local position in the block
         int gi = i - p + g.oy, gj = j - q + g.ox;
         int li, lj;
         if (g.wrap) { gi = wrap_index(gi, g.ny); gj = wrap_index(gj, g.nx); li = gi; lj = gj; }
         else { li = gi - g.gy0; lj = gj - g.gx0; gi = wrap_index(gi, g.ny); gj = wrap_index(gj, g.nx); }
         if (li < 0 || li >= g.ly || lj < 0 || lj >= g.lx) continue;       // (outside the block: the host sized the halo)
-        const int im = max(li - 1, 0), ip = min(li + 1, g.ly - 1), jm = max(lj - 1, 0), jp = min(lj + 1, g.lx - 1);
-        const double* r0 = z + (size_t)im * g.lx;
-        const double* r1 = z + (size_t)li * g.lx;
-        const double* r2 = z + (size_t)ip * g.lx;
-        const double z11 = r1[lj];
-        double A = 0.0, Bc = 0.0, C = 0.0;
-        if (gj >= 1 && gj <= g.nx - 2)
-            A = __ddiv_rn(__dsub_rn(__dsub_rn(r1[jp], z11), __dsub_rn(z11, r1[jm])), __dmul_rn(dx, dx));
-        if (gi >= 1 && gj >= 1) {
-            const double d1 = __ddiv_rn(__dsub_rn(z11, r1[jm]), dx);
-            const double d0 = __ddiv_rn(__dsub_rn(r0[lj], r0[jm]), dx);
-            Bc = __ddiv_rn(__dsub_rn(d1, d0), dx);
-        }
-        if (gi >= 1 && gi <= g.ny - 2)
-            C = __ddiv_rn(__dsub_rn(__dsub_rn(r2[lj], z11), __dsub_rn(z11, r0[lj])), __dmul_rn(dy, dy));
+        // the stencils of dem.py:88-101 on the float64 elevations: k_curv_planes<double>, once per call (four float64
+        // divisions per tap, done here, were most of this kernel)
+        const size_t o = (size_t)li * g.lx + lj;
+        const double A = pa[o], Bc = pb[o], C = pc[o];
         // dem.py:103-104: d2z_dx2 cos^2 - 2 d2z_dxdy sin cos + d2z_dy2 sin^2 (numpy's order)
         const double cv = __dadd_rn(__dsub_rn(__dmul_rn(A, k_cc), __dmul_rn(__dmul_rn(__dmul_rn(2.0, Bc), sa), ca)),
                                     __dmul_rn(C, k_ss));
@@ -183,9 +188,35 @@ k_score_f64(const double* __restrict__ z, Geom g, double dx, double dy,
 }
 
 int launch_score_f64(sc_ctx* ctx, const int* cells_dev, int m, int n_templ, double* amp_dev, double* snr_dev) {
-    hipLaunchKernelGGL(k_score_f64, dim3(m, n_templ), dim3(256), 0, ctx->stream, ctx->z_dev, ctx->g, ctx->dx, ctx->dy,
+    // the windows first: offsets from the host's copy of the descriptors (the last search's), one kernel for all templates
+    std::vector<unsigned long long> off((size_t)n_templ + 1, 0ull);
+    int maxbox = 1;
+    for (int k = 0; k < n_templ; ++k) {
+        const int box = ctx->h_templ[k].wh * ctx->h_templ[k].ww;
+        off[k + 1] = off[k] + (unsigned long long)box;
+        maxbox = std::max(maxbox, box);
+    }
+    const size_t obytes = sizeof(unsigned long long) * ((size_t)n_templ + 1);
+    int rc = sc_ensure(ctx, ctx->score_w, obytes + sizeof(double) * (size_t)off[n_templ] + 64);
+    if (rc) return rc;
+    unsigned long long* woff = (unsigned long long*)ctx->score_w.p;
+    double* wbuf = (double*)((char*)ctx->score_w.p + ((obytes + 63) & ~(size_t)63));
+    SC_HIP(ctx, hipMemcpyAsync(woff, off.data(), obytes, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));                       // (`off` is a local)
+    hipLaunchKernelGGL(k_window_f64, dim3((maxbox + 255) / 256, n_templ), dim3(256), 0, ctx->stream,
+                       (const TemplDev*)ctx->templ.p, ctx->g, (const double*)ctx->xaxis.p, (const double*)ctx->yaxis.p,
+                       (const unsigned long long*)woff, wbuf);
+    SC_HIP(ctx, hipGetLastError());
+    const size_t nc = (size_t)ctx->g.ly * ctx->g.lx;
+    if ((rc = sc_ensure(ctx, ctx->score_abc, 3 * nc * sizeof(double)))) return rc;
+    double* pa = (double*)ctx->score_abc.p;
+    hipLaunchKernelGGL(k_curv_planes<double>, dim3((ctx->g.lx + 255) / 256, ctx->g.ly), dim3(256), 0, ctx->stream,
+                       ctx->z_dev, ctx->g, ctx->dx, ctx->dy, pa, pa + nc, pa + 2 * nc);
+    SC_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_score_f64, dim3(m, n_templ), dim3(256), 0, ctx->stream, (const double*)pa, (const double*)(pa + nc),
+                       (const double*)(pa + 2 * nc), ctx->g,
                        (const TemplDev*)ctx->templ.p, n_templ, (const double*)ctx->sums.p, (const double*)ctx->xaxis.p,
-                       (const double*)ctx->yaxis.p, cells_dev, amp_dev, snr_dev);
+                       (const double*)ctx->yaxis.p, (const unsigned long long*)woff, (const double*)wbuf, cells_dev, amp_dev, snr_dev);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
 }
@@ -1170,7 +1201,7 @@ int launch_curv_planes(sc_ctx* ctx) {
     const Geom& g = ctx->g;
     dim3 grid((g.lx + 255) / 256, g.ly);
     sc_prof_begin(ctx, SC_K_CURV);
-    hipLaunchKernelGGL(k_curv_planes, grid, dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(k_curv_planes<float>, grid, dim3(256), 0, ctx->stream,
                        ctx->z_dev, g, ctx->dx, ctx->dy, (float*)ctx->A.p,
                        (float*)ctx->B.p, (float*)ctx->C.p);
     sc_prof_end(ctx);
