@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 6
+#define SC_ABI_VERSION 7
 
 #define SC_OK               0
 #define SC_ERR_INVALID     -1   /* bad argument                                */
@@ -321,7 +321,7 @@ int sc_get_resolution_stats(sc_ctx* ctx, long long* wins, long long* near_floor)
 
 /* Near-ties of the FFT searches since the last sc_reset_best, one byte per core cell, (cy1-cy0) x (cx1-cx0):
  * 1 where some template scored within the relative window of option "near_window" of the cell's running best
- * (either side of it) without equalling it.  A float32 FFT convolution carries an SNR error of up to half the
+ * (either side of it; equal scores included since ABI 7).  A float32 FFT convolution carries an SNR error of up to half the
  * path's tie window (scarplet_amd: oracle-measured): between two templates closer than
  * that, which one the record holds is rounding noise.  The real-space path flags the same way with the option on - and
  * equal scores as well (its per-cell float32 sums can give two templates a rounding apart the same bits).  scarplet_amd.match(..., exact=True) reads the flags and
@@ -337,6 +337,21 @@ int sc_get_near_ties(sc_ctx* ctx, uint8_t* out);
  * are settled the way the reference settles them.  Built-in templates only (SC_ERR_UNSUPPORTED otherwise); the
  * context must hold the cells' neighbourhoods (a whole DEM does). */
 int sc_score_cells_f64(sc_ctx* ctx, const int32_t* cells, int m, double* amp, double* snr);
+
+/* The near-ties of the FFT searches since the last sc_reset_best as EVENTS (round 5, ABI 7): three 32-bit words each -
+ * the cell (index into the core planes, row-major), the id of the template that was being scored, the id of the
+ * template that held the cell's record at that moment (SC_ID_NONE: none yet) - one per (cell, template) whose score
+ * came within option "near_window" of the record, either side.  The true float64 argmax of a flagged cell is the
+ * record's final holder or one of the templates its events name (two templates further apart than the window differ by
+ * more than twice the path's error: the lower one cannot be the argmax), so scarplet_amd.match(..., exact=True) scores
+ * exactly those (cell, template) pairs in float64 (sc_score_pairs_f64).  *n_events = events recorded; the device list
+ * holds two per core cell (a million at least): a larger count, or one above `capacity`, copies nothing - the caller
+ * takes the route without events (real-space search of the flagged cells, sc_score_cells_f64). */
+int sc_get_near_events(sc_ctx* ctx, uint32_t* events, long long capacity, long long* n_events);
+
+/* sc_score_cells_f64 for (cell, template) PAIRS: pair k = global cell (cells[2k], cells[2k+1]) against template
+ * templates[k] of the last sc_match in this context (its index in hand-over order); amp, snr = m doubles each. */
+int sc_score_pairs_f64(sc_ctx* ctx, const int32_t* cells, const int32_t* templates, int m, double* amp, double* snr);
 
 /* Per-template scalars of the last sc_match / sc_match_template call:
  * n = count(W != 0) + eps (core.py:350) and sum(W**2) (core.py:356). */

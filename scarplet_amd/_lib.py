@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCARPLET_HIP_LIB") or os.path.join(_HERE, "libscarplet_hip.so")
 
 SC_OK = 0
-ABI_VERSION = 6
+ABI_VERSION = 7
 ID_NONE = 0xFFFFFFFF
 COMM_ID_BYTES = 128
 
@@ -104,6 +104,8 @@ SIGNATURES = {
     "sc_curvature_f64": (C.c_int, [_P] + [C.c_double] * 4 + [_dp]),
     "sc_get_near_ties": (C.c_int, [_P, _bp]),
     "sc_score_cells_f64": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, _dp, _dp]),
+    "sc_get_near_events": (C.c_int, [_P, _up, C.c_longlong, C.POINTER(C.c_longlong)]),
+    "sc_score_pairs_f64": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, _dp, _dp]),
     "sc_get_resolution_stats": (C.c_int, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "sc_get_template_sums": (C.c_int, [_P, C.c_int, _dp, _dp]),
     "sc_profile": (C.c_int, [_P, C.c_int]),
@@ -407,6 +409,35 @@ class Context(object):
         snr = np.empty((m, int(n_templates)), dtype=np.float64)
         self._check(self.lib.sc_score_cells_f64(self._h, cells.ctypes.data_as(C.POINTER(C.c_int32)), m,
                                                 _as(amp, _dp), _as(snr, _dp)), "sc_score_cells_f64")
+        return amp, snr
+
+    def near_events(self):
+        """The near-ties of the FFT searches since the last reset as events, (n, 3) uint32: cell (row-major index into the
+        core planes), id of the template scored, id of the record's holder at that moment (sc_get_near_events) - or None
+        where the device list overflowed (more events than two per core cell)."""
+        n = C.c_longlong(0)
+        self._check(self.lib.sc_get_near_events(self._h, None, 0, C.byref(n)), "sc_get_near_events")
+        want = int(n.value)
+        if want == 0:
+            return np.zeros((0, 3), dtype=np.uint32)
+        ev = np.empty((want, 3), dtype=np.uint32)
+        self._check(self.lib.sc_get_near_events(self._h, _as(ev, _up), want, C.byref(n)), "sc_get_near_events")
+        h, w = self.core_shape()
+        if int(n.value) != want or want > max(2 * h * w, 1 << 20):
+            return None
+        return ev
+
+    def score_pairs_f64(self, cells, templates):
+        """(amp, snr) float64, each (m,): match_template() in float64 at global cell cells[k] for template templates[k]
+        (index in the last match's hand-over order) - sc_score_pairs_f64."""
+        cells = np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, 2)
+        templates = np.ascontiguousarray(templates, dtype=np.int32).reshape(-1)
+        m = len(cells)
+        amp = np.empty(m, dtype=np.float64)
+        snr = np.empty(m, dtype=np.float64)
+        i32 = C.POINTER(C.c_int32)
+        self._check(self.lib.sc_score_pairs_f64(self._h, cells.ctypes.data_as(i32), templates.ctypes.data_as(i32), m,
+                                                _as(amp, _dp), _as(snr, _dp)), "sc_score_pairs_f64")
         return amp, snr
 
     def comm_destroy(self):

@@ -514,6 +514,8 @@ class Matcher(object):
         self._cells64 = None
         if not len(cells):
             return
+        if self._settle_by_events(flags, Template, scale, params, angles, kwargs):
+            return
         ph, pw = self.EXACT_PATCH
         todo = sorted({(int(i) // ph, int(j) // pw) for i, j in cells})
         # what the second pass would cost against the search it follows (the planner's per-cell figures): a large DEM
@@ -576,6 +578,55 @@ class Matcher(object):
                 aux.ctx.set_option("near_window", 0.0)
                 aux.ctx.clear_windows()
         self._score_float64(last, arr_main, bbox)
+
+    EXACT_USE_EVENTS = True                      # (False: always the longer route - tests, comparisons)
+
+    def _settle_by_events(self, flags, Template, scale, params, angles, kwargs):
+        """exact=True, the short route (round 5, end): the row pass also LISTS its near-ties - (cell, template scored,
+        holder of the record at that moment) - and the float64 argmax of a flagged cell can only be the record's final
+        holder or a template one of its events names (a template further below the record than the window is below it
+        in float64 too: the window is twice the path's error).  Exactly those (cell, template) pairs are scored in
+        float64 on the device (sc_score_pairs_f64) and the cell takes their argmax in fold order: no second search at
+        all.  False - the longer route through the real-space path follows - where the list overflowed, the pairs
+        would be more float64 work than EXACT_MAX_F64, or the scorer does not serve the templates."""
+        if not self.EXACT_USE_EVENTS:
+            return False
+        ev = self.ctx.near_events()
+        if ev is None:
+            return False
+        arr, bbox, _ = self.describe(Template, scale, params, angles, **kwargs)
+        n_t = len(arr)
+        ids_of = np.fromiter((int(arr[k].id) for k in range(n_t)), dtype=np.int64, count=n_t)
+        idx_of = np.full(int(ids_of.max()) + 2, -1, dtype=np.int64)
+        idx_of[ids_of] = np.arange(n_t)
+        h, w = flags.shape
+        _, _, best_id = self.ctx.get_best()
+        fl = np.flatnonzero(flags.ravel()).astype(np.int64)
+        cell = np.concatenate([ev[:, 0].astype(np.int64), ev[:, 0].astype(np.int64), fl])
+        tid = np.concatenate([ev[:, 1].astype(np.int64), ev[:, 2].astype(np.int64), best_id.ravel()[fl].astype(np.int64)])
+        ok = (tid >= 0) & (tid < len(idx_of) - 1)
+        cell, tix = cell[ok], idx_of[np.where(ok, tid, 0)[ok]]
+        ok = tix >= 0
+        key = np.unique(cell[ok] * n_t + tix[ok])
+        cell, tix = key // n_t, key % n_t
+        box = (bbox[1] - bbox[0] + 1) * (bbox[3] - bbox[2] + 1)
+        if float(len(key)) * box > self.EXACT_MAX_F64:
+            return False
+        gi, gj = cell // w + self.core[0], cell % w + self.core[2]
+        try:
+            amp, snr = self.ctx.score_pairs_f64(np.column_stack([gi, gj]), tix)
+        except _lib.ScarpletHipError as e:
+            if "built-in templates only" in str(e):
+                return False
+            raise
+        # per cell the largest float64 SNR, ties to the earlier template of the fold order (the hand-over order)
+        order = np.lexsort((tix, -snr, cell))
+        first = np.ones(len(order), dtype=bool)
+        first[1:] = cell[order][1:] != cell[order][:-1]
+        win = order[first]
+        self._cells64 = (gi[win] - self.core[0], gj[win] - self.core[2], amp[win], snr[win], ids_of[tix[win]])
+        self.exact_stats.update(float64_cells=int(len(win)), float64_pairs=int(len(key)), events=int(len(ev)), route="events")
+        return True
 
     # exact=True, third step: window of the real-space path's near-tie flags - twice its largest measured SNR error (1.0e-4
     # in single cells of round 5's fuzz on supports of thousands of taps; 4e-5 on the tests' DEMs) - and how much float64

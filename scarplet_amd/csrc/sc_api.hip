@@ -46,7 +46,7 @@ size_t sc_total_bytes(sc_ctx* c) {
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->norm_part, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
                      &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats, &c->digest, &c->split_s, &c->split_a, &c->split_i,
-                     &c->near, &c->score, &c->score_w, &c->score_abc};
+                     &c->near, &c->near_ev, &c->score, &c->score_w, &c->score_abc};
     size_t s = 0;
     for (DevBuf* b : arr) s += b->cap;
     for (auto& w : c->windows) s += (size_t)w.h * w.wd * 5;
@@ -224,7 +224,7 @@ extern "C" void sc_destroy(sc_ctx* c) {
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->norm_part, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
                      &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats, &c->digest, &c->split_s, &c->split_a, &c->split_i,
-                     &c->near, &c->score, &c->score_w, &c->score_abc};
+                     &c->near, &c->near_ev, &c->score, &c->score_w, &c->score_abc};
     for (DevBuf* b : arr) buf_free(*b);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp[k]);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp_in[k]);
@@ -470,6 +470,7 @@ extern "C" int sc_reset_best(sc_ctx* ctx) {
                        (unsigned long long*)ctx->res_stats.p);
     SC_HIP(ctx, hipGetLastError());
     if (ctx->near.p) SC_HIP(ctx, hipMemsetAsync(ctx->near.p, 0, ctx->near.cap, ctx->stream));
+    if (ctx->near_ev.p) SC_HIP(ctx, hipMemsetAsync(ctx->near_ev.p, 0, 16, ctx->stream));
     return SC_OK;
 }
 
@@ -486,30 +487,61 @@ extern "C" int sc_get_near_ties(sc_ctx* ctx, uint8_t* out) {
     return sc_sync(ctx);
 }
 
-extern "C" int sc_score_cells_f64(sc_ctx* ctx, const int32_t* cells, int m, double* amp, double* snr) {
-    if (!ctx || !cells || m <= 0 || !amp || !snr) return SC_ERR_INVALID;
+extern "C" int sc_get_near_events(sc_ctx* ctx, uint32_t* events, long long capacity, long long* n_events) {
+    if (!ctx || !n_events || capacity < 0 || (capacity > 0 && !events)) return SC_ERR_INVALID;
+    *n_events = 0;
+    if (!ctx->near_ev.p) return SC_OK;                   // no FFT search has run with the option on
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long n = 0;
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SC_HIP(ctx, hipMemcpy(&n, ctx->near_ev.p, sizeof(n), hipMemcpyDeviceToHost));
+    *n_events = (long long)n;                            // (beyond the list's capacity: the rest was dropped - the caller sees it)
+    const unsigned long long held = std::min<unsigned long long>(n, (ctx->near_ev.cap - 16) / 12);
+    const unsigned long long take = std::min<unsigned long long>(held, (unsigned long long)capacity);
+    if (held > (unsigned long long)capacity || n > held) return SC_OK;     // the caller asks again with room, or gives up
+    if (take) SC_HIP(ctx, hipMemcpy(events, (const char*)ctx->near_ev.p + 16, 12 * take, hipMemcpyDeviceToHost));
+    return SC_OK;
+}
+
+// shared by sc_score_cells_f64 (tsel = nullptr: every cell against every template) and sc_score_pairs_f64
+static int score_f64(sc_ctx* ctx, const int32_t* cells, const int32_t* tsel, int m, double* amp, double* snr, const char* who) {
     if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
     const int n = ctx->last_batch;
-    if (n <= 0) return sc_fail(ctx, SC_ERR_INVALID, "sc_score_cells_f64: no search has run in this context");
+    if (n <= 0) return sc_fail(ctx, SC_ERR_INVALID, "%s: no search has run in this context", who);
     if (ctx->templ_windows)
-        return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_score_cells_f64: built-in templates only (a plugin's window is float32 on the device)");
+        return sc_fail(ctx, SC_ERR_UNSUPPORTED, "%s: built-in templates only (a plugin's window is float32 on the device)", who);
     SC_HIP(ctx, hipSetDevice(ctx->device));
-    for (int k = 0; k < m; ++k)
+    for (int k = 0; k < m; ++k) {
         if (cells[2 * k] < 0 || cells[2 * k] >= ctx->g.ny || cells[2 * k + 1] < 0 || cells[2 * k + 1] >= ctx->g.nx)
-            return sc_fail(ctx, SC_ERR_INVALID, "sc_score_cells_f64: cell %d outside the DEM", k);
-    const size_t nout = (size_t)m * n;
-    int rc = sc_ensure(ctx, ctx->score, sizeof(int32_t) * 2 * (size_t)m + 16 + sizeof(double) * 2 * nout);
+            return sc_fail(ctx, SC_ERR_INVALID, "%s: cell %d outside the DEM", who, k);
+        if (tsel && (tsel[k] < 0 || tsel[k] >= n))
+            return sc_fail(ctx, SC_ERR_INVALID, "%s: pair %d names template %d of %d", who, k, tsel[k], n);
+    }
+    const size_t nout = tsel ? (size_t)m : (size_t)m * n;
+    int rc = sc_ensure(ctx, ctx->score, sizeof(int32_t) * 3 * (size_t)m + 16 + sizeof(double) * 2 * nout);
     if (rc) return rc;
     double* d_amp = (double*)ctx->score.p;
     double* d_snr = d_amp + nout;
     int* d_cells = (int*)(d_snr + nout);
+    int* d_tsel = tsel ? d_cells + 2 * (size_t)m : nullptr;
     SC_HIP(ctx, hipMemcpyAsync(d_cells, cells, sizeof(int32_t) * 2 * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
+    if (tsel) SC_HIP(ctx, hipMemcpyAsync(d_tsel, tsel, sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
     // (grid.y is limited to 65535: the templates of a search are at most a few thousand)
-    if (n > 65535) return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_score_cells_f64: %d templates", n);
-    if ((rc = launch_score_f64(ctx, d_cells, m, n, d_amp, d_snr))) return rc;
+    if (!tsel && n > 65535) return sc_fail(ctx, SC_ERR_UNSUPPORTED, "%s: %d templates", who, n);
+    if ((rc = launch_score_f64(ctx, d_cells, d_tsel, m, n, d_amp, d_snr))) return rc;
     SC_HIP(ctx, hipMemcpyAsync(amp, d_amp, sizeof(double) * nout, hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(snr, d_snr, sizeof(double) * nout, hipMemcpyDeviceToHost, ctx->stream));
     return sc_sync(ctx);
+}
+
+extern "C" int sc_score_pairs_f64(sc_ctx* ctx, const int32_t* cells, const int32_t* templates, int m, double* amp, double* snr) {
+    if (!ctx || !cells || !templates || m <= 0 || !amp || !snr) return SC_ERR_INVALID;
+    return score_f64(ctx, cells, templates, m, amp, snr, "sc_score_pairs_f64");
+}
+
+extern "C" int sc_score_cells_f64(sc_ctx* ctx, const int32_t* cells, int m, double* amp, double* snr) {
+    if (!ctx || !cells || m <= 0 || !amp || !snr) return SC_ERR_INVALID;
+    return score_f64(ctx, cells, nullptr, m, amp, snr, "sc_score_cells_f64");
 }
 
 extern "C" int sc_get_resolution_stats(sc_ctx* ctx, long long* wins, long long* near_floor) {

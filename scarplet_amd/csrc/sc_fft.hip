@@ -2184,6 +2184,11 @@ struct RowArgs {
     // cannot vouch for and that the host re-scores on the real-space path
     float near_w;
     uint8_t* near;
+    // ... and, per near-tie, an EVENT (cell, id of the template scored, id of the record's holder at that moment) appended to a
+    // list (round 5, end): the candidates of a flagged cell - the only templates its float64 argmax can be, sc_get_near_events
+    uint32_t* ev;                       // 3 words per event (nullptr: flags only)
+    unsigned long long* ev_count;       // events so far (counts on beyond the capacity: the host sees the overflow)
+    unsigned long long ev_cap;
 };
 // One launch may serve several tile pairs (grid.y): pair = ra.pair + blockIdx.y,
 // its Y planes ystride planes further on.  More workgroups per launch fill the
@@ -2824,11 +2829,24 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                         // the range (lean variant) or masked to 0 never wins
                         const bool won = (FULL || in) && snr > b_snr[k];
                         if constexpr (NEAR) {
-                            // a score within the window of the running best, either side of it, that does not EQUAL it
-                            // (an even or odd template at -pi/2 and +pi/2 is one template: bit-identical scores)
+                            // a score within the window of the running best, either side of it - EQUAL scores included since the
+                            // end of round 5: two templates proportional to each other on a degenerate support (a Ricker window two
+                            // cells wide) score the same bits and differ at 1e-8 in float64; the grid's end twins (-pi/2, +pi/2: one
+                            // template) cost the event route two float64 pairs per cell they hold
                             const float top = fmaxf(snr, b_snr[k]);
-                            const bool nt = in && snr > 0.f && snr != b_snr[k] && fabsf(snr - b_snr[k]) <= ra.near_w * top;
+                            const bool nt = in && snr > 0.f && fabsf(snr - b_snr[k]) <= ra.near_w * top;
                             nearm |= nt ? (1u << k) : 0u;
+                            if (nt && ra.ev) {             // (before the record moves: b_ix still names the holder)
+                                const unsigned long long slot = atomicAdd(ra.ev_count, 1ull);
+                                if (slot < ra.ev_cap) {
+                                    const uint32_t hx = (b_ix[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                                    uint32_t* e = ra.ev + 3 * slot;
+                                    e[0] = (uint32_t)(off_of(part) + (size_t)cj);
+                                    e[1] = tp->id;
+                                    // a holder from an earlier launch (or none yet: SC_ID_NONE) stands in the record's id plane
+                                    e[2] = hx != 0xFFu ? templ[ra.first + hx].id : at_bytes(best_id + off_of(part), 4u * (uint32_t)cj);
+                                }
+                            }
                         }
                         if constexpr (RARE) {
                             wonm[m - m0][part] = won;
@@ -3594,6 +3612,14 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                 if (fresh) SC_HIP(ctx, hipMemsetAsync(ctx->near.p, 0, nc_, ctx->stream));     // (sc_reset_best clears it from then on)
                 ra.near_w = ctx->near_w;
                 ra.near = (uint8_t*)ctx->near.p;
+                // the event list: two per core cell or a million, whichever is more (12 bytes each); counter in front
+                const unsigned long long cap = std::max<unsigned long long>(2ull * nc_, 1ull << 20);
+                const bool fresh_ev = ctx->near_ev.cap < 16 + 12 * cap;
+                if ((rc = sc_ensure(ctx, ctx->near_ev, 16 + 12 * cap))) return rc;
+                if (fresh_ev) SC_HIP(ctx, hipMemsetAsync(ctx->near_ev.p, 0, 16, ctx->stream));
+                ra.ev_count = (unsigned long long*)ctx->near_ev.p;
+                ra.ev = (uint32_t*)((char*)ctx->near_ev.p + 16);
+                ra.ev_cap = (ctx->near_ev.cap - 16) / 12;
             }
             int nsplit = 1;
             if (fast && !near && !to_maps && !full_masks && fg.Tx <= 1024 && ctx->variant != 15 && !(ctx->sib & 1)) {

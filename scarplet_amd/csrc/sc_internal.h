@@ -122,6 +122,7 @@ struct sc_ctx {
     float kappa = 4.f;         // float32 resolution floor of the FFT path, in units of eps (sc_set_option "kappa")
     float near_w = 0.f;        // sc_set_option "near_window": the FFT row pass flags near-ties (sc_get_near_ties)
     DevBuf near;               // one byte per core cell
+    DevBuf near_ev;            // the near-tie events of the FFT row pass: a 64-bit count, then 3 words per event (sc_get_near_events)
     DevBuf score;              // sc_score_cells_f64: the cell list and the two float64 outputs
     DevBuf score_w;            // ... and the templates' float64 windows (offsets, then the windows)
     DevBuf score_abc;          // ... and the three stencil planes of the block in float64 (rebuilt at every call)
@@ -191,7 +192,8 @@ int launch_dem_digest(sc_ctx* ctx, unsigned long long* out_dev);
 int launch_curv_alpha(sc_ctx* ctx, float cc, float sc2, float ss, int plane = 0);
 int launch_curv_f64(sc_ctx* ctx, double c2, double sn, double cs, double s2, double* out_dev);
 int launch_curv_alpha_batch(sc_ctx* ctx, const float (*coef)[3], int nb);
-int launch_score_f64(sc_ctx* ctx, const int* cells_dev, int m, int n_templ, double* amp_dev, double* snr_dev);
+// tsel_dev: nullptr - every cell against every template (m x n_templ outputs); else pair k = (cell k, template tsel[k]) (m outputs)
+int launch_score_f64(sc_ctx* ctx, const int* cells_dev, const int* tsel_dev, int m, int n_templ, double* amp_dev, double* snr_dev);
 int launch_windows(sc_ctx* ctx, int first, int n, int wh_max, int ww_max);
 int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_max, int ww_max, bool long_runs);
 bool direct_window_fits(int ww);

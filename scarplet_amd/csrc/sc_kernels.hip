@@ -129,8 +129,9 @@ k_score_f64(const double* __restrict__ pa, const double* __restrict__ pb, const 
             const TemplDev* __restrict__ templ, int n_templ, const double* __restrict__ sums,
             const double* __restrict__ xaxis, const double* __restrict__ yaxis,
             const unsigned long long* __restrict__ woff, const double* __restrict__ wbuf,
-            const int* __restrict__ cells, double* __restrict__ amp_out, double* __restrict__ snr_out) {
-    const int ci = blockIdx.x, it = blockIdx.y;
+            const int* __restrict__ cells, const int* __restrict__ tsel, double* __restrict__ amp_out, double* __restrict__ snr_out) {
+    // tsel: (cell, template) PAIRS - block ci scores cell ci against template tsel[ci] (grid.y = 1) - instead of the full table
+    const int ci = blockIdx.x, it = tsel ? tsel[ci] : (int)blockIdx.y;
     const int i = cells[2 * ci], j = cells[2 * ci + 1];                  // global cell
     const TemplDev t = templ[it];
     // curvature mix of this template's orientation: cc, sc2, ss are not in TemplDev - the same expression as the
@@ -182,12 +183,13 @@ k_score_f64(const double* __restrict__ pa, const double* __restrict__ pb, const 
             if ((t.flags & SC_FLAG_ERR_XR_LE0) ? (xr <= 0.0) : (xr >= 0.0)) snr = 0.0;
         }
         if (!(i >= t.ilo && i <= t.ihi && j >= t.jlo && j <= t.jhi)) { amp = 0.0; snr = 0.0; }
-        amp_out[(size_t)ci * n_templ + it] = amp;
-        snr_out[(size_t)ci * n_templ + it] = snr;
+        const size_t oo = tsel ? (size_t)ci : (size_t)ci * n_templ + it;
+        amp_out[oo] = amp;
+        snr_out[oo] = snr;
     }
 }
 
-int launch_score_f64(sc_ctx* ctx, const int* cells_dev, int m, int n_templ, double* amp_dev, double* snr_dev) {
+int launch_score_f64(sc_ctx* ctx, const int* cells_dev, const int* tsel_dev, int m, int n_templ, double* amp_dev, double* snr_dev) {
     // the windows first: offsets from the host's copy of the descriptors (the last search's), one kernel for all templates
     std::vector<unsigned long long> off((size_t)n_templ + 1, 0ull);
     int maxbox = 1;
@@ -213,10 +215,10 @@ int launch_score_f64(sc_ctx* ctx, const int* cells_dev, int m, int n_templ, doub
     hipLaunchKernelGGL(k_curv_planes<double>, dim3((ctx->g.lx + 255) / 256, ctx->g.ly), dim3(256), 0, ctx->stream,
                        ctx->z_dev, ctx->g, ctx->dx, ctx->dy, pa, pa + nc, pa + 2 * nc);
     SC_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_score_f64, dim3(m, n_templ), dim3(256), 0, ctx->stream, (const double*)pa, (const double*)(pa + nc),
+    hipLaunchKernelGGL(k_score_f64, dim3(m, tsel_dev ? 1 : n_templ), dim3(256), 0, ctx->stream, (const double*)pa, (const double*)(pa + nc),
                        (const double*)(pa + 2 * nc), ctx->g,
                        (const TemplDev*)ctx->templ.p, n_templ, (const double*)ctx->sums.p, (const double*)ctx->xaxis.p,
-                       (const double*)ctx->yaxis.p, (const unsigned long long*)woff, (const double*)wbuf, cells_dev, amp_dev, snr_dev);
+                       (const double*)ctx->yaxis.p, (const unsigned long long*)woff, (const double*)wbuf, cells_dev, tsel_dev, amp_dev, snr_dev);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
 }

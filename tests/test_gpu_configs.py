@@ -62,14 +62,23 @@ def test_c5_grandcanyon_channel_readme_example(gpu_ctx):
     # DEM (measured alone: 5 cells whose two best templates lie 1e-6 apart in the oracle's float64 SNRs, against 10
     # cells up to 7e-5 apart on the FFT path), and the cells THAT path decides inside its own rounding (~3 000) are
     # scored in float64 for all 181 templates (sc_score_cells_f64): every decidable cell carries the oracle's argmax
-    m = sl.Matcher(grid(z, dx, dy), ctx=gpu_ctx)
-    with pytest.warns(UserWarning, match="searching the whole DEM on the real-space path"):
-        res = m.search(sl.Channel, 10., [0.1], _plan.angle_grid(), method="fft", exact=True).result()
-    chk = fold_check(res, z, dx, dy, orc.RICKER, 10., [0.1], _plan.angle_grid(), "direct")
-    print("     exact=True:", m.exact_stats, m.method_used)
-    report("C5 grand canyon channel 1 x 181, exact=True", chk, "direct", max_inexact=0)
-    assert chk["n_bad"] == 0, chk
-    assert m.method_used == "direct" and m.exact_stats["flagged_cells"] > 0.1 * z.size and m.exact_stats["float64_cells"] > 0
+    # Round 5, end: the row pass LISTS its near-ties (sc_get_near_events) and only the (cell, template) pairs the list names
+    # are scored in float64 (sc_score_pairs_f64) - no second search; the longer route stays for lists that overflow.
+    for events in (False, True):
+        m = sl.Matcher(grid(z, dx, dy), ctx=gpu_ctx)
+        m.EXACT_USE_EVENTS = events
+        if events:
+            res = m.search(sl.Channel, 10., [0.1], _plan.angle_grid(), method="fft", exact=True).result()
+        else:
+            with pytest.warns(UserWarning, match="searching the whole DEM on the real-space path"):
+                res = m.search(sl.Channel, 10., [0.1], _plan.angle_grid(), method="fft", exact=True).result()
+        path = "fft" if events else "direct"                    # (the cells the mode did not touch keep that path's values)
+        chk = fold_check(res, z, dx, dy, orc.RICKER, 10., [0.1], _plan.angle_grid(), path)
+        print("     exact=True:", m.exact_stats, m.method_used)
+        report("C5 grand canyon channel 1 x 181, exact=True%s" % (" (events)" if events else ""), chk, path, max_inexact=0)
+        assert chk["n_bad"] == 0, chk
+        assert m.method_used == path and m.exact_stats["flagged_cells"] > 0.1 * z.size and m.exact_stats["float64_cells"] > 0
+        assert (m.exact_stats.get("route") == "events") == events, m.exact_stats
     res2 = sl.match(grid(z, dx, dy), sl.Channel, scale=10., age=0.1, ang_min=-np.pi / 2, ang_max=np.pi / 2, exact=True)
     # (the public keyword reaches the same path: the same (age, orientation) in every cell; the float64-scored cells'
     #  amplitudes and SNRs agree to 1e-12 - the templates' sum(W**2) is accumulated with float64 atomics, whose order
