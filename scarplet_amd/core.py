@@ -632,7 +632,7 @@ class Matcher(object):
     # in single cells of round 5's fuzz on supports of thousands of taps; 4e-5 on the tests' DEMs) - and how much float64
     # work is started at most
     EXACT_WINDOW_DIRECT = 2e-4
-    EXACT_MAX_F64 = 4e11                         # cells x templates x support-box cells
+    EXACT_MAX_F64 = 2e12                         # (cell, template) pairs x support-box cells (~3e11 a second; the C3 search: 4.8e11)
 
     def _score_float64(self, last, arr_main, bbox):
         """The cells the real-space path decided inside its own rounding: match_template() in float64 for every
