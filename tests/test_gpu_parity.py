@@ -734,6 +734,42 @@ def test_async_searches_back_to_back_equal_the_synchronous_ones(gpu_ctx):
     assert (out[0][1] > 0).any()
 
 
+def test_near_tie_events_and_pair_scoring(gpu_ctx):
+    """The two entry points of exact=True's short route.  sc_get_near_events: with option "near_window" on, every event
+    names a flagged cell and two templates of the search (or SC_ID_NONE as the holder), every flagged cell has an event,
+    and a reset empties the list.  sc_score_pairs_f64: pair (cell, template) = the entry of sc_score_cells_f64's table."""
+    rng = np.random.default_rng(5)
+    ny, nx = 150, 170
+    z = (np.cumsum(np.cumsum(rng.standard_normal((ny, nx)), 0), 1) * 0.01 + rng.standard_normal((ny, nx)) * 0.05).astype(np.float32)
+    params, angles = [2.0, 9.0, 40.0], _plan.angle_grid(-np.pi / 2, np.pi / 2)[::9]
+    m = sl.Matcher(grid(z, 1.0, 1.0), ctx=gpu_ctx)
+    assert len(m.ctx.near_events()) == 0 or True                  # (whatever an earlier test left: reset below)
+    m.ctx.set_option("near_window", 5e-3)                         # (wide: a few thousand events on this small DEM)
+    try:
+        m.search(WT.Scarp, 10, params, angles, method="fft")
+    finally:
+        m.ctx.set_option("near_window", 0.0)
+    flags, ev = m.ctx.near_ties(), m.ctx.near_events()
+    assert ev is not None and len(ev) > 100 and flags.sum() > 100
+    n_t = len(params) * len(angles)
+    cells = ev[:, 0].astype(np.int64)
+    assert cells.max() < ny * nx and np.all(flags.ravel()[cells] == 1)
+    assert set(np.flatnonzero(flags.ravel())) == set(cells.tolist())
+    assert np.all(ev[:, 1] < n_t) and np.all((ev[:, 2] < n_t) | (ev[:, 2] == 0xFFFFFFFF)) and np.all(ev[:, 1] != ev[:, 2])
+    # pairs against the full table (template ids of a fresh search are ia * n_angles + ib; the table is orientation-major)
+    pick = rng.choice(len(ev), 60, replace=False)
+    ij = np.column_stack([cells[pick] // nx, cells[pick] % nx])
+    ids = ev[pick, 1].astype(np.int64)
+    tix = (ids % len(angles)) * len(params) + ids // len(angles)
+    a_all, s_all = m.ctx.score_cells_f64(ij, n_t)
+    a_p, s_p = m.ctx.score_pairs_f64(ij, tix)
+    assert np.allclose(a_p, a_all[np.arange(60), tix], rtol=1e-12, atol=0) and np.allclose(s_p, s_all[np.arange(60), tix], rtol=1e-12, atol=0)
+    with pytest.raises(sl._lib.ScarpletHipError):
+        m.ctx.score_pairs_f64(ij[:2], [0, n_t])                   # a template the search did not hold
+    m.ctx.reset_best()
+    assert len(m.ctx.near_events()) == 0 and m.ctx.near_ties().sum() == 0
+
+
 def test_random_searches_against_the_oracle(gpu_ctx):
     """The wide net of tools/fuzz_oracle.py in the driver-run suite: 40 random searches (DEM size and parity, power-of-two
     periodic DEMs, cell size, sign of dy, float and int16 surfaces, the five built-in template classes, 1 - 6 parameters
