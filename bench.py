@@ -236,7 +236,7 @@ def cpu_baseline(pool, g, params, angles, max_workers=32):
 
 
 # ----------------------------------------------------------------------------- verification
-def verify_window(pool, res, g, kind, scale, params, angles, plan, method="fft"):
+def verify_window(pool, res, g, kind, scale, params, angles, plan, method="fft", also=None):
     """A window of the finished search against the oracle, every template of the
     grid (oracle.snr_stack_window + check_fold, tolerances oracle.PARITY).  The
     window straddles the corner where four FFT tiles meet when the plan is tiled."""
@@ -262,11 +262,19 @@ def verify_window(pool, res, g, kind, scale, params, angles, plan, method="fft")
                          np.tile(angles, len(params)), tie_rtol=orc.tie_window(method, kind),
                          amp_tol=(P["amp"][0], P["amp"][1] * np.max(np.abs(a_st))),
                          snr_tol=(P["snr"][0], P["snr"][1] * np.max(s_st)))
-    return {"ok": chk["n_bad"] == 0, "window": list(win), "templates": T, "cells": chk["n"], "bad": chk["n_bad"],
-            "cells_off_the_oracle_argmax": chk["n_inexact"], "cells_below_abs_tolerance": chk["n_below_only"],
-            "exact_argmax_frac": round(chk["exact_frac"], 6), "near_tie_cells": chk["n_tie"],
-            "max_rel_snr_err": float("%.3g" % chk["snr_err"]), "max_rel_amp_err": float("%.3g" % chk["amp_err"]),
-            "tie_rtol": orc.tie_window(method, kind), "oracle_s": round(time.time() - t0, 1)}
+    out = {"ok": chk["n_bad"] == 0, "window": list(win), "templates": T, "cells": chk["n"], "bad": chk["n_bad"],
+           "cells_off_the_oracle_argmax": chk["n_inexact"], "cells_below_abs_tolerance": chk["n_below_only"],
+           "exact_argmax_frac": round(chk["exact_frac"], 6), "near_tie_cells": chk["n_tie"],
+           "max_rel_snr_err": float("%.3g" % chk["snr_err"]), "max_rel_amp_err": float("%.3g" % chk["amp_err"]),
+           "tie_rtol": orc.tie_window(method, kind), "oracle_s": round(time.time() - t0, 1)}
+    if also is not None:                     # a second result on the same window and stacks (the exact mode's)
+        sub2 = tuple(np.asarray(r)[win[0]:win[1], win[2]:win[3]] for r in also)
+        chk2 = orc.check_fold(sub2, a_st.reshape(T, h, wd), s_st.reshape(T, h, wd), np.repeat(params, len(angles)),
+                              np.tile(angles, len(params)), tie_rtol=orc.tie_window(method, kind),
+                              amp_tol=(P["amp"][0], P["amp"][1] * np.max(np.abs(a_st))),
+                              snr_tol=(P["snr"][0], P["snr"][1] * np.max(s_st)))
+        out["also"] = {"bad": chk2["n_bad"], "cells_off_the_oracle_argmax": chk2["n_inexact"]}
+    return out
 
 
 def so_sha256():
@@ -291,6 +299,29 @@ def measured_traffic(default_workload):
         return t.get("bytes_per_launch", {})
     except Exception:
         return None
+
+
+def exact_leg(g, Template, scale, params, angles, device, method):
+    """sl.match(..., exact=True) on the workload: (result arrays, line entry) - the near-ties the float32 FFT path cannot
+    decide settled in float64 on the device (scarplet_amd.core).  Never costs the line: an error
+    is reported as such."""
+    import warnings
+    import scarplet_amd as sl
+    try:
+        mx = sl.Matcher(g, device=device)
+        t1 = time.perf_counter()
+        with warnings.catch_warnings(record=True) as wl:
+            warnings.simplefilter("always")
+            mx.search(Template, scale, params, angles, method=method, exact=True)
+            rx = mx.result()
+        dt = time.perf_counter() - t1
+        entry = {"seconds": round(dt, 3), "call": "Matcher(data).search(..., exact=True).result() - upload and planes outside",
+                 "stats": dict(getattr(mx, "exact_stats", {}))}
+        if wl:
+            entry["warnings"] = [str(w.message)[:200] for w in wl][:3]
+        return rx, entry
+    except Exception as e:
+        return None, {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 # ----------------------------------------------------------------------------- the other BASELINE configs
@@ -352,9 +383,14 @@ def other_config_line(a, cfg, steps, warmup, device, pool):
         line["end_to_end_ms"] = {"first_call": round(1e3 * secs[0], 2), "repeat_call": round(1e3 * secs[1], 2),
                                  "call": "sl.match(data, Template, scale=...)" if (len(params) == 1 or len(params) == 35)
                                          else "Matcher(data).search(...).result()"}
+    rx = None
+    if cfg == "C1F" and not a.no_e2e:
+        rx, line["exact_mode"] = exact_leg(g, Template, scales[0], params, angles, device, b.method)
     if pool is not None and not a.no_verify:
         res = m.ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
-        ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan, b.method)
+        ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan, b.method, also=rx)
+        if "also" in ver:
+            line["exact_mode"].update(ver.pop("also"))
         line["verified"] = ver["ok"]
         line["verification"] = {k: ver[k] for k in ("window", "templates", "cells", "bad", "cells_off_the_oracle_argmax",
                                                     "max_rel_snr_err", "note") if k in ver}
@@ -1069,16 +1105,21 @@ def main():
                                              "template descriptors, search, float64 (4,ny,nx) result conversion and D2H. "
                                              "seconds: the first call (fresh result pages); repeat_call_seconds: the "
                                              "same call again, result block recycled"}
+        rx = None
+        if default_workload and not a.no_e2e:
+            rx, out["exact_mode"] = exact_leg(g, Template, scales[0], params, angles, device, a.method)
         if not a.no_verify:
             # the result of the public call above; without it, the record the timed loop left behind
             # (the last scale's, for C5)
             if res is None:
                 res = ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
-            ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan, a.method)
+            ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan, a.method, also=rx)
+            if "also" in ver:
+                out["exact_mode"].update(ver.pop("also"))
             out["verified"] = ver["ok"]
             out["verification"] = ver
             out["verification"]["of"] = "the arrays sl.match returned" if "end_to_end" in out else "the timed loop's record"
-        del res
+        del res, rx
         if default_workload and not a.no_other_configs:
             # (after the end-to-end call: these load their own DEMs into the same context)
             oc = {}
