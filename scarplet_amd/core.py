@@ -608,8 +608,24 @@ class Matcher(object):
         ok = (tid >= 0) & (tid < len(idx_of) - 1)
         cell, tix = cell[ok], idx_of[np.where(ok, tid, 0)[ok]]
         ok = tix >= 0
-        key = np.unique(cell[ok] * n_t + tix[ok])
+        cell, tix = cell[ok], tix[ok]
+        # the grid's two end orientations are one template for the symmetric built-ins (_without_end_twin): the later one
+        # earlier one stands in for both, and a cell whose candidates are those two alone has nothing
+        # for float64 to decide (their SNRs differ by its rounding noise: one maximum by the parity policy)
+        n_par = len(params)
+        if len(self._without_end_twin(arr, n_par, angles)) != n_t:
+            tix = np.where(tix >= n_t - n_par, tix - (n_t - n_par), tix)
+        key = np.unique(cell * n_t + tix)
         cell, tix = key // n_t, key % n_t
+        several = np.ones(len(cell), dtype=bool)
+        if len(cell):
+            same_prev = np.concatenate([[False], cell[1:] == cell[:-1]])
+            same_next = np.concatenate([cell[1:] == cell[:-1], [False]])
+            several = same_prev | same_next
+        key, cell, tix = key[several], cell[several], tix[several]
+        if not len(key):                                 # (every flagged cell held the two end twins alone)
+            self.exact_stats.update(float64_cells=0, float64_pairs=0, events=int(len(ev)), route="events")
+            return True
         box = (bbox[1] - bbox[0] + 1) * (bbox[3] - bbox[2] + 1)
         if float(len(key)) * box > self.EXACT_MAX_F64:
             return False
