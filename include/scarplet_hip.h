@@ -324,9 +324,10 @@ int sc_get_resolution_stats(sc_ctx* ctx, long long* wins, long long* near_floor)
  * (either side of it; equal scores included since ABI 7).  A float32 FFT convolution carries an SNR error of up to half the
  * path's tie window (scarplet_amd: oracle-measured): between two templates closer than
  * that, which one the record holds is rounding noise.  The real-space path flags the same way with the option on - and
- * equal scores as well (its per-cell float32 sums can give two templates a rounding apart the same bits).  scarplet_amd.match(..., exact=True) reads the flags and
- * re-scores those cells on the real-space path (exact per cell): the argmax of every cell is then the float64
- * reference's.  All zero when the option is 0 (the default: the flag costs the row pass ~10 %). */
+ * equal scores as well (its per-cell float32 sums can give two templates a rounding apart the same bits).
+ * scarplet_amd.match(..., exact=True) settles the flagged cells in float64 (sc_get_near_events + sc_score_pairs_f64;
+ * or, where the event list overflowed, a real-space search of them + sc_score_cells_f64): the argmax of every cell
+ * is then the float64 reference's.  All zero when the option is 0 (the default: flags and events cost the row pass 13 %). */
 int sc_get_near_ties(sc_ctx* ctx, uint8_t* out);
 
 /* match_template() at single cells in FLOAT64 - core.py:297-377 as the real-space closed form, the template

@@ -388,7 +388,7 @@ class Matcher(object):
         (cell, template) pairs are scored in float64 on the device (_settle_by_events).  Where the list overflows, or the
         search runs on the real-space path, the longer route: that path's own flags, every template in float64 for its
         flagged cells (_rescore_near_ties, _direct_exact).  The marked cells of ``result()`` carry the float64 answer;
-        the device record itself keeps the float32 one.  Cost: ~25 % on the row pass plus the pairs (C3: 3.4 -> 5.7 s)."""
+        the device record itself keeps the float32 one.  Cost: 13 % on the row pass plus the pairs (C3: 3.2 -> 5 s)."""
         params = np.atleast_1d(np.asarray(params, dtype=float))
         angles = np.atleast_1d(np.asarray(angles, dtype=float))
         self._patches = []

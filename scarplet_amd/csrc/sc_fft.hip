@@ -2392,6 +2392,12 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
 #define SC_I2_GRP 8         // output pairs per record branch of the row pass (SC_I2_RAREWIN); 4, 2, 1: the 2048 kernel spills 44 - 92 B
 #endif
 #ifndef SC_I2_RAREWIN
+#ifndef SC_I2_NEAR_WAVES
+#define SC_I2_NEAR_WAVES 3  // waves per SIMD the near-tie variant is compiled for
+#endif
+#ifndef SC_I2_NEAR_RARE
+#define SC_I2_NEAR_RARE 1   // the near-tie variant of the row pass on the deferred record update too (0: selects and a test per output)
+#endif
 #ifndef SC_I2_RARE512
 #define SC_I2_RARE512 1     // the deferred record update in the 512-cell row kernels too (round 5, end: row pass of the small grids -4.5 %; 0: selects)
 #endif
@@ -2435,7 +2441,7 @@ __host__ __device__ constexpr size_t inv_rows_fast_lds_split() {
 #define SC_I2_WAVES_FULL 3
 #endif
 template <int TX, bool FULL, bool MAPS, bool PT, bool SPLITK = false, bool NEAR = false>
-__global__ void __launch_bounds__(inv_rows_fast_threads<TX>(), ((FULL && !MAPS) || NEAR) ? SC_I2_WAVES_FULL : SC_I2_WAVES)
+__global__ void __launch_bounds__(inv_rows_fast_threads<TX>(), NEAR ? SC_I2_NEAR_WAVES : (FULL && !MAPS) ? SC_I2_WAVES_FULL : SC_I2_WAVES)
 k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 RowArgs ra, Geom g, const TileDev* __restrict__ tiles,
                 const TemplDev* __restrict__ templ, const double* __restrict__ sums,
@@ -2765,6 +2771,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             covers[part] = !row_of(part) || (r && lo == 0 && hi == t.vx - 1);
         }
         const bool all_in = SC_I2_STATIC && !FULL && !MAPS && covers[0] && covers[1];     // workgroup-uniform
+        const float near_lo = NEAR ? 1.f - 1.0001f * ra.near_w - 2e-7f : 1.f;             // (NEAR, deferred form: candidates score above the record times this)
         auto stage3 = [&](auto static_tag) {
         constexpr bool STATIC = decltype(static_tag)::value;
 #pragma unroll
@@ -2780,8 +2787,8 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             // (RARE: every row length since the end of round 5.  The 512-cell kernels kept the selects while the deferred form
             //  cost them a scratch reload inside the template loop; it no longer does - 16 B outside the loop in the dealt-out
             //  form - and their row pass is 4.5 % faster with it: C1F 35.2 -> 34.9 ms, profiles/r05_launch_forms.txt)
-            // (NEAR compares every score with the record as it stands: no deferred update)
-            constexpr bool RARE = SC_I2_RAREWIN && (TX >= 1024 || SC_I2_RARE512) && !NEAR;
+            // (NEAR, SC_I2_NEAR_RARE: the branch also stands for the near-ties - a score above the record LESS the window)
+            constexpr bool RARE = SC_I2_RAREWIN && (TX >= 1024 || SC_I2_RARE512) && (!NEAR || SC_I2_NEAR_RARE);
             // (GRP outputs pairs per branch: the fewer cells a branch stands for, the more rarely it is taken)
             constexpr int GRP = (RARE && SC_I2_GRP < R3) ? SC_I2_GRP : R3;
 #pragma unroll
@@ -2828,7 +2835,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                         // sc_fold: take if greater, ties keep the incumbent; a cell outside
                         // the range (lean variant) or masked to 0 never wins
                         const bool won = (FULL || in) && snr > b_snr[k];
-                        if constexpr (NEAR) {
+                        if constexpr (NEAR && !RARE) {
                             // a score within the window of the running best, either side of it - EQUAL scores included since the
                             // end of round 5: two templates proportional to each other on a degenerate support (a Ricker window two
                             // cells wide) score the same bits and differ at 1e-8 in float64; the grid's end twins (-pi/2, +pi/2: one
@@ -2849,9 +2856,11 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                             }
                         }
                         if constexpr (RARE) {
-                            wonm[m - m0][part] = won;
+                            // (NEAR: a candidate - a win, or a score inside the window below the record; near_lo = 1 - near_w less a hair)
+                            const bool cand = NEAR ? (in && snr > b_snr[k] * near_lo) : won;
+                            wonm[m - m0][part] = cand;
                             snrs[m - m0][part] = snr;
-                            anyw = anyw || won;
+                            anyw = anyw || cand;
                         } else {
                             b_snr[k] = won ? snr : b_snr[k];
                             b_xr[k] = won ? xr : b_xr[k];
@@ -2875,6 +2884,24 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                     for (int part = 0; part < 2; ++part) {
                         const int k = best_of(u * R3 + m, part);
                         const float snr = snrs[m - m0][part];
+                        if constexpr (NEAR) {
+                            // the near-tie test of the select form on the candidates (all of them inside the cell's range), against
+                            // the record as it stands now - where two templates ride one transform the second meets the first's update
+                            const float top = fmaxf(snr, b_snr[k]);
+                            const bool nt = wonm[m - m0][part] && snr > 0.f && fabsf(snr - b_snr[k]) <= ra.near_w * top;
+                            nearm |= nt ? (1u << k) : 0u;
+                            if (nt && ra.ev) {
+                                const unsigned long long slot = atomicAdd(ra.ev_count, 1ull);
+                                if (slot < ra.ev_cap) {
+                                    const int cj = col_of(u * R3 + m);
+                                    const uint32_t hx = (b_ix[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                                    uint32_t* e = ra.ev + 3 * slot;
+                                    e[0] = (uint32_t)(off_of(part) + (size_t)cj);
+                                    e[1] = tpp[part]->id;
+                                    e[2] = hx != 0xFFu ? templ[ra.first + hx].id : at_bytes(best_id + off_of(part), 4u * (uint32_t)cj);
+                                }
+                            }
+                        }
                         const bool won = wonm[m - m0][part] && snr > b_snr[k];
                         b_snr[k] = won ? snr : b_snr[k];
                         b_xr[k] = won ? (part ? xc.y : xc.x) : b_xr[k];
