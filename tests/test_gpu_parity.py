@@ -775,7 +775,7 @@ def test_random_searches_against_the_oracle(gpu_ctx):
     periodic DEMs, cell size, sign of dy, float and int16 surfaces, the five built-in template classes, 1 - 6 parameters
     x 1 - 7 orientations incl. the -pi/2, 0, +pi/2 windows) through the FFT path, the real-space path, method="auto" and
     exact=True against the oracle: NO cell outside oracle.PARITY on any path, and with exact=True no cell whose
-    (age, angle) is not the oracle's own argmax.  (370 searches of the same generator: profiles/r05_fuzz_oracle.txt.)"""
+    (age, angle) is not the oracle's own argmax.  (970 searches of the same generator: profiles/r05_fuzz_oracle.txt.)"""
     kinds = {WT.Scarp: orc.SCARP, WT.Ricker: orc.RICKER, WT.Channel: orc.RICKER,
              WT.RightFacingUpperBreakScarp: "right_upper_break", WT.LeftFacingUpperBreakScarp: "left_upper_break"}
     classes = [WT.Scarp, WT.Scarp, WT.Channel, WT.Ricker, WT.LeftFacingUpperBreakScarp, WT.RightFacingUpperBreakScarp]
