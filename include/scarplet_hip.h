@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 7
+#define SC_ABI_VERSION 8
 
 #define SC_OK               0
 #define SC_ERR_INVALID     -1   /* bad argument                                */
@@ -102,7 +102,7 @@ typedef struct sc_plan {
 /* ---- lifetime ---------------------------------------------------------- */
 int  sc_abi_version(void);
 /* Which sources this binary was compiled from: the first 16 hex digits of the SHA-256 over the
- * library's sources (the four .hip files of csrc, sc_internal.h, this header) in the Makefile's order, worked out
+ * library's sources (the five .hip files of csrc, sc_internal.h, this header) in the Makefile's order, worked out
  * at build time - `make -C scarplet_amd/csrc print-build-id` prints the same string for the tree
  * at hand.  bench.py prints it in every line and __graft_entry__.build() compares the two: a
  * stale prebuilt binary is visible instead of silently benchmarked. */
@@ -353,6 +353,28 @@ int sc_get_near_events(sc_ctx* ctx, uint32_t* events, long long capacity, long l
 /* sc_score_cells_f64 for (cell, template) PAIRS: pair k = global cell (cells[2k], cells[2k+1]) against template
  * templates[k] of the last sc_match in this context (its index in hand-over order); amp, snr = m doubles each. */
 int sc_score_pairs_f64(sc_ctx* ctx, const int32_t* cells, const int32_t* templates, int m, double* amp, double* snr);
+
+/*
+ * exact=True on the device (round 6, ABI 8): the reference's fold is an argmax over float64 SNR maps (compare(),
+ * core.py:230-240); this call makes the record's (age, orientation) of every near-tie cell that argmax.  After an sc_match
+ * with option "near_window" on (either path lists its near-ties since ABI 8): the flagged cells become slots in cell
+ * order, every cell's candidates - the record's final holder and the templates its events name - become a list, exactly
+ * those (cell, template) pairs are scored in float64 (sc_score_pairs_f64's arithmetic, one workgroup per pair; a template
+ * named twice in a list, or a list of one template, is not scored), and every cell takes the largest float64 SNR, ties to
+ * the earlier template of the hand-over order.  The winner's id goes into the record (amp and snr rounded to float32: what
+ * sc_get_best, sc_gather_result and sc_fold_ranks then see) and its float64 (amp, snr) are kept as patches that
+ * sc_get_result lays over the converted planes - until the next sc_match or sc_reset_best.  No host pass over the planes:
+ * three 8-byte read-backs size the buffers.
+ *   n_twin    the last n_twin templates of the search stand for its first n_twin (the orientation grid's two ends are one
+ *             template for the symmetric built-ins: +pi/2 against -pi/2, core.py:173-175 - their float64 SNRs differ by
+ *             rounding noise, one maximum by the parity policy); 0: none.  A cell whose winner is the template the record
+ *             names (or its twin) keeps the record's id
+ *   max_work  > 0: nothing is scored when pairs x the largest support box exceeds it (SC_ERR_UNSUPPORTED)
+ *   stats     8 values: flagged cells, pairs listed, pairs scored, cells scored, cells whose template changed, events, 0, 0
+ * SC_ERR_UNSUPPORTED also when the event list overflowed (the caller takes a longer route: sc_get_near_ties +
+ * sc_score_cells_f64) and for templates with host-uploaded windows.
+ */
+int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long long* stats);
 
 /* Per-template scalars of the last sc_match / sc_match_template call:
  * n = count(W != 0) + eps (core.py:350) and sum(W**2) (core.py:356). */

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCARPLET_HIP_LIB") or os.path.join(_HERE, "libscarplet_hip.so")
 
 SC_OK = 0
-ABI_VERSION = 7
+ABI_VERSION = 8
 ID_NONE = 0xFFFFFFFF
 COMM_ID_BYTES = 128
 
@@ -106,6 +106,7 @@ SIGNATURES = {
     "sc_score_cells_f64": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, _dp, _dp]),
     "sc_get_near_events": (C.c_int, [_P, _up, C.c_longlong, C.POINTER(C.c_longlong)]),
     "sc_score_pairs_f64": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, _dp, _dp]),
+    "sc_settle_exact": (C.c_int, [_P, C.c_int, C.c_double, C.POINTER(C.c_longlong)]),
     "sc_get_resolution_stats": (C.c_int, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "sc_get_template_sums": (C.c_int, [_P, C.c_int, _dp, _dp]),
     "sc_profile": (C.c_int, [_P, C.c_int]),
@@ -441,6 +442,14 @@ class Context(object):
         self._check(self.lib.sc_score_pairs_f64(self._h, cells.ctypes.data_as(i32), templates.ctypes.data_as(i32), m,
                                                 _as(amp, _dp), _as(snr, _dp)), "sc_score_pairs_f64")
         return amp, snr
+
+    def settle_exact(self, n_twin=0, max_work=0.0):
+        """exact=True on the device (sc_settle_exact): the near-tie cells of the last search (option "near_window") take
+        their float64 argmax among the templates their events name.  Returns the counters as a dict."""
+        st = (C.c_longlong * 8)()
+        self._check(self.lib.sc_settle_exact(self._h, int(n_twin), float(max_work), st), "sc_settle_exact")
+        return {"flagged_cells": int(st[0]), "pairs_listed": int(st[1]), "float64_pairs": int(st[2]),
+                "float64_cells": int(st[3]), "changed_cells": int(st[4]), "events": int(st[5])}
 
     def comm_destroy(self):
         """Drop this context's RCCL communicator (sc_comm_destroy); nothing to do without one."""

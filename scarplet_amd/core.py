@@ -380,15 +380,15 @@ class Matcher(object):
                group=None, reset=True, sync=True, exact=False, **kwargs):
         """Fold every (param, angle) template into the running best.
 
-        ``exact=True``: the argmax of EVERY cell is the float64 reference's.  The FFT path is exact in (age,
-        orientation) except where two templates score closer together than its float32 convolution resolves - a handful
-        of cells per million on a DEM with a noise floor (11 of 262 144 on the int16 Grand Canyon DEM).  With the flag on,
-        the row pass marks the cells where some template came within EXACT_WINDOW of the running best and lists which
-        (sc_get_near_events); the float64 argmax of a marked cell can only be among those templates, and exactly those
-        (cell, template) pairs are scored in float64 on the device (_settle_by_events).  Where the list overflows, or the
-        search runs on the real-space path, the longer route: that path's own flags, every template in float64 for its
-        flagged cells (_rescore_near_ties, _direct_exact).  The marked cells of ``result()`` carry the float64 answer;
-        the device record itself keeps the float32 one.  Cost: 13 % on the row pass plus the pairs (C3: 3.2 -> 5 s)."""
+        ``exact=True``: the argmax of EVERY cell is the float64 reference's.  The float32 paths are exact in (age,
+        orientation) except where two templates score closer together than their arithmetic resolves - a handful of
+        cells per million on a DEM with a noise floor (11 of 262 144 on the int16 Grand Canyon DEM, 502 of 1e8 on the
+        benchmark DEM).  With the flag on, the search marks the cells where some template came within EXACT_WINDOW of the
+        running best and lists which; the float64 argmax of a marked cell can only be among those templates, and exactly
+        those (cell, template) pairs are scored in float64 on the device, which also picks the winner and writes it into
+        the record (_search_exact, sc_settle_exact).  ``exact=None``: on for the built-in template classes, off for
+        plugins whose windows the host uploads (no float64 form on the device).  Cost: 13 % on the row pass plus the
+        pairs."""
         params = np.atleast_1d(np.asarray(params, dtype=float))
         angles = np.atleast_1d(np.asarray(angles, dtype=float))
         self._patches = []
@@ -414,37 +414,20 @@ class Matcher(object):
         if sync and reset:
             from scarplet_amd import _hostpool
             pre = _hostpool.prefault((4, self.core[1] - self.core[0], self.core[3] - self.core[2]))
-        flagged = False
-        direct_last = None
+        if exact is None:
+            exact = bool(reset and sync and len(arr) and all(int(arr[k].kind) != _WT.KIND_WINDOW for k in (0, len(arr) - 1)))
         if exact:
+            if not (reset and sync):
+                raise ValueError("exact=True needs reset=True and sync=True")
             self.exact_stats = {"flagged_cells": 0, "patches": 0, "changed_cells": 0, "float64_cells": 0}
-        if exact and sp.method == _plan.METHOD_FFT:
-            if not (reset and sync and self.whole):
-                raise ValueError("exact=True needs reset=True, sync=True and a whole-DEM matcher")
-            kinds = {int(t.kind) for t in arr[:1]} | {int(arr[len(arr) - 1].kind)}
-            win = max(self.EXACT_WINDOW.get(k, max(self.EXACT_WINDOW.values())) for k in kinds)
-            self.ctx.set_option("near_window", win)
-            try:
-                self.ctx.match(arr, sp, sync=True)
-                flagged = True
-            except _lib.ScarpletHipError as e:
-                # per-cell masks (generic plugins, UpperBreak error masks) or a tile size the flagging row
-                # kernel is not built for: the whole search on the exact path instead
-                if "near-tie flags" not in str(e):
-                    raise
-                self.ctx.set_option("near_window", 0.0)
-                self.plan, sp = self.plan_for(bbox, max_area, "direct", group, n_params=len(params))
-                arr = self._without_end_twin(arr, len(params), angles)
-                direct_last = self._direct_exact(arr, sp)
-            finally:
-                self.ctx.set_option("near_window", 0.0)
-        elif exact and reset and sync and self.whole:
-            # the real-space path was chosen (by name, or by `auto` for a small support): exact per cell up to ITS float32
-            # rounding - the cells it decides inside that are settled in float64 like the third step of the FFT route
-            arr = self._without_end_twin(arr, len(params), angles)
-            direct_last = self._direct_exact(arr, sp)
-        else:
-            self.ctx.match(arr, sp, sync=sync)
+            self._search_exact(arr, sp, bbox, max_area, method, group, Template, scale, params, angles, kwargs)
+            del pre
+            self.params, self.angles = params, angles
+            self.n_templates = len(arr)
+            self._id_par = np.concatenate([self._id_par, np.repeat(params, len(angles))])
+            self._id_ang = np.concatenate([self._id_ang, np.tile(angles, len(params))])
+            return self
+        self.ctx.match(arr, sp, sync=sync)
         # (not joined: a search shorter than the touching finds the block still referenced by the thread and takes a
         #  fresh one, as before - never slower than without)
         del pre
@@ -452,25 +435,104 @@ class Matcher(object):
         if method == "auto" and reset and sync and self.method_used == "fft":
             self._exact_path_if_unresolved(arr, bbox, max_area, group, len(params))
         elif method == "fft" and reset and sync:
-            # the FFT path was asked for by name: it is handed out as it is, but not silently where
-            # the device's own statistic says it cannot resolve this surface in float32
-            wins, near = self.ctx.resolution_stats()
-            self.unresolved_frac = near / wins if wins else 0.0
-            if self.unresolved_frac > self.UNRESOLVED_MAX:
-                import warnings
-                warnings.warn("method='fft': %.1f %% of the cells this search won lie within the float32 "
-                              "resolution floor of the FFT convolution (a surface without a noise floor of its "
-                              "own); their argmax is rounding noise - method='auto' or 'direct' gives the exact "
-                              "real-space answer" % (100 * self.unresolved_frac))
+            self._warn_if_unresolved()
         self.params, self.angles = params, angles
         self.n_templates = len(arr)
         self._id_par = np.concatenate([self._id_par, np.repeat(params, len(angles))])
         self._id_ang = np.concatenate([self._id_ang, np.tile(angles, len(params))])
-        if flagged and self.method_used == "fft":
-            self._rescore_near_ties(Template, scale, params, angles, kwargs)
-        elif direct_last is not None:
-            self._score_float64(direct_last, arr, bbox)
         return self
+
+    def _warn_if_unresolved(self):
+        """The FFT path was asked for by name: it is handed out as it is, but not silently where the device's own
+        statistic says it cannot resolve this surface in float32."""
+        wins, near = self.ctx.resolution_stats()
+        self.unresolved_frac = near / wins if wins else 0.0
+        if self.unresolved_frac > self.UNRESOLVED_MAX:
+            import warnings
+            warnings.warn("method='fft': %.1f %% of the cells this search won lie within the float32 "
+                          "resolution floor of the FFT convolution (a surface without a noise floor of its "
+                          "own); their argmax is rounding noise - method='auto' or 'direct' gives the exact "
+                          "real-space answer" % (100 * self.unresolved_frac))
+
+    def _search_exact(self, arr, sp, bbox, max_area, method, group, Template, scale, params, angles, kwargs):
+        """exact=True (round 6: settled on the device).  The search runs with option "near_window" on - either path then
+        flags its near-ties and lists them as events (cell, template scored, holder of the record) - and sc_settle_exact
+        scores exactly the (cell, template) pairs those events name in float64 and gives every flagged cell its float64
+        argmax: the record's (age, orientation) becomes the reference's (compare(), core.py:230-240, folds float64 maps),
+        the float64 (amp, snr) ride along as patches under the result.  No host pass over the planes.
+
+        Which path: the FFT tiles where the planner chose them and the row kernel can flag (no per-cell masks); the
+        real-space path otherwise - by name, by `auto` for a small support, for UpperBreak's error masks, or because the
+        device's own statistic says the FFT convolution cannot resolve this surface in float32 (method="auto", as without
+        the mode).  A list that overflows, or more float64 work than EXACT_MAX_F64, takes the longer routes of round 5."""
+        import warnings
+        n_par = len(params)
+        n_twin = len(arr) - len(self._without_end_twin(arr, n_par, angles))
+        kinds = {int(arr[0].kind), int(arr[len(arr) - 1].kind)}
+        win_fft = max(self.EXACT_WINDOW.get(k, max(self.EXACT_WINDOW.values())) for k in kinds)
+        fft = sp.method == _plan.METHOD_FFT
+        try:
+            if fft:
+                self.ctx.set_option("near_window", win_fft)
+                try:
+                    self.ctx.match(arr, sp, sync=True)
+                except _lib.ScarpletHipError as e:
+                    # per-cell masks (generic plugins, UpperBreak error masks) or a tile size the flagging row kernel is
+                    # not built for: the whole search on the real-space path instead
+                    if "near-tie flags" not in str(e):
+                        raise
+                    fft = False
+                if fft and method == "auto":
+                    wins, near = self.ctx.resolution_stats()
+                    self.unresolved_frac = near / wins if wins else 0.0
+                    if self.unresolved_frac > self.UNRESOLVED_MAX:
+                        note = ("the FFT path cannot resolve %.1f %% of this surface's cells in float32 (no noise floor "
+                                "of its own)" % (100 * self.unresolved_frac))
+                        ww = bbox[3] - bbox[2] + 1
+                        n_cells = (self.core[1] - self.core[0]) * (self.core[3] - self.core[2])
+                        if not _plan.direct_window_fits(ww) or \
+                                _plan.direct_cost(max_area) > 100 * _plan.fft_cost(self.plan, n_cells, n_par):
+                            warnings.warn(note + "; method='direct' is exact but much slower here - not taken automatically")
+                        else:
+                            warnings.warn(note + ": searched again on the exact real-space path")
+                            fft = False
+                elif fft and method == "fft":
+                    self._warn_if_unresolved()
+                if not fft:
+                    self.plan, sp = self.plan_for(bbox, max_area, "direct", group, n_params=n_par)
+                    self.ctx.reset_best()
+            if not fft:
+                self.ctx.set_option("near_window", self.EXACT_WINDOW_DIRECT)
+                self.ctx.match(arr, sp, sync=True)
+        finally:
+            self.ctx.set_option("near_window", 0.0)
+        self.method_used = "fft" if fft else "direct"
+        if self.EXACT_USE_EVENTS:
+            try:
+                st = self.ctx.settle_exact(n_twin, self.EXACT_MAX_F64)
+                self.exact_stats.update(st, route="device")
+                return
+            except _lib.ScarpletHipError as e:
+                msg = str(e)
+                if "built-in templates only" in msg:
+                    warnings.warn("exact=True: a plugin's window exists in float32 on the device only - the float32 result "
+                                  "stands (the built-in template classes are settled in float64)")
+                    self.exact_stats["skipped"] = True
+                    return
+                if "overflowed" not in msg and "too much float64 work" not in msg:
+                    raise
+                self.exact_stats["settle"] = msg
+        # the longer routes (round 5): host lists
+        if not self.whole:
+            warnings.warn("exact=True: the near-ties of this block were not settled (%s)" % self.exact_stats.get("settle", "host route off"))
+            self.exact_stats["skipped"] = True
+            return
+        if fft:
+            self._rescore_near_ties(Template, scale, params, angles, kwargs)
+        else:
+            last = [tuple(c) for c in np.argwhere(self.ctx.near_ties())]
+            self.exact_stats["flagged_cells"] = len(last)
+            self._score_float64([(i + self.core[0], j + self.core[2]) for i, j in last], arr, bbox)
 
     @staticmethod
     def _without_end_twin(arr, n_params, angles):
@@ -514,8 +576,6 @@ class Matcher(object):
         self.exact_stats = {"flagged_cells": int(len(cells)), "patches": 0, "changed_cells": 0, "float64_cells": 0}
         self._cells64 = None
         if not len(cells):
-            return
-        if self._settle_by_events(flags, Template, scale, params, angles, kwargs):
             return
         ph, pw = self.EXACT_PATCH
         todo = sorted({(int(i) // ph, int(j) // pw) for i, j in cells})
@@ -580,70 +640,7 @@ class Matcher(object):
                 aux.ctx.clear_windows()
         self._score_float64(last, arr_main, bbox)
 
-    EXACT_USE_EVENTS = True                      # (False: always the longer route - tests, comparisons)
-
-    def _settle_by_events(self, flags, Template, scale, params, angles, kwargs):
-        """exact=True, the short route (round 5, end): the row pass also LISTS its near-ties - (cell, template scored,
-        holder of the record at that moment) - and the float64 argmax of a flagged cell can only be the record's final
-        holder or a template one of its events names (a template further below the record than the window is below it
-        in float64 too: the window is twice the path's error).  Exactly those (cell, template) pairs are scored in
-        float64 on the device (sc_score_pairs_f64) and the cell takes their argmax in fold order: no second search at
-        all.  False - the longer route through the real-space path follows - where the list overflowed, the pairs
-        would be more float64 work than EXACT_MAX_F64, or the scorer does not serve the templates."""
-        if not self.EXACT_USE_EVENTS:
-            return False
-        ev = self.ctx.near_events()
-        if ev is None:
-            return False
-        arr, bbox, _ = self.describe(Template, scale, params, angles, **kwargs)
-        n_t = len(arr)
-        ids_of = np.fromiter((int(arr[k].id) for k in range(n_t)), dtype=np.int64, count=n_t)
-        idx_of = np.full(int(ids_of.max()) + 2, -1, dtype=np.int64)
-        idx_of[ids_of] = np.arange(n_t)
-        h, w = flags.shape
-        _, _, best_id = self.ctx.get_best()
-        fl = np.flatnonzero(flags.ravel()).astype(np.int64)
-        cell = np.concatenate([ev[:, 0].astype(np.int64), ev[:, 0].astype(np.int64), fl])
-        tid = np.concatenate([ev[:, 1].astype(np.int64), ev[:, 2].astype(np.int64), best_id.ravel()[fl].astype(np.int64)])
-        ok = (tid >= 0) & (tid < len(idx_of) - 1)
-        cell, tix = cell[ok], idx_of[np.where(ok, tid, 0)[ok]]
-        ok = tix >= 0
-        cell, tix = cell[ok], tix[ok]
-        # the grid's two end orientations are one template for the symmetric built-ins (_without_end_twin): the later one
-        # earlier one stands in for both, and a cell whose candidates are those two alone has nothing
-        # for float64 to decide (their SNRs differ by its rounding noise: one maximum by the parity policy)
-        n_par = len(params)
-        if len(self._without_end_twin(arr, n_par, angles)) != n_t:
-            tix = np.where(tix >= n_t - n_par, tix - (n_t - n_par), tix)
-        key = np.unique(cell * n_t + tix)
-        cell, tix = key // n_t, key % n_t
-        several = np.ones(len(cell), dtype=bool)
-        if len(cell):
-            same_prev = np.concatenate([[False], cell[1:] == cell[:-1]])
-            same_next = np.concatenate([cell[1:] == cell[:-1], [False]])
-            several = same_prev | same_next
-        key, cell, tix = key[several], cell[several], tix[several]
-        if not len(key):                                 # (every flagged cell held the two end twins alone)
-            self.exact_stats.update(float64_cells=0, float64_pairs=0, events=int(len(ev)), route="events")
-            return True
-        box = (bbox[1] - bbox[0] + 1) * (bbox[3] - bbox[2] + 1)
-        if float(len(key)) * box > self.EXACT_MAX_F64:
-            return False
-        gi, gj = cell // w + self.core[0], cell % w + self.core[2]
-        try:
-            amp, snr = self.ctx.score_pairs_f64(np.column_stack([gi, gj]), tix)
-        except _lib.ScarpletHipError as e:
-            if "built-in templates only" in str(e):
-                return False
-            raise
-        # per cell the largest float64 SNR, ties to the earlier template of the fold order (the hand-over order)
-        order = np.lexsort((tix, -snr, cell))
-        first = np.ones(len(order), dtype=bool)
-        first[1:] = cell[order][1:] != cell[order][:-1]
-        win = order[first]
-        self._cells64 = (gi[win] - self.core[0], gj[win] - self.core[2], amp[win], snr[win], ids_of[tix[win]])
-        self.exact_stats.update(float64_cells=int(len(win)), float64_pairs=int(len(key)), events=int(len(ev)), route="events")
-        return True
+    EXACT_USE_EVENTS = True                      # (False: always the longer, host-side routes - tests, comparisons)
 
     # exact=True, third step: window of the real-space path's near-tie flags - twice its largest measured SNR error (1.0e-4
     # in single cells of round 5's fuzz on supports of thousands of taps; 4e-5 on the tests' DEMs) - and how much float64
@@ -808,7 +805,7 @@ def calculate_best_fit_parameters(dem, Template, scale, age,
     are accepted but not forwarded to the template (core.py:145, 182)."""
     device = kwargs.pop("device", 0)
     method = kwargs.pop("method", "auto")
-    exact = kwargs.pop("exact", False)
+    exact = kwargs.pop("exact", None)
     m = Matcher(dem, device=device)
     try:
         m.search(Template, scale, [age], _plan.angle_grid(ang_min, ang_max),
@@ -826,7 +823,7 @@ def calculate_best_fit_parameters_serial(dem, Template, scale,
     (best_amp, best_age, best_angle, best_snr)."""
     device = kwargs.pop("device", 0)
     method = kwargs.pop("method", "auto")
-    exact = kwargs.pop("exact", False)
+    exact = kwargs.pop("exact", None)
     m = Matcher(dem, device=device)
     try:
         m.search(Template, scale, _plan.age_grid(),
@@ -857,10 +854,11 @@ def match(data, Template, **kwargs):
     grid 10**arange(0, 3.5, 0.1), returns the 4-tuple (amp, age, angle, snr).
     Keyword arguments: ``scale``, ``age``, ``ang_max``, ``ang_min`` as in the
     reference, plus ``device=`` (GPU ordinal), ``method=`` ('auto', 'fft',
-    'direct'), ``ages=`` (override the age grid), ``exact=`` (True: every cell's
-    (age, orientation) is the float64 reference's argmax - the cells where the
-    FFT path saw a near-tie are searched again on the real-space path,
-    Matcher.search) and ``fold=``:
+    'direct'), ``ages=`` (override the age grid), ``exact=`` (default: on for
+    the built-in template classes - every cell's (age, orientation) is the
+    float64 reference's argmax: the near-ties of the float32 search are scored
+    in float64 on the device, Matcher.search; ``exact=False``: the float32
+    search as it is, 5 - 10 % faster) and ``fold=``:
 
     ``fold="fused"`` (default): ONE device search, the running best folded in
     the kernels - ties keep the incumbent, orientation-major order.
@@ -895,7 +893,7 @@ def match(data, Template, **kwargs):
         return calculate_best_fit_parameters(data, Template, **kwargs)
     device = kwargs.pop("device", 0)
     method = kwargs.pop("method", "auto")
-    exact = kwargs.pop("exact", False)
+    exact = kwargs.pop("exact", None)
     ages = kwargs.pop("ages", None)
     scale = kwargs.pop("scale")
     ang_max = kwargs.pop("ang_max", np.pi / 2)

@@ -46,7 +46,7 @@ size_t sc_total_bytes(sc_ctx* c) {
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->norm_part, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
                      &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats, &c->digest, &c->split_s, &c->split_a, &c->split_i,
-                     &c->near, &c->near_ev, &c->score, &c->score_w, &c->score_abc};
+                     &c->near, &c->near_ev, &c->score, &c->score_w, &c->score_abc, &c->st_slot, &c->st_work, &c->st_pairs, &c->st_patch};
     size_t s = 0;
     for (DevBuf* b : arr) s += b->cap;
     for (auto& w : c->windows) s += (size_t)w.h * w.wd * 5;
@@ -224,7 +224,7 @@ extern "C" void sc_destroy(sc_ctx* c) {
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->norm_part, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
                      &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats, &c->digest, &c->split_s, &c->split_a, &c->split_i,
-                     &c->near, &c->near_ev, &c->score, &c->score_w, &c->score_abc};
+                     &c->near, &c->near_ev, &c->score, &c->score_w, &c->score_abc, &c->st_slot, &c->st_work, &c->st_pairs, &c->st_patch};
     for (DevBuf* b : arr) buf_free(*b);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp[k]);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp_in[k]);
@@ -471,6 +471,24 @@ extern "C" int sc_reset_best(sc_ctx* ctx) {
     SC_HIP(ctx, hipGetLastError());
     if (ctx->near.p) SC_HIP(ctx, hipMemsetAsync(ctx->near.p, 0, ctx->near.cap, ctx->stream));
     if (ctx->near_ev.p) SC_HIP(ctx, hipMemsetAsync(ctx->near_ev.p, 0, 16, ctx->stream));
+    ctx->patch_n = 0;
+    return SC_OK;
+}
+
+int sc_near_buffers(sc_ctx* ctx, unsigned long long** ev_count, uint32_t** ev, unsigned long long* ev_cap) {
+    const size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
+    const bool fresh = ctx->near.cap < nc;
+    int rc = sc_ensure(ctx, ctx->near, nc);
+    if (rc) return rc;
+    if (fresh) SC_HIP(ctx, hipMemsetAsync(ctx->near.p, 0, ctx->near.cap, ctx->stream));
+    // the event list: two per core cell or a million, whichever is more (12 bytes each); counter in front
+    const unsigned long long cap = std::max<unsigned long long>(2ull * nc, 1ull << 20);
+    const bool fresh_ev = ctx->near_ev.cap < 16 + 12 * cap;
+    if ((rc = sc_ensure(ctx, ctx->near_ev, 16 + 12 * cap))) return rc;
+    if (fresh_ev) SC_HIP(ctx, hipMemsetAsync(ctx->near_ev.p, 0, 16, ctx->stream));
+    *ev_count = (unsigned long long*)ctx->near_ev.p;
+    *ev = (uint32_t*)((char*)ctx->near_ev.p + 16);
+    *ev_cap = (ctx->near_ev.cap - 16) / 12;
     return SC_OK;
 }
 
@@ -600,6 +618,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
         return sc_fail(ctx, SC_ERR_INVALID, "unknown method %d", plan->method);
     int rc = check_templates(ctx, t, n, plan);
     if (rc) return rc;
+    if (!to_maps) ctx->patch_n = 0;            // (the record moves on: what sc_settle_exact patched no longer describes it)
     const Geom& g = ctx->g;
     FftGeom fg{};
     const int group = std::max(1, plan->group);
@@ -943,6 +962,7 @@ int sc_result_planes(sc_ctx* ctx, const double* param_of_id, const double* angle
     if ((rc = sc_launch_result(ctx, (const float*)ctx->best_amp.p, (const float*)ctx->best_snr.p,
                                (const uint32_t*)ctx->best_id.p, tab, tab + n_ids, n_ids, nc, planes)))
         return rc;
+    if (ctx->patch_n && (rc = sc_apply_patches(ctx, tab, tab + n_ids, n_ids, nc, planes))) return rc;
     *planes_out = planes;
     *nc_out = nc;
     return SC_OK;

@@ -3632,21 +3632,10 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             if (near) {
                 if (!fast || full_masks)
                     return sc_fail(ctx, SC_ERR_UNSUPPORTED, "near-tie flags need the fast row kernel without per-cell masks");
-                const size_t nc_ = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
-                const bool fresh = ctx->near.cap < nc_;
-                int rc = sc_ensure(ctx, ctx->near, nc_);
+                int rc = sc_near_buffers(ctx, &ra.ev_count, &ra.ev, &ra.ev_cap);
                 if (rc) return rc;
-                if (fresh) SC_HIP(ctx, hipMemsetAsync(ctx->near.p, 0, nc_, ctx->stream));     // (sc_reset_best clears it from then on)
                 ra.near_w = ctx->near_w;
                 ra.near = (uint8_t*)ctx->near.p;
-                // the event list: two per core cell or a million, whichever is more (12 bytes each); counter in front
-                const unsigned long long cap = std::max<unsigned long long>(2ull * nc_, 1ull << 20);
-                const bool fresh_ev = ctx->near_ev.cap < 16 + 12 * cap;
-                if ((rc = sc_ensure(ctx, ctx->near_ev, 16 + 12 * cap))) return rc;
-                if (fresh_ev) SC_HIP(ctx, hipMemsetAsync(ctx->near_ev.p, 0, 16, ctx->stream));
-                ra.ev_count = (unsigned long long*)ctx->near_ev.p;
-                ra.ev = (uint32_t*)((char*)ctx->near_ev.p + 16);
-                ra.ev_cap = (ctx->near_ev.cap - 16) / 12;
             }
             int nsplit = 1;
             if (fast && !near && !to_maps && !full_masks && fg.Tx <= 1024 && ctx->variant != 15 && !(ctx->sib & 1)) {

@@ -123,6 +123,11 @@ struct sc_ctx {
     float near_w = 0.f;        // sc_set_option "near_window": the FFT row pass flags near-ties (sc_get_near_ties)
     DevBuf near;               // one byte per core cell
     DevBuf near_ev;            // the near-tie events of the FFT row pass: a 64-bit count, then 3 words per event (sc_get_near_events)
+    // sc_settle_exact: slot of every flagged cell (one word per core cell, valid at flagged cells), the work lists, and the
+    // patches - per flagged cell its index and the float64 (amp, snr, id) sc_get_result writes over the converted record;
+    // patch_n: how many the current record carries (0 after any sc_match / sc_reset_best)
+    DevBuf st_slot, st_work, st_pairs, st_patch;
+    size_t patch_n = 0;
     DevBuf score;              // sc_score_cells_f64: the cell list and the two float64 outputs
     DevBuf score_w;            // ... and the templates' float64 windows (offsets, then the windows)
     DevBuf score_abc;          // ... and the three stencil planes of the block in float64 (rebuilt at every call)
@@ -183,6 +188,10 @@ void sc_prof_collect(sc_ctx* ctx);
 #define SC_RECORD_BYTES 12
 int sc_launch_result(sc_ctx* ctx, const float* amp, const float* snr, const uint32_t* id, const double* tab_par,
                      const double* tab_ang, int n_ids, size_t n, double* planes);
+// flag plane and event list of option "near_window" (allocated and cleared on first use; sc_reset_best clears them from then on)
+int sc_near_buffers(sc_ctx* ctx, unsigned long long** ev_count, uint32_t** ev, unsigned long long* ev_cap);
+// sc_settle.hip: the patches of sc_settle_exact over four converted float64 planes of nc cells each
+int sc_apply_patches(sc_ctx* ctx, const double* tab_par, const double* tab_ang, int n_ids, size_t nc, double* planes);
 int sc_result_planes(sc_ctx* ctx, const double* param_of_id, const double* angle_of_id, int n_ids,
                      double** planes_out, size_t* nc_out);
 
@@ -193,6 +202,7 @@ int launch_curv_alpha(sc_ctx* ctx, float cc, float sc2, float ss, int plane = 0)
 int launch_curv_f64(sc_ctx* ctx, double c2, double sn, double cs, double s2, double* out_dev);
 int launch_curv_alpha_batch(sc_ctx* ctx, const float (*coef)[3], int nb);
 // tsel_dev: nullptr - every cell against every template (m x n_templ outputs); else pair k = (cell k, template tsel[k]) (m outputs)
+int score_prepare_f64(sc_ctx* ctx, int n_templ, const unsigned long long** woff_out, const double** wbuf_out, const double** planes_out);
 int launch_score_f64(sc_ctx* ctx, const int* cells_dev, const int* tsel_dev, int m, int n_templ, double* amp_dev, double* snr_dev);
 int launch_windows(sc_ctx* ctx, int first, int n, int wh_max, int ww_max);
 int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_max, int ww_max, bool long_runs);

@@ -189,8 +189,9 @@ k_score_f64(const double* __restrict__ pa, const double* __restrict__ pb, const 
     }
 }
 
-int launch_score_f64(sc_ctx* ctx, const int* cells_dev, const int* tsel_dev, int m, int n_templ, double* amp_dev, double* snr_dev) {
-    // the windows first: offsets from the host's copy of the descriptors (the last search's), one kernel for all templates
+// What the float64 scorers read, rebuilt at every call: the templates' float64 windows (offsets from the host's copy of the
+// last search's descriptors, one kernel for all templates) and the three stencil planes of the block in float64.
+int score_prepare_f64(sc_ctx* ctx, int n_templ, const unsigned long long** woff_out, const double** wbuf_out, const double** planes_out) {
     std::vector<unsigned long long> off((size_t)n_templ + 1, 0ull);
     int maxbox = 1;
     for (int k = 0; k < n_templ; ++k) {
@@ -215,10 +216,21 @@ int launch_score_f64(sc_ctx* ctx, const int* cells_dev, const int* tsel_dev, int
     hipLaunchKernelGGL(k_curv_planes<double>, dim3((ctx->g.lx + 255) / 256, ctx->g.ly), dim3(256), 0, ctx->stream,
                        ctx->z_dev, ctx->g, ctx->dx, ctx->dy, pa, pa + nc, pa + 2 * nc);
     SC_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_score_f64, dim3(m, tsel_dev ? 1 : n_templ), dim3(256), 0, ctx->stream, (const double*)pa, (const double*)(pa + nc),
-                       (const double*)(pa + 2 * nc), ctx->g,
+    *woff_out = woff;
+    *wbuf_out = wbuf;
+    *planes_out = pa;
+    return SC_OK;
+}
+
+int launch_score_f64(sc_ctx* ctx, const int* cells_dev, const int* tsel_dev, int m, int n_templ, double* amp_dev, double* snr_dev) {
+    const unsigned long long* woff = nullptr;
+    const double *wbuf = nullptr, *pa = nullptr;
+    int rc = score_prepare_f64(ctx, n_templ, &woff, &wbuf, &pa);
+    if (rc) return rc;
+    const size_t nc = (size_t)ctx->g.ly * ctx->g.lx;
+    hipLaunchKernelGGL(k_score_f64, dim3(m, tsel_dev ? 1 : n_templ), dim3(256), 0, ctx->stream, pa, pa + nc, pa + 2 * nc, ctx->g,
                        (const TemplDev*)ctx->templ.p, n_templ, (const double*)ctx->sums.p, (const double*)ctx->xaxis.p,
-                       (const double*)ctx->yaxis.p, (const unsigned long long*)woff, (const double*)wbuf, cells_dev, tsel_dev, amp_dev, snr_dev);
+                       (const double*)ctx->yaxis.p, woff, wbuf, cells_dev, tsel_dev, amp_dev, snr_dev);
     SC_HIP(ctx, hipGetLastError());
     return SC_OK;
 }
@@ -591,10 +603,12 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
           const double* __restrict__ yaxis, float* __restrict__ best_snr,
           float* __restrict__ best_amp, uint32_t* __restrict__ best_id,
           float* __restrict__ map_amp, float* __restrict__ map_snr,
-          float near_w, uint8_t* __restrict__ near) {
+          float near_w, uint8_t* __restrict__ near, unsigned long long* __restrict__ ev_count,
+          uint32_t* __restrict__ ev, unsigned long long ev_cap) {
     // near_w > 0 (the host layer's exact mode): a byte per core cell, set where a template scored within near_w
     // (relative) of the cell's running best, equal scores included - the cells whose argmax is decided inside THIS path's
-    // own float32 error and that sc_score_cells_f64 settles (see k_inv_rows_fast, NEAR)
+    // own float32 error - and an event (cell, template scored, holder of the record) per near-tie, as the FFT row pass
+    // lists them (k_inv_rows_fast, NEAR): sc_settle_exact scores exactly those pairs in float64
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TXW = 256 * NB, TY = DR2_WAVES * RW;
     const int lane = threadIdx.x & 63;
@@ -994,8 +1008,19 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                             const float bs = b_snr[rr][n][u];
                             // (EQUAL float32 scores are flagged too: two templates a rounding apart can score the same bits here
                             //  and differ in float64 - exact twins, Scarp at -pi/2 and +pi/2, cost the float64 pass their cells)
-                            if (snr > 0.f && fabsf(snr - bs) <= near_w * fmaxf(snr, bs))
-                                near[(size_t)(gi - g.cy0 + zt) * cw + (gj - g.cx0)] = (uint8_t)1;
+                            if (snr > 0.f && fabsf(snr - bs) <= near_w * fmaxf(snr, bs)) {
+                                const size_t o = (size_t)(gi - g.cy0 + zt) * cw + (gj - g.cx0);
+                                near[o] = (uint8_t)1;
+                                if (ev) {                    // (before the fold: the id plane still names the holder - this lane's own store)
+                                    const unsigned long long slot = atomicAdd(ev_count, 1ull);
+                                    if (slot < ev_cap) {
+                                        uint32_t* e = ev + 3 * slot;
+                                        e[0] = (uint32_t)o;
+                                        e[1] = t.id;
+                                        e[2] = best_id[o];
+                                    }
+                                }
+                            }
                         }
                         if (sc_fold(b_snr[rr][n][u], w_amp, w_id, snr, amp, t.id)) {
                             // (zt: the cells' offsets are worked out here, at a win - hoisted out of the template loop
@@ -1341,14 +1366,14 @@ int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_ma
                        (const uint8_t*)ctx->win_m.p, (float2*)ctx->dwin.p, (int4*)ctx->spans.p);
     sc_prof_end(ctx);
     SC_HIP(ctx, hipGetLastError());
-    // near-tie flags of the exact mode (option "near_window"): the byte plane of sc_get_near_ties
+    // near-tie flags of the exact mode (option "near_window"): the byte plane of sc_get_near_ties, and the event list
     const bool near_on = ctx->near_w > 0.f && !to_maps;
+    unsigned long long* ev_count = nullptr;
+    uint32_t* ev = nullptr;
+    unsigned long long ev_cap = 0;
     if (near_on) {
-        const size_t nc_ = (size_t)ch * cw;
-        const bool fresh = ctx->near.cap < nc_;
-        int rc = sc_ensure(ctx, ctx->near, nc_);
+        int rc = sc_near_buffers(ctx, &ev_count, &ev, &ev_cap);
         if (rc) return rc;
-        if (fresh) SC_HIP(ctx, hipMemsetAsync(ctx->near.p, 0, nc_, ctx->stream));
     }
     // patch: 512 x 16 cells where that still gives every CU a workgroup, else 256 x 16, else 256 x 8
     const size_t lds = (size_t)DR2_LDS_FLOATS * sizeof(float);
@@ -1368,7 +1393,7 @@ int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_ma
                            (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p,                     \
                            to_maps ? (float*)ctx->map_amp.p : nullptr,                             \
                            to_maps ? (float*)ctx->map_snr.p : nullptr,                             \
-                           near_on ? ctx->near_w : 0.f, near_on ? (uint8_t*)ctx->near.p : nullptr); \
+                           near_on ? ctx->near_w : 0.f, near_on ? (uint8_t*)ctx->near.p : nullptr, ev_count, ev, ev_cap); \
         sc_prof_end(ctx);                                                                          \
     }
     // (variant 11: T3 in the weighted form on every row; long_runs: some template of the launch has

@@ -1,0 +1,494 @@
+// sc_settle_exact: the float64 argmax of every near-tie cell, settled on the device (round 6).
+//
+// The reference folds float64 SNR maps (compare(), core.py:230-240: the argmax over templates of float64 numbers); the
+// float32 searches here decide a cell to within their own rounding.  With option "near_window" on, both paths flag the
+// cells where a template scored within the window of the running best and list an event (cell, template scored, holder of
+// the record) per near-tie.  A template further below the record than the window is below it in float64 too, so a flagged
+// cell's float64 argmax is its final holder or a template one of its events names.  This file turns the flags and the
+// events into per-cell candidate lists, scores exactly those (cell, template) pairs with match_template()'s float64
+// arithmetic (core.py:340-377 as the real-space closed form: k_st_score, the same expressions as k_score_f64), takes
+// the argmax in fold order, writes it into the record and keeps the float64 (amp, snr) as patches that sc_get_result
+// lays over the converted planes.  Round 5 did the list building on the host (1.2 GB of record copied out, np.argwhere
+// over the flag plane, np.unique / np.lexsort over millions of keys): 1.9 s of the 5.1 s the exact C3 search took.
+//
+// Pipeline (all on the context's stream; three 8-byte read-backs size the next step's buffers):
+//   k_st_flag_count / k_st_scan1 / k_st_slots   flagged cells -> slots in cell order (neighbouring pairs share their
+//                                               curvature neighbourhood in L2), cnt[slot] = 1 (the final holder)
+//   k_st_events<false>                          cnt[slot] += candidates the slot's events add
+//   k_st_sum / k_st_scan1 / k_st_offsets        exclusive scan -> off[slot]
+//   k_st_init_lists, k_st_events<true>          pair lists: entry 0 the final holder, then the events' templates
+//   k_window_f64, k_curv_planes<double>         (score_prepare_f64)
+//   k_st_score                                  one workgroup per pair; repeats of a template in a list and lists of one
+//                                               template are not scored
+//   k_st_resolve                                per slot the largest float64 SNR, ties to the earlier template
+#include "sc_internal.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int ST_CH = 4096;                    // cells / counts per workgroup of the scans: 256 threads x 16
+constexpr unsigned ST_STATS = 8;               // 64-bit counters: 0 flagged cells, 1 pairs listed, 2 pairs scored, 3 cells scored, 4 changed
+
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned u = __shfl_up(v, d, 64);
+        if ((int)(threadIdx.x & 63) >= d) v += u;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread over a workgroup of NW waves; *total = the workgroup's sum
+template <int NW>
+__device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned* total) {
+    __shared__ unsigned wsum[NW];
+    const unsigned inc = wave_incl_scan(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const unsigned s = wsum[k];
+        base += k < w ? s : 0u;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// the 16 flag bytes of thread t of workgroup b (flags are 0 or 1), as four words; cells beyond nc read 0
+__device__ __forceinline__ uint4 flags16(const uint8_t* __restrict__ near, size_t nc, size_t c0) {
+    uint4 f = make_uint4(0, 0, 0, 0);
+    if (c0 + 16 <= nc) {
+        f = *reinterpret_cast<const uint4*>(near + c0);
+    } else if (c0 < nc) {
+        unsigned w[4] = {0, 0, 0, 0};
+        for (size_t k = c0; k < nc; ++k) w[(k - c0) >> 2] |= (unsigned)(near[k] != 0) << (8 * ((k - c0) & 3));
+        f = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    f.x &= 0x01010101u; f.y &= 0x01010101u; f.z &= 0x01010101u; f.w &= 0x01010101u;
+    return f;
+}
+
+__global__ void __launch_bounds__(256)
+k_st_flag_count(const uint8_t* __restrict__ near, size_t nc, unsigned* __restrict__ blk) {
+    const uint4 f = flags16(near, nc, (size_t)blockIdx.x * ST_CH + 16 * threadIdx.x);
+    unsigned tot;
+    block_excl_scan<4>(__popc(f.x) + __popc(f.y) + __popc(f.z) + __popc(f.w), &tot);
+    if (threadIdx.x == 0) blk[blockIdx.x] = tot;
+}
+
+// in-place exclusive scan of n workgroup sums by ONE workgroup of 1024 threads; *total = their sum
+__global__ void __launch_bounds__(1024)
+k_st_scan1(unsigned* __restrict__ blk, unsigned n, unsigned long long* __restrict__ total) {
+    const unsigned per = (n + 1023) / 1024;
+    const unsigned lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    unsigned s = 0;
+    for (unsigned k = lo; k < hi; ++k) s += blk[k];
+    unsigned tot;
+    unsigned base = block_excl_scan<16>(s, &tot);
+    for (unsigned k = lo; k < hi; ++k) {
+        const unsigned v = blk[k];
+        blk[k] = base;
+        base += v;
+    }
+    if (threadIdx.x == 0) *total = tot;
+}
+
+__global__ void __launch_bounds__(256)
+k_st_slots(const uint8_t* __restrict__ near, size_t nc, const unsigned* __restrict__ blk, uint32_t* __restrict__ cell_of,
+           uint32_t* __restrict__ slot_of, unsigned* __restrict__ cnt) {
+    const size_t c0 = (size_t)blockIdx.x * ST_CH + 16 * threadIdx.x;
+    const uint4 f = flags16(near, nc, c0);
+    unsigned tot;
+    unsigned s = blk[blockIdx.x] + block_excl_scan<4>(__popc(f.x) + __popc(f.y) + __popc(f.z) + __popc(f.w), &tot);
+    const unsigned w[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if ((w[k >> 2] >> (8 * (k & 3))) & 1u) {
+            cell_of[s] = (uint32_t)(c0 + k);
+            slot_of[c0 + k] = s;
+            cnt[s] = 1u;                       // (the record's final holder)
+            ++s;
+        }
+}
+
+__global__ void __launch_bounds__(256)
+k_st_sum(const unsigned* __restrict__ in, unsigned n, unsigned* __restrict__ blk) {
+    const unsigned i0 = blockIdx.x * ST_CH + 16 * threadIdx.x;
+    unsigned s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += i0 + k < n ? in[i0 + k] : 0u;
+    unsigned tot;
+    block_excl_scan<4>(s, &tot);
+    if (threadIdx.x == 0) blk[blockIdx.x] = tot;
+}
+
+// out[i] = exclusive prefix of in[0 .. n) (out has n + 1 entries: the last is the total)
+__global__ void __launch_bounds__(256)
+k_st_offsets(const unsigned* __restrict__ in, unsigned n, const unsigned* __restrict__ blk, unsigned* __restrict__ out) {
+    const unsigned i0 = blockIdx.x * ST_CH + 16 * threadIdx.x;
+    unsigned v[16], s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { v[k] = i0 + k < n ? in[i0 + k] : 0u; s += v[k]; }
+    unsigned tot;
+    unsigned base = blk[blockIdx.x] + block_excl_scan<4>(s, &tot);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (i0 + k <= n) out[i0 + k] = base;
+        base += v[k];
+    }
+}
+
+// template id -> its index in the last search's hand-over order, the grid's end twins collapsed (the last n_twin
+// templates stand for the first n_twin: Scarp at +pi/2 is minus Scarp at -pi/2, a Ricker the same template - one
+// maximum by the parity policy); -1: not a template of this search
+struct IdMap {
+    const int32_t* tab;
+    uint32_t n_ids;
+    int32_t n, n_twin;
+    __device__ __forceinline__ int32_t operator()(uint32_t id) const {
+        if (id >= n_ids) return -1;
+        int32_t t = tab[id];
+        if (t >= n - n_twin) t -= n - n_twin;
+        return t;
+    }
+};
+
+// FILL = false: cnt[slot] += what the event adds to its cell's list; true: the same candidates into the lists
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+k_st_events(const uint32_t* __restrict__ ev, unsigned long long n_ev, const uint32_t* __restrict__ slot_of,
+            const uint32_t* __restrict__ best_id, IdMap map, unsigned* __restrict__ cnt, const unsigned* __restrict__ off,
+            int32_t* __restrict__ pair_t, uint32_t* __restrict__ pair_slot) {
+    const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_ev) return;
+    const uint32_t cell = ev[3 * k];
+    const int32_t ms = map(ev[3 * k + 1]), mh = map(ev[3 * k + 2]), mf = map(best_id[cell]);
+    const bool a = ms >= 0 && ms != mf, b = mh >= 0 && mh != mf && mh != ms;
+    if (!a && !b) return;
+    const uint32_t slot = slot_of[cell];
+    if (!FILL) {
+        atomicAdd(cnt + slot, (unsigned)a + (unsigned)b);
+    } else {
+        unsigned pos = off[slot] + atomicAdd(cnt + slot, (unsigned)a + (unsigned)b);
+        if (a) { pair_t[pos] = ms; pair_slot[pos] = slot; ++pos; }
+        if (b) { pair_t[pos] = mh; pair_slot[pos] = slot; }
+    }
+}
+
+// entry 0 of every list: the record's final holder; the fill counters start behind it
+__global__ void __launch_bounds__(256)
+k_st_init_lists(unsigned n_slots, const uint32_t* __restrict__ cell_of, const uint32_t* __restrict__ best_id, IdMap map,
+                const unsigned* __restrict__ off, unsigned* __restrict__ fill, int32_t* __restrict__ pair_t,
+                uint32_t* __restrict__ pair_slot) {
+    const unsigned s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_slots) return;
+    const unsigned pos = off[s];
+    pair_t[pos] = map(best_id[cell_of[s]]);
+    pair_slot[pos] = s;
+    fill[s] = 1u;
+}
+
+__device__ __forceinline__ int wrap1(int x, int n) { return x < 0 ? x + n : (x >= n ? x - n : x); }
+
+// match_template() of one (cell, template) pair in float64 - k_score_f64's arithmetic on the lists of sc_settle_exact.
+// One workgroup per list entry; an entry that repeats an earlier template of its list, or whose list names one
+// template only, is marked (snr = -1) and not scored.
+__global__ void __launch_bounds__(256)
+k_st_score(const double* __restrict__ pa, const double* __restrict__ pb, const double* __restrict__ pc, Geom g,
+           const TemplDev* __restrict__ templ, const double* __restrict__ sums,
+           const double* __restrict__ xaxis, const double* __restrict__ yaxis,
+           const unsigned long long* __restrict__ woff, const double* __restrict__ wbuf,
+           const unsigned* __restrict__ off, const int32_t* __restrict__ pair_t, const uint32_t* __restrict__ pair_slot,
+           const uint32_t* __restrict__ cell_of, double* __restrict__ amp_out, double* __restrict__ snr_out) {
+    const unsigned pos = blockIdx.x;
+    const uint32_t slot = pair_slot[pos];
+    const int it = pair_t[pos];
+    const unsigned lo = off[slot], hi = off[slot + 1];
+    bool dup = false, other = false;
+    for (unsigned k = lo; k < hi; ++k) {                                   // (workgroup-uniform: scalar loads)
+        const int tk = pair_t[k];
+        dup = dup || (k < pos && tk == it);
+        other = other || (tk >= 0 && tk != it);
+    }
+    if (it < 0 || dup || !other) {
+        if (threadIdx.x == 0) { snr_out[pos] = -1.0; amp_out[pos] = 0.0; }
+        return;
+    }
+    const int cw = g.cx1 - g.cx0;
+    const uint32_t cell = cell_of[slot];
+    const int i = g.cy0 + (int)(cell / (uint32_t)cw), j = g.cx0 + (int)(cell % (uint32_t)cw);     // global cell
+    const TemplDev t = templ[it];
+    // the orientation's curvature mix, dem.py:103-104 (cos_a / sin_a of the descriptor are those of alpha = -orientation)
+    const double ca = t.cos_a, sa = -t.sin_a;
+    const double k_cc = __dmul_rn(ca, ca), k_ss = __dmul_rn(sa, sa);
+    const double* __restrict__ wt = wbuf + woff[it];
+    double xc = 0.0, t3 = 0.0;
+    const int box = t.wh * t.ww;
+    // element e = a ww + b of the window's box, 256 apart per step: (a, b) carried instead of divided out
+    const int da = 256 / t.ww, db = 256 - da * t.ww;
+    int a = (int)threadIdx.x / t.ww, b = (int)threadIdx.x - a * t.ww;
+    for (int e = threadIdx.x; e < box; e += 256) {
+        const double w = wt[e];
+        if (w != 0.0) {                                                     // (W != 0 is the mask M, core.py:348)
+            // curvature at global ((i - p + oy) mod ny, (j - q + ox) mod nx), p = pmin + a, q = qmin + b
+            int gi = i - (t.pmin + a) + g.oy, gj = j - (t.qmin + b) + g.ox;
+            int li, lj;
+            if (g.wrap) { li = wrap1(gi, g.ny); lj = wrap1(gj, g.nx); }
+            else { li = gi - g.gy0; lj = gj - g.gx0; }
+            if (li >= 0 && li < g.ly && lj >= 0 && lj < g.lx) {            // (outside a halo block: the host sized the halo)
+                const size_t o = (size_t)li * g.lx + lj;
+                const double A = pa[o], Bc = pb[o], C = pc[o];
+                const double cv = __dadd_rn(__dsub_rn(__dmul_rn(A, k_cc), __dmul_rn(__dmul_rn(__dmul_rn(2.0, Bc), sa), ca)),
+                                            __dmul_rn(C, k_ss));
+                xc = fma(w, cv, xc);
+                t3 = fma(cv, cv, t3);
+            }
+        }
+        a += da;
+        b += db;
+        if (b >= t.ww) { b -= t.ww; ++a; }
+    }
+    __shared__ double red[2][4];
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        xc += __shfl_down(xc, sft, 64);
+        t3 += __shfl_down(t3, sft, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = xc; red[1][threadIdx.x >> 6] = t3; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        xc = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        t3 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const double n = sums[2 * it] + SC_EPS, ts = sums[2 * it + 1];
+        double amp = xc / ts;
+        const double T1 = ts * (amp * amp);
+        const double err = (1.0 / n) * (T1 - 2.0 * amp * xc + t3) + SC_EPS;
+        double snr = fabs(T1 / err);
+        if (t.flags & (SC_FLAG_ERR_XR_LE0 | SC_FLAG_ERR_XR_GE0)) {
+            const double xr = __dadd_rn(__dmul_rn(xaxis[j], t.cos_a), __dmul_rn(yaxis[i], t.sin_a));
+            if ((t.flags & SC_FLAG_ERR_XR_LE0) ? (xr <= 0.0) : (xr >= 0.0)) snr = 0.0;
+        }
+        if (!(i >= t.ilo && i <= t.ihi && j >= t.jlo && j <= t.jhi)) { amp = 0.0; snr = 0.0; }
+        if (!(snr >= 0.0)) snr = 0.0;                                      // (a NaN never wins a cell here)
+        amp_out[pos] = amp;
+        snr_out[pos] = snr;
+    }
+}
+
+// Per slot: the largest float64 SNR of its list, ties to the earlier template of the fold order (the hand-over order:
+// what the device's own fold keeps).  The winner goes into the record (id; amp and snr rounded to float32) and into the
+// patch (float64); a cell whose winner is the template the record already names keeps that id (of two end twins the one
+// the float32 fold chose).
+__global__ void __launch_bounds__(256)
+k_st_resolve(unsigned n_slots, const unsigned* __restrict__ off, const int32_t* __restrict__ pair_t,
+             const double* __restrict__ pair_amp, const double* __restrict__ pair_snr, const uint32_t* __restrict__ cell_of,
+             const TemplDev* __restrict__ templ, float* __restrict__ best_snr, float* __restrict__ best_amp,
+             uint32_t* __restrict__ best_id, double* __restrict__ p_amp, double* __restrict__ p_snr,
+             uint32_t* __restrict__ p_id, unsigned long long* __restrict__ stats) {
+    const unsigned s = blockIdx.x * 256 + threadIdx.x;
+    unsigned scored = 0, changed = 0;
+    if (s < n_slots) {
+        const unsigned lo = off[s], hi = off[s + 1];
+        double bs = -1.0, ba = 0.0;
+        int bt = -1;
+        for (unsigned k = lo; k < hi; ++k) {
+            const double v = pair_snr[k];
+            if (v < 0.0) continue;
+            ++scored;
+            const int tk = pair_t[k];
+            if (v > bs || (v == bs && tk < bt)) { bs = v; ba = pair_amp[k]; bt = tk; }
+        }
+        uint32_t id = SC_ID_NONE;
+        if (bs > 0.0) {
+            const uint32_t cell = cell_of[s];
+            changed = bt != pair_t[lo];
+            id = changed ? templ[bt].id : best_id[cell];
+            best_id[cell] = id;
+            best_snr[cell] = (float)bs;
+            best_amp[cell] = (float)ba;
+        }
+        p_amp[s] = ba;
+        p_snr[s] = bs;
+        p_id[s] = id;
+    }
+    unsigned c1 = scored ? 1u : 0u;
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        scored += __shfl_down(scored, sft, 64);
+        changed += __shfl_down(changed, sft, 64);
+        c1 += __shfl_down(c1, sft, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && scored) {
+        atomicAdd(stats + 2, (unsigned long long)scored);
+        atomicAdd(stats + 3, (unsigned long long)c1);
+        if (changed) atomicAdd(stats + 4, (unsigned long long)changed);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_st_apply(unsigned n_slots, const uint32_t* __restrict__ cell_of, const double* __restrict__ p_amp,
+           const double* __restrict__ p_snr, const uint32_t* __restrict__ p_id, const double* __restrict__ par,
+           const double* __restrict__ ang, uint32_t n_ids, size_t nc, double* __restrict__ out) {
+    const unsigned s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_slots) return;
+    const uint32_t id = p_id[s];
+    if (!(p_snr[s] > 0.0) || id >= n_ids) return;
+    const size_t c = cell_of[s];
+    out[c] = p_amp[s];
+    out[nc + c] = par[id];
+    out[2 * nc + c] = ang[id];
+    out[3 * nc + c] = p_snr[s];
+}
+
+inline size_t up64(size_t b) { return (b + 63) & ~(size_t)63; }
+
+}  // namespace
+
+// the patch buffer: cell_of (u32 x n), id (u32 x n), amp, snr (f64 x n)
+static void patch_views(sc_ctx* ctx, size_t n, uint32_t** cell_of, uint32_t** p_id, double** p_amp, double** p_snr) {
+    char* p = (char*)ctx->st_patch.p;
+    *p_amp = (double*)p;
+    *p_snr = (double*)(p + up64(8 * n));
+    *cell_of = (uint32_t*)(p + 2 * up64(8 * n));
+    *p_id = (uint32_t*)(p + 2 * up64(8 * n) + up64(4 * n));
+}
+
+int sc_apply_patches(sc_ctx* ctx, const double* tab_par, const double* tab_ang, int n_ids, size_t nc, double* planes) {
+    const size_t n = ctx->patch_n;
+    if (!n) return SC_OK;
+    uint32_t *cell_of, *p_id;
+    double *p_amp, *p_snr;
+    patch_views(ctx, n, &cell_of, &p_id, &p_amp, &p_snr);
+    hipLaunchKernelGGL(k_st_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned)n, (const uint32_t*)cell_of,
+                       (const double*)p_amp, (const double*)p_snr, (const uint32_t*)p_id, tab_par, tab_ang, (uint32_t)n_ids, nc, planes);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+}
+
+extern "C" int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long long* stats_out) {
+    if (!ctx || !stats_out || n_twin < 0) return SC_ERR_INVALID;
+    for (unsigned k = 0; k < ST_STATS; ++k) stats_out[k] = 0;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    const int n = ctx->last_batch;
+    if (n <= 0) return sc_fail(ctx, SC_ERR_INVALID, "sc_settle_exact: no search has run in this context");
+    if (n_twin > n / 2) return sc_fail(ctx, SC_ERR_INVALID, "sc_settle_exact: %d end twins of %d templates", n_twin, n);
+    if (ctx->templ_windows)
+        return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_settle_exact: built-in templates only (a plugin's window is float32 on the device)");
+    ctx->patch_n = 0;
+    if (!ctx->near.p || !ctx->near_ev.p) return SC_OK;                    // no search has run with the option on: nothing flagged
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const Geom& g = ctx->g;
+    const size_t nc = (size_t)(g.cy1 - g.cy0) * (g.cx1 - g.cx0);
+    unsigned long long n_ev = 0;
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SC_HIP(ctx, hipMemcpy(&n_ev, ctx->near_ev.p, sizeof(n_ev), hipMemcpyDeviceToHost));
+    stats_out[5] = (long long)n_ev;
+    if (n_ev > (ctx->near_ev.cap - 16) / 12)
+        return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_settle_exact: the event list overflowed (%llu near-ties, room for %llu)",
+                       n_ev, (unsigned long long)((ctx->near_ev.cap - 16) / 12));
+    if (3 * n_ev + nc >= 0xFFFFFFFFull) return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_settle_exact: %llu events", n_ev);
+    const uint32_t* ev = (const uint32_t*)((const char*)ctx->near_ev.p + 16);
+    const uint8_t* near = (const uint8_t*)ctx->near.p;
+
+    // id -> index table from the host's copy of the last search's descriptors
+    uint32_t max_id = 0;
+    for (int k = 0; k < n; ++k) max_id = std::max(max_id, ctx->h_templ[k].id);
+    if (max_id > (1u << 26)) return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_settle_exact: template id %u", max_id);
+    std::vector<int32_t> idtab((size_t)max_id + 1, -1);
+    for (int k = 0; k < n; ++k) idtab[ctx->h_templ[k].id] = k;
+
+    // ---- flagged cells -> slots --------------------------------------------------------------------------------
+    const unsigned nblk = (unsigned)((nc + ST_CH - 1) / ST_CH);
+    int rc;
+    if ((rc = sc_ensure(ctx, ctx->st_slot, 4 * nc))) return rc;
+    // work buffer, first part: stats | block sums (flags) | id table
+    const size_t o_blk = up64(8 * ST_STATS), o_tab = o_blk + up64(4 * (size_t)nblk), o_end0 = o_tab + up64(4 * idtab.size());
+    // (sized once for the most it can need given the events: slots <= events)
+    const size_t ns_max = (size_t)std::min<unsigned long long>(n_ev, nc);
+    const unsigned nblk2_max = (unsigned)((ns_max + 1 + ST_CH - 1) / ST_CH);
+    const size_t o_cnt = o_end0, o_off = o_cnt + up64(4 * (ns_max + 1)), o_blk2 = o_off + up64(4 * (ns_max + 2)),
+                 o_end = o_blk2 + up64(4 * (size_t)nblk2_max);
+    if ((rc = sc_ensure(ctx, ctx->st_work, o_end))) return rc;
+    char* wk = (char*)ctx->st_work.p;
+    unsigned long long* stats = (unsigned long long*)wk;
+    unsigned* blk = (unsigned*)(wk + o_blk);
+    int32_t* d_tab = (int32_t*)(wk + o_tab);
+    unsigned* cnt = (unsigned*)(wk + o_cnt);
+    unsigned* off = (unsigned*)(wk + o_off);
+    unsigned* blk2 = (unsigned*)(wk + o_blk2);
+    if ((rc = sc_ensure(ctx, ctx->st_patch, 2 * up64(8 * ns_max) + 2 * up64(4 * ns_max) + 64))) return rc;
+    SC_HIP(ctx, hipMemsetAsync(stats, 0, 8 * ST_STATS, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(d_tab, idtab.data(), 4 * idtab.size(), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_st_flag_count, dim3(nblk), dim3(256), 0, ctx->stream, near, nc, blk);
+    hipLaunchKernelGGL(k_st_scan1, dim3(1), dim3(1024), 0, ctx->stream, blk, nblk, stats);
+    SC_HIP(ctx, hipGetLastError());
+    unsigned long long n_slots = 0;
+    SC_HIP(ctx, hipMemcpyAsync(&n_slots, stats, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));                       // (also: idtab is a local)
+    stats_out[0] = (long long)n_slots;
+    if (!n_slots) return SC_OK;
+    if (n_slots > ns_max) return sc_fail(ctx, SC_ERR_INVALID, "sc_settle_exact: %llu flagged cells but %llu events", n_slots, n_ev);
+    const unsigned ns = (unsigned)n_slots;
+    uint32_t *cell_of, *p_id;
+    double *p_amp, *p_snr;
+    patch_views(ctx, ns, &cell_of, &p_id, &p_amp, &p_snr);
+    uint32_t* slot_of = (uint32_t*)ctx->st_slot.p;
+    const IdMap map{d_tab, max_id + 1, n, n_twin};
+    hipLaunchKernelGGL(k_st_slots, dim3(nblk), dim3(256), 0, ctx->stream, near, nc, (const unsigned*)blk, cell_of, slot_of, cnt);
+    const unsigned evb = (unsigned)((n_ev + 255) / 256);
+    hipLaunchKernelGGL(k_st_events<false>, dim3(evb), dim3(256), 0, ctx->stream, ev, n_ev, (const uint32_t*)slot_of,
+                       (const uint32_t*)ctx->best_id.p, map, cnt, (const unsigned*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr);
+    // ---- list offsets ------------------------------------------------------------------------------------------
+    const unsigned nblk2 = (ns + 1 + ST_CH - 1) / ST_CH;
+    hipLaunchKernelGGL(k_st_sum, dim3(nblk2), dim3(256), 0, ctx->stream, (const unsigned*)cnt, ns, blk2);
+    hipLaunchKernelGGL(k_st_scan1, dim3(1), dim3(1024), 0, ctx->stream, blk2, nblk2, stats + 1);
+    hipLaunchKernelGGL(k_st_offsets, dim3(nblk2), dim3(256), 0, ctx->stream, (const unsigned*)cnt, ns, (const unsigned*)blk2, off);
+    SC_HIP(ctx, hipGetLastError());
+    unsigned long long n_pairs = 0;
+    SC_HIP(ctx, hipMemcpyAsync(&n_pairs, stats + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    stats_out[1] = (long long)n_pairs;
+    // how much float64 work that is at most: pairs x the largest support box (the caller's bound: nothing is started beyond it)
+    int maxbox = 1;
+    for (int k = 0; k < n; ++k) maxbox = std::max(maxbox, ctx->h_templ[k].wh * ctx->h_templ[k].ww);
+    if (max_work > 0.0 && (double)n_pairs * (double)maxbox > max_work)
+        return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_settle_exact: too much float64 work (%llu pairs on %llu cells, boxes of up to %d cells)",
+                       n_pairs, n_slots, maxbox);
+    // ---- pair lists ----------------------------------------------------------------------------------------------
+    const size_t np = (size_t)n_pairs;
+    if ((rc = sc_ensure(ctx, ctx->st_pairs, 2 * up64(8 * np) + 2 * up64(4 * np) + 64))) return rc;
+    char* pp = (char*)ctx->st_pairs.p;
+    double* pair_amp = (double*)pp;
+    double* pair_snr = (double*)(pp + up64(8 * np));
+    int32_t* pair_t = (int32_t*)(pp + 2 * up64(8 * np));
+    uint32_t* pair_slot = (uint32_t*)(pp + 2 * up64(8 * np) + up64(4 * np));
+    hipLaunchKernelGGL(k_st_init_lists, dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, ns, (const uint32_t*)cell_of,
+                       (const uint32_t*)ctx->best_id.p, map, (const unsigned*)off, cnt, pair_t, pair_slot);
+    hipLaunchKernelGGL(k_st_events<true>, dim3(evb), dim3(256), 0, ctx->stream, ev, n_ev, (const uint32_t*)slot_of,
+                       (const uint32_t*)ctx->best_id.p, map, cnt, (const unsigned*)off, pair_t, pair_slot);
+    SC_HIP(ctx, hipGetLastError());
+    // ---- float64 scores ------------------------------------------------------------------------------------------
+    const unsigned long long* woff = nullptr;
+    const double *wbuf = nullptr, *pa = nullptr;
+    if ((rc = score_prepare_f64(ctx, n, &woff, &wbuf, &pa))) return rc;
+    const size_t npl = (size_t)g.ly * g.lx;
+    hipLaunchKernelGGL(k_st_score, dim3((unsigned)np), dim3(256), 0, ctx->stream, pa, pa + npl, pa + 2 * npl, g,
+                       (const TemplDev*)ctx->templ.p, (const double*)ctx->sums.p, (const double*)ctx->xaxis.p,
+                       (const double*)ctx->yaxis.p, woff, wbuf, (const unsigned*)off, (const int32_t*)pair_t,
+                       (const uint32_t*)pair_slot, (const uint32_t*)cell_of, pair_amp, pair_snr);
+    hipLaunchKernelGGL(k_st_resolve, dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, ns, (const unsigned*)off, (const int32_t*)pair_t,
+                       (const double*)pair_amp, (const double*)pair_snr, (const uint32_t*)cell_of, (const TemplDev*)ctx->templ.p,
+                       (float*)ctx->best_snr.p, (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p, p_amp, p_snr, p_id, stats);
+    SC_HIP(ctx, hipGetLastError());
+    unsigned long long h[ST_STATS] = {0};
+    SC_HIP(ctx, hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    rc = sc_sync(ctx);
+    if (rc) return rc;
+    stats_out[2] = (long long)h[2];
+    stats_out[3] = (long long)h[3];
+    stats_out[4] = (long long)h[4];
+    ctx->patch_n = ns;
+    return SC_OK;
+}
