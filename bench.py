@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--ages", type=int, default=0, help="ages of the grid (default: the config's)")
     ap.add_argument("--angles", type=int, default=0, help="orientations (default: the config's)")
     ap.add_argument("--method", default="fft")
+    ap.add_argument("--mode", default="exact", choices=["exact", "float32"],
+                    help="exact (default): every step settles its near-ties in float64 on the device - the argmax (age, "
+                         "orientation) of every cell is the float64 reference's, what sl.match delivers by default; float32: "
+                         "the float32 search as it is (sl.match(..., exact=False))")
     ap.add_argument("--group", type=int, default=0, help="templates per inverse launch (0: auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -261,7 +265,7 @@ def verify_window(pool, res, g, kind, scale, params, angles, plan, method="fft",
     chk = orc.check_fold(sub, a_st.reshape(T, h, wd), s_st.reshape(T, h, wd), np.repeat(params, len(angles)),
                          np.tile(angles, len(params)), tie_rtol=orc.tie_window(method, kind),
                          amp_tol=(P["amp"][0], P["amp"][1] * np.max(np.abs(a_st))),
-                         snr_tol=(P["snr"][0], P["snr"][1] * np.max(s_st)))
+                         snr_tol=(orc.snr_tolerance(kind)[0], orc.snr_tolerance(kind)[1] * np.max(s_st)))
     out = {"ok": chk["n_bad"] == 0, "window": list(win), "templates": T, "cells": chk["n"], "bad": chk["n_bad"],
            "cells_off_the_oracle_argmax": chk["n_inexact"], "cells_below_abs_tolerance": chk["n_below_only"],
            "exact_argmax_frac": round(chk["exact_frac"], 6), "near_tie_cells": chk["n_tie"],
@@ -272,7 +276,7 @@ def verify_window(pool, res, g, kind, scale, params, angles, plan, method="fft",
         chk2 = orc.check_fold(sub2, a_st.reshape(T, h, wd), s_st.reshape(T, h, wd), np.repeat(params, len(angles)),
                               np.tile(angles, len(params)), tie_rtol=orc.tie_window(method, kind),
                               amp_tol=(P["amp"][0], P["amp"][1] * np.max(np.abs(a_st))),
-                              snr_tol=(P["snr"][0], P["snr"][1] * np.max(s_st)))
+                              snr_tol=(orc.snr_tolerance(kind)[0], orc.snr_tolerance(kind)[1] * np.max(s_st)))
         out["also"] = {"bad": chk2["n_bad"], "cells_off_the_oracle_argmax": chk2["n_inexact"]}
     return out
 
@@ -301,27 +305,19 @@ def measured_traffic(default_workload):
         return None
 
 
-def exact_leg(g, Template, scale, params, angles, device, method):
-    """sl.match(..., exact=True) on the workload: (result arrays, line entry) - the near-ties the float32 FFT path cannot
-    decide settled in float64 on the device (scarplet_amd.core).  Never costs the line: an error
-    is reported as such."""
-    import warnings
-    import scarplet_amd as sl
+def other_mode_leg(step, ctx, a, units, steps=0):
+    """The same workload in the mode the headline is NOT timed in (the float32 search when the line is exact, and the other
+    way round): a short timed loop of its own after the headline's, reported beside it.  Never costs the line."""
+    import copy
     try:
-        mx = sl.Matcher(g, device=device)
-        t1 = time.perf_counter()
-        with warnings.catch_warnings(record=True) as wl:
-            warnings.simplefilter("always")
-            mx.search(Template, scale, params, angles, method=method, exact=True)
-            rx = mx.result()
-        dt = time.perf_counter() - t1
-        entry = {"seconds": round(dt, 3), "call": "Matcher(data).search(..., exact=True).result() - upload and planes outside",
-                 "stats": dict(getattr(mx, "exact_stats", {}))}
-        if wl:
-            entry["warnings"] = [str(w.message)[:200] for w in wl][:3]
-        return rx, entry
+        b = copy.copy(a)
+        b.steps, b.warmup, b.warmup_seconds = (steps or min(a.steps, 2)), 1 if a.steps > 2 else 0, 0.0
+        dt, _ = timed_loop(step, ctx, b, None)
+        return {"value": round(units / (dt / b.steps) / 1e6, 1), "unit": "Mpx·template/s",
+                "ms_per_step": round(1e3 * dt / b.steps, 2 if dt / b.steps >= 0.01 else 4), "steps": b.steps,
+                "roofline_frac": round(units / (dt / b.steps) * ALGO_BYTES_PER_UNIT / 1e9 / HBM_PEAK_GBS, 4)}
     except Exception as e:
-        return None, {"error": "%s: %s" % (type(e).__name__, e)}
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 # ----------------------------------------------------------------------------- the other BASELINE configs
@@ -348,31 +344,39 @@ def other_config_line(a, cfg, steps, warmup, device, pool):
     for sc in scales:
         arr, bbox, area = m.describe(Template, sc, params, angles)
         plan, sp = m.plan_for(bbox, area, b.method, None, n_params=len(params))
-        descs.append((arr, sp, plan))
+        descs.append((arr, sp, plan, m.exact_window_for(arr, sp), m.end_twins(arr, len(params), angles)))
+    settle_stats = {}
 
-    def step():
-        for (arr_, sp_, _) in descs:               # one result set per scale (C5)
-            m.ctx.reset_best()
-            m.ctx.match(arr_, sp_, sync=True)
-    dt, prof = timed_loop(step, m.ctx, b, None)
+    def make_step(exact):
+        def step():
+            for (arr_, sp_, _, win_, twin_) in descs:      # one result set per scale (C5)
+                st_ = m.run_described(arr_, sp_, win_ if exact else 0.0, twin_)
+                if st_:
+                    settle_stats.update(st_)
+        return step
+    dt, prof = timed_loop(make_step(a.mode == "exact"), m.ctx, b, None)
     ms = 1e3 * dt / steps
     value = units / (dt / steps) / 1e6
     plan = descs[-1][2]
-    line = {"workload": label, "value": round(value, 1), "unit": "Mpx·template/s", "ms_per_step": round(ms, 3),
-            "steps": steps, "warmup": WARMUP_RUN[0],
+    line = {"workload": label, "mode": a.mode, "value": round(value, 1), "unit": "Mpx·template/s", "ms_per_step": round(ms, 3),
+            "steps": steps, "warmup": WARMUP_RUN[0], "warmup_seconds": b.warmup_seconds,
             "tiles": "%dx%d of %dx%d" % (plan.nty, plan.ntx, plan.Ty, plan.Tx),
             "roofline_frac": round(value * 1e6 * ALGO_BYTES_PER_UNIT / 1e9 / HBM_PEAK_GBS, 4),
             "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in prof.items() if v[0]}}
+    if a.mode == "exact":
+        line["settle"] = dict(settle_stats)            # (the last scale's counters)
+        line["float32_mode"] = other_mode_leg(make_step(False), m.ctx, b, units)
     if not a.no_e2e and len(scales) == 1:
         # the call a user makes (C1F: the reference's flagship example, sl.match(load_carrizo(), Scarp, scale=100.)): upload,
         # curvature planes, descriptors, search, float64 result planes, D2H - the first call and the same call again
         def call():
+            ex = a.mode == "exact"
             if len(params) == 1:
                 return sl.match(g, Template, scale=scales[0], age=float(params[0]), ang_min=float(angles[0]),
-                                ang_max=float(angles[-1]), device=device, method=b.method)
+                                ang_max=float(angles[-1]), device=device, method=b.method, exact=ex)
             if len(params) == 35 and len(angles) == 181:
-                return sl.match(g, Template, scale=scales[0], device=device, method=b.method)
-            return sl.Matcher(g, device=device).search(Template, scales[0], params, angles, method=b.method).result()
+                return sl.match(g, Template, scale=scales[0], device=device, method=b.method, exact=ex)
+            return sl.Matcher(g, device=device).search(Template, scales[0], params, angles, method=b.method, exact=ex).result()
         secs = []
         for _ in range(2):
             m.ctx.sync()
@@ -383,14 +387,11 @@ def other_config_line(a, cfg, steps, warmup, device, pool):
         line["end_to_end_ms"] = {"first_call": round(1e3 * secs[0], 2), "repeat_call": round(1e3 * secs[1], 2),
                                  "call": "sl.match(data, Template, scale=...)" if (len(params) == 1 or len(params) == 35)
                                          else "Matcher(data).search(...).result()"}
-    rx = None
-    if cfg == "C1F" and not a.no_e2e:
-        rx, line["exact_mode"] = exact_leg(g, Template, scales[0], params, angles, device, b.method)
     if pool is not None and not a.no_verify:
+        # the record the timed loop's mode leaves behind (the last scale's, for C5)
+        make_step(a.mode == "exact")()
         res = m.ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
-        ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan, b.method, also=rx)
-        if "also" in ver:
-            line["exact_mode"].update(ver.pop("also"))
+        ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan, b.method)
         line["verified"] = ver["ok"]
         line["verification"] = {k: ver[k] for k in ("window", "templates", "cells", "bad", "cells_off_the_oracle_argmax",
                                                     "max_rel_snr_err", "note") if k in ver}
@@ -699,7 +700,7 @@ def build_sharding(sh, backend, a, rank, world, device, transport, g, Template, 
 
         def after_warmup():
             om.fold_seconds = 0.0
-        return {"step": step, "after_warmup": after_warmup, "plan": om.m.plan, "ctx": om.m.ctx,
+        return {"step": step, "after_warmup": after_warmup, "plan": om.m.plan, "ctx": om.m.ctx, "mode": "float32",
                 "part": "orientation grid in %d chunks, whole DEM on every rank, records folded by two all-reduces" % world,
                 "extra_seconds": lambda: om.fold_seconds, "gather_seconds": lambda: None,
                 "result": lambda: om.result_array()}
@@ -715,13 +716,16 @@ def build_sharding(sh, backend, a, rank, world, device, transport, g, Template, 
     dm.m.params, dm.m.angles = np.asarray(params, float), np.asarray(angles, float)
     halo_s, gather_s = [0.0], [0.0]
     full_box, gather_out = [None], [None]
+    # exact mode: every rank settles the near-ties of its own block in float64 (sc_settle_exact on the halo-extended block:
+    # the halo covers the templates' reach) before the gather - the record that travels carries the float64 argmax
+    win = dm.m.exact_window_for(arr, sp) if a.mode == "exact" else 0.0
+    twin = dm.m.end_twins(arr, len(params), angles)
 
     def step():
         t_ = time.perf_counter()
         dm.load(z_core, bbox)              # the exchange is part of a search
         halo_s[0] += time.perf_counter() - t_
-        dm.m.ctx.reset_best()
-        dm.m.ctx.match(arr, sp, sync=True)
+        dm.m.run_described(arr, sp, win, twin)
         # ... and so is the gather: the orientation sharding's step ends with the folded
         # record on every rank, this one's with the assembled maps on rank 0
         t_ = time.perf_counter()
@@ -733,7 +737,7 @@ def build_sharding(sh, backend, a, rank, world, device, transport, g, Template, 
     def after_warmup():
         halo_s[0] = 0.0
         gather_s[0] = 0.0
-    return {"step": step, "after_warmup": after_warmup, "plan": plan, "ctx": dm.m.ctx, "part": part,
+    return {"step": step, "after_warmup": after_warmup, "plan": plan, "ctx": dm.m.ctx, "part": part, "mode": a.mode,
             "extra_seconds": lambda: halo_s[0], "gather_seconds": lambda: gather_s[0],
             "result": lambda: np.stack(full_box[0]) if full_box[0] is not None else None}
 
@@ -788,6 +792,7 @@ def run_shardings(a, rank, world, device, dist, transport, pool, g, Template, sc
                 ms = 1e3 * dt / a.steps
                 line = base_line(units / (dt / a.steps) / 1e6, ms, plan, "%d (%s)" % (world, built["part"]), prof, world)
                 line["transport"] = label
+                line.setdefault("config", {})["mode"] = built.get("mode", getattr(a, "mode", "float32"))
                 line["rccl"] = {"nranks": int(infos[0]["nranks"]),
                                 "devices": [{"rank": i_["rank"], "device": i_["device"], "bus_id": i_["bus_id"]} for i_ in infos],
                                 "note": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice of every rank's communicator "
@@ -818,7 +823,13 @@ def run_shardings(a, rank, world, device, dist, transport, pool, g, Template, sc
                 runs[sh] = {"error": "%s: %s" % (type(e).__name__, e), "ms_per_step": None}
     if rank != 0:
         return None
-    first = min(runs, key=lambda k: runs[k]["ms_per_step"] if runs[k]["ms_per_step"] is not None else float("inf"))
+    # the top-level line: the faster sharding among those that ran in the mode asked for (exact: the tiles - the
+    # orientation sharding folds float32 records; its line rides along as the float32 figure)
+    def rank_key(k):
+        ms_ = runs[k]["ms_per_step"]
+        in_mode = "error" not in runs[k] and runs[k].get("config", {}).get("mode") == getattr(a, "mode", "float32")
+        return (ms_ is None, not in_mode, ms_ if ms_ is not None else float("inf"))
+    first = min(runs, key=rank_key)
     out = runs[first]
     if "error" in out:
         # nothing ran: the line is still printed - value null, the errors in it - and the exit code says so
@@ -866,7 +877,8 @@ def roofline_block(value, world, prof, units, steps, method, default_workload):
         r["traffic"] = t[dom]
         r["kernel_hbm_frac"] = round(t[dom] / avg_s / (HBM_PEAK_GBS * 1e9), 4)
         per_step = sum(t.get(k, 0) * prof[k][0] / steps for k in prof if prof[k][0])
-        if all(k in t for k in prof if prof[k][0]):
+        # (k_settle: one bracket per sc_settle_exact call - a dozen small kernels, 2 % of the exact step - is not in the table)
+        if all(k in t for k in prof if prof[k][0] and k != "k_settle"):
             r["traffic_ratio"] = round(per_step / (ALGO_BYTES_PER_UNIT * units), 4)
             r["traffic_bytes_per_step"] = int(per_step)
     return r
@@ -904,6 +916,8 @@ def main():
                 _pl.TILE_PENALTY[int(k_)] = _pl.TILE_PENALTY_Y[int(k_)] = float(v_)
     g, Template, scales, params, angles, label, kind = workload(a)     # same seed on every rank
     ny, nx = g._griddata.shape
+    if a.emulate_ranks:
+        a.mode = "float32"                     # (the one-GPU emulations time the float32 search of every chunk / block)
     pool = None
     if rank == 0 and not a.emulate_ranks and not (a.no_verify and (a.no_cpu_baseline or world > 1)):
         pool = make_pool(g, kind, scales[0])   # forked before the first HIP call below (and before
@@ -932,10 +946,11 @@ def main():
         return {
             "metric": "Mpixel·template/s (DEM pixels × ages × orientations / s)",
             "value": round(value, 1), "unit": "Mpx·template/s", "n_gpus": n_gpus,
-            "steps": a.steps, "warmup": a.warmup, "warmup_steps_run": WARMUP_RUN[0], "ms_per_step": round(ms, 2 if ms >= 10 else 4),
+            "steps": a.steps, "warmup": a.warmup, "warmup_steps_run": WARMUP_RUN[0],
+            "warmup_seconds": (a.warmup_seconds if world == 1 else 0.0), "ms_per_step": round(ms, 2 if ms >= 10 else 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" if a.config in ("C2", "C3") else "reference sample DEM (tests/golden)",
-            "config": {"workload": label, "method": a.method,
+            "config": {"workload": label, "method": a.method, "mode": a.mode,
                        "tiles": ("%dx%d of %dx%d" % (plan.nty, plan.ntx, plan.Ty, plan.Tx)) if a.method == "fft" else "-",
                        "group": int(getattr(plan, "group", 0)), "ranks": ranks_label},
             "roofline": roofline_block(value, n_gpus, prof, units, a.steps, a.method, default_workload),
@@ -1024,12 +1039,17 @@ def main():
         for sc in scales:
             arr, bbox, area = m.describe(Template, sc, params, angles)
             plan, sp = m.plan_for(bbox, area, a.method, a.group or None, n_params=len(params))
-            descs.append((arr, sp, plan))
+            descs.append((arr, sp, plan, m.exact_window_for(arr, sp), m.end_twins(arr, len(params), angles)))
+        settle_stats = {}
 
-        def step():
-            for (arr_, sp_, _) in descs:               # one result set per scale (C5)
-                m.ctx.reset_best()
-                m.ctx.match(arr_, sp_, sync=True)
+        def make_step(exact):
+            def step():
+                for (arr_, sp_, _, win_, twin_) in descs:      # one result set per scale (C5)
+                    st_ = m.run_described(arr_, sp_, win_ if exact else 0.0, twin_)
+                    if st_:
+                        settle_stats.update(st_)
+            return step
+        step = make_step(a.mode == "exact")
         ctx = m.ctx
         plan = descs[-1][2]
 
@@ -1066,13 +1086,14 @@ def main():
             # the whole call a user makes: upload of z, curvature planes, descriptors, search,
             # float64 result planes, D2H
             def call():
+                ex = a.mode == "exact"
                 if default_workload:
-                    return sl.match(g, Template, scale=scales[0], device=device, method=a.method)
+                    return sl.match(g, Template, scale=scales[0], device=device, method=a.method, exact=ex)
                 if len(params) == 1:
                     return sl.match(g, Template, scale=scales[0], age=float(params[0]), ang_min=float(angles[0]),
-                                    ang_max=float(angles[-1]), device=device, method=a.method)
+                                    ang_max=float(angles[-1]), device=device, method=a.method, exact=ex)
                 return sl.Matcher(g, device=device).search(Template, scales[0], params, angles, method=a.method,
-                                                           group=a.group or None).result()
+                                                           group=a.group or None, exact=ex).result()
             # Two calls right after the timed loop (the GPU still at its working clocks), BOTH reported as peers:
             # `value` / `seconds` is the FIRST - what a single sl.match of a fresh process pays, the 32 bytes per
             # cell of its result faulted in as fresh host pages under the copy; `repeat_call_seconds` is the same
@@ -1106,16 +1127,23 @@ def main():
                                              "seconds: the first call (fresh result pages); repeat_call_seconds: the "
                                              "same call again, result block recycled"}
         rx = None
-        if default_workload and not a.no_e2e:
-            rx, out["exact_mode"] = exact_leg(g, Template, scales[0], params, angles, device, a.method)
+        if a.mode == "exact":
+            out["settle"] = dict(settle_stats)
+        if default_workload:
+            other = "float32" if a.mode == "exact" else "exact"
+            out[other + "_mode"] = other_mode_leg(make_step(a.mode != "exact"), ctx, a, units)
+            if not a.no_e2e and not a.no_verify:
+                # the public call in the other mode, verified on the same window and stacks as the default call's result
+                rx = sl.match(g, Template, scale=scales[0], device=device, method=a.method, exact=(a.mode != "exact"))
         if not a.no_verify:
             # the result of the public call above; without it, the record the timed loop left behind
             # (the last scale's, for C5)
             if res is None:
+                step()                                  # (the timed mode's record, whatever ran in between)
                 res = ctx.get_result(np.repeat(params, len(angles)), np.tile(angles, len(params)))
             ver = verify_window(pool, res, g, kind, scales[-1], params, angles, plan, a.method, also=rx)
             if "also" in ver:
-                out["exact_mode"].update(ver.pop("also"))
+                out[("float32" if a.mode == "exact" else "exact") + "_mode"]["verification"] = ver.pop("also")
             out["verified"] = ver["ok"]
             out["verification"] = ver
             out["verification"]["of"] = "the arrays sl.match returned" if "end_to_end" in out else "the timed loop's record"

@@ -365,12 +365,13 @@ int sc_score_pairs_f64(sc_ctx* ctx, const int32_t* cells, const int32_t* templat
  * sc_get_best, sc_gather_result and sc_fold_ranks then see) and its float64 (amp, snr) are kept as patches that
  * sc_get_result lays over the converted planes - until the next sc_match or sc_reset_best.  No host pass over the planes:
  * three 8-byte read-backs size the buffers.
- *   n_twin    the last n_twin templates of the search stand for its first n_twin (the orientation grid's two ends are one
- *             template for the symmetric built-ins: +pi/2 against -pi/2, core.py:173-175 - their float64 SNRs differ by
- *             rounding noise, one maximum by the parity policy); 0: none.  A cell whose winner is the template the record
- *             names (or its twin) keeps the record's id
+ *   n_twin    the last n_twin templates of the search are one CLASS with its first n_twin (the orientation grid's two ends
+ *             are one template for the symmetric built-ins: +pi/2 against -pi/2, core.py:173-175 - their float64 SNRs
+ *             differ by rounding noise, one maximum by the parity policy); 0: none.  One member of a class is scored per
+ *             cell - the record's holder where its class is named - as itself (its amplitude carries its own sign)
  *   max_work  > 0: nothing is scored when pairs x the largest support box exceeds it (SC_ERR_UNSUPPORTED)
- *   stats     8 values: flagged cells, pairs listed, pairs scored, cells scored, cells whose template changed, events, 0, 0
+ *   stats     8 values: flagged cells, pairs listed, pairs scored, cells scored, cells whose template changed, events,
+ *             0, taps the scores weighed
  * SC_ERR_UNSUPPORTED also when the event list overflowed (the caller takes a longer route: sc_get_near_ties +
  * sc_score_cells_f64) and for templates with host-uploaded windows.
  */
@@ -388,7 +389,8 @@ int sc_get_template_sums(sc_ctx* ctx, int n, double* n_out, double* ts_out);
 #define SC_K_FWD_COLS    4
 #define SC_K_INV_COLS    5
 #define SC_K_INV_ROWS    6
-#define SC_K_COUNT       7
+#define SC_K_SETTLE      7      /* sc_settle_exact: all its kernels as one bracket */
+#define SC_K_COUNT       8
 /* HIP-event timing of every launch on the context's stream. */
 int sc_profile(sc_ctx* ctx, int enable);
 int sc_profile_get(sc_ctx* ctx, int kernel, long long* launches,

@@ -22,8 +22,8 @@ ID_NONE = 0xFFFFFFFF
 COMM_ID_BYTES = 128
 
 K_NAMES = ("k_curv", "k_windows", "k_direct", "k_fwd_rows", "k_fwd_cols",
-           "k_inv_cols", "k_inv_rows")
-K_CURV, K_WINDOWS, K_DIRECT, K_FWD_ROWS, K_FWD_COLS, K_INV_COLS, K_INV_ROWS = range(7)
+           "k_inv_cols", "k_inv_rows", "k_settle")
+K_CURV, K_WINDOWS, K_DIRECT, K_FWD_ROWS, K_FWD_COLS, K_INV_COLS, K_INV_ROWS, K_SETTLE = range(8)
 
 XFER_RECV, XFER_SEND, XFER_LOCAL = 0, 1, 2
 
@@ -449,7 +449,8 @@ class Context(object):
         st = (C.c_longlong * 8)()
         self._check(self.lib.sc_settle_exact(self._h, int(n_twin), float(max_work), st), "sc_settle_exact")
         return {"flagged_cells": int(st[0]), "pairs_listed": int(st[1]), "float64_pairs": int(st[2]),
-                "float64_cells": int(st[3]), "changed_cells": int(st[4]), "events": int(st[5])}
+                "float64_cells": int(st[3]), "changed_cells": int(st[4]), "events": int(st[5]),
+                "taps": int(st[7])}
 
     def comm_destroy(self):
         """Drop this context's RCCL communicator (sc_comm_destroy); nothing to do without one."""

@@ -442,6 +442,34 @@ class Matcher(object):
         self._id_ang = np.concatenate([self._id_ang, np.tile(angles, len(params))])
         return self
 
+    def run_described(self, arr, sp, exact_window=0.0, n_twin=0):
+        """One search of descriptors already built (``describe`` + ``plan_for``): reset, sc_match and - with
+        ``exact_window`` > 0 - the float64 settle of its near-ties (sc_settle_exact; ``n_twin``: templates of the last
+        orientation that are the first orientation's, end_twins()).  What bench.py times as one step; returns the
+        settle's counters or None."""
+        self.ctx.reset_best()
+        if not exact_window > 0.0:
+            self.ctx.match(arr, sp, sync=True)
+            return None
+        self.ctx.set_option("near_window", float(exact_window))
+        try:
+            self.ctx.match(arr, sp, sync=True)
+        finally:
+            self.ctx.set_option("near_window", 0.0)
+        return self.ctx.settle_exact(n_twin, self.EXACT_MAX_F64)
+
+    def exact_window_for(self, arr, sp):
+        """The near-tie window exact=True searches these descriptors with: by path and template family."""
+        if sp.method != _plan.METHOD_FFT:
+            return self.EXACT_WINDOW_DIRECT
+        kinds = {int(arr[0].kind), int(arr[len(arr) - 1].kind)}
+        return max(self.EXACT_WINDOW.get(k, max(self.EXACT_WINDOW.values())) for k in kinds)
+
+    def end_twins(self, arr, n_params, angles):
+        """How many templates at the end of the orientation-major list ``arr`` repeat its first ones: n_params where the
+        grid runs from -pi/2 to +pi/2 and the class is one of the symmetric built-ins (_without_end_twin), else 0."""
+        return len(arr) - len(self._without_end_twin(arr, n_params, angles))
+
     def _warn_if_unresolved(self):
         """The FFT path was asked for by name: it is handed out as it is, but not silently where the device's own
         statistic says it cannot resolve this surface in float32."""
@@ -467,10 +495,9 @@ class Matcher(object):
         the mode).  A list that overflows, or more float64 work than EXACT_MAX_F64, takes the longer routes of round 5."""
         import warnings
         n_par = len(params)
-        n_twin = len(arr) - len(self._without_end_twin(arr, n_par, angles))
-        kinds = {int(arr[0].kind), int(arr[len(arr) - 1].kind)}
-        win_fft = max(self.EXACT_WINDOW.get(k, max(self.EXACT_WINDOW.values())) for k in kinds)
+        n_twin = self.end_twins(arr, n_par, angles)
         fft = sp.method == _plan.METHOD_FFT
+        win_fft = self.exact_window_for(arr, sp) if fft else 0.0
         try:
             if fft:
                 self.ctx.set_option("near_window", win_fft)

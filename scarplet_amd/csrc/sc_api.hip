@@ -46,7 +46,7 @@ size_t sc_total_bytes(sc_ctx* c) {
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->norm_part, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
                      &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats, &c->digest, &c->split_s, &c->split_a, &c->split_i,
-                     &c->near, &c->near_ev, &c->score, &c->score_w, &c->score_abc, &c->st_slot, &c->st_work, &c->st_pairs, &c->st_patch};
+                     &c->near, &c->near_ev, &c->score, &c->score_w, &c->score_abc, &c->st_slot, &c->st_work, &c->st_pairs, &c->st_patch, &c->st_spans};
     size_t s = 0;
     for (DevBuf* b : arr) s += b->cap;
     for (auto& w : c->windows) s += (size_t)w.h * w.wd * 5;
@@ -224,7 +224,7 @@ extern "C" void sc_destroy(sc_ctx* c) {
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->norm_part, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
                      &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats, &c->digest, &c->split_s, &c->split_a, &c->split_i,
-                     &c->near, &c->near_ev, &c->score, &c->score_w, &c->score_abc, &c->st_slot, &c->st_work, &c->st_pairs, &c->st_patch};
+                     &c->near, &c->near_ev, &c->score, &c->score_w, &c->score_abc, &c->st_slot, &c->st_work, &c->st_pairs, &c->st_patch, &c->st_spans};
     for (DevBuf* b : arr) buf_free(*b);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp[k]);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp_in[k]);
@@ -1111,7 +1111,7 @@ extern "C" int sc_profile_get(sc_ctx* ctx, int kernel, long long* launches, doub
 
 extern "C" const char* sc_kernel_name(int kernel) {
     static const char* names[SC_K_COUNT] = {"k_curv", "k_windows", "k_direct", "k_fwd_rows",
-                                            "k_fwd_cols", "k_inv_cols", "k_inv_rows"};
+                                            "k_fwd_cols", "k_inv_cols", "k_inv_rows", "k_settle"};
     return (kernel >= 0 && kernel < SC_K_COUNT) ? names[kernel] : "?";
 }
 

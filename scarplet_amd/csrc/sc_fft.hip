@@ -2393,7 +2393,13 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
 #endif
 #ifndef SC_I2_RAREWIN
 #ifndef SC_I2_NEAR_WAVES
-#define SC_I2_NEAR_WAVES 3  // waves per SIMD the near-tie variant is compiled for
+#define SC_I2_NEAR_WAVES 4  // waves per SIMD the near-tie variant is compiled for (round 6: four, like the plain kernel - event loop, amplitude stored at a win)
+#endif
+#ifndef SC_I2_NEAR_AMPW
+#define SC_I2_NEAR_AMPW 1
+#endif
+#ifndef SC_I2_NEAR_LOOP
+#define SC_I2_NEAR_LOOP 1   // (round 6) the near-tie events of a record branch from a loop over a mask instead of one site per output
 #endif
 #ifndef SC_I2_NEAR_RARE
 #define SC_I2_NEAR_RARE 1   // the near-tie variant of the row pass on the deferred record update too (0: selects and a test per output)
@@ -2441,7 +2447,7 @@ __host__ __device__ constexpr size_t inv_rows_fast_lds_split() {
 #define SC_I2_WAVES_FULL 3
 #endif
 template <int TX, bool FULL, bool MAPS, bool PT, bool SPLITK = false, bool NEAR = false>
-__global__ void __launch_bounds__(inv_rows_fast_threads<TX>(), NEAR ? SC_I2_NEAR_WAVES : (FULL && !MAPS) ? SC_I2_WAVES_FULL : SC_I2_WAVES)
+__global__ void __launch_bounds__(inv_rows_fast_threads<TX>(), NEAR ? (PT ? 3 : SC_I2_NEAR_WAVES) : (FULL && !MAPS) ? SC_I2_WAVES_FULL : SC_I2_WAVES)
 k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 RowArgs ra, Geom g, const TileDev* __restrict__ tiles,
                 const TemplDev* __restrict__ templ, const double* __restrict__ sums,
@@ -2611,6 +2617,10 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     // write-back (the kernel is VALU-bound: every instruction per cell counts).
     constexpr int NBEST = PT ? NC : 2 * NC;
     constexpr uint32_t NONE = 0xFFFFFFFFu;
+    // NEAR (round 6): a winner's amplitude is STORED when it wins (the record branch) instead of its transform output
+    // being carried in sixteen registers to the write-back - the same product of the same two floats; with the event
+    // loop's temporaries the near-tie variant then fits the plain kernel's four waves per SIMD
+    constexpr bool AMPW = NEAR && !PT && SC_I2_NEAR_LOOP && SC_I2_NEAR_AMPW;
     auto best_of = [](int c, int part) { return PT ? c : 2 * c + part; };
     float b_snr[NBEST], b_xr[NBEST];
     uint32_t b_ix[NBEST / 4];                  // one byte per cell (0xFF: unchanged)
@@ -2772,6 +2782,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         }
         const bool all_in = SC_I2_STATIC && !FULL && !MAPS && covers[0] && covers[1];     // workgroup-uniform
         const float near_lo = NEAR ? 1.f - 1.0001f * ra.near_w - 2e-7f : 1.f;             // (NEAR, deferred form: candidates score above the record times this)
+        const float near_up = 1.f - ra.near_w;                                            // (a winner times this at or below the record it beat: a near-tie)
         auto stage3 = [&](auto static_tag) {
         constexpr bool STATIC = decltype(static_tag)::value;
 #pragma unroll
@@ -2857,7 +2868,11 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                         }
                         if constexpr (RARE) {
                             // (NEAR: a candidate - a win, or a score inside the window below the record; near_lo = 1 - near_w less a hair)
+#ifdef SC_I2_NEAR_NOMUL                    // timing probe only: the near-tie variant without its window (flags nothing below the record)
+                            const bool cand = won;
+#else
                             const bool cand = NEAR ? (in && snr > b_snr[k] * near_lo) : won;
+#endif
                             wonm[m - m0][part] = cand;
                             snrs[m - m0][part] = snr;
                             anyw = anyw || cand;
@@ -2877,6 +2892,22 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
             // branch: where two templates ride one transform (PT) the second meets the first's update there.
             // Same order, same values: the record is identical.
             if (RARE && !MAPS && __builtin_amdgcn_ballot_w64(anyw) != 0ull) {
+                // NEAR, one template per transform (round 6): the events of a branch's near-ties come from a LOOP over a mask
+                // after the record's update (sixteen unrolled emission sites, each with its atomic and its addresses, cost the
+                // kernel 41 registers and its fourth wave per SIMD: 168 -> 128).
+                constexpr bool NEAR_LOOP = NEAR && !PT && SC_I2_NEAR_LOOP;
+                // NEAR_LOOP: which of the branch's outputs are near-ties costs no vector instruction of its own - a candidate
+                // that does NOT win lies inside the window below the record (that is what made it a candidate); one that
+                // wins is tested against the window's upper side under the branch its amplitude's store takes anyway.
+                // Bits of ntm: the lane's near-tie outputs; old_ix: the holders as the branch found them (an event names
+                // the holder it met).  The branch is NOT rare (a cell is won dozens of times in a search: most waves
+                // see a win per template); a near-tie is - three in a million outputs.
+                uint32_t ntm = 0;
+                uint32_t old_ix[NBEST / 4];
+                if constexpr (NEAR_LOOP) {
+#pragma unroll
+                    for (int q = 0; q < NBEST / 4; ++q) old_ix[q] = b_ix[q];
+                }
 #pragma unroll
                 for (int m = m0; m < m0 + GRP; ++m) {
                     const v2 xc = vw[pk::B<R3, true>::pos(m)];
@@ -2884,7 +2915,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                     for (int part = 0; part < 2; ++part) {
                         const int k = best_of(u * R3 + m, part);
                         const float snr = snrs[m - m0][part];
-                        if constexpr (NEAR) {
+                        if constexpr (NEAR && !NEAR_LOOP) {
                             // the near-tie test of the select form on the candidates (all of them inside the cell's range), against
                             // the record as it stands now - where two templates ride one transform the second meets the first's update
                             const float top = fmaxf(snr, b_snr[k]);
@@ -2903,10 +2934,49 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                             }
                         }
                         const bool won = wonm[m - m0][part] && snr > b_snr[k];
-                        b_snr[k] = won ? snr : b_snr[k];
-                        b_xr[k] = won ? (part ? xc.y : xc.x) : b_xr[k];
+                        if constexpr (NEAR_LOOP) {
+                            bool nt = wonm[m - m0][part] && !won;                 // below the record, inside the window (equal scores too)
+                            if constexpr (AMPW) {
+                                if (__builtin_amdgcn_ballot_w64(won) != 0ull) {
+                                    nt = nt || (won && snr * near_up <= b_snr[k]); // won, and the record it beat lies inside the window
+                                    if (won)
+                                        at_bytes(best_amp + off_of(part), 4u * (uint32_t)col_of(u * R3 + m)) = (part ? xc.y : xc.x) * ka[part];
+                                }
+                            } else {
+                                nt = nt || (won && snr * near_up <= b_snr[k]);
+                                b_xr[k] = won ? (part ? xc.y : xc.x) : b_xr[k];
+                            }
+                            if (__builtin_amdgcn_ballot_w64(nt) != 0ull) ntm |= nt ? (1u << (2 * (m - m0) + part)) : 0u;
+                            b_snr[k] = won ? snr : b_snr[k];
+                        } else {
+                            b_snr[k] = won ? snr : b_snr[k];
+                            b_xr[k] = won ? (part ? xc.y : xc.x) : b_xr[k];
+                        }
                         const uint32_t bm = 0xFFu << (8 * (k & 3));
                         b_ix[k >> 2] = won ? ((b_ix[k >> 2] & ~bm) | (tix[part] & bm)) : b_ix[k >> 2];
+                    }
+                }
+                if constexpr (NEAR_LOOP) {
+                    // the events, after the update: the outputs' scores and values are dead by now - the loop's temporaries
+                    // take their registers instead of a fourth wave per SIMD (round 6: 168 registers -> 128)
+                    while (ntm) {                          // (per lane; a near-tie is three in a million outputs)
+                        const int bit = __builtin_ctz(ntm);
+                        ntm &= ntm - 1;
+                        const int part = bit & 1, c = u * R3 + m0 + (bit >> 1), k = 2 * c + part;
+                        nearm |= 1u << k;
+                        if (ra.ev) {
+                            const unsigned long long slot = atomicAdd(ra.ev_count, 1ull);
+                            if (slot < ra.ev_cap) {
+                                const uint32_t hx = (old_ix[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                                const int cj = col_of(c);
+                                const size_t cell = (part ? offB : offA) + (size_t)cj;
+                                uint32_t* e = ra.ev + 3 * slot;
+                                e[0] = (uint32_t)cell;
+                                e[1] = part ? tpp[1]->id : tpp[0]->id;
+                                // a holder from an earlier launch (or none yet: SC_ID_NONE) stands in the record's id plane
+                                e[2] = hx != 0xFFu ? templ[ra.first + hx].id : best_id[cell];
+                            }
+                        }
                     }
                 }
             }
@@ -2933,8 +3003,8 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         // (d = (T1 / snr - eps) n), not in the template loop.
         int n_won = 0, n_near = 0;
         // one won cell into the statistic: template ix of the launch holds it with raw output b_xr[k], SNR b_snr[k]
-        auto count = [&](int k, const float* e) {
-            const float T1 = b_xr[k] * b_xr[k] * e[1], fl = fmaf(fabsf(b_xr[k]), e[2], e[3]);
+        auto count = [&](int k, const float* e, float xr_) {
+            const float T1 = xr_ * xr_ * e[1], fl = fmaf(fabsf(xr_), e[2], e[3]);
             const float d = (T1 / b_snr[k] - (float)SC_EPS) / e[4];
             ++n_won;
             n_near += (fl > 0.f && d < 256.f * fl) ? 1 : 0;
@@ -2960,7 +3030,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                     at_bytes(ra.s2 + pl_ + off_of(part), o) = won ? b_snr[k] : 0.f;
                     at_bytes(ra.a2 + pl_ + off_of(part), o) = won ? b_xr[k] * e[0] : 0.f;
                     at_bytes(ra.i2 + pl_ + off_of(part), o) = won ? templ[ra.first + (won ? ix : 0)].id : SC_ID_NONE;
-                    if (won && b_snr[k] > 0.f) count(k, e);
+                    if (won && b_snr[k] > 0.f) count(k, e, b_xr[k]);
                 }
             }
         }
@@ -2981,9 +3051,10 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 const uint32_t o = 4u * (uint32_t)col_of(c);
                 const float* e = epi + EPI_FLOATS * ix;
                 at_bytes(best_snr + off_of(part), o) = b_snr[k];
-                at_bytes(best_amp + off_of(part), o) = b_xr[k] * e[0];
+                if constexpr (!AMPW) at_bytes(best_amp + off_of(part), o) = b_xr[k] * e[0];
                 at_bytes(best_id + off_of(part), o) = templ[ra.first + ix].id;
-                count(k, e);
+                // (AMPW: the statistic's transform output back from the stored amplitude - a count, not a result)
+                count(k, e, AMPW ? at_bytes(best_amp + off_of(part), o) / e[0] : b_xr[k]);
             }
         }
         }

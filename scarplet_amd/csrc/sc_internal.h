@@ -126,7 +126,7 @@ struct sc_ctx {
     // sc_settle_exact: slot of every flagged cell (one word per core cell, valid at flagged cells), the work lists, and the
     // patches - per flagged cell its index and the float64 (amp, snr, id) sc_get_result writes over the converted record;
     // patch_n: how many the current record carries (0 after any sc_match / sc_reset_best)
-    DevBuf st_slot, st_work, st_pairs, st_patch;
+    DevBuf st_slot, st_work, st_pairs, st_patch, st_spans;
     size_t patch_n = 0;
     DevBuf score;              // sc_score_cells_f64: the cell list and the two float64 outputs
     DevBuf score_w;            // ... and the templates' float64 windows (offsets, then the windows)

@@ -17,7 +17,7 @@
 //   k_st_events<false>                          cnt[slot] += candidates the slot's events add
 //   k_st_sum / k_st_scan1 / k_st_offsets        exclusive scan -> off[slot]
 //   k_st_init_lists, k_st_events<true>          pair lists: entry 0 the final holder, then the events' templates
-//   k_window_f64, k_curv_planes<double>         (score_prepare_f64)
+//   k_window_f64, k_curv_planes<double>         (score_prepare_f64); k_st_sums: n and sum(W**2) in a fixed order
 //   k_st_score                                  one workgroup per pair; repeats of a template in a list and lists of one
 //                                               template are not scored
 //   k_st_resolve                                per slot the largest float64 SNR, ties to the earlier template
@@ -142,19 +142,17 @@ k_st_offsets(const unsigned* __restrict__ in, unsigned n, const unsigned* __rest
     }
 }
 
-// template id -> its index in the last search's hand-over order, the grid's end twins collapsed (the last n_twin
-// templates stand for the first n_twin: Scarp at +pi/2 is minus Scarp at -pi/2, a Ricker the same template - one
-// maximum by the parity policy); -1: not a template of this search
+// template id -> its index in the last search's hand-over order (-1: not a template of this search), and the CLASS of an
+// index: the grid's end twins are one class (the last n_twin templates stand for the first n_twin - Scarp at +pi/2 is
+// minus Scarp at -pi/2, a Ricker the same template: their float64 SNRs differ by rounding noise, one maximum by the parity
+// policy).  The lists hold real indices - a template is scored as itself, its amplitude carries its own sign - and at
+// most one member of a class per cell: the record's holder where its class is named, else the first listed.
 struct IdMap {
     const int32_t* tab;
     uint32_t n_ids;
     int32_t n, n_twin;
-    __device__ __forceinline__ int32_t operator()(uint32_t id) const {
-        if (id >= n_ids) return -1;
-        int32_t t = tab[id];
-        if (t >= n - n_twin) t -= n - n_twin;
-        return t;
-    }
+    __device__ __forceinline__ int32_t operator()(uint32_t id) const { return id < n_ids ? tab[id] : -1; }
+    __device__ __forceinline__ int32_t cls(int32_t t) const { return t >= n - n_twin ? t - (n - n_twin) : t; }
 };
 
 // FILL = false: cnt[slot] += what the event adds to its cell's list; true: the same candidates into the lists
@@ -167,7 +165,8 @@ k_st_events(const uint32_t* __restrict__ ev, unsigned long long n_ev, const uint
     if (k >= n_ev) return;
     const uint32_t cell = ev[3 * k];
     const int32_t ms = map(ev[3 * k + 1]), mh = map(ev[3 * k + 2]), mf = map(best_id[cell]);
-    const bool a = ms >= 0 && ms != mf, b = mh >= 0 && mh != mf && mh != ms;
+    const int32_t cf = mf >= 0 ? map.cls(mf) : -1;
+    const bool a = ms >= 0 && map.cls(ms) != cf, b = mh >= 0 && map.cls(mh) != cf && map.cls(mh) != (ms >= 0 ? map.cls(ms) : -1);
     if (!a && !b) return;
     const uint32_t slot = slot_of[cell];
     if (!FILL) {
@@ -192,27 +191,88 @@ k_st_init_lists(unsigned n_slots, const uint32_t* __restrict__ cell_of, const ui
     fill[s] = 1u;
 }
 
+// n = count(W != 0) and sum(W**2) of every template from its float64 window, in a FIXED order (one workgroup per template,
+// strided partial sums, a shuffle tree, the four waves in order).  The search's own sums (k_windows) are accumulated with
+// float64 atomics: their last bit changes from run to run - and where templates are proportional to each other (a window one
+// cell wide at +-pi/2 for the youngest ages on a coarse DEM: the same SNR in exact arithmetic) that bit would decide the
+// argmax differently every run.  With these the settle is the same in every bit every time.
+__global__ void __launch_bounds__(256)
+k_st_sums(const TemplDev* __restrict__ templ, const unsigned long long* __restrict__ woff, const double* __restrict__ wbuf,
+          double* __restrict__ sums) {
+    const int it = blockIdx.x;
+    const int box = templ[it].wh * templ[it].ww;
+    const double* __restrict__ wt = wbuf + woff[it];
+    double n = 0.0, ts = 0.0;
+    for (int e = threadIdx.x; e < box; e += 256) {
+        const double w = wt[e];
+        n += w != 0.0 ? 1.0 : 0.0;
+        ts = fma(w, w, ts);
+    }
+    __shared__ double red[2][4];
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        n += __shfl_down(n, sft, 64);
+        ts += __shfl_down(ts, sft, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = n; red[1][threadIdx.x >> 6] = ts; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sums[2 * it] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        sums[2 * it + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    }
+}
+
+// The support of every row of every float64 window: first and last non-zero column (a window is |xr| < c & |yr| < d - a
+// convex region: one run per row, with the odd zero inside where xr == 0 exactly), and per template the longest run.  The
+// supports of the searches' windows are a SEVENTH of their boxes (a thin young scarp at 45 degrees: seven taps a row in a
+// box 145 wide): the scorer walks the runs, not the boxes.  grid = (rows / 4, templates), one wave per row.
+__global__ void __launch_bounds__(256)
+k_st_spans(const TemplDev* __restrict__ templ, const unsigned long long* __restrict__ woff, const double* __restrict__ wbuf,
+           const unsigned* __restrict__ soff, int2* __restrict__ spans, int* __restrict__ maxlen) {
+    const int it = blockIdx.y, a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wh = templ[it].wh, ww = templ[it].ww;
+    if (a >= wh) return;
+    const double* __restrict__ row = wbuf + woff[it] + (size_t)a * ww;
+    int first = 0x7FFFFFFF, last = -1;
+    for (int b0 = 0; b0 < ww; b0 += 64) {
+        const int b = b0 + lane;
+        const unsigned long long m = __ballot(b < ww && row[b < ww ? b : 0] != 0.0);
+        if (m) {
+            first = min(first, b0 + (int)__builtin_ctzll(m));
+            last = b0 + 63 - (int)__builtin_clzll(m);
+        }
+    }
+    if (lane == 0) {
+        spans[soff[it] + a] = last >= first ? make_int2(first, last) : make_int2(0, -1);     // (an empty row: a run of no cells)
+        if (last >= first) atomicMax(maxlen + it, last - first + 1);
+    }
+}
+
 __device__ __forceinline__ int wrap1(int x, int n) { return x < 0 ? x + n : (x >= n ? x - n : x); }
 
 // match_template() of one (cell, template) pair in float64 - k_score_f64's arithmetic on the lists of sc_settle_exact.
-// One workgroup per list entry; an entry that repeats an earlier template of its list, or whose list names one
-// template only, is marked (snr = -1) and not scored.
+// One workgroup per list entry; an entry whose template (or its end twin) the list holds a second time, or whose list names
+// one template only, is marked (snr = -1) and not scored.
 __global__ void __launch_bounds__(256)
 k_st_score(const double* __restrict__ pa, const double* __restrict__ pb, const double* __restrict__ pc, Geom g,
            const TemplDev* __restrict__ templ, const double* __restrict__ sums,
            const double* __restrict__ xaxis, const double* __restrict__ yaxis,
            const unsigned long long* __restrict__ woff, const double* __restrict__ wbuf,
+           const unsigned* __restrict__ soff, const int2* __restrict__ spans, const int* __restrict__ maxlen,
            const unsigned* __restrict__ off, const int32_t* __restrict__ pair_t, const uint32_t* __restrict__ pair_slot,
-           const uint32_t* __restrict__ cell_of, double* __restrict__ amp_out, double* __restrict__ snr_out) {
+           const uint32_t* __restrict__ cell_of, IdMap map, double* __restrict__ amp_out, double* __restrict__ snr_out) {
     const unsigned pos = blockIdx.x;
     const uint32_t slot = pair_slot[pos];
     const int it = pair_t[pos];
     const unsigned lo = off[slot], hi = off[slot + 1];
     bool dup = false, other = false;
+    const int ci = it >= 0 ? map.cls(it) : -1;
     for (unsigned k = lo; k < hi; ++k) {                                   // (workgroup-uniform: scalar loads)
         const int tk = pair_t[k];
-        dup = dup || (k < pos && tk == it);
-        other = other || (tk >= 0 && tk != it);
+        const int ck = tk >= 0 ? map.cls(tk) : -2;
+        // of a class one member is scored: the record's holder (entry 0), else the smallest index listed - whatever order
+        // the events' atomics filled the list in (the same template listed twice: the earlier entry)
+        dup = dup || (ck == ci && k != pos && (k == lo || (pos != lo && (tk < it || (tk == it && k < pos)))));
+        other = other || (tk >= 0 && ck != ci);
     }
     if (it < 0 || dup || !other) {
         if (threadIdx.x == 0) { snr_out[pos] = -1.0; amp_out[pos] = 0.0; }
@@ -227,30 +287,40 @@ k_st_score(const double* __restrict__ pa, const double* __restrict__ pb, const d
     const double k_cc = __dmul_rn(ca, ca), k_ss = __dmul_rn(sa, sa);
     const double* __restrict__ wt = wbuf + woff[it];
     double xc = 0.0, t3 = 0.0;
-    const int box = t.wh * t.ww;
-    // element e = a ww + b of the window's box, 256 apart per step: (a, b) carried instead of divided out
-    const int da = 256 / t.ww, db = 256 - da * t.ww;
-    int a = (int)threadIdx.x / t.ww, b = (int)threadIdx.x - a * t.ww;
-    for (int e = threadIdx.x; e < box; e += 256) {
-        const double w = wt[e];
-        if (w != 0.0) {                                                     // (W != 0 is the mask M, core.py:348)
-            // curvature at global ((i - p + oy) mod ny, (j - q + ox) mod nx), p = pmin + a, q = qmin + b
-            int gi = i - (t.pmin + a) + g.oy, gj = j - (t.qmin + b) + g.ox;
-            int li, lj;
-            if (g.wrap) { li = wrap1(gi, g.ny); lj = wrap1(gj, g.nx); }
-            else { li = gi - g.gy0; lj = gj - g.gx0; }
-            if (li >= 0 && li < g.ly && lj >= 0 && lj < g.lx) {            // (outside a halo block: the host sized the halo)
-                const size_t o = (size_t)li * g.lx + lj;
-                const double A = pa[o], Bc = pb[o], C = pc[o];
-                const double cv = __dadd_rn(__dsub_rn(__dmul_rn(A, k_cc), __dmul_rn(__dmul_rn(__dmul_rn(2.0, Bc), sa), ca)),
-                                            __dmul_rn(C, k_ss));
-                xc = fma(w, cv, xc);
-                t3 = fma(cv, cv, t3);
-            }
+    // The runs of the window's rows (k_st_spans), L = the template's longest run rounded up to a power of two (64 at most)
+    // lanes per row and 256 / L rows at a time: a thin window keeps its lanes busy, a wide one walks its runs in steps
+    // of 64.  The kernel is bound by the bytes it pulls through L2, not by its load latencies: fetching the plane
+    // values whether or not a tap weighs anything took 180 ms instead of 78 on the C3 search, walking whole boxes
+    // (seven cells for every tap) 78 instead of what the runs take - profiles/r06_settle.txt.
+    int ls = 0;
+    {
+        const int ml = maxlen[it];
+        while ((1 << ls) < ml && ls < 6) ++ls;
+    }
+    const int L = 1 << ls, R = 256 >> ls;
+    const int bl = (int)threadIdx.x & (L - 1);
+    const int2* __restrict__ sp_t = spans + soff[it];
+    for (int a = (int)threadIdx.x >> ls; a < t.wh; a += R) {
+        const int2 sp = sp_t[a];
+        // curvature at global ((i - p + oy) mod ny, (j - q + ox) mod nx), p = pmin + a, q = qmin + b
+        const int gi = i - (t.pmin + a) + g.oy;
+        const int li = g.wrap ? wrap1(gi, g.ny) : gi - g.gy0;
+        if (li < 0 || li >= g.ly) continue;                               // (outside a halo block: the host sized the halo)
+        const double* __restrict__ wrow = wt + (size_t)a * t.ww;
+        const size_t orow = (size_t)li * g.lx;
+        for (int b = sp.x + bl; b <= sp.y; b += L) {
+            const double w = wrow[b];
+            if (w == 0.0) continue;                                        // (W != 0 is the mask M, core.py:348)
+            const int gj = j - (t.qmin + b) + g.ox;
+            const int lj = g.wrap ? wrap1(gj, g.nx) : gj - g.gx0;
+            if (lj < 0 || lj >= g.lx) continue;
+            const size_t o = orow + lj;
+            const double A = pa[o], Bc = pb[o], C = pc[o];
+            const double cv = __dadd_rn(__dsub_rn(__dmul_rn(A, k_cc), __dmul_rn(__dmul_rn(__dmul_rn(2.0, Bc), sa), ca)),
+                                        __dmul_rn(C, k_ss));
+            xc = fma(w, cv, xc);
+            t3 = fma(cv, cv, t3);
         }
-        a += da;
-        b += db;
-        if (b >= t.ww) { b -= t.ww; ++a; }
     }
     __shared__ double red[2][4];
     for (int sft = 32; sft > 0; sft >>= 1) {
@@ -280,16 +350,17 @@ k_st_score(const double* __restrict__ pa, const double* __restrict__ pb, const d
 
 // Per slot: the largest float64 SNR of its list, ties to the earlier template of the fold order (the hand-over order:
 // what the device's own fold keeps).  The winner goes into the record (id; amp and snr rounded to float32) and into the
-// patch (float64); a cell whose winner is the template the record already names keeps that id (of two end twins the one
-// the float32 fold chose).
+// patch (float64).  A class is scored once per cell, the record's holder standing for its own: an unchanged cell keeps
+// its id and gets the float64 values of that very template.
 __global__ void __launch_bounds__(256)
 k_st_resolve(unsigned n_slots, const unsigned* __restrict__ off, const int32_t* __restrict__ pair_t,
              const double* __restrict__ pair_amp, const double* __restrict__ pair_snr, const uint32_t* __restrict__ cell_of,
-             const TemplDev* __restrict__ templ, float* __restrict__ best_snr, float* __restrict__ best_amp,
-             uint32_t* __restrict__ best_id, double* __restrict__ p_amp, double* __restrict__ p_snr,
-             uint32_t* __restrict__ p_id, unsigned long long* __restrict__ stats) {
+             const TemplDev* __restrict__ templ, const double* __restrict__ sums, float* __restrict__ best_snr,
+             float* __restrict__ best_amp, uint32_t* __restrict__ best_id, double* __restrict__ p_amp,
+             double* __restrict__ p_snr, uint32_t* __restrict__ p_id, unsigned long long* __restrict__ stats) {
     const unsigned s = blockIdx.x * 256 + threadIdx.x;
     unsigned scored = 0, changed = 0;
+    unsigned long long taps = 0;                   // (what the scores cost: the taps they weighed)
     if (s < n_slots) {
         const unsigned lo = off[s], hi = off[s + 1];
         double bs = -1.0, ba = 0.0;
@@ -299,13 +370,14 @@ k_st_resolve(unsigned n_slots, const unsigned* __restrict__ off, const int32_t* 
             if (v < 0.0) continue;
             ++scored;
             const int tk = pair_t[k];
+            taps += (unsigned long long)sums[2 * tk];
             if (v > bs || (v == bs && tk < bt)) { bs = v; ba = pair_amp[k]; bt = tk; }
         }
         uint32_t id = SC_ID_NONE;
         if (bs > 0.0) {
             const uint32_t cell = cell_of[s];
             changed = bt != pair_t[lo];
-            id = changed ? templ[bt].id : best_id[cell];
+            id = templ[bt].id;
             best_id[cell] = id;
             best_snr[cell] = (float)bs;
             best_amp[cell] = (float)ba;
@@ -319,10 +391,12 @@ k_st_resolve(unsigned n_slots, const unsigned* __restrict__ off, const int32_t* 
         scored += __shfl_down(scored, sft, 64);
         changed += __shfl_down(changed, sft, 64);
         c1 += __shfl_down(c1, sft, 64);
+        taps += __shfl_down(taps, sft, 64);
     }
     if ((threadIdx.x & 63) == 0 && scored) {
         atomicAdd(stats + 2, (unsigned long long)scored);
         atomicAdd(stats + 3, (unsigned long long)c1);
+        atomicAdd(stats + 7, taps);
         if (changed) atomicAdd(stats + 4, (unsigned long long)changed);
     }
 }
@@ -409,7 +483,8 @@ extern "C" int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long lo
     const size_t ns_max = (size_t)std::min<unsigned long long>(n_ev, nc);
     const unsigned nblk2_max = (unsigned)((ns_max + 1 + ST_CH - 1) / ST_CH);
     const size_t o_cnt = o_end0, o_off = o_cnt + up64(4 * (ns_max + 1)), o_blk2 = o_off + up64(4 * (ns_max + 2)),
-                 o_end = o_blk2 + up64(4 * (size_t)nblk2_max);
+                 o_sums = o_blk2 + up64(4 * (size_t)nblk2_max), o_soff = o_sums + up64(16 * (size_t)n),
+                 o_mlen = o_soff + up64(4 * ((size_t)n + 1)), o_end = o_mlen + up64(4 * (size_t)n);
     if ((rc = sc_ensure(ctx, ctx->st_work, o_end))) return rc;
     char* wk = (char*)ctx->st_work.p;
     unsigned long long* stats = (unsigned long long*)wk;
@@ -418,9 +493,23 @@ extern "C" int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long lo
     unsigned* cnt = (unsigned*)(wk + o_cnt);
     unsigned* off = (unsigned*)(wk + o_off);
     unsigned* blk2 = (unsigned*)(wk + o_blk2);
+    double* sums64 = (double*)(wk + o_sums);
+    unsigned* soff = (unsigned*)(wk + o_soff);
+    int* maxlen = (int*)(wk + o_mlen);
+    // rows of every template's window before it: the offsets of the run table
+    std::vector<unsigned> h_soff((size_t)n + 1, 0u);
+    int wh_max = 1;
+    for (int k = 0; k < n; ++k) {
+        h_soff[k + 1] = h_soff[k] + (unsigned)ctx->h_templ[k].wh;
+        wh_max = std::max(wh_max, ctx->h_templ[k].wh);
+    }
     if ((rc = sc_ensure(ctx, ctx->st_patch, 2 * up64(8 * ns_max) + 2 * up64(4 * ns_max) + 64))) return rc;
+    sc_prof_begin(ctx, SC_K_SETTLE);              // (one bracket over the whole call: every return below closes it)
+    struct ProfEnd { sc_ctx* c; ~ProfEnd() { sc_prof_end(c); } } prof_end{ctx};
     SC_HIP(ctx, hipMemsetAsync(stats, 0, 8 * ST_STATS, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(d_tab, idtab.data(), 4 * idtab.size(), hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(soff, h_soff.data(), 4 * h_soff.size(), hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemsetAsync(maxlen, 0, 4 * (size_t)n, ctx->stream));
     hipLaunchKernelGGL(k_st_flag_count, dim3(nblk), dim3(256), 0, ctx->stream, near, nc, blk);
     hipLaunchKernelGGL(k_st_scan1, dim3(1), dim3(1024), 0, ctx->stream, blk, nblk, stats);
     SC_HIP(ctx, hipGetLastError());
@@ -474,21 +563,27 @@ extern "C" int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long lo
     const double *wbuf = nullptr, *pa = nullptr;
     if ((rc = score_prepare_f64(ctx, n, &woff, &wbuf, &pa))) return rc;
     const size_t npl = (size_t)g.ly * g.lx;
+    hipLaunchKernelGGL(k_st_sums, dim3(n), dim3(256), 0, ctx->stream, (const TemplDev*)ctx->templ.p, woff, wbuf, sums64);
+    if ((rc = sc_ensure(ctx, ctx->st_spans, sizeof(int2) * (size_t)h_soff[n] + 64))) return rc;
+    hipLaunchKernelGGL(k_st_spans, dim3((wh_max + 3) / 4, n), dim3(256), 0, ctx->stream, (const TemplDev*)ctx->templ.p, woff, wbuf,
+                       (const unsigned*)soff, (int2*)ctx->st_spans.p, maxlen);
     hipLaunchKernelGGL(k_st_score, dim3((unsigned)np), dim3(256), 0, ctx->stream, pa, pa + npl, pa + 2 * npl, g,
-                       (const TemplDev*)ctx->templ.p, (const double*)ctx->sums.p, (const double*)ctx->xaxis.p,
-                       (const double*)ctx->yaxis.p, woff, wbuf, (const unsigned*)off, (const int32_t*)pair_t,
-                       (const uint32_t*)pair_slot, (const uint32_t*)cell_of, pair_amp, pair_snr);
+                       (const TemplDev*)ctx->templ.p, (const double*)sums64, (const double*)ctx->xaxis.p,
+                       (const double*)ctx->yaxis.p, woff, wbuf, (const unsigned*)soff, (const int2*)ctx->st_spans.p,
+                       (const int*)maxlen, (const unsigned*)off, (const int32_t*)pair_t,
+                       (const uint32_t*)pair_slot, (const uint32_t*)cell_of, map, pair_amp, pair_snr);
     hipLaunchKernelGGL(k_st_resolve, dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, ns, (const unsigned*)off, (const int32_t*)pair_t,
                        (const double*)pair_amp, (const double*)pair_snr, (const uint32_t*)cell_of, (const TemplDev*)ctx->templ.p,
-                       (float*)ctx->best_snr.p, (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p, p_amp, p_snr, p_id, stats);
+                       (const double*)sums64, (float*)ctx->best_snr.p, (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p, p_amp, p_snr, p_id, stats);
     SC_HIP(ctx, hipGetLastError());
     unsigned long long h[ST_STATS] = {0};
     SC_HIP(ctx, hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-    rc = sc_sync(ctx);
-    if (rc) return rc;
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     stats_out[2] = (long long)h[2];
     stats_out[3] = (long long)h[3];
     stats_out[4] = (long long)h[4];
+    stats_out[7] = (long long)h[7];
     ctx->patch_n = ns;
+    ctx->async_in_flight = false;
     return SC_OK;
 }

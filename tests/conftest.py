@@ -48,7 +48,7 @@ def oracle_pool(request):
     import multiprocessing as mp
     import scarplet_oracle  # noqa: F401  (workers inherit the module)
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    pool = mp.get_context("fork").Pool(max(1, min(n, 48)))
+    pool = mp.get_context("fork").Pool(max(1, min(n, 96)))
     yield pool
     pool.terminate()
     pool.join()

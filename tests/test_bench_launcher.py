@@ -160,6 +160,7 @@ class _FakeTransport(object):
 def _args(**kw):
     class A:
         steps, warmup, prof_stride, opt, shard, halo, method, group, partition = 2, 1, 0, "", "auto", "rccl", "fft", 0, "tiles"
+        mode = "exact"
     for k, v in kw.items():
         setattr(A, k, v)
     return A
@@ -185,6 +186,7 @@ def test_rccl_failure_falls_back_to_the_host_transport(monkeypatch):
             return {"step": step, "after_warmup": lambda: None, "plan": None, "ctx": shared, "part": "p",
                     "extra_seconds": lambda: 0.0, "gather_seconds": lambda: None, "result": lambda: None}
         return {"step": lambda: None, "after_warmup": lambda: None, "plan": None, "ctx": ctx_host, "part": "part",
+                "mode": "exact" if sh == "tiles" else "float32",
                 "extra_seconds": lambda: 0.002, "gather_seconds": (lambda: 0.004) if sh == "tiles" else (lambda: None),
                 "result": lambda: None}
     monkeypatch.setattr(bench, "build_sharding", fake_build)
@@ -202,7 +204,10 @@ def test_rccl_failure_falls_back_to_the_host_transport(monkeypatch):
     by = {("tiles" if "gather_ms" in b else "orientations"): b for b in both}
     assert by["orientations"]["transport"].startswith("host (RCCL failed: RuntimeError: sc_comm_init")
     assert by["tiles"]["transport"].startswith("host (RCCL failed: RuntimeError: sc_halo_exchange")
-    assert "failed" not in out and out["sharding"] in ("orientations", "tiles")
+    # exact mode: the top-level line is the sharding that settles its near-ties (the tiles), the orientation sharding's
+    # float32 line rides along
+    assert "failed" not in out and out["sharding"] == "tiles" and out["config"]["mode"] == "exact"
+    assert out["orientations"]["config"]["mode"] == "float32"
 
 
 def test_every_transport_failing_still_prints_a_line(monkeypatch):

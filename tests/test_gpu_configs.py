@@ -102,7 +102,7 @@ def test_c5_grandcanyon_channel_five_scales(gpu_ctx):
             chk = orc.check_fold(res, a_st.reshape(T, *z.shape), s_st.reshape(T, *z.shape),
                                  np.repeat([0.1], T), angles,
                                  tie_rtol=orc.tie_window(method, orc.RICKER), amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
-                                 snr_tol=(SNR_RTOL, SNR_ATOL * np.max(s_st)))
+                                 snr_tol=(orc.snr_tolerance(orc.RICKER)[0], SNR_ATOL * np.max(s_st)))
             report("C5 scale %g %s" % (scale, method), chk, method)
             assert chk["n_bad"] == 0, (scale, method, chk["n_bad"])
 
@@ -120,7 +120,7 @@ def test_channel_several_widths_in_one_fold(gpu_ctx):
     chk = orc.check_fold(res, a_st.reshape(T, *z.shape), s_st.reshape(T, *z.shape),
                          np.repeat(widths, len(angles)), np.tile(angles, len(widths)),
                          tie_rtol=TIE_RTOL, amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
-                         snr_tol=(SNR_RTOL, SNR_ATOL * np.max(s_st)))
+                         snr_tol=(orc.snr_tolerance(orc.RICKER)[0], SNR_ATOL * np.max(s_st)))
     assert chk["n_bad"] == 0, chk["n_bad"]
     assert len(np.unique(res[1][res[3] > 0])) > 1     # more than one width wins somewhere
 

@@ -172,7 +172,7 @@ def fold_check(res, z, dx, dy, kind, scale, params, angles, method="fft"):
     angs = np.tile(np.asarray(angles, float), len(params))
     return orc.check_fold(res, a_st.reshape(T, ny, nx), s_st.reshape(T, ny, nx), ages, angs,
                           tie_rtol=orc.tie_window(method, kind), amp_tol=(AMP_RTOL, AMP_ATOL * np.max(np.abs(a_st))),
-                          snr_tol=(SNR_RTOL, SNR_ATOL * np.max(s_st)))
+                          snr_tol=(orc.snr_tolerance(kind)[0], orc.snr_tolerance(kind)[1] * np.max(s_st)))
 
 
 @pytest.mark.parametrize("method", ["direct", "fft"])
@@ -226,10 +226,12 @@ def test_small_searches_reference(gpu_ctx):
             assert same.mean() >= EXACT_MIN, float(same.mean())
 
 
-def golden_check(res, gold):
+def golden_check(res, gold, tie_rtol=orc.tie_window("fft", orc.SCARP)):
     """Against a reference golden without the per-template stack: cells whose
     (age, angle) equal the golden's must match in amp/snr; any other cell must
-    be a near-tie, i.e. reach the golden's (maximal) SNR within TIE_RTOL."""
+    be a near-tie, i.e. reach the golden's (maximal) SNR within the tie window of
+    the template family (the reference's goldens are Scarp searches: 1e-4)."""
+    TIE_RTOL = tie_rtol
     amp, age, ang, snr = [np.asarray(a) for a in res]
     g_amp, g_age, g_ang, g_snr = gold
     same = np.isclose(age, g_age, rtol=1e-9) & (ang == g_ang)
@@ -298,7 +300,7 @@ def test_noise_free_surfaces_resolution_floor(gpu_ctx):
         A, S, K = A.reshape(T, ny, nx), S.reshape(T, ny, nx), K.reshape(T, ny, nx)
         ages_t, angs_t = np.repeat(params, len(angles)), np.tile(angles, len(params))
         tol = dict(tie_rtol=TIE_RTOL, amp_tol=(AMP_RTOL, AMP_ATOL * np.abs(A).max()),
-                   snr_tol=(SNR_RTOL, SNR_ATOL * S.max()))
+                   snr_tol=(orc.snr_tolerance(kind)[0], orc.snr_tolerance(kind)[1] * S.max()))
         m = sl.Matcher(grid(z, dx, dy), ctx=gpu_ctx)
         arr, bbox, area = m.describe(cls, scale, np.asarray(params, float), np.asarray(angles, float))
         p = _plan.Plan(m.ny, m.nx, m.core, bbox, whole=True, method=_plan.METHOD_FFT, t_max=tmax)
@@ -806,7 +808,8 @@ def test_random_searches_against_the_oracle(gpu_ctx):
         T = len(params) * len(angles)
         ages, angs = np.repeat(np.asarray(params, float), len(angles)), np.tile(angles, len(params))
         A, S = a_st.reshape(T, ny, nx), s_st.reshape(T, ny, nx)
-        tol = dict(amp_tol=(AMP_RTOL, AMP_ATOL * float(np.max(np.abs(A)))), snr_tol=(SNR_RTOL, SNR_ATOL * float(np.max(S))))
+        tol = dict(amp_tol=(AMP_RTOL, AMP_ATOL * float(np.max(np.abs(A)))),
+                   snr_tol=(orc.snr_tolerance(kind)[0], orc.snr_tolerance(kind)[1] * float(np.max(S))))
         cells += ny * nx
         for name, kw in (("fft", dict(method="fft")), ("direct", dict(method="direct")), ("auto", dict(method="auto")),
                          ("exact", dict(method="fft", exact=True))):
@@ -838,7 +841,8 @@ def test_exact_mode_on_the_real_space_path(gpu_ctx):
         T = len(params) * len(angles)
         ages, angs = np.repeat(np.asarray(params, float), len(angles)), np.tile(angles, len(params))
         A, S = a_st.reshape(T, ny, nx), s_st.reshape(T, ny, nx)
-        tol = dict(amp_tol=(AMP_RTOL, AMP_ATOL * float(np.max(np.abs(A)))), snr_tol=(SNR_RTOL, SNR_ATOL * float(np.max(S))))
+        tol = dict(amp_tol=(AMP_RTOL, AMP_ATOL * float(np.max(np.abs(A)))),
+                   snr_tol=(orc.snr_tolerance(kind)[0], orc.snr_tolerance(kind)[1] * float(np.max(S))))
         off = {}
         for exact in (False, True):
             m = sl.Matcher(grid(z, de, dy), ctx=gpu_ctx)

@@ -50,6 +50,10 @@ def test_fft_kernels_fit_their_occupancy():
     t = kernel_table("sc_fft.hip")
     row = t["k_inv_rows_fast<2048, false, false, false, false, false>"]
     assert row["scratch"] == 0 and row["vgpr"] <= 128, row             # four waves per SIMD, nothing spilled
+    # round 6: the near-tie variant (exact=True, the default of sl.match) at the same occupancy - its events come from a
+    # loop over a mask after the record's update, a winner's amplitude is stored at the win
+    near = t["k_inv_rows_fast<2048, false, false, false, false, true>"]
+    assert near["scratch"] == 0 and near["vgpr"] <= 128, near
     # round 5: column length 512, half a wave per column: two 512-thread workgroups per CU (its scratch - the
     # phase factors of the parking prologue - lies outside the template loop)
     for name in ("k_inv_cols_h2<false, false>", "k_inv_cols_h2<true, false>"):

@@ -56,7 +56,7 @@ for case in range(n_cases):
     angs = np.tile(np.asarray(angles, float), len(params))
     A, S = a_st.reshape(T, ny, nx), s_st.reshape(T, ny, nx)
     tol = dict(amp_tol=(orc.PARITY["amp"][0], orc.PARITY["amp"][1] * float(np.max(np.abs(A)))),
-               snr_tol=(orc.PARITY["snr"][0], orc.PARITY["snr"][1] * float(np.max(S))))
+               snr_tol=(orc.snr_tolerance(kind)[0], orc.snr_tolerance(kind)[1] * float(np.max(S))))
     line = "case %3d %4dx%-4d %-26s de %.1f dy %+.1f scale %6.1f %d x %d" % (case, ny, nx, cls.__name__, de, dy, scale,
                                                                            len(params), len(angles))
     for name, kw in (("fft", dict(method="fft")), ("direct", dict(method="direct")), ("auto", dict(method="auto")),
