@@ -573,6 +573,110 @@ def snr_stack_windows(z, dx, dy, kind, scale, ages, angles, wins, margin, pool, 
     return stacks
 
 
+def _windows_direct_chunk(job):
+    """A run of templates against SEVERAL small windows, in real space (snr_stack_windows_direct)."""
+    (crops, gis, gjs, ny, nx, dx, dy, kind, scale, margin, pairs) = job
+    cy, cx = crops[0].shape
+    planes = []
+    for zc, gi, gj in zip(crops, gis, gjs):
+        # dem.py:88-101 on the crop with the zero borders of the FULL grid (as _window_one)
+        A, B, C = curvature_components(zc, dx, dy)
+        A[:, (gj == 0) | (gj == nx - 1)] = 0
+        B[:, gj == 0] = 0
+        B[gi == 0, :] = 0
+        C[(gi == 0) | (gi == ny - 1), :] = 0
+        planes.append((A, B, C))
+    h, w = cy - 2 * margin, cx - 2 * margin
+    out = []
+    for (age, angle) in pairs:
+        W, _, err = template_arrays(kind, scale, age, angle, cx, cy, dx)
+        M = (W != 0)
+        n = np.sum(M) + EPS                                   # core.py:350
+        template_sum = np.sum(W ** 2)                         # core.py:356
+        amps = np.zeros((len(crops), h, w))
+        snrs = np.zeros((len(crops), h, w))
+        rows, cols = np.flatnonzero(M.any(axis=1)), np.flatnonzero(M.any(axis=0))
+        alpha = -angle
+        if kind != RICKER:
+            xm, ym = window_limit_axes(nx, ny, dx, alpha, scarp_c(age), scale)
+        if len(rows):
+            k0, k1, l0, l1 = rows[0], rows[-1], cols[0], cols[-1]
+            Wf = W[k0:k1 + 1, l0:l1 + 1][::-1, ::-1]            # W[k1 - a, l1 - b]
+            Mf = M[k0:k1 + 1, l0:l1 + 1][::-1, ::-1]
+            bh, bw = Wf.shape
+            for q, (A, B, C) in enumerate(planes):
+                # xcorr[i, j] = sum_kl W[k, l] curv[i - cy//2 - k, j - cx//2 - l] (core.py:359 with its fftshift; xcorr_direct):
+                # the curvature rows i - cy//2 - k1 .. i - cy//2 - k0 against W's rows k1 .. k0
+                # (indices modulo the crop: the template's centre sits at cy//2, so these come out around the window itself)
+                r0, c0 = (margin - cy // 2 - k1) % cy, (margin - cx // 2 - l1) % cx
+                if r0 + bh + h - 1 > cy or c0 + bw + w - 1 > cx or bh + h - 1 > 2 * margin + h or bw + w - 1 > 2 * margin + w:
+                    raise ValueError("margin does not cover the template's reach")
+                reg = (slice(r0, r0 + bh + h - 1), slice(c0, c0 + bw + w - 1))
+                cv = A[reg] * np.cos(angle) ** 2 - 2 * B[reg] * np.sin(angle) * np.cos(angle) + C[reg] * np.sin(angle) ** 2
+                cv2 = cv ** 2
+                for i in range(h):
+                    for j in range(w):
+                        xcorr = np.sum(Wf * cv[i:i + bh, j:j + bw])
+                        T3 = np.sum(cv2[i:i + bh, j:j + bw][Mf])
+                        amp = xcorr / template_sum
+                        T1 = template_sum * (amp ** 2)
+                        with np.errstate(divide="ignore", invalid="ignore"):
+                            error = (1 / n) * (T1 - 2 * amp * xcorr + T3) + EPS
+                            amps[q, i, j], snrs[q, i, j] = amp, np.abs(T1 / error)
+        else:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                amps[:] = np.float64(0.0) / template_sum
+                snrs[:] = np.abs(amps * 0 / EPS)
+        for q, (gi, gj) in enumerate(zip(gis, gjs)):
+            gi_in, gj_in = gi[margin:cy - margin], gj[margin:cx - margin]
+            if kind in (RIGHT_UPPER, LEFT_UPPER):
+                x, y = grid_axes(nx, ny, dx)
+                xr = x[gj_in][None, :] * np.cos(alpha) + y[gi_in][:, None] * np.sin(alpha)
+                snrs[q][(xr <= 0) if kind == RIGHT_UPPER else (xr >= 0)] = 0
+            if kind != RICKER:
+                lim = ym[gi_in][:, None] | xm[gj_in][None, :]
+                amps[q][lim] = 0
+                snrs[q][lim] = 0
+        out.append((amps, snrs))
+    return out
+
+
+def snr_stack_windows_direct(z, dx, dy, kind, scale, ages, angles, wins, margin, pool=None):
+    """snr_stack_windows for MANY SMALL windows of one shape (tests that probe dozens of single cells against the whole
+    template grid), evaluated in real space: the template is built once per (age, angle) on the crops' common grid and
+    correlated with each window's curvature as the closed form of core.py:359 / 363 (xcorr_direct's sum, restricted to
+    the window's few cells and the template's support) instead of six FFTs of every crop.  The same quantities as
+    snr_stack_window to float64 summation order (1e-12; tests/test_oracle.py compares the two), at a hundredth of the cost
+    for 2 x 2 windows."""
+    z = np.asarray(z)
+    ny, nx = z.shape
+    shapes = {(i1 - i0, j1 - j0) for (i0, i1, j0, j1) in wins}
+    if len(shapes) != 1:
+        raise ValueError("windows of one shape")
+    crops, gis, gjs = [], [], []
+    for (i0, i1, j0, j1) in wins:
+        gi = np.arange(i0 - margin, i1 + margin) % ny
+        gj = np.arange(j0 - margin, j1 + margin) % nx
+        if (len(gi) - ny) % 2 or (len(gj) - nx) % 2:
+            raise ValueError("crop and DEM sizes must have the same parity")
+        crops.append(np.asarray(z[np.ix_(gi, gj)], dtype=float))
+        gis.append(gi)
+        gjs.append(gj)
+    pairs = [(age, ang) for age in ages for ang in angles]
+    nproc = (getattr(pool, "_processes", None) or 1) if pool is not None else 1
+    per = max(1, -(-len(pairs) // (2 * nproc)))
+    jobs = [(crops, gis, gjs, ny, nx, dx, dy, kind, scale, margin, pairs[a:a + per]) for a in range(0, len(pairs), per)]
+    res = pool.map(_windows_direct_chunk, jobs, chunksize=1) if pool is not None else [_windows_direct_chunk(j) for j in jobs]
+    flat = [r for chunk in res for r in chunk]
+    h, w = next(iter(shapes))
+    stacks = []
+    for q in range(len(wins)):
+        amp = np.array([f[0][q] for f in flat]).reshape(len(ages), len(angles), h, w)
+        snr = np.array([f[1][q] for f in flat]).reshape(amp.shape)
+        stacks.append((amp, snr))
+    return stacks
+
+
 # Stated parity tolerances of the float32 device path against this float64
 # oracle (DESIGN.md "Parity"); shared by tests/, smoke() and bench.py's check:
 #   amp : |d| <= rtol*|amp| + atol*max|amp|      snr likewise

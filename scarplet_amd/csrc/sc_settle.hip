@@ -18,7 +18,8 @@
 //   k_st_sum / k_st_scan1 / k_st_offsets        exclusive scan -> off[slot]
 //   k_st_init_lists, k_st_events<true>          pair lists: entry 0 the final holder, then the events' templates
 //   k_window_f64, k_curv_planes<double>         (score_prepare_f64); k_st_sums: n and sum(W**2) in a fixed order
-//   k_st_score                                  one workgroup per pair; repeats of a template in a list and lists of one
+//   k_st_spans                                  the windows' row runs (their supports are a seventh of their boxes)
+//   k_st_score                                  one wave per pair; repeats of a template in a list and lists of one
 //                                               template are not scored
 //   k_st_resolve                                per slot the largest float64 SNR, ties to the earlier template
 #include "sc_internal.h"
@@ -250,8 +251,9 @@ k_st_spans(const TemplDev* __restrict__ templ, const unsigned long long* __restr
 __device__ __forceinline__ int wrap1(int x, int n) { return x < 0 ? x + n : (x >= n ? x - n : x); }
 
 // match_template() of one (cell, template) pair in float64 - k_score_f64's arithmetic on the lists of sc_settle_exact.
-// One workgroup per list entry; an entry whose template (or its end twin) the list holds a second time, or whose list names
-// one template only, is marked (snr = -1) and not scored.
+// One WAVE per list entry (four entries per workgroup: the windows that meet in near-ties are thin - 1 700 taps on average
+// on the C3 search - and a workgroup per pair spent its time starting up and reducing); an entry whose template (or its
+// end twin) the list holds a second time, or whose list names one template only, is marked (snr = -1) and not scored.
 __global__ void __launch_bounds__(256)
 k_st_score(const double* __restrict__ pa, const double* __restrict__ pb, const double* __restrict__ pc, Geom g,
            const TemplDev* __restrict__ templ, const double* __restrict__ sums,
@@ -259,14 +261,17 @@ k_st_score(const double* __restrict__ pa, const double* __restrict__ pb, const d
            const unsigned long long* __restrict__ woff, const double* __restrict__ wbuf,
            const unsigned* __restrict__ soff, const int2* __restrict__ spans, const int* __restrict__ maxlen,
            const unsigned* __restrict__ off, const int32_t* __restrict__ pair_t, const uint32_t* __restrict__ pair_slot,
-           const uint32_t* __restrict__ cell_of, IdMap map, double* __restrict__ amp_out, double* __restrict__ snr_out) {
-    const unsigned pos = blockIdx.x;
+           const uint32_t* __restrict__ cell_of, IdMap map, unsigned n_pairs, double* __restrict__ amp_out,
+           double* __restrict__ snr_out) {
+    const unsigned pos = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));    // (wave-uniform: scalar loads below)
+    const int lane = threadIdx.x & 63;
+    if (pos >= n_pairs) return;
     const uint32_t slot = pair_slot[pos];
     const int it = pair_t[pos];
     const unsigned lo = off[slot], hi = off[slot + 1];
     bool dup = false, other = false;
     const int ci = it >= 0 ? map.cls(it) : -1;
-    for (unsigned k = lo; k < hi; ++k) {                                   // (workgroup-uniform: scalar loads)
+    for (unsigned k = lo; k < hi; ++k) {
         const int tk = pair_t[k];
         const int ck = tk >= 0 ? map.cls(tk) : -2;
         // of a class one member is scored: the record's holder (entry 0), else the smallest index listed - whatever order
@@ -275,7 +280,7 @@ k_st_score(const double* __restrict__ pa, const double* __restrict__ pb, const d
         other = other || (tk >= 0 && ck != ci);
     }
     if (it < 0 || dup || !other) {
-        if (threadIdx.x == 0) { snr_out[pos] = -1.0; amp_out[pos] = 0.0; }
+        if (lane == 0) { snr_out[pos] = -1.0; amp_out[pos] = 0.0; }
         return;
     }
     const int cw = g.cx1 - g.cx0;
@@ -287,51 +292,67 @@ k_st_score(const double* __restrict__ pa, const double* __restrict__ pb, const d
     const double k_cc = __dmul_rn(ca, ca), k_ss = __dmul_rn(sa, sa);
     const double* __restrict__ wt = wbuf + woff[it];
     double xc = 0.0, t3 = 0.0;
-    // The runs of the window's rows (k_st_spans), L = the template's longest run rounded up to a power of two (64 at most)
-    // lanes per row and 256 / L rows at a time: a thin window keeps its lanes busy, a wide one walks its runs in steps
-    // of 64.  The kernel is bound by the bytes it pulls through L2, not by its load latencies: fetching the plane
-    // values whether or not a tap weighs anything took 180 ms instead of 78 on the C3 search, walking whole boxes
-    // (seven cells for every tap) 78 instead of what the runs take - profiles/r06_settle.txt.
-    int ls = 0;
-    {
-        const int ml = maxlen[it];
-        while ((1 << ls) < ml && ls < 6) ++ls;
-    }
-    const int L = 1 << ls, R = 256 >> ls;
-    const int bl = (int)threadIdx.x & (L - 1);
-    const int2* __restrict__ sp_t = spans + soff[it];
-    for (int a = (int)threadIdx.x >> ls; a < t.wh; a += R) {
-        const int2 sp = sp_t[a];
-        // curvature at global ((i - p + oy) mod ny, (j - q + ox) mod nx), p = pmin + a, q = qmin + b
+    // The runs of the window's rows (k_st_spans).  L = the template's longest run rounded up to a power of two lanes per
+    // row, 64 / L rows at a time.  (The bytes through L2 are what this kernel costs: fetching the plane values whether or
+    // not a tap weighs anything took 180 ms instead of 78 on the C3 search, walking whole boxes - seven cells for every
+    // tap - 78 instead of 43, a workgroup per pair 43 instead of what a wave per pair takes: profiles/r06_settle.txt.)
+    // One tap: curvature at global ((i - p + oy) mod ny, (j - q + ox) mod nx), p = pmin + a, q = qmin + b
+    auto row_of = [&](int a, size_t& orow) {
         const int gi = i - (t.pmin + a) + g.oy;
         const int li = g.wrap ? wrap1(gi, g.ny) : gi - g.gy0;
-        if (li < 0 || li >= g.ly) continue;                               // (outside a halo block: the host sized the halo)
-        const double* __restrict__ wrow = wt + (size_t)a * t.ww;
-        const size_t orow = (size_t)li * g.lx;
-        for (int b = sp.x + bl; b <= sp.y; b += L) {
-            const double w = wrow[b];
-            if (w == 0.0) continue;                                        // (W != 0 is the mask M, core.py:348)
-            const int gj = j - (t.qmin + b) + g.ox;
-            const int lj = g.wrap ? wrap1(gj, g.nx) : gj - g.gx0;
-            if (lj < 0 || lj >= g.lx) continue;
-            const size_t o = orow + lj;
-            const double A = pa[o], Bc = pb[o], C = pc[o];
-            const double cv = __dadd_rn(__dsub_rn(__dmul_rn(A, k_cc), __dmul_rn(__dmul_rn(__dmul_rn(2.0, Bc), sa), ca)),
-                                        __dmul_rn(C, k_ss));
-            xc = fma(w, cv, xc);
-            t3 = fma(cv, cv, t3);
+        orow = (size_t)(li < 0 || li >= g.ly ? 0 : li) * g.lx;
+        return li >= 0 && li < g.ly;                                       // (outside a halo block: the host sized the halo)
+    };
+    auto col_of = [&](int b, int& lj) {
+        const int gj = j - (t.qmin + b) + g.ox;
+        lj = g.wrap ? wrap1(gj, g.nx) : gj - g.gx0;
+        return lj >= 0 && lj < g.lx;
+    };
+    auto tap = [&](double w, size_t o) {
+        const double A = pa[o], Bc = pb[o], C = pc[o];
+        const double cv = __dadd_rn(__dsub_rn(__dmul_rn(A, k_cc), __dmul_rn(__dmul_rn(__dmul_rn(2.0, Bc), sa), ca)),
+                                    __dmul_rn(C, k_ss));
+        xc = fma(w, cv, xc);
+        t3 = fma(cv, cv, t3);
+    };
+    const int2* __restrict__ sp_t = spans + soff[it];
+    const int ml = maxlen[it];
+    if (ml <= 64) {
+        // every run fits the lanes of its row: one tap per lane and row, two row groups in flight
+        int ls = 0;
+        while ((1 << ls) < ml) ++ls;
+        const int R = 64 >> ls, bl = lane & ((1 << ls) - 1);
+        for (int a0 = lane >> ls; a0 < t.wh; a0 += 2 * R) {
+            const int a1 = a0 + R;
+            const int2 s0 = sp_t[a0], s1 = a1 < t.wh ? sp_t[a1] : make_int2(0, -1);
+            size_t or0, or1;
+            const bool r0 = row_of(a0, or0), r1 = a1 < t.wh && row_of(a1, or1);
+            const int b0 = s0.x + bl, b1 = s1.x + bl;
+            const bool v0 = r0 && b0 <= s0.y, v1 = r1 && b1 <= s1.y;
+            const double w0 = v0 ? wt[(size_t)a0 * t.ww + b0] : 0.0, w1 = v1 ? wt[(size_t)a1 * t.ww + b1] : 0.0;
+            int l0, l1;
+            const bool c0 = v0 && w0 != 0.0 && col_of(b0, l0), c1 = v1 && w1 != 0.0 && col_of(b1, l1);     // (W != 0 is the mask M, core.py:348)
+            if (c0) tap(w0, or0 + l0);
+            if (c1) tap(w1, or1 + l1);
+        }
+    } else {
+        for (int a = 0; a < t.wh; ++a) {
+            const int2 sp = sp_t[a];
+            size_t orow;
+            if (!row_of(a, orow)) continue;
+            const double* __restrict__ wrow = wt + (size_t)a * t.ww;
+            for (int b = sp.x + lane; b <= sp.y; b += 64) {
+                const double w = wrow[b];
+                int lj;
+                if (w != 0.0 && col_of(b, lj)) tap(w, orow + lj);
+            }
         }
     }
-    __shared__ double red[2][4];
     for (int sft = 32; sft > 0; sft >>= 1) {
         xc += __shfl_down(xc, sft, 64);
         t3 += __shfl_down(t3, sft, 64);
     }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = xc; red[1][threadIdx.x >> 6] = t3; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        xc = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        t3 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (lane == 0) {
         const double n = sums[2 * it] + SC_EPS, ts = sums[2 * it + 1];
         double amp = xc / ts;
         const double T1 = ts * (amp * amp);
@@ -567,11 +588,11 @@ extern "C" int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long lo
     if ((rc = sc_ensure(ctx, ctx->st_spans, sizeof(int2) * (size_t)h_soff[n] + 64))) return rc;
     hipLaunchKernelGGL(k_st_spans, dim3((wh_max + 3) / 4, n), dim3(256), 0, ctx->stream, (const TemplDev*)ctx->templ.p, woff, wbuf,
                        (const unsigned*)soff, (int2*)ctx->st_spans.p, maxlen);
-    hipLaunchKernelGGL(k_st_score, dim3((unsigned)np), dim3(256), 0, ctx->stream, pa, pa + npl, pa + 2 * npl, g,
+    hipLaunchKernelGGL(k_st_score, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, ctx->stream, pa, pa + npl, pa + 2 * npl, g,
                        (const TemplDev*)ctx->templ.p, (const double*)sums64, (const double*)ctx->xaxis.p,
                        (const double*)ctx->yaxis.p, woff, wbuf, (const unsigned*)soff, (const int2*)ctx->st_spans.p,
                        (const int*)maxlen, (const unsigned*)off, (const int32_t*)pair_t,
-                       (const uint32_t*)pair_slot, (const uint32_t*)cell_of, map, pair_amp, pair_snr);
+                       (const uint32_t*)pair_slot, (const uint32_t*)cell_of, map, (unsigned)np, pair_amp, pair_snr);
     hipLaunchKernelGGL(k_st_resolve, dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, ns, (const unsigned*)off, (const int32_t*)pair_t,
                        (const double*)pair_amp, (const double*)pair_snr, (const uint32_t*)cell_of, (const TemplDev*)ctx->templ.p,
                        (const double*)sums64, (float*)ctx->best_snr.p, (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p, p_amp, p_snr, p_id, stats);

@@ -153,3 +153,24 @@ def test_window_stack_equals_whole_dem_stack(shape):
             assert np.allclose(aw, a[:, :, i0:i1, j0:j1], rtol=1e-9, atol=1e-12 * np.abs(a).max())
             assert np.allclose(sw, s[:, :, i0:i1, j0:j1], rtol=1e-7, atol=1e-10 * s.max())
             assert np.array_equal(sw == 0, s[:, :, i0:i1, j0:j1] == 0)
+
+
+def test_windows_direct_equals_windows_by_fft():
+    """snr_stack_windows_direct (real-space closed form at a few cells: what the GPU tests probe the exact mode's cells
+    with) against snr_stack_window (the reference's FFT form on the crop): every template family, even and odd sizes,
+    windows on the DEM's wrap edges.  Float64 summation order apart (1e-12), the same numbers and the same masks."""
+    rng = np.random.default_rng(1)
+    for (ny, nx, de, kind, scale, ages, m) in ((120, 116, 1.0, orc.SCARP, 8., [1., 10.], 30), (121, 116, 2.0, orc.SCARP, 12., [2.], 30),
+                                               (120, 117, 1.0, orc.RICKER, 3., [0.3], 50), (117, 119, 1.0, orc.RIGHT_UPPER, 6., [5.], 30),
+                                               (116, 116, 1.0, orc.LEFT_UPPER, 6., [5.], 30)):
+        z = np.cumsum(rng.standard_normal((ny, nx)), 0) * 0.03 + rng.standard_normal((ny, nx)) * 0.05
+        angles = orc.angle_grid()[::45]
+        h, w = 2 + ny % 2, 2 + nx % 2
+        wins = [(5, 5 + h, 7, 7 + w), (ny - h, ny, nx - w, nx), (0, h, 0, w), (60, 60 + h, 40, 40 + w)]
+        dy = -de if kind == orc.RICKER else de
+        st = orc.snr_stack_windows_direct(z, de, dy, kind, scale, ages, angles, wins, m)
+        for wn, (a, s) in zip(wins, st):
+            a2, s2 = orc.snr_stack_window(z, de, dy, kind, scale, ages, angles, wn, m)
+            assert ((a2 == 0) == (a == 0)).all() and ((s2 == 0) == (s == 0)).all(), kind
+            assert np.all(np.abs(a - a2) <= 1e-10 * (np.abs(a2) + 1e-9 * np.max(np.abs(a2)))), kind
+            assert np.all(np.abs(s - s2) <= 1e-10 * (np.abs(s2) + 1e-9 * np.max(s2))), kind
