@@ -701,6 +701,7 @@ def build_sharding(sh, backend, a, rank, world, device, transport, g, Template, 
         def after_warmup():
             om.fold_seconds = 0.0
         return {"step": step, "after_warmup": after_warmup, "plan": om.m.plan, "ctx": om.m.ctx, "mode": "float32",
+                "work": lambda: (int(om.m.plan.nty * om.m.plan.ntx), 0 if mine is None else len(mine)),
                 "part": "orientation grid in %d chunks, whole DEM on every rank, records folded by two all-reduces" % world,
                 "extra_seconds": lambda: om.fold_seconds, "gather_seconds": lambda: None,
                 "result": lambda: om.result_array()}
@@ -738,8 +739,29 @@ def build_sharding(sh, backend, a, rank, world, device, transport, g, Template, 
         halo_s[0] = 0.0
         gather_s[0] = 0.0
     return {"step": step, "after_warmup": after_warmup, "plan": plan, "ctx": dm.m.ctx, "part": part, "mode": a.mode,
+            "work": lambda: (int(plan.nty * plan.ntx), len(arr)),
             "extra_seconds": lambda: halo_s[0], "gather_seconds": lambda: gather_s[0],
             "result": lambda: np.stack(full_box[0]) if full_box[0] is not None else None}
+
+
+# One GPU, BASELINE config C3 (36 tiles of 2048 x 2048, 6335 templates), round 6: 3.29 s per exact step, 3.165 s float32 -
+# the per-(tile, template) cost the first multi-GPU run is read against
+MS_PER_TILE_TEMPLATE = {"exact": 3290.0 / (36 * 6335), "float32": 3165.0 / (36 * 6335)}
+
+
+def predicted_step(works, mode, measured_ms):
+    """What every rank of a sharding has to do - (FFT tiles, templates) - and what that costs at the single-GPU rate of
+    the same kernels: the slowest rank bounds the step; the exchange (halo / fold / gather) comes on top.  Printed beside
+    the measurement so that the first real N-GPU run can be read against it."""
+    per = MS_PER_TILE_TEMPLATE.get(mode, MS_PER_TILE_TEMPLATE["float32"])
+    units = [int(t_) * int(n_) for (t_, n_) in works]
+    pred = max(units) * per if units else 0.0
+    return {"tiles_x_templates_per_rank": units, "tiles_per_rank": [int(t_) for (t_, _) in works],
+            "templates_per_rank": [int(n_) for (_, n_) in works],
+            "ms_per_tile_template_1gpu": round(per, 5), "search_ms_per_step": round(pred, 1),
+            "measured_over_predicted": round(measured_ms / pred, 3) if pred > 0 else None,
+            "note": "tiles x templates of the slowest rank x the one-GPU cost of a (2048 x 2048 tile, template) on the C3 search "
+                    "(round 6); smaller tiles cost more per cell, and the halo exchange / fold / gather are not in it"}
 
 
 def run_shardings(a, rank, world, device, dist, transport, pool, g, Template, scales, params, angles, kind, units,
@@ -788,6 +810,7 @@ def run_shardings(a, rank, world, device, dist, transport, pool, g, Template, sc
             gs = built["gather_seconds"]()
             gath = transport.gather(gs / a.steps, 0) if gs is not None else None
             tels = transport.gather(dict(LAST_TELEMETRY), 0)
+            works = transport.gather(built["work"]() if "work" in built else None, 0)
             if rank == 0:
                 ms = 1e3 * dt / a.steps
                 line = base_line(units / (dt / a.steps) / 1e6, ms, plan, "%d (%s)" % (world, built["part"]), prof, world)
@@ -798,6 +821,8 @@ def run_shardings(a, rank, world, device, dist, transport, pool, g, Template, sc
                                 "note": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice of every rank's communicator "
                                         "(sc_comm_info); nranks 0 = no RCCL communicator (host transport)"}
                 line["gpu_per_rank"] = tels
+                if works and all(w_ is not None for w_ in works):
+                    line["predicted"] = predicted_step(works, built.get("mode", "float32"), ms)
                 line["ipc"] = {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get(IPC_VAR),
                                "attempt": os.environ.get("SCARPLET_BENCH_IPC_ATTEMPT", "launcher's environment")}
                 key = "fold_ms" if sh == "orientations" else "halo_exchange_ms"

@@ -2395,6 +2395,9 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
 #ifndef SC_I2_NEAR_WAVES
 #define SC_I2_NEAR_WAVES 4  // waves per SIMD the near-tie variant is compiled for (round 6: four, like the plain kernel - event loop, amplitude stored at a win)
 #endif
+#ifndef SC_I2_SITE
+#define SC_I2_SITE 0        // lab (round 6): the record's update under a branch per output inside the record branch - measured, not kept
+#endif
 #ifndef SC_I2_NEAR_AMPW
 #define SC_I2_NEAR_AMPW 1
 #endif
@@ -2934,26 +2937,33 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                             }
                         }
                         const bool won = wonm[m - m0][part] && snr > b_snr[k];
+                        // (SC_I2_SITE, lab: the record moves under a branch of its own per output.  A cell is won nine times in a
+                        //  search of 6335 templates - ln 6335: the float32 SNRs come in no particular order, whatever order
+                        //  the orientations are searched in - 0.14 % of all (cell, template) pairs; the branch above stands
+                        //  for 1024 cells of the wave and is taken three times in four, one output's 64 cells hold a win one
+                        //  time in twelve.  Skipping the update's 80 vector instructions eleven times in twelve is worth
+                        //  nothing: C3 3.16 -> 3.16 .. 3.22 s with it, five record entries in scratch -
+                        //  profiles/r06_row_pass_probes.txt: the row pass is not bound by its vector instruction count)
+                        const bool any_won = !SC_I2_SITE || PT || __builtin_amdgcn_ballot_w64(won) != 0ull;
                         if constexpr (NEAR_LOOP) {
                             bool nt = wonm[m - m0][part] && !won;                 // below the record, inside the window (equal scores too)
-                            if constexpr (AMPW) {
-                                if (__builtin_amdgcn_ballot_w64(won) != 0ull) {
-                                    nt = nt || (won && snr * near_up <= b_snr[k]); // won, and the record it beat lies inside the window
+                            if (any_won) {
+                                nt = nt || (won && snr * near_up <= b_snr[k]);    // won, and the record it beat lies inside the window
+                                if constexpr (AMPW) {
                                     if (won)
                                         at_bytes(best_amp + off_of(part), 4u * (uint32_t)col_of(u * R3 + m)) = (part ? xc.y : xc.x) * ka[part];
+                                } else {
+                                    b_xr[k] = won ? (part ? xc.y : xc.x) : b_xr[k];
                                 }
-                            } else {
-                                nt = nt || (won && snr * near_up <= b_snr[k]);
-                                b_xr[k] = won ? (part ? xc.y : xc.x) : b_xr[k];
                             }
                             if (__builtin_amdgcn_ballot_w64(nt) != 0ull) ntm |= nt ? (1u << (2 * (m - m0) + part)) : 0u;
-                            b_snr[k] = won ? snr : b_snr[k];
-                        } else {
-                            b_snr[k] = won ? snr : b_snr[k];
-                            b_xr[k] = won ? (part ? xc.y : xc.x) : b_xr[k];
                         }
-                        const uint32_t bm = 0xFFu << (8 * (k & 3));
-                        b_ix[k >> 2] = won ? ((b_ix[k >> 2] & ~bm) | (tix[part] & bm)) : b_ix[k >> 2];
+                        if (any_won) {
+                            b_snr[k] = won ? snr : b_snr[k];
+                            if constexpr (!NEAR_LOOP) b_xr[k] = won ? (part ? xc.y : xc.x) : b_xr[k];
+                            const uint32_t bm = 0xFFu << (8 * (k & 3));
+                            b_ix[k >> 2] = won ? ((b_ix[k >> 2] & ~bm) | (tix[part] & bm)) : b_ix[k >> 2];
+                        }
                     }
                 }
                 if constexpr (NEAR_LOOP) {

@@ -186,7 +186,7 @@ def test_rccl_failure_falls_back_to_the_host_transport(monkeypatch):
             return {"step": step, "after_warmup": lambda: None, "plan": None, "ctx": shared, "part": "p",
                     "extra_seconds": lambda: 0.0, "gather_seconds": lambda: None, "result": lambda: None}
         return {"step": lambda: None, "after_warmup": lambda: None, "plan": None, "ctx": ctx_host, "part": "part",
-                "mode": "exact" if sh == "tiles" else "float32",
+                "mode": "exact" if sh == "tiles" else "float32", "work": lambda: (5, 6335) if sh == "tiles" else (36, 805),
                 "extra_seconds": lambda: 0.002, "gather_seconds": (lambda: 0.004) if sh == "tiles" else (lambda: None),
                 "result": lambda: None}
     monkeypatch.setattr(bench, "build_sharding", fake_build)
@@ -208,6 +208,9 @@ def test_rccl_failure_falls_back_to_the_host_transport(monkeypatch):
     # float32 line rides along
     assert "failed" not in out and out["sharding"] == "tiles" and out["config"]["mode"] == "exact"
     assert out["orientations"]["config"]["mode"] == "float32"
+    # what each rank had to do, and what that costs at the one-GPU rate: the first real run is read against it
+    assert out["predicted"]["tiles_x_templates_per_rank"] == [5 * 6335] and out["predicted"]["search_ms_per_step"] > 0
+    assert out["orientations"]["predicted"]["tiles_per_rank"] == [36]
 
 
 def test_every_transport_failing_still_prints_a_line(monkeypatch):
