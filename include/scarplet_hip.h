@@ -336,8 +336,9 @@ int sc_get_near_ties(sc_ctx* ctx, uint8_t* out);
  * the order they were handed over: amp, snr = m x n doubles each, masks applied (core.py:369-375).  The last step
  * of scarplet_amd.match(..., exact=True): the cells where two templates lie inside the float32 paths' own rounding
  * are settled the way the reference settles them.  Built-in templates only (SC_ERR_UNSUPPORTED otherwise); the
- * context must hold the cells' neighbourhoods (a whole DEM does). */
-int sc_score_cells_f64(sc_ctx* ctx, const int32_t* cells, int m, double* amp, double* snr);
+ * context must hold the cells' neighbourhoods (a whole DEM does).  n_templates: what the caller sized amp / snr for -
+ * SC_ERR_INVALID unless it is the number of templates of that last sc_match (ABI 8). */
+int sc_score_cells_f64(sc_ctx* ctx, const int32_t* cells, int m, int n_templates, double* amp, double* snr);
 
 /* The near-ties of the FFT searches since the last sc_reset_best as EVENTS (round 5, ABI 7): three 32-bit words each -
  * the cell (index into the core planes, row-major), the id of the template that was being scored, the id of the
@@ -346,8 +347,9 @@ int sc_score_cells_f64(sc_ctx* ctx, const int32_t* cells, int m, double* amp, do
  * record's final holder or one of the templates its events name (two templates further apart than the window differ by
  * more than twice the path's error: the lower one cannot be the argmax), so scarplet_amd.match(..., exact=True) scores
  * exactly those (cell, template) pairs in float64 (sc_score_pairs_f64).  *n_events = events recorded; the device list
- * holds two per core cell (a million at least): a larger count, or one above `capacity`, copies nothing - the caller
- * takes the route without events (real-space search of the flagged cells, sc_score_cells_f64). */
+ * holds two per core cell (a million at least).  A count above `capacity` copies nothing and returns SC_OK (the caller asks
+ * again with room); a list that OVERFLOWED on the device answers SC_ERR_UNSUPPORTED (ABI 8: said by the call, not left to
+ * the caller's arithmetic) - the caller takes the route without events (sc_get_near_ties + sc_score_cells_f64). */
 int sc_get_near_events(sc_ctx* ctx, uint32_t* events, long long capacity, long long* n_events);
 
 /* sc_score_cells_f64 for (cell, template) PAIRS: pair k = global cell (cells[2k], cells[2k+1]) against template

@@ -16,7 +16,8 @@ result block at once (one Matcher per device) are never handed the same block.
 
 Memory: the module pins at most MAX_BLOCKS blocks (one by default: a result the caller has
 dropped stays faulted in for the next call of the same size - 3.2 GB for a 10000 x 10000
-DEM).  ``scarplet_amd.release_host_buffers()`` gives unreferenced blocks back to the
+DEM; a caller that still HOLDS the previous result gets a fresh, unrecycled block, as
+without the pool: drop results before the next call, or set SCARPLET_HOSTPOOL_BLOCKS=2).  ``scarplet_amd.release_host_buffers()`` gives unreferenced blocks back to the
 system, and ``SCARPLET_HOSTPOOL_BLOCKS=0`` in the environment switches the recycling off.
 """
 import os
@@ -80,7 +81,13 @@ def prefault(shape, dtype=np.float64):
         for i in range(len(_blocks)):
             if _blocks[i].nbytes == n and _free_at(i):
                 return None                              # a recycled block of that size is waiting already
-    blk = empty(shape, dtype)                            # (registers a fresh block with the pool when there is room)
+        # (advisor, round 5) a block the pool cannot KEEP is not worth touching: with every slot held by a caller - the
+        # usual `r = match(...)` loop holding the previous result - empty() hands out an unregistered block, the thread
+        # would zero 3.2 GB that are freed when it ends, and get_result would take yet another fresh block
+        held = sum(0 if _free_at(i) else 1 for i in range(len(_blocks)))
+        if held >= MAX_BLOCKS:
+            return None
+    blk = empty(shape, dtype)                            # (registers a fresh block with the pool: there is room)
 
     def touch(a):
         flat = a.reshape(-1).view(np.uint8)

@@ -103,7 +103,7 @@ SIGNATURES = {
     "sc_curvature": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, _fp]),
     "sc_curvature_f64": (C.c_int, [_P] + [C.c_double] * 4 + [_dp]),
     "sc_get_near_ties": (C.c_int, [_P, _bp]),
-    "sc_score_cells_f64": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, _dp, _dp]),
+    "sc_score_cells_f64": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int, C.c_int, _dp, _dp]),
     "sc_get_near_events": (C.c_int, [_P, _up, C.c_longlong, C.POINTER(C.c_longlong)]),
     "sc_score_pairs_f64": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, _dp, _dp]),
     "sc_settle_exact": (C.c_int, [_P, C.c_int, C.c_double, C.POINTER(C.c_longlong)]),
@@ -408,7 +408,7 @@ class Context(object):
         m = len(cells)
         amp = np.empty((m, int(n_templates)), dtype=np.float64)
         snr = np.empty((m, int(n_templates)), dtype=np.float64)
-        self._check(self.lib.sc_score_cells_f64(self._h, cells.ctypes.data_as(C.POINTER(C.c_int32)), m,
+        self._check(self.lib.sc_score_cells_f64(self._h, cells.ctypes.data_as(C.POINTER(C.c_int32)), m, int(n_templates),
                                                 _as(amp, _dp), _as(snr, _dp)), "sc_score_cells_f64")
         return amp, snr
 
@@ -417,15 +417,17 @@ class Context(object):
         core planes), id of the template scored, id of the record's holder at that moment (sc_get_near_events) - or None
         where the device list overflowed (more events than two per core cell)."""
         n = C.c_longlong(0)
-        self._check(self.lib.sc_get_near_events(self._h, None, 0, C.byref(n)), "sc_get_near_events")
-        want = int(n.value)
-        if want == 0:
-            return np.zeros((0, 3), dtype=np.uint32)
-        h, w = self.core_shape()
-        if want > max(2 * h * w, 1 << 20):               # more than the device list holds: dropped events
-            return None
-        ev = np.empty((want, 3), dtype=np.uint32)
-        self._check(self.lib.sc_get_near_events(self._h, _as(ev, _up), want, C.byref(n)), "sc_get_near_events")
+        try:
+            self._check(self.lib.sc_get_near_events(self._h, None, 0, C.byref(n)), "sc_get_near_events")
+            want = int(n.value)
+            if want == 0:
+                return np.zeros((0, 3), dtype=np.uint32)
+            ev = np.empty((want, 3), dtype=np.uint32)
+            self._check(self.lib.sc_get_near_events(self._h, _as(ev, _up), want, C.byref(n)), "sc_get_near_events")
+        except ScarpletHipError as e:
+            if "overflowed" in str(e):                   # (the library says so itself since ABI 8)
+                return None
+            raise
         if int(n.value) != want:
             return None
         return ev

@@ -369,10 +369,14 @@ class Matcher(object):
 
     # -- searches -------------------------------------------------------------------
     # exact=True: relative window within which the FFT row pass flags near-ties (option "near_window"), by template
-    # family - twice the path's tie window, itself twice the largest SNR error measured on the path (DESIGN.md
-    # section 6): Scarp-like 1e-4, Ricker 7e-4 (a Ricker window's support is the float64 underflow of its
-    # exponential: tiles with far more energy, a larger float32 error)
-    EXACT_WINDOW = {_WT.KIND_SCARP: 3.5e-4, _WT.KIND_RICKER: 1.4e-3}     # (round 5's fuzz: single cells of the Scarp family 1.6e-4 off)
+    # family: TWICE the largest float32 SNR error measured on the path, plus a tenth.  (With scores off by at most e, the
+    # float64 argmax scores within 2 e of the final holder of the record, hence within 2 e of whatever held the record
+    # when it was scored or displaced: it is named by an event or is the holder - DESIGN.md section 6.)  Scarp family:
+    # e = 1.6e-4 (single cells of round 5's fuzz on random-walk surfaces; 4.3e-5 on the benchmark DEM).  Ricker: e =
+    # 3.2e-4 (the int16 Grand Canyon DEM at scale 5: a Ricker window's support is the float64 underflow of its
+    # exponential - tiles with far more energy, a larger float32 error); round 5 flagged inside twice that (1.4e-3: a
+    # quarter of that DEM's cells for one to decide).
+    EXACT_WINDOW = {_WT.KIND_SCARP: 3.5e-4, _WT.KIND_RICKER: 7e-4}
     EXACT_MAX_COST = 50.0                        # re-scoring is not started beyond this many times the search's own cost
     EXACT_PATCH = (8, 256)                       # rows x columns re-scored around a flagged cell: one real-space workgroup
 

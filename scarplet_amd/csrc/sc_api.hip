@@ -513,10 +513,12 @@ extern "C" int sc_get_near_events(sc_ctx* ctx, uint32_t* events, long long capac
     unsigned long long n = 0;
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SC_HIP(ctx, hipMemcpy(&n, ctx->near_ev.p, sizeof(n), hipMemcpyDeviceToHost));
-    *n_events = (long long)n;                            // (beyond the list's capacity: the rest was dropped - the caller sees it)
+    *n_events = (long long)n;
     const unsigned long long held = std::min<unsigned long long>(n, (ctx->near_ev.cap - 16) / 12);
     const unsigned long long take = std::min<unsigned long long>(held, (unsigned long long)capacity);
-    if (held > (unsigned long long)capacity || n > held) return SC_OK;     // the caller asks again with room, or gives up
+    if (n > held)                                        // the device list overflowed: events were dropped - said, not left to the caller's arithmetic
+        return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_get_near_events: the event list overflowed (%llu near-ties, room for %llu)", n, held);
+    if (held > (unsigned long long)capacity) return SC_OK;                  // the caller asks again with room (*n_events says how much)
     if (take) SC_HIP(ctx, hipMemcpy(events, (const char*)ctx->near_ev.p + 16, 12 * take, hipMemcpyDeviceToHost));
     return SC_OK;
 }
@@ -557,8 +559,12 @@ extern "C" int sc_score_pairs_f64(sc_ctx* ctx, const int32_t* cells, const int32
     return score_f64(ctx, cells, templates, m, amp, snr, "sc_score_pairs_f64");
 }
 
-extern "C" int sc_score_cells_f64(sc_ctx* ctx, const int32_t* cells, int m, double* amp, double* snr) {
+extern "C" int sc_score_cells_f64(sc_ctx* ctx, const int32_t* cells, int m, int n_templates, double* amp, double* snr) {
     if (!ctx || !cells || m <= 0 || !amp || !snr) return SC_ERR_INVALID;
+    // (the caller sized amp / snr for m x n_templates values: it must be the number this context will write)
+    if (n_templates != ctx->last_batch)
+        return sc_fail(ctx, SC_ERR_INVALID, "sc_score_cells_f64: the caller expects %d templates, the last search held %d",
+                       n_templates, ctx->last_batch);
     return score_f64(ctx, cells, nullptr, m, amp, snr, "sc_score_cells_f64");
 }
 

@@ -308,32 +308,48 @@ k_st_score(const double* __restrict__ pa, const double* __restrict__ pb, const d
         lj = g.wrap ? wrap1(gj, g.nx) : gj - g.gx0;
         return lj >= 0 && lj < g.lx;
     };
-    auto tap = [&](double w, size_t o) {
-        const double A = pa[o], Bc = pb[o], C = pc[o];
-        const double cv = __dadd_rn(__dsub_rn(__dmul_rn(A, k_cc), __dmul_rn(__dmul_rn(__dmul_rn(2.0, Bc), sa), ca)),
-                                    __dmul_rn(C, k_ss));
-        xc = fma(w, cv, xc);
-        t3 = fma(cv, cv, t3);
-    };
     const int2* __restrict__ sp_t = spans + soff[it];
     const int ml = maxlen[it];
     if (ml <= 64) {
-        // every run fits the lanes of its row: one tap per lane and row, two row groups in flight
+        // every run fits the lanes of its row: one tap per lane and row, ROWS row groups in flight - the loads of a group are a
+        // chain (run -> weight -> three plane values), and what bounds the kernel is how many of them it keeps in the air
         int ls = 0;
         while ((1 << ls) < ml) ++ls;
         const int R = 64 >> ls, bl = lane & ((1 << ls) - 1);
-        for (int a0 = lane >> ls; a0 < t.wh; a0 += 2 * R) {
-            const int a1 = a0 + R;
-            const int2 s0 = sp_t[a0], s1 = a1 < t.wh ? sp_t[a1] : make_int2(0, -1);
-            size_t or0, or1;
-            const bool r0 = row_of(a0, or0), r1 = a1 < t.wh && row_of(a1, or1);
-            const int b0 = s0.x + bl, b1 = s1.x + bl;
-            const bool v0 = r0 && b0 <= s0.y, v1 = r1 && b1 <= s1.y;
-            const double w0 = v0 ? wt[(size_t)a0 * t.ww + b0] : 0.0, w1 = v1 ? wt[(size_t)a1 * t.ww + b1] : 0.0;
-            int l0, l1;
-            const bool c0 = v0 && w0 != 0.0 && col_of(b0, l0), c1 = v1 && w1 != 0.0 && col_of(b1, l1);     // (W != 0 is the mask M, core.py:348)
-            if (c0) tap(w0, or0 + l0);
-            if (c1) tap(w1, or1 + l1);
+        constexpr int ROWS = 4;
+        for (int a0 = lane >> ls; a0 < t.wh; a0 += ROWS * R) {
+            int2 sp[ROWS];
+            size_t orow[ROWS];
+            bool v[ROWS];
+            double w[ROWS];
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u) {
+                const int a = a0 + u * R;
+                sp[u] = a < t.wh ? sp_t[a] : make_int2(0, -1);
+                v[u] = a < t.wh && row_of(a, orow[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u) {
+                const int b = sp[u].x + bl;
+                v[u] = v[u] && b <= sp[u].y;
+                w[u] = v[u] ? wt[(size_t)(a0 + u * R) * t.ww + b] : 0.0;
+            }
+            double A[ROWS], Bc[ROWS], C[ROWS];
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u) {
+                int lj = 0;
+                v[u] = v[u] && w[u] != 0.0 && col_of(sp[u].x + bl, lj);    // (W != 0 is the mask M, core.py:348)
+                const size_t o = v[u] ? orow[u] + lj : 0;
+                if (v[u]) { A[u] = pa[o]; Bc[u] = pb[o]; C[u] = pc[o]; }
+            }
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u)
+                if (v[u]) {
+                    const double cv = __dadd_rn(__dsub_rn(__dmul_rn(A[u], k_cc), __dmul_rn(__dmul_rn(__dmul_rn(2.0, Bc[u]), sa), ca)),
+                                                __dmul_rn(C[u], k_ss));
+                    xc = fma(w[u], cv, xc);
+                    t3 = fma(cv, cv, t3);
+                }
         }
     } else {
         for (int a = 0; a < t.wh; ++a) {
@@ -341,10 +357,24 @@ k_st_score(const double* __restrict__ pa, const double* __restrict__ pb, const d
             size_t orow;
             if (!row_of(a, orow)) continue;
             const double* __restrict__ wrow = wt + (size_t)a * t.ww;
-            for (int b = sp.x + lane; b <= sp.y; b += 64) {
-                const double w = wrow[b];
-                int lj;
-                if (w != 0.0 && col_of(b, lj)) tap(w, orow + lj);
+            for (int b = sp.x + lane; b <= sp.y; b += 128) {
+                const int b2 = b + 64;
+                const double w0 = wrow[b], w1 = b2 <= sp.y ? wrow[b2] : 0.0;
+                int l0, l1;
+                const bool c0 = w0 != 0.0 && col_of(b, l0), c1 = w1 != 0.0 && col_of(b2, l1);
+                double A0, B0, C0, A1, B1, C1;
+                if (c0) { A0 = pa[orow + l0]; B0 = pb[orow + l0]; C0 = pc[orow + l0]; }
+                if (c1) { A1 = pa[orow + l1]; B1 = pb[orow + l1]; C1 = pc[orow + l1]; }
+                if (c0) {
+                    const double cv = __dadd_rn(__dsub_rn(__dmul_rn(A0, k_cc), __dmul_rn(__dmul_rn(__dmul_rn(2.0, B0), sa), ca)), __dmul_rn(C0, k_ss));
+                    xc = fma(w0, cv, xc);
+                    t3 = fma(cv, cv, t3);
+                }
+                if (c1) {
+                    const double cv = __dadd_rn(__dsub_rn(__dmul_rn(A1, k_cc), __dmul_rn(__dmul_rn(__dmul_rn(2.0, B1), sa), ca)), __dmul_rn(C1, k_ss));
+                    xc = fma(w1, cv, xc);
+                    t3 = fma(cv, cv, t3);
+                }
             }
         }
     }
@@ -560,12 +590,16 @@ extern "C" int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long lo
     SC_HIP(ctx, hipMemcpyAsync(&n_pairs, stats + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     stats_out[1] = (long long)n_pairs;
-    // how much float64 work that is at most: pairs x the largest support box (the caller's bound: nothing is started beyond it)
+    // how much float64 work that is at most (the caller's bound: nothing is started beyond it): the pairs that can come to be
+    // scored - every list entry behind the holder's, and the holder's own where there is one - x the largest support box.
+    // (Most lists of a search over few orientations hold the record's holder alone: the grid's end twins tie in every cell
+    //  either of them holds, and a list of one class is not scored.)
     int maxbox = 1;
     for (int k = 0; k < n; ++k) maxbox = std::max(maxbox, ctx->h_templ[k].wh * ctx->h_templ[k].ww);
-    if (max_work > 0.0 && (double)n_pairs * (double)maxbox > max_work)
-        return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_settle_exact: too much float64 work (%llu pairs on %llu cells, boxes of up to %d cells)",
-                       n_pairs, n_slots, maxbox);
+    const unsigned long long may_score = std::min<unsigned long long>(n_pairs, 2ull * (n_pairs - std::min(n_pairs, n_slots)));
+    if (max_work > 0.0 && (double)may_score * (double)maxbox > max_work)
+        return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_settle_exact: too much float64 work (up to %llu pairs on %llu cells, boxes of up to %d cells)",
+                       may_score, n_slots, maxbox);
     // ---- pair lists ----------------------------------------------------------------------------------------------
     const size_t np = (size_t)n_pairs;
     if ((rc = sc_ensure(ctx, ctx->st_pairs, 2 * up64(8 * np) + 2 * up64(4 * np) + 64))) return rc;

@@ -875,6 +875,9 @@ def test_float64_scoring_of_single_cells(gpu_ctx):
         cells[:4] = [[0, 0], [ny - 1, nx - 1], [ny // 2, 0], [0, nx // 2]]
         n_t = len(params) * len(angles)
         amp, snr = m.ctx.score_cells_f64(cells, n_t)
+        # (ABI 8: the count the caller sized its arrays for is checked against the search the context holds)
+        with pytest.raises(sl._lib.ScarpletHipError, match="expects"):
+            m.ctx.score_cells_f64(cells, n_t - 1)
         k = 0
         for ang in angles:                                  # hand-over order: orientation-major
             for par in params:
