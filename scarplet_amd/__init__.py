@@ -6,7 +6,7 @@ plugin classes, with the work done by hand-written HIP kernels reached through
 a C-ABI shared library (include/scarplet_hip.h).
 """
 
-from scarplet_amd.core import (match, match_template, compare, load,  # noqa: F401
+from scarplet_amd.core import (match, match_scales, match_template, compare, load,  # noqa: F401
                                calculate_best_fit_parameters,
                                calculate_best_fit_parameters_serial, Matcher)
 from scarplet_amd import WindowedTemplate, dem  # noqa: F401

@@ -33,7 +33,7 @@ from scarplet_amd import _lib, _plan
 from scarplet_amd import WindowedTemplate as _WT
 from scarplet_amd.dem import DEMGrid
 
-__all__ = ["match", "match_template", "compare", "load",
+__all__ = ["match", "match_scales", "match_template", "compare", "load",
            "calculate_best_fit_parameters",
            "calculate_best_fit_parameters_serial", "Matcher"]
 
@@ -791,6 +791,18 @@ class Matcher(object):
             out = self._apply_patches(out)
         return out
 
+    def search_scales(self, Template, scales, params, angles, method="auto", exact=None, **kwargs):
+        """A multi-scale job (BASELINE config C5: Channel at five scales x 181 orientations; the reference runs it as one
+        sl.match per scale on the same data, docs/source/examples/channels.ipynb - its 4-plane result has no scale
+        plane): one search per scale on THIS matcher, whose context keeps every orientation's curvature spectra from
+        the first scale on (option "spectra_mb": the later scales skip the curvature passes where the tile plan stays
+        the same - the same bits either way).  Returns a list of (4, h, w) float64 arrays, one per scale."""
+        out = []
+        for sc in scales:
+            self.search(Template, sc, params, angles, method=method, exact=exact, **kwargs)
+            out.append(np.array(self.result_array()))      # (a copy: large results are views of a recycled host block)
+        return out
+
     def match_template(self, Template, scale, age, angle, method="auto",
                        **kwargs):
         if getattr(self, "nan_dem", False):
@@ -934,6 +946,27 @@ def match(data, Template, **kwargs):
         m.search(Template, scale, _plan.age_grid() if ages is None else ages,
                  _plan.angle_grid(ang_min, ang_max), method=method, exact=exact)
         return m.result()
+    finally:
+        m.ctx.clear_windows()
+
+
+def match_scales(data, Template, scales, **kwargs):
+    """``match`` for several scales of one template family on one DEM (the reference: one sl.match call per scale,
+    channels.ipynb): the DEM goes to the device once, the orientations' curvature spectra are computed once.  Keyword
+    arguments as ``match`` (``age=`` or the 35-age grid, ``ang_min`` / ``ang_max``, ``method``, ``exact``, ``device``).
+    Returns a list with one (4, ny, nx) array per scale - the planes of ``match``: amp, age, angle, snr."""
+    device = kwargs.pop("device", 0)
+    method = kwargs.pop("method", "auto")
+    exact = kwargs.pop("exact", None)
+    ages = kwargs.pop("ages", None)
+    ang_max = kwargs.pop("ang_max", np.pi / 2)
+    ang_min = kwargs.pop("ang_min", -np.pi / 2)
+    params = [kwargs.pop("age")] if "age" in kwargs else (_plan.age_grid() if ages is None else ages)
+    if kwargs:
+        raise TypeError("match_scales: unexpected keyword arguments %s" % sorted(kwargs))
+    m = Matcher(data, device=device)
+    try:
+        return m.search_scales(Template, scales, params, _plan.angle_grid(ang_min, ang_max), method=method, exact=exact)
     finally:
         m.ctx.clear_windows()
 

@@ -352,29 +352,52 @@ k_st_score(const double* __restrict__ pa, const double* __restrict__ pb, const d
                 }
         }
     } else {
-        for (int a = 0; a < t.wh; ++a) {
-            const int2 sp = sp_t[a];
-            size_t orow;
-            if (!row_of(a, orow)) continue;
-            const double* __restrict__ wrow = wt + (size_t)a * t.ww;
-            for (int b = sp.x + lane; b <= sp.y; b += 128) {
-                const int b2 = b + 64;
-                const double w0 = wrow[b], w1 = b2 <= sp.y ? wrow[b2] : 0.0;
-                int l0, l1;
-                const bool c0 = w0 != 0.0 && col_of(b, l0), c1 = w1 != 0.0 && col_of(b2, l1);
-                double A0, B0, C0, A1, B1, C1;
-                if (c0) { A0 = pa[orow + l0]; B0 = pb[orow + l0]; C0 = pc[orow + l0]; }
-                if (c1) { A1 = pa[orow + l1]; B1 = pb[orow + l1]; C1 = pc[orow + l1]; }
-                if (c0) {
-                    const double cv = __dadd_rn(__dsub_rn(__dmul_rn(A0, k_cc), __dmul_rn(__dmul_rn(__dmul_rn(2.0, B0), sa), ca)), __dmul_rn(C0, k_ss));
-                    xc = fma(w0, cv, xc);
-                    t3 = fma(cv, cv, t3);
-                }
-                if (c1) {
-                    const double cv = __dadd_rn(__dsub_rn(__dmul_rn(A1, k_cc), __dmul_rn(__dmul_rn(__dmul_rn(2.0, B1), sa), ca)), __dmul_rn(C1, k_ss));
-                    xc = fma(w1, cv, xc);
-                    t3 = fma(cv, cv, t3);
-                }
+        // runs longer than the wave: a lane takes the columns lane, lane + 64, ... of a row; FOUR rows and two columns of each
+        // in flight (a wide window - a Ricker's support, an old scarp's - is tens of thousands of taps for one wave: row
+        // after row with a load chain each it took a third of a millisecond a pair)
+        constexpr int ROWS = 4, CH = 2;
+        for (int a0 = 0; a0 < t.wh; a0 += ROWS) {
+            int2 sp[ROWS];
+            size_t orow[ROWS];
+            bool rv[ROWS];
+            int more = 0;
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u) {
+                sp[u] = a0 + u < t.wh ? sp_t[a0 + u] : make_int2(0, -1);
+                rv[u] = a0 + u < t.wh && row_of(a0 + u, orow[u]);
+                more = max(more, rv[u] ? sp[u].y - sp[u].x + 1 : 0);
+            }
+            for (int c0 = 0; c0 < more; c0 += 64 * CH) {                 // (wave-uniform bound: the longest of the four runs)
+                double w[ROWS][CH], A[ROWS][CH], Bc[ROWS][CH], C[ROWS][CH];
+                bool v[ROWS][CH];
+                size_t o[ROWS][CH];
+#pragma unroll
+                for (int u = 0; u < ROWS; ++u)
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int bcol = sp[u].x + c0 + 64 * c + lane;
+                        v[u][c] = rv[u] && bcol <= sp[u].y;
+                        w[u][c] = v[u][c] ? wt[(size_t)(a0 + u) * t.ww + bcol] : 0.0;
+                    }
+#pragma unroll
+                for (int u = 0; u < ROWS; ++u)
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        int lj = 0;
+                        v[u][c] = v[u][c] && w[u][c] != 0.0 && col_of(sp[u].x + c0 + 64 * c + lane, lj);
+                        o[u][c] = v[u][c] ? orow[u] + lj : 0;
+                        if (v[u][c]) { A[u][c] = pa[o[u][c]]; Bc[u][c] = pb[o[u][c]]; C[u][c] = pc[o[u][c]]; }
+                    }
+#pragma unroll
+                for (int u = 0; u < ROWS; ++u)
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+                        if (v[u][c]) {
+                            const double cv = __dadd_rn(__dsub_rn(__dmul_rn(A[u][c], k_cc), __dmul_rn(__dmul_rn(__dmul_rn(2.0, Bc[u][c]), sa), ca)),
+                                                        __dmul_rn(C[u][c], k_ss));
+                            xc = fma(w[u][c], cv, xc);
+                            t3 = fma(cv, cv, t3);
+                        }
             }
         }
     }

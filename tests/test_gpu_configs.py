@@ -107,6 +107,21 @@ def test_c5_grandcanyon_channel_five_scales(gpu_ctx):
             assert chk["n_bad"] == 0, (scale, method, chk["n_bad"])
 
 
+def test_c5_match_scales_equals_one_match_per_scale(gpu_ctx):
+    """sl.match_scales (round 6: BASELINE config C5 through ONE entry point - the DEM uploaded once, the orientations'
+    curvature spectra computed for the first scale and kept for the others) against one sl.match per scale, as the reference
+    runs the job (channels.ipynb): the same bits in every plane, in the default (exact) and in the float32 mode."""
+    z, dx, dy = dem_fixture("dem_grandcanyon.npz")
+    scales = [5., 10., 20., 40., 80.]
+    for exact in (None, False):
+        many = sl.match_scales(grid(z, dx, dy), sl.Channel, scales, age=0.1, exact=exact)
+        assert len(many) == 5 and all(r.shape == (4,) + z.shape for r in many)
+        for sc, r in zip(scales, many):
+            one = sl.match(grid(z, dx, dy), sl.Channel, scale=sc, age=0.1, exact=exact)
+            assert np.array_equal(r, one), (sc, exact)
+    assert not np.array_equal(many[0][3], many[1][3])
+
+
 def test_channel_several_widths_in_one_fold(gpu_ctx):
     """The second constructor argument of Ricker is the wavelet frequency: several of
     them fold in one device search like ages do for Scarp."""
