@@ -372,11 +372,12 @@ class Matcher(object):
     # family: TWICE the largest float32 SNR error measured on the path, plus a tenth.  (With scores off by at most e, the
     # float64 argmax scores within 2 e of the final holder of the record, hence within 2 e of whatever held the record
     # when it was scored or displaced: it is named by an event or is the holder - DESIGN.md section 6.)  Scarp family:
-    # e = 1.6e-4 (single cells of round 5's fuzz on random-walk surfaces; 4.3e-5 on the benchmark DEM).  Ricker: e =
-    # 3.2e-4 (the int16 Grand Canyon DEM at scale 5: a Ricker window's support is the float64 underflow of its
-    # exponential - tiles with far more energy, a larger float32 error); round 5 flagged inside twice that (1.4e-3: a
-    # quarter of that DEM's cells for one to decide).
-    EXACT_WINDOW = {_WT.KIND_SCARP: 3.5e-4, _WT.KIND_RICKER: 7e-4}
+    # e = 2.74e-4 (ONE search of round 6's 2 000-search fuzz on random-walk surfaces, profiles/r06_fuzz_oracle.txt; 1.6e-4
+    # in round 5's, 4.3e-5 on the benchmark DEM - the window was 3.5e-4 until that search).  Ricker: e = 3.2e-4 (the int16
+    # Grand Canyon DEM at scale 5: a Ricker window's support is the float64 underflow of its exponential - tiles with far
+    # more energy, a larger float32 error; 4.9e-5 in the fuzz); round 5 flagged inside twice that (1.4e-3: a quarter of
+    # that DEM's cells for one to decide).
+    EXACT_WINDOW = {_WT.KIND_SCARP: 6e-4, _WT.KIND_RICKER: 7e-4}
     EXACT_MAX_COST = 50.0                        # re-scoring is not started beyond this many times the search's own cost
     EXACT_PATCH = (8, 256)                       # rows x columns re-scored around a flagged cell: one real-space workgroup
 
@@ -673,10 +674,10 @@ class Matcher(object):
 
     EXACT_USE_EVENTS = True                      # (False: always the longer, host-side routes - tests, comparisons)
 
-    # exact=True, third step: window of the real-space path's near-tie flags - twice its largest measured SNR error (1.0e-4
-    # in single cells of round 5's fuzz on supports of thousands of taps; 4e-5 on the tests' DEMs) - and how much float64
-    # work is started at most
-    EXACT_WINDOW_DIRECT = 2e-4
+    # exact=True on the real-space path: the window of its near-tie flags and events - twice its largest measured SNR error
+    # plus a tenth (2.15e-4 in ONE search of round 6's fuzz, the one above; 1.0e-4 in round 5's, 4e-5 on the tests' DEMs) -
+    # and how much float64 work is started at most
+    EXACT_WINDOW_DIRECT = 4.8e-4
     EXACT_MAX_F64 = 2e12                         # (cell, template) pairs x support-box cells (~3e11 a second; the C3 search: 4.8e11)
 
     def _score_float64(self, last, arr_main, bbox):

@@ -60,14 +60,15 @@ for case in range(n_cases):
     line = "case %3d %4dx%-4d %-26s de %.1f dy %+.1f scale %6.1f %d x %d" % (case, ny, nx, cls.__name__, de, dy, scale,
                                                                            len(params), len(angles))
     for name, kw in (("fft", dict(method="fft")), ("direct", dict(method="direct")), ("auto", dict(method="auto")),
-                     ("exact", dict(method="fft", exact=True))):
+                     ("exact", dict(method="fft", exact=True)), ("exact-direct", dict(method="direct", exact=True)),
+                     ("exact-auto", dict(method="auto", exact=True))):
         try:
             m = sl.Matcher(g)
             res = m.search(cls, scale, params, angles, **kw).result_array()
         except Exception as e:                                    # (a window the real-space slab does not hold, ...)
             line += "  | %s: %s" % (name, str(e)[:60])
             continue
-        window = orc.tie_window("direct" if name in ("direct", "exact") else "fft", kind)
+        window = orc.tie_window("direct" if name in ("direct", "exact", "exact-direct", "exact-auto") else "fft", kind)
         chk = orc.check_fold(res, A, S, ages, angs, tie_rtol=window, **tol)
         t = tot.setdefault(name, dict(cases=0, cells=0, bad=0, inexact=0, snr_err=0.0, amp_err=0.0, worst=None))
         t["cases"] += 1
@@ -78,6 +79,8 @@ for case in range(n_cases):
             t["snr_err"], t["worst"] = chk["snr_err"], case
         t["amp_err"] = max(t["amp_err"], chk["amp_err"])
         line += "  | %s bad %d off-argmax %d err %.1e" % (name, chk["n_bad"], chk["n_inexact"], chk["snr_err"])
+        if name.startswith("exact"):
+            line += " (%s)" % getattr(m, "exact_stats", {}).get("route", "host")
         if ONLY and chk["n_bad"]:
             for (i, j) in np.argwhere(~chk["ok"])[:6]:
                 hit = np.nonzero((ages == res[1][i, j]) & (angs == res[2][i, j]))[0]
