@@ -12,8 +12,8 @@
 // over the flag plane, np.unique / np.lexsort over millions of keys): 1.9 s of the 5.1 s the exact C3 search took.
 //
 // Pipeline (all on the context's stream; three 8-byte read-backs size the next step's buffers):
-//   k_st_flag_count / k_st_scan1 / k_st_slots   flagged cells -> slots in cell order (neighbouring pairs share their
-//                                               curvature neighbourhood in L2), cnt[slot] = 1 (the final holder)
+//   k_st_flag_count / k_st_scan1 / k_st_slots   flagged cells -> slots, numbered 64 x 64 tile by tile (neighbouring pairs share
+//                                               their curvature neighbourhood in L2), cnt[slot] = 1 (the final holder)
 //   k_st_events<false>                          cnt[slot] += candidates the slot's events add
 //   k_st_sum / k_st_scan1 / k_st_offsets        exclusive scan -> off[slot]
 //   k_st_init_lists, k_st_events<true>          pair lists: entry 0 the final holder, then the events' templates
@@ -59,23 +59,41 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned* total)
     return base + inc - v;
 }
 
-// the 16 flag bytes of thread t of workgroup b (flags are 0 or 1), as four words; cells beyond nc read 0
-__device__ __forceinline__ uint4 flags16(const uint8_t* __restrict__ near, size_t nc, size_t c0) {
-    uint4 f = make_uint4(0, 0, 0, 0);
-    if (c0 + 16 <= nc) {
-        f = *reinterpret_cast<const uint4*>(near + c0);
-    } else if (c0 < nc) {
-        unsigned w[4] = {0, 0, 0, 0};
-        for (size_t k = c0; k < nc; ++k) w[(k - c0) >> 2] |= (unsigned)(near[k] != 0) << (8 * ((k - c0) & 3));
-        f = make_uint4(w[0], w[1], w[2], w[3]);
+// Slots are numbered TILE by tile: workgroup b of the flag scans takes the 64 x 64 cells of tile (b / tiles_x, b % tiles_x),
+// thread t the 16 cells of columns 16 (t & 3) .. of its row t >> 2.  Neighbouring slots are then neighbouring cells in BOTH
+// directions, and the scorer's waves - which walk the curvature planes around their cells - find each other's lines in L2
+// (row-major order: a thousand waves per XCD strung along one DEM row, 17 MB of planes between a line's first and second use).
+struct TileMap {
+    int ch, cw, tiles_x;
+    __device__ __forceinline__ bool cell0(unsigned b, unsigned t, int& row, int& col) const {
+        row = (int)(b / (unsigned)tiles_x) * 64 + (int)(t >> 2);
+        col = (int)(b % (unsigned)tiles_x) * 64 + 16 * (int)(t & 3);
+        return row < ch && col < cw;
     }
-    f.x &= 0x01010101u; f.y &= 0x01010101u; f.z &= 0x01010101u; f.w &= 0x01010101u;
-    return f;
+};
+
+// the 16 flag bytes of a thread (flags are 0 or 1), as four words; cells beyond the row's end read 0
+__device__ __forceinline__ uint4 flags16(const uint8_t* __restrict__ near, const TileMap& tm, unsigned b, unsigned t, size_t& c0) {
+    int row, col;
+    unsigned w[4] = {0, 0, 0, 0};
+    c0 = 0;
+    if (tm.cell0(b, t, row, col)) {
+        c0 = (size_t)row * tm.cw + col;
+        const int n = min(16, tm.cw - col);
+        if (n == 16 && (c0 & 15) == 0) {
+            const uint4 f = *reinterpret_cast<const uint4*>(near + c0);
+            w[0] = f.x; w[1] = f.y; w[2] = f.z; w[3] = f.w;
+        } else {
+            for (int k = 0; k < n; ++k) w[k >> 2] |= (unsigned)(near[c0 + k] != 0) << (8 * (k & 3));
+        }
+    }
+    return make_uint4(w[0] & 0x01010101u, w[1] & 0x01010101u, w[2] & 0x01010101u, w[3] & 0x01010101u);
 }
 
 __global__ void __launch_bounds__(256)
-k_st_flag_count(const uint8_t* __restrict__ near, size_t nc, unsigned* __restrict__ blk) {
-    const uint4 f = flags16(near, nc, (size_t)blockIdx.x * ST_CH + 16 * threadIdx.x);
+k_st_flag_count(const uint8_t* __restrict__ near, TileMap tm, unsigned* __restrict__ blk) {
+    size_t c0;
+    const uint4 f = flags16(near, tm, blockIdx.x, threadIdx.x, c0);
     unsigned tot;
     block_excl_scan<4>(__popc(f.x) + __popc(f.y) + __popc(f.z) + __popc(f.w), &tot);
     if (threadIdx.x == 0) blk[blockIdx.x] = tot;
@@ -99,10 +117,10 @@ k_st_scan1(unsigned* __restrict__ blk, unsigned n, unsigned long long* __restric
 }
 
 __global__ void __launch_bounds__(256)
-k_st_slots(const uint8_t* __restrict__ near, size_t nc, const unsigned* __restrict__ blk, uint32_t* __restrict__ cell_of,
+k_st_slots(const uint8_t* __restrict__ near, TileMap tm, const unsigned* __restrict__ blk, uint32_t* __restrict__ cell_of,
            uint32_t* __restrict__ slot_of, unsigned* __restrict__ cnt) {
-    const size_t c0 = (size_t)blockIdx.x * ST_CH + 16 * threadIdx.x;
-    const uint4 f = flags16(near, nc, c0);
+    size_t c0;
+    const uint4 f = flags16(near, tm, blockIdx.x, threadIdx.x, c0);
     unsigned tot;
     unsigned s = blk[blockIdx.x] + block_excl_scan<4>(__popc(f.x) + __popc(f.y) + __popc(f.z) + __popc(f.w), &tot);
     const unsigned w[4] = {f.x, f.y, f.z, f.w};
@@ -263,7 +281,11 @@ k_st_score(const double* __restrict__ pa, const double* __restrict__ pb, const d
            const unsigned* __restrict__ off, const int32_t* __restrict__ pair_t, const uint32_t* __restrict__ pair_slot,
            const uint32_t* __restrict__ cell_of, IdMap map, unsigned n_pairs, double* __restrict__ amp_out,
            double* __restrict__ snr_out) {
-    const unsigned pos = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));    // (wave-uniform: scalar loads below)
+    // workgroups are dealt round-robin to the eight XCDs (each with an L2 of its own): XCD x takes the x-th EIGHTH of the pair
+    // list in order, so that the waves that share an L2 work on neighbouring cells
+    const unsigned nb8 = (gridDim.x + 7) / 8;
+    const unsigned lb = (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3);
+    const unsigned pos = __builtin_amdgcn_readfirstlane(lb * 4 + (threadIdx.x >> 6));            // (wave-uniform: scalar loads below)
     const int lane = threadIdx.x & 63;
     if (pos >= n_pairs) return;
     const uint32_t slot = pair_slot[pos];
@@ -548,7 +570,9 @@ extern "C" int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long lo
     for (int k = 0; k < n; ++k) idtab[ctx->h_templ[k].id] = k;
 
     // ---- flagged cells -> slots --------------------------------------------------------------------------------
-    const unsigned nblk = (unsigned)((nc + ST_CH - 1) / ST_CH);
+    const int ch_ = g.cy1 - g.cy0, cw_ = g.cx1 - g.cx0;
+    const TileMap tm{ch_, cw_, (cw_ + 63) / 64};
+    const unsigned nblk = (unsigned)(((ch_ + 63) / 64) * tm.tiles_x);          // one scan workgroup per 64 x 64 tile
     int rc;
     if ((rc = sc_ensure(ctx, ctx->st_slot, 4 * nc))) return rc;
     // work buffer, first part: stats | block sums (flags) | id table
@@ -584,7 +608,7 @@ extern "C" int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long lo
     SC_HIP(ctx, hipMemcpyAsync(d_tab, idtab.data(), 4 * idtab.size(), hipMemcpyHostToDevice, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(soff, h_soff.data(), 4 * h_soff.size(), hipMemcpyHostToDevice, ctx->stream));
     SC_HIP(ctx, hipMemsetAsync(maxlen, 0, 4 * (size_t)n, ctx->stream));
-    hipLaunchKernelGGL(k_st_flag_count, dim3(nblk), dim3(256), 0, ctx->stream, near, nc, blk);
+    hipLaunchKernelGGL(k_st_flag_count, dim3(nblk), dim3(256), 0, ctx->stream, near, tm, blk);
     hipLaunchKernelGGL(k_st_scan1, dim3(1), dim3(1024), 0, ctx->stream, blk, nblk, stats);
     SC_HIP(ctx, hipGetLastError());
     unsigned long long n_slots = 0;
@@ -599,7 +623,7 @@ extern "C" int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long lo
     patch_views(ctx, ns, &cell_of, &p_id, &p_amp, &p_snr);
     uint32_t* slot_of = (uint32_t*)ctx->st_slot.p;
     const IdMap map{d_tab, max_id + 1, n, n_twin};
-    hipLaunchKernelGGL(k_st_slots, dim3(nblk), dim3(256), 0, ctx->stream, near, nc, (const unsigned*)blk, cell_of, slot_of, cnt);
+    hipLaunchKernelGGL(k_st_slots, dim3(nblk), dim3(256), 0, ctx->stream, near, tm, (const unsigned*)blk, cell_of, slot_of, cnt);
     const unsigned evb = (unsigned)((n_ev + 255) / 256);
     hipLaunchKernelGGL(k_st_events<false>, dim3(evb), dim3(256), 0, ctx->stream, ev, n_ev, (const uint32_t*)slot_of,
                        (const uint32_t*)ctx->best_id.p, map, cnt, (const unsigned*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr);
@@ -645,7 +669,8 @@ extern "C" int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long lo
     if ((rc = sc_ensure(ctx, ctx->st_spans, sizeof(int2) * (size_t)h_soff[n] + 64))) return rc;
     hipLaunchKernelGGL(k_st_spans, dim3((wh_max + 3) / 4, n), dim3(256), 0, ctx->stream, (const TemplDev*)ctx->templ.p, woff, wbuf,
                        (const unsigned*)soff, (int2*)ctx->st_spans.p, maxlen);
-    hipLaunchKernelGGL(k_st_score, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, ctx->stream, pa, pa + npl, pa + 2 * npl, g,
+    // (a multiple of eight workgroups: the kernel deals the pair list out over the XCDs in eighths)
+    hipLaunchKernelGGL(k_st_score, dim3((unsigned)(((np + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, ctx->stream, pa, pa + npl, pa + 2 * npl, g,
                        (const TemplDev*)ctx->templ.p, (const double*)sums64, (const double*)ctx->xaxis.p,
                        (const double*)ctx->yaxis.p, woff, wbuf, (const unsigned*)soff, (const int2*)ctx->st_spans.p,
                        (const int*)maxlen, (const unsigned*)off, (const int32_t*)pair_t,
