@@ -151,8 +151,30 @@ def _cpu_one(job):
 _CPU_CTX = None       # (z float64, dx, dy, kind, scale): set BEFORE the pool is forked
 
 
+def cpu_quota():
+    """CPUs the container's cgroup grants (cpu.max: quota / period), or None: 16 of the 256 visible on the GPU boxes."""
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, p = open(path).read().split()[:2]
+            if q != "max":
+                return float(q) / float(p)
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / p
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def host_cores():
-    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    """Cores this process can really use: its affinity mask, capped by the cgroup's CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    q = cpu_quota()
+    return max(1, min(n, int(q + 0.5))) if q else n
 
 
 def mem_available_bytes():
@@ -233,8 +255,8 @@ def cpu_baseline(pool, g, params, angles, max_workers=32):
             "with_fft_threads": threaded,
             "sample": "%d of the %d templates (stratified over ages and orientations) on the full %dx%d DEM, "
                       "oracle/scarplet_oracle.py (float64, scipy.fft single-threaded per template), process pool: "
-                      "%d templates at a time like core.py:180-183 (%d cores visible, %.0f GB RAM available, "
-                      "12 GB per template), wall %.1f s, mean %.1f s per template per worker; the full search's "
+                      "%d templates at a time like core.py:180-183 (%d cores usable: affinity capped by the cgroup's CPU "
+                      "quota; %.0f GB RAM available, 12 GB per template), wall %.1f s, mean %.1f s per template per worker; the full search's "
                       "rate is this figure by extrapolation (x%d templates)" % (
                           len(jobs), n_all, ny, nx, conc, cores, avail / 1e9, dt, float(np.mean(per)), n_all)}
 

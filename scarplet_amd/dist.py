@@ -349,15 +349,21 @@ class DistMatcher(object):
         return self
 
     def search(self, Template, scale, params, angles, z_core, method="fft",
-               group=None, **kwargs):
+               group=None, exact=None, **kwargs):
+        """This rank's part of the tiled search.  ``exact`` (default: on for the built-in template classes, as in
+        ``scarplet_amd.match``): the near-ties of the rank's own block are settled in float64 on its device before the
+        gather (sc_settle_exact: the halo covers the templates' reach and the curvature stencil) - the record that
+        travels carries the float64 argmax, its amplitude and SNR rounded to float32."""
         params = np.atleast_1d(np.asarray(params, dtype=float))
         angles = np.atleast_1d(np.asarray(angles, dtype=float))
         arr, bbox, max_area = self.m.describe(Template, scale, params, angles, **kwargs)
         self.load(z_core, bbox)
         self.m.plan, sp = self.m.plan_for(bbox, max_area, method, group,
                                           n_params=len(params))
-        self.m.ctx.reset_best()
-        self.m.ctx.match(arr, sp)
+        if exact is None:
+            exact = all(int(arr[k].kind) != 2 for k in (0, len(arr) - 1))         # (2: SC_KIND_WINDOW, a host-uploaded plugin)
+        self.exact_stats = self.m.run_described(arr, sp, self.m.exact_window_for(arr, sp) if exact else 0.0,
+                                                self.m.end_twins(arr, len(params), angles))
         self.m.params, self.m.angles = params, angles
         return self
 
