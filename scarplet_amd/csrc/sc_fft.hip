@@ -2398,6 +2398,9 @@ k_inv_rows(const float2* __restrict__ yw, const float2* __restrict__ ym,
 #ifndef SC_I2_SITE
 #define SC_I2_SITE 0        // lab (round 6): the record's update under a branch per output inside the record branch - measured, not kept
 #endif
+#ifndef SC_I2_AMPW_PLAIN
+#define SC_I2_AMPW_PLAIN 0  // lab (round 6): the plain row kernel stores a winner's amplitude at the win as well
+#endif
 #ifndef SC_I2_NEAR_AMPW
 #define SC_I2_NEAR_AMPW 1
 #endif
@@ -2623,12 +2626,25 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
     // NEAR (round 6): a winner's amplitude is STORED when it wins (the record branch) instead of its transform output
     // being carried in sixteen registers to the write-back - the same product of the same two floats; with the event
     // loop's temporaries the near-tie variant then fits the plain kernel's four waves per SIMD
-    constexpr bool AMPW = NEAR && !PT && SC_I2_NEAR_LOOP && SC_I2_NEAR_AMPW;
+    constexpr bool AMPW = (NEAR && !PT && SC_I2_NEAR_LOOP && SC_I2_NEAR_AMPW) ||
+                          (SC_I2_AMPW_PLAIN && !NEAR && !PT && !MAPS && !FULL && !SPLITK);      // (lab: the plain kernel too)
+    static_assert(!(AMPW && SPLITK && !NEAR), "a later share's amplitudes go to its own plane");
     auto best_of = [](int c, int part) { return PT ? c : 2 * c + part; };
     float b_snr[NBEST], b_xr[NBEST];
     uint32_t b_ix[NBEST / 4];                  // one byte per cell (0xFF: unchanged)
     uint32_t nearm = 0;                        // NEAR: bit k - some template came within near_w of cell k's running best
-    static_assert(!NEAR || (!SPLITK && !MAPS && !FULL), "near-tie flags: the plain fold only");
+    static_assert(!NEAR || (!MAPS && !FULL), "near-tie flags: the plain fold only");
+    // SPLITK + NEAR (round 6): a later share starts from the record as the launch found it - a FLOOR without a holder - instead
+    // of from nothing: its templates win (and are near-ties) against what the search has reached, not against the best of the
+    // few templates of the share (a share that starts from zero meets a "record" an order of magnitude more often, and
+    // names candidates the final record is far above).  The merged result is the same: the share hands on only what beat
+    // the floor, and the merge takes the shares in order.
+    // EVERY share of such a launch - the first too - hands its winners to k_merge_split in a scratch record of its own: a first
+    // share that wrote the record itself would move the floor under the workgroups of the other shares that start later
+    // (the same final record, but other near-ties listed from run to run).
+    const bool later = SPLITK && (NEAR || blockIdx.z > 0);
+    const size_t share_plane = SPLITK ? (size_t)(NEAR ? blockIdx.z : blockIdx.z - 1) * ra.nc : 0;
+    float* const amp_dst = later ? ra.a2 + share_plane : best_amp;                            // (AMPW: where a winner's amplitude goes)
 #pragma unroll
     for (int c = 0; c < NBEST / 4; ++c) b_ix[c] = NONE;
 #pragma unroll
@@ -2636,7 +2652,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         const int cj = col_of(c);
 #pragma unroll
         for (int part = 0; part < (PT ? 1 : 2); ++part) {
-            const bool ok = !MAPS && row_of(part) && cj >= 0 && cj < tile_of(part).vx && !(SPLITK && blockIdx.z > 0);
+            const bool ok = !MAPS && row_of(part) && cj >= 0 && cj < tile_of(part).vx && !(SPLITK && !NEAR && blockIdx.z > 0);
             // (a cell outside the tile's valid extent holds +inf: nothing compares greater, so the
             //  templates whose window-limit rectangle covers the whole tile row need no range test
             //  per output - STATIC below; such a cell is never written back, its winner byte stays NONE)
@@ -2951,7 +2967,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                                 nt = nt || (won && snr * near_up <= b_snr[k]);    // won, and the record it beat lies inside the window
                                 if constexpr (AMPW) {
                                     if (won)
-                                        at_bytes(best_amp + off_of(part), 4u * (uint32_t)col_of(u * R3 + m)) = (part ? xc.y : xc.x) * ka[part];
+                                        at_bytes(amp_dst + off_of(part), 4u * (uint32_t)col_of(u * R3 + m)) = (part ? xc.y : xc.x) * ka[part];
                                 } else {
                                     b_xr[k] = won ? (part ? xc.y : xc.x) : b_xr[k];
                                 }
@@ -2960,7 +2976,14 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                         }
                         if (any_won) {
                             b_snr[k] = won ? snr : b_snr[k];
-                            if constexpr (!NEAR_LOOP) b_xr[k] = won ? (part ? xc.y : xc.x) : b_xr[k];
+                            if constexpr (!NEAR_LOOP) {
+                                if constexpr (AMPW) {
+                                    if (won)
+                                        at_bytes(amp_dst + off_of(part), 4u * (uint32_t)col_of(u * R3 + m)) = (part ? xc.y : xc.x) * ka[part];
+                                } else {
+                                    b_xr[k] = won ? (part ? xc.y : xc.x) : b_xr[k];
+                                }
+                            }
                             const uint32_t bm = 0xFFu << (8 * (k & 3));
                             b_ix[k >> 2] = won ? ((b_ix[k >> 2] & ~bm) | (tix[part] & bm)) : b_ix[k >> 2];
                         }
@@ -3021,13 +3044,13 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
         };
         bool later_share = false;
         if constexpr (SPLITK) {
-            if (blockIdx.z > 0) {
+            if (later) {
                 // a later share of the launch's transforms: its own record, EVERY valid cell written (zero where
                 // none of its templates scored), for k_merge_split to fold into the record in order.  Its winners
                 // go into the statistic like the first share's (a cell counts once per share that scored on it:
                 // the statistic is a fraction of wins, and every share's wins are wins of this launch's templates)
                 later_share = true;
-                const size_t pl_ = (size_t)(blockIdx.z - 1) * ra.nc;
+                const size_t pl_ = share_plane;
 #pragma unroll
                 for (int k = 0; k < NBEST; ++k) {
                     const int c = PT ? k : k >> 1, part = PT ? 0 : (k & 1);
@@ -3038,9 +3061,13 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                     const uint32_t o = 4u * (uint32_t)cj;
                     const float* e = epi + EPI_FLOATS * (won ? ix : (uint32_t)tlo);
                     at_bytes(ra.s2 + pl_ + off_of(part), o) = won ? b_snr[k] : 0.f;
-                    at_bytes(ra.a2 + pl_ + off_of(part), o) = won ? b_xr[k] * e[0] : 0.f;
+                    if constexpr (AMPW) {                    // (a winner's amplitude is in the share's plane since it won)
+                        if (!won) at_bytes(ra.a2 + pl_ + off_of(part), o) = 0.f;
+                    } else {
+                        at_bytes(ra.a2 + pl_ + off_of(part), o) = won ? b_xr[k] * e[0] : 0.f;
+                    }
                     at_bytes(ra.i2 + pl_ + off_of(part), o) = won ? templ[ra.first + (won ? ix : 0)].id : SC_ID_NONE;
-                    if (won && b_snr[k] > 0.f) count(k, e, b_xr[k]);
+                    if (won && b_snr[k] > 0.f) count(k, e, AMPW ? at_bytes(ra.a2 + pl_ + off_of(part), o) / e[0] : b_xr[k]);
                 }
             }
         }
@@ -3085,16 +3112,34 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
 // share's template takes a cell only where it scored strictly higher - what the one fold over all of the
 // launch's templates does (sc_fold).  Cells the launch did not cover hold what an earlier launch of the
 // search left there, already merged: nothing is greater than itself.
+template <bool NEAR>
 __global__ void __launch_bounds__(256)
 k_merge_split(float* __restrict__ best_snr, float* __restrict__ best_amp, uint32_t* __restrict__ best_id,
-              const float* __restrict__ s2, const float* __restrict__ a2, const uint32_t* __restrict__ i2,
-              size_t nc, int nparts) {
+              float* __restrict__ s2, const float* __restrict__ a2, const uint32_t* __restrict__ i2,
+              size_t nc, int nparts, float near_w, uint8_t* __restrict__ near, unsigned long long* __restrict__ ev_count,
+              uint32_t* __restrict__ ev, unsigned long long ev_cap) {
+    // NEAR (round 6): a share's winner within the window of the record it meets here, either side, is a near-tie like any
+    // other - flagged and listed (cell, the share's template, the record's holder) - and a share's entry is consumed (zeroed)
+    // once read: a cell a later launch does not cover would otherwise meet its own old score again, as a tie, launch after launch.
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nc; i += (size_t)gridDim.x * 256) {
         float bs = best_snr[i], ba = 0.f;
         uint32_t bi = 0;
         bool took = false;
         for (int h = 0; h < nparts; ++h) {
             const float s = s2[(size_t)h * nc + i];
+            if (NEAR && s > 0.f) {
+                s2[(size_t)h * nc + i] = 0.f;
+                if (fabsf(s - bs) <= near_w * fmaxf(s, bs)) {
+                    near[i] = (uint8_t)1;
+                    const unsigned long long slot = atomicAdd(ev_count, 1ull);
+                    if (slot < ev_cap) {
+                        uint32_t* e = ev + 3 * slot;
+                        e[0] = (uint32_t)i;
+                        e[1] = i2[(size_t)h * nc + i];
+                        e[2] = took ? bi : best_id[i];
+                    }
+                }
+            }
             if (s > bs) { bs = s; ba = a2[(size_t)h * nc + i]; bi = i2[(size_t)h * nc + i]; took = true; }
         }
         if (took) { best_snr[i] = bs; best_amp[i] = ba; best_id[i] = bi; }
@@ -3672,7 +3717,12 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             // 255 templates - the winner's byte - in shares of at most SC_MAX_GROUP transforms each; C1F's 7 batched
             // orientations of 35 ages are then ONE row-pass launch of four shares at four waves per SIMD instead of
             // seven launches of two
-            const bool can_split = fast && !(ctx->near_w > 0.f) && !to_maps && !full_masks && fg.Tx <= 1024 && ctx->variant != 15 &&
+            // (with near-tie flags on - the exact mode - only for searches of several templates per orientation: a share meets the
+            //  record as the launch found it, not what the shares before it have reached, and lists near-ties against that floor
+            //  that the sequential fold would not; a Ricker's SNR varies slowly with the orientation - on C5, one template per
+            //  orientation, the split cost more in float64 pairs than it saved in the pass: 14.0 -> 17.3 ms; C1F 51.7 -> 46.6)
+            const bool near_split_ok = !(ctx->near_w > 0.f) || (!xp && G >= 4);
+            const bool can_split = fast && near_split_ok && !to_maps && !full_masks && fg.Tx <= 1024 && ctx->variant != 15 &&
                                    !(ctx->sib & 1) && ctx->variant != 20;
             // How many shares: up to four (any number, not only powers of two) while the launch stays within ~4 300 waves -
             // the four per SIMD the kernel's 128 registers allow and 5 % (measured at C1F, 1 044 single-wave rows: two
@@ -3719,7 +3769,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
                 ra.near = (uint8_t*)ctx->near.p;
             }
             int nsplit = 1;
-            if (fast && !near && !to_maps && !full_masks && fg.Tx <= 1024 && ctx->variant != 15 && !(ctx->sib & 1)) {
+            if (fast && near_split_ok && !to_maps && !full_masks && fg.Tx <= 1024 && ctx->variant != 15 && !(ctx->sib & 1)) {
                 const int ngl = nbc * (PTV ? (G + 1) / 2 : G);
                 // (option "split_fill": the waves the dealt-out row pass may come to instead of the chip's resident
                 //  capacity for the kernel; every share at least four transforms, at most SC_MAX_GROUP - its 64-bit mask)
@@ -3730,7 +3780,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
             }
             if (nsplit > 1) {
                 const size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
-                const size_t need = (size_t)3 * nc * sizeof(float);          // up to four shares: three scratch records
+                const size_t need = (size_t)4 * nc * sizeof(float);          // up to four shares: three scratch records (four with near-tie flags on)
                 const bool fresh = ctx->split_s.cap < need;
                 int rc;
                 if ((rc = sc_ensure(ctx, ctx->split_s, need))) return rc;
@@ -3772,17 +3822,19 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
     }
 #define LAUNCH_FAST(T, FULLV)                                                  \
     { if (to_maps) LAUNCH_FAST2(T, FULLV, true) else LAUNCH_FAST2(T, FULLV, false) }
-#define LAUNCH_SPLIT(T)                                                        \
+#define LAUNCH_SPLIT2(T, NEARV)                                                \
     {                                                                          \
-        int rc = set_lds(ctx, k_inv_rows_fast<T, false, false, PTV, true>, inv_rows_fast_lds_split<T>()); \
+        int rc = set_lds(ctx, k_inv_rows_fast<T, false, false, PTV, true, NEARV>, inv_rows_fast_lds_split<T>()); \
         if (rc) return rc;                                                     \
-        hipLaunchKernelGGL((k_inv_rows_fast<T, false, false, PTV, true>), gridr,   \
+        hipLaunchKernelGGL((k_inv_rows_fast<T, false, false, PTV, true, NEARV>), gridr,   \
                            dim3(inv_rows_fast_threads<T>()), inv_rows_fast_lds_split<T>(), FAST_ARGS); \
         const unsigned mb_ = (unsigned)std::min<size_t>((ra.nc + 255) / 256, 2048); \
-        hipLaunchKernelGGL(k_merge_split, dim3(mb_), dim3(256), 0, ctx->stream, (float*)ctx->best_snr.p, \
-                           (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p, (const float*)ra.s2,   \
-                           (const float*)ra.a2, (const uint32_t*)ra.i2, ra.nc, nsplit - 1);            \
+        hipLaunchKernelGGL(k_merge_split<NEARV>, dim3(mb_), dim3(256), 0, ctx->stream, (float*)ctx->best_snr.p, \
+                           (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p, ra.s2,                \
+                           (const float*)ra.a2, (const uint32_t*)ra.i2, ra.nc, (NEARV) ? nsplit : nsplit - 1, ra.near_w, ra.near, \
+                           ra.ev_count, ra.ev, ra.ev_cap);                                           \
     }
+#define LAUNCH_SPLIT(T) { if (near) LAUNCH_SPLIT2(T, true) else LAUNCH_SPLIT2(T, false) }
 #define LAUNCH_NEAR(T)                                                         \
     {                                                                          \
         int rc = set_lds(ctx, k_inv_rows_fast<T, false, false, PTV, false, true>, inv_rows_fast_lds<T>()); \
@@ -3790,14 +3842,14 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
         hipLaunchKernelGGL((k_inv_rows_fast<T, false, false, PTV, false, true>), gridr,   \
                            dim3(inv_rows_fast_threads<T>()), inv_rows_fast_lds<T>(), FAST_ARGS); \
     }
-            if (near) {
+            if (nsplit > 1) {
+                if (fg.Tx == 512) LAUNCH_SPLIT(512) else LAUNCH_SPLIT(1024)
+            } else if (near) {
                 switch (fg.Tx) {
                     case 512: LAUNCH_NEAR(512) break;
                     case 1024: LAUNCH_NEAR(1024) break;
                     default: LAUNCH_NEAR(2048) break;
                 }
-            } else if (nsplit > 1) {
-                if (fg.Tx == 512) LAUNCH_SPLIT(512) else LAUNCH_SPLIT(1024)
             } else if (fast) {
                 switch (fg.Tx) {
                     case 512: if (full_masks) LAUNCH_FAST(512, true) else LAUNCH_FAST(512, false) break;
@@ -3813,6 +3865,7 @@ int fft_inverse_fold(sc_ctx* ctx, const FftGeom& fg, int first, int n,
 #undef LAUNCH_FAST
 #undef LAUNCH_FAST2
 #undef LAUNCH_SPLIT
+#undef LAUNCH_SPLIT2
 #undef LAUNCH_NEAR
 #undef ROW_ARGS
 #undef FAST_ARGS
