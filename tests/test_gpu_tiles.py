@@ -86,7 +86,14 @@ def test_rccl_single_rank_halo_exchange():
     for k in range(4):
         assert np.allclose(res[k], whole[k], rtol=2e-3, atol=1e-6 * np.abs(whole[k]).max() + 1e-12)
     # final gather (sc_gather_result): with one rank the root places its own planes
+    # (exact mode, the default: the record that travels carries the float64 argmax with amp / snr ROUNDED to float32 -
+    #  every rank's cells alike - where result() lays the float64 values over its own planes)
     full = dm.gather(0)
+    assert np.array_equal(full[1], res[1]) and np.array_equal(full[2], res[2])
+    for k in (0, 3):
+        assert np.allclose(full[k], res[k], rtol=1e-7, atol=0)
+    dm.search(sl.Scarp, 10, params, angles, z, method="fft", exact=False)
+    full, res = dm.gather(0), dm.result()
     for k in range(4):
         assert np.array_equal(full[k], res[k])
 
