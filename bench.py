@@ -327,13 +327,16 @@ def measured_traffic(default_workload):
         return None
 
 
-def other_mode_leg(step, ctx, a, units, steps=0):
+def other_mode_leg(step, ctx, a, units, like_main=False):
     """The same workload in the mode the headline is NOT timed in (the float32 search when the line is exact, and the other
-    way round): a short timed loop of its own after the headline's, reported beside it.  Never costs the line."""
+    way round): a timed loop of its own after the headline's, reported beside it.  ``like_main``: the same steps and warm-up
+    as the line itself (the small configs: milliseconds); else two steps after one untimed one (C3: seconds each).  Never
+    costs the line."""
     import copy
     try:
         b = copy.copy(a)
-        b.steps, b.warmup, b.warmup_seconds = (steps or min(a.steps, 2)), 1 if a.steps > 2 else 0, 0.0
+        if not like_main:
+            b.steps, b.warmup, b.warmup_seconds = min(a.steps, 2), 1 if a.steps > 2 else 0, 0.0
         dt, _ = timed_loop(step, ctx, b, None)
         return {"value": round(units / (dt / b.steps) / 1e6, 1), "unit": "Mpx·template/s",
                 "ms_per_step": round(1e3 * dt / b.steps, 2 if dt / b.steps >= 0.01 else 4), "steps": b.steps,
@@ -387,7 +390,7 @@ def other_config_line(a, cfg, steps, warmup, device, pool):
             "kernels_ms_per_step": {k: round(v[1] / steps, 3) for k, v in prof.items() if v[0]}}
     if a.mode == "exact":
         line["settle"] = dict(settle_stats)            # (the last scale's counters)
-        line["float32_mode"] = other_mode_leg(make_step(False), m.ctx, b, units)
+        line["float32_mode"] = other_mode_leg(make_step(False), m.ctx, b, units, like_main=True)
     if not a.no_e2e and len(scales) == 1:
         # the call a user makes (C1F: the reference's flagship example, sl.match(load_carrizo(), Scarp, scale=100.)): upload,
         # curvature planes, descriptors, search, float64 result planes, D2H - the first call and the same call again

@@ -7,6 +7,7 @@ def find(pat):
     return sorted(glob.glob(os.path.join(root, pat), recursive=True))
 
 def short(n):
+    n = n.replace("(anonymous namespace)::", "")
     n = n.split("(")[0]
     for a, b in (("void ", ""), ("HIP_vector_type<float, 2u>", "f2")):
         n = n.replace(a, b)
