@@ -675,9 +675,9 @@ class Matcher(object):
     EXACT_USE_EVENTS = True                      # (False: always the longer, host-side routes - tests, comparisons)
 
     # exact=True on the real-space path: the window of its near-tie flags and events - twice its largest measured SNR error
-    # plus a tenth (2.15e-4 in ONE search of round 6's fuzz, the one above; 1.0e-4 in round 5's, 4e-5 on the tests' DEMs) -
-    # and how much float64 work is started at most
-    EXACT_WINDOW_DIRECT = 4.8e-4
+    # plus a tenth (2.98e-4 in ONE search of round 6's 4 100-search fuzz - a single old-scarp template, thousands of taps;
+    # 2.15e-4 in another; 1.0e-4 in round 5's, 4e-5 on the tests' DEMs) - and how much float64 work is started at most
+    EXACT_WINDOW_DIRECT = 6.6e-4
     EXACT_MAX_F64 = 2e12                         # (cell, template) pairs x support-box cells (~3e11 a second; the C3 search: 4.8e11)
 
     def _score_float64(self, last, arr_main, bbox):
