@@ -55,7 +55,7 @@ SLOTS = (("k_curv", ("k_curv_alpha", "k_curv_planes<float")), ("k_windows", ("k_
          ("k_inv_cols", ("k_inv_cols",)), ("k_inv_rows", ("k_inv_rows",)))
 out = {"so_sha256": h, "bytes_per_launch": {}, "detail": {},
        "_note": "bytes per kernel launch, per profiling slot of the library, from rocprofv3 --pmc FETCH_SIZE / "
-                "WRITE_SIZE (separate passes, bench.py --angles 2), FETCH_SIZE doubled per MI355X_MICROARCH.md; "
+                "WRITE_SIZE (separate passes, bench.py --angles 2 --mode float32: the plain kernels - the near-tie row pass moves the same planes), FETCH_SIZE doubled per MI355X_MICROARCH.md; "
                 "k_inv_cols = mean k_inv_cols_w8 launch (option i1_pairs: two tile pairs, the last of a chunk one; 35 templates, all columns), k_inv_rows = "
                 "mean k_inv_rows_fast launch; the forward slots average their curvature and template launches"}
 for key, pats in SLOTS:
