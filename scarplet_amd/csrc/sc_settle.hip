@@ -177,12 +177,14 @@ struct IdMap {
 // FILL = false: cnt[slot] += what the event adds to its cell's list; true: the same candidates into the lists
 template <bool FILL>
 __global__ void __launch_bounds__(256)
-k_st_events(const uint32_t* __restrict__ ev, unsigned long long n_ev, const uint32_t* __restrict__ slot_of,
+k_st_events(const uint32_t* __restrict__ ev, unsigned long long n_ev, const uint8_t* __restrict__ near, size_t nc,
+            const uint32_t* __restrict__ slot_of,
             const uint32_t* __restrict__ best_id, IdMap map, unsigned* __restrict__ cnt, const unsigned* __restrict__ off,
             int32_t* __restrict__ pair_t, uint32_t* __restrict__ pair_slot) {
     const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= n_ev) return;
     const uint32_t cell = ev[3 * k];
+    if (cell >= nc || !near[cell]) return;         // (an event's cell is flagged by the kernel that lists it: slot_of holds a slot there only)
     const int32_t ms = map(ev[3 * k + 1]), mh = map(ev[3 * k + 2]), mf = map(best_id[cell]);
     const int32_t cf = mf >= 0 ? map.cls(mf) : -1;
     const bool a = ms >= 0 && map.cls(ms) != cf, b = mh >= 0 && map.cls(mh) != cf && map.cls(mh) != (ms >= 0 ? map.cls(ms) : -1);
@@ -625,7 +627,7 @@ extern "C" int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long lo
     const IdMap map{d_tab, max_id + 1, n, n_twin};
     hipLaunchKernelGGL(k_st_slots, dim3(nblk), dim3(256), 0, ctx->stream, near, tm, (const unsigned*)blk, cell_of, slot_of, cnt);
     const unsigned evb = (unsigned)((n_ev + 255) / 256);
-    hipLaunchKernelGGL(k_st_events<false>, dim3(evb), dim3(256), 0, ctx->stream, ev, n_ev, (const uint32_t*)slot_of,
+    hipLaunchKernelGGL(k_st_events<false>, dim3(evb), dim3(256), 0, ctx->stream, ev, n_ev, near, nc, (const uint32_t*)slot_of,
                        (const uint32_t*)ctx->best_id.p, map, cnt, (const unsigned*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr);
     // ---- list offsets ------------------------------------------------------------------------------------------
     const unsigned nblk2 = (ns + 1 + ST_CH - 1) / ST_CH;
@@ -657,7 +659,7 @@ extern "C" int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long lo
     uint32_t* pair_slot = (uint32_t*)(pp + 2 * up64(8 * np) + up64(4 * np));
     hipLaunchKernelGGL(k_st_init_lists, dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, ns, (const uint32_t*)cell_of,
                        (const uint32_t*)ctx->best_id.p, map, (const unsigned*)off, cnt, pair_t, pair_slot);
-    hipLaunchKernelGGL(k_st_events<true>, dim3(evb), dim3(256), 0, ctx->stream, ev, n_ev, (const uint32_t*)slot_of,
+    hipLaunchKernelGGL(k_st_events<true>, dim3(evb), dim3(256), 0, ctx->stream, ev, n_ev, near, nc, (const uint32_t*)slot_of,
                        (const uint32_t*)ctx->best_id.p, map, cnt, (const unsigned*)off, pair_t, pair_slot);
     SC_HIP(ctx, hipGetLastError());
     // ---- float64 scores ------------------------------------------------------------------------------------------
