@@ -5,7 +5,10 @@
 
 One "step" is one search of the 35-age x 181-orientation Scarp grid (scale
 100) over the 10000 x 10000 synthetic DEM of BASELINE.md (config C3), DEM
-already resident in HBM.  With N > 1 (launched by torch.distributed.run, one
+already resident in HBM - in the mode sl.match delivers by default (--mode
+exact: the float32 search with its near-ties listed, then sc_settle_exact -
+the argmax (age, orientation) of every cell is the float64 reference's); the
+float32 search alone (--mode float32) is timed beside it (`float32_mode`).  With N > 1 (launched by torch.distributed.run, one
 rank per GPU) the same DEM is cut into a py x px tile grid (C4: 2 x 4), every
 rank exchanges halos over RCCL and searches its tile: total work is fixed, so
 scaling is "strong".  torch is used for the launcher contract only (rank
@@ -13,6 +16,8 @@ rendezvous, barrier, max-reduce of the timings); the product path is
 ctypes -> libscarplet_hip.so.
 
 Besides the contract's fields the JSON line carries
+  config.mode, settle, float32_mode   the mode timed, the settle's counters of a
+                 step, the other mode's short loop and its verification
   roofline       dominant kernel against the 28-B / 8 TB/s HBM roofline; its
                  `traffic` is the PMC-measured bytes per launch, printed only
                  when profiles/traffic.json was measured on this very .so
@@ -42,7 +47,8 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_UNIT = 28.0        # bytes per px.template
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
 # profiling slot of the library -> kernel symbols as rocprofv3 lists them
-KERNEL_SYMBOLS = {"k_inv_cols": "k_inv_cols_w8<T> (column length 512: k_inv_cols_h2; paired templates at 2048: k_inv_cols_w4)", "k_inv_rows": "k_inv_rows_fast<T,false,false,false,false,false>"}
+KERNEL_SYMBOLS = {"k_inv_cols": "k_inv_cols_w8<T> (column length 512: k_inv_cols_h2; paired templates at 2048: k_inv_cols_w4)",
+                  "k_inv_rows": "k_inv_rows_fast<T,false,false,false,false,NEAR> (NEAR = true in the exact mode)"}
 
 
 def parse():
