@@ -340,16 +340,17 @@ int sc_get_near_ties(sc_ctx* ctx, uint8_t* out);
  * SC_ERR_INVALID unless it is the number of templates of that last sc_match (ABI 8). */
 int sc_score_cells_f64(sc_ctx* ctx, const int32_t* cells, int m, int n_templates, double* amp, double* snr);
 
-/* The near-ties of the FFT searches since the last sc_reset_best as EVENTS (round 5, ABI 7): three 32-bit words each -
- * the cell (index into the core planes, row-major), the id of the template that was being scored, the id of the
- * template that held the cell's record at that moment (SC_ID_NONE: none yet) - one per (cell, template) whose score
- * came within option "near_window" of the record, either side.  The true float64 argmax of a flagged cell is the
- * record's final holder or one of the templates its events name (two templates further apart than the window differ by
- * more than twice the path's error: the lower one cannot be the argmax), so scarplet_amd.match(..., exact=True) scores
- * exactly those (cell, template) pairs in float64 (sc_score_pairs_f64).  *n_events = events recorded; the device list
- * holds two per core cell (a million at least).  A count above `capacity` copies nothing and returns SC_OK (the caller asks
- * again with room); a list that OVERFLOWED on the device answers SC_ERR_UNSUPPORTED (ABI 8: said by the call, not left to
- * the caller's arithmetic) - the caller takes the route without events (sc_get_near_ties + sc_score_cells_f64). */
+/* The near-ties of the searches since the last sc_reset_best as EVENTS (round 5; ABI 8: FOUR 32-bit words each, both paths) -
+ * the cell (index into the core planes, row-major), the id of the template that was being scored, the id of the template
+ * that held the cell's record at that moment (SC_ID_NONE: none yet), the float32 bits of the LARGER of their two scores -
+ * one per (cell, template) whose score came within option "near_window" of the record, either side.  The true float64
+ * argmax of a flagged cell is the record's final holder or one of the templates its events name (two templates further
+ * apart than the window differ by more than twice the path's error: the lower one cannot be the argmax), and only events
+ * whose larger score lies within the window of the FINAL record can name it: sc_settle_exact scores exactly those (cell,
+ * template) pairs in float64.  *n_events = events recorded; the device list holds two per core cell (a million at least).
+ * A count above `capacity` copies nothing and returns SC_OK (the caller asks again with room); a list that OVERFLOWED on
+ * the device answers SC_ERR_UNSUPPORTED (ABI 8: said by the call, not left to the caller's arithmetic) - the caller takes
+ * the route without events (sc_get_near_ties + sc_score_cells_f64). */
 int sc_get_near_events(sc_ctx* ctx, uint32_t* events, long long capacity, long long* n_events);
 
 /* sc_score_cells_f64 for (cell, template) PAIRS: pair k = global cell (cells[2k], cells[2k+1]) against template

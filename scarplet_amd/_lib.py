@@ -413,16 +413,16 @@ class Context(object):
         return amp, snr
 
     def near_events(self):
-        """The near-ties of the FFT searches since the last reset as events, (n, 3) uint32: cell (row-major index into the
-        core planes), id of the template scored, id of the record's holder at that moment (sc_get_near_events) - or None
-        where the device list overflowed (more events than two per core cell)."""
+        """The near-ties of the searches since the last reset as events, (n, 4) uint32: cell (row-major index into the
+        core planes), id of the template scored, id of the record's holder at that moment, float32 bits of the larger of
+        their two scores (sc_get_near_events) - or None where the device list overflowed (more events than two per core cell)."""
         n = C.c_longlong(0)
         try:
             self._check(self.lib.sc_get_near_events(self._h, None, 0, C.byref(n)), "sc_get_near_events")
             want = int(n.value)
             if want == 0:
-                return np.zeros((0, 3), dtype=np.uint32)
-            ev = np.empty((want, 3), dtype=np.uint32)
+                return np.zeros((0, 4), dtype=np.uint32)
+            ev = np.empty((want, 4), dtype=np.uint32)
             self._check(self.lib.sc_get_near_events(self._h, _as(ev, _up), want, C.byref(n)), "sc_get_near_events")
         except ScarpletHipError as e:
             if "overflowed" in str(e):                   # (the library says so itself since ABI 8)

@@ -483,12 +483,13 @@ int sc_near_buffers(sc_ctx* ctx, unsigned long long** ev_count, uint32_t** ev, u
     if (fresh) SC_HIP(ctx, hipMemsetAsync(ctx->near.p, 0, ctx->near.cap, ctx->stream));
     // the event list: two per core cell or a million, whichever is more (12 bytes each); counter in front
     const unsigned long long cap = std::max<unsigned long long>(2ull * nc, 1ull << 20);
-    const bool fresh_ev = ctx->near_ev.cap < 16 + 12 * cap;
-    if ((rc = sc_ensure(ctx, ctx->near_ev, 16 + 12 * cap))) return rc;
+    const bool fresh_ev = ctx->near_ev.cap < 16 + 4 * SC_EVENT_WORDS * cap;
+    if ((rc = sc_ensure(ctx, ctx->near_ev, 16 + 4 * SC_EVENT_WORDS * cap))) return rc;
     if (fresh_ev) SC_HIP(ctx, hipMemsetAsync(ctx->near_ev.p, 0, 16, ctx->stream));
     *ev_count = (unsigned long long*)ctx->near_ev.p;
     *ev = (uint32_t*)((char*)ctx->near_ev.p + 16);
-    *ev_cap = (ctx->near_ev.cap - 16) / 12;
+    *ev_cap = (ctx->near_ev.cap - 16) / (4 * SC_EVENT_WORDS);
+    ctx->near_w_used = ctx->near_w;
     return SC_OK;
 }
 
@@ -514,12 +515,12 @@ extern "C" int sc_get_near_events(sc_ctx* ctx, uint32_t* events, long long capac
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SC_HIP(ctx, hipMemcpy(&n, ctx->near_ev.p, sizeof(n), hipMemcpyDeviceToHost));
     *n_events = (long long)n;
-    const unsigned long long held = std::min<unsigned long long>(n, (ctx->near_ev.cap - 16) / 12);
+    const unsigned long long held = std::min<unsigned long long>(n, (ctx->near_ev.cap - 16) / (4 * SC_EVENT_WORDS));
     const unsigned long long take = std::min<unsigned long long>(held, (unsigned long long)capacity);
     if (n > held)                                        // the device list overflowed: events were dropped - said, not left to the caller's arithmetic
         return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_get_near_events: the event list overflowed (%llu near-ties, room for %llu)", n, held);
     if (held > (unsigned long long)capacity) return SC_OK;                  // the caller asks again with room (*n_events says how much)
-    if (take) SC_HIP(ctx, hipMemcpy(events, (const char*)ctx->near_ev.p + 16, 12 * take, hipMemcpyDeviceToHost));
+    if (take) SC_HIP(ctx, hipMemcpy(events, (const char*)ctx->near_ev.p + 16, 4 * SC_EVENT_WORDS * take, hipMemcpyDeviceToHost));
     return SC_OK;
 }
 

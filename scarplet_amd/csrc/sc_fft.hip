@@ -2877,11 +2877,12 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                                 const unsigned long long slot = atomicAdd(ra.ev_count, 1ull);
                                 if (slot < ra.ev_cap) {
                                     const uint32_t hx = (b_ix[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                                    uint32_t* e = ra.ev + 3 * slot;
+                                    uint32_t* e = ra.ev + SC_EVENT_WORDS * slot;
                                     e[0] = (uint32_t)(off_of(part) + (size_t)cj);
                                     e[1] = tp->id;
                                     // a holder from an earlier launch (or none yet: SC_ID_NONE) stands in the record's id plane
                                     e[2] = hx != 0xFFu ? templ[ra.first + hx].id : at_bytes(best_id + off_of(part), 4u * (uint32_t)cj);
+                                    e[3] = __float_as_uint(top);
                                 }
                             }
                         }
@@ -2922,6 +2923,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 // the holder it met).  The branch is NOT rare (a cell is won dozens of times in a search: most waves
                 // see a win per template); a near-tie is - three in a million outputs.
                 uint32_t ntm = 0;
+                float top1 = 0.f;
                 uint32_t old_ix[NBEST / 4];
                 if constexpr (NEAR_LOOP) {
 #pragma unroll
@@ -2945,10 +2947,11 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                                 if (slot < ra.ev_cap) {
                                     const int cj = col_of(u * R3 + m);
                                     const uint32_t hx = (b_ix[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                                    uint32_t* e = ra.ev + 3 * slot;
+                                    uint32_t* e = ra.ev + SC_EVENT_WORDS * slot;
                                     e[0] = (uint32_t)(off_of(part) + (size_t)cj);
                                     e[1] = tpp[part]->id;
                                     e[2] = hx != 0xFFu ? templ[ra.first + hx].id : at_bytes(best_id + off_of(part), 4u * (uint32_t)cj);
+                                    e[3] = __float_as_uint(top);
                                 }
                             }
                         }
@@ -2972,7 +2975,10 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                                     b_xr[k] = won ? (part ? xc.y : xc.x) : b_xr[k];
                                 }
                             }
-                            if (__builtin_amdgcn_ballot_w64(nt) != 0ull) ntm |= nt ? (1u << (2 * (m - m0) + part)) : 0u;
+                            if (__builtin_amdgcn_ballot_w64(nt) != 0ull) {
+                                top1 = (nt && ntm == 0u) ? fmaxf(snr, b_snr[k]) : top1;     // (b_snr[k]: still the record the output met)
+                                ntm |= nt ? (1u << (2 * (m - m0) + part)) : 0u;
+                            }
                         }
                         if (any_won) {
                             b_snr[k] = won ? snr : b_snr[k];
@@ -2992,6 +2998,7 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                 if constexpr (NEAR_LOOP) {
                     // the events, after the update: the outputs' scores and values are dead by now - the loop's temporaries
                     // take their registers instead of a fourth wave per SIMD (round 6: 168 registers -> 128)
+                    bool first_ev = true;
                     while (ntm) {                          // (per lane; a near-tie is three in a million outputs)
                         const int bit = __builtin_ctz(ntm);
                         ntm &= ntm - 1;
@@ -3003,11 +3010,16 @@ k_inv_rows_fast(const float2* __restrict__ yw, const float2* __restrict__ ym,
                                 const uint32_t hx = (old_ix[k >> 2] >> (8 * (k & 3))) & 0xFFu;
                                 const int cj = col_of(c);
                                 const size_t cell = (part ? offB : offA) + (size_t)cj;
-                                uint32_t* e = ra.ev + 3 * slot;
+                                // the larger of the two scores: taken where the lane's FIRST near-tie of the branch was found; a second
+                                // one in the same lane and branch (one in 1e11) says +inf - never dropped by the settle
+                                const float top = first_ev ? top1 : __builtin_inff();
+                                first_ev = false;
+                                uint32_t* e = ra.ev + SC_EVENT_WORDS * slot;
                                 e[0] = (uint32_t)cell;
                                 e[1] = part ? tpp[1]->id : tpp[0]->id;
                                 // a holder from an earlier launch (or none yet: SC_ID_NONE) stands in the record's id plane
                                 e[2] = hx != 0xFFu ? templ[ra.first + hx].id : best_id[cell];
+                                e[3] = __float_as_uint(top);
                             }
                         }
                     }
@@ -3133,10 +3145,11 @@ k_merge_split(float* __restrict__ best_snr, float* __restrict__ best_amp, uint32
                     near[i] = (uint8_t)1;
                     const unsigned long long slot = atomicAdd(ev_count, 1ull);
                     if (slot < ev_cap) {
-                        uint32_t* e = ev + 3 * slot;
+                        uint32_t* e = ev + SC_EVENT_WORDS * slot;
                         e[0] = (uint32_t)i;
                         e[1] = i2[(size_t)h * nc + i];
                         e[2] = took ? bi : best_id[i];
+                        e[3] = __float_as_uint(fmaxf(s, bs));
                     }
                 }
             }

@@ -9,6 +9,9 @@
 #include "../../include/scarplet_hip.h"
 
 #define SC_EPS 2.220446049250313e-16      // np.spacing(1), core.py:340
+// a near-tie event: cell, id of the template scored, id of the record's holder, float32 bits of the LARGER of the two scores
+// (round 6: the settle drops an event whose scores the final record has left behind by more than the window)
+#define SC_EVENT_WORDS 4
 
 // Timing-only ablation bits (skip loads / transforms / stores of a kernel; the
 // results are wrong while one is set).  They exist only in a -DSC_ABLATE build
@@ -121,6 +124,7 @@ struct sc_ctx {
     int last_batch = 0;
     float kappa = 4.f;         // float32 resolution floor of the FFT path, in units of eps (sc_set_option "kappa")
     float near_w = 0.f;        // sc_set_option "near_window": the FFT row pass flags near-ties (sc_get_near_ties)
+    float near_w_used = 0.f;   // the window the events of the current record were listed with (the last sc_match's, when on)
     DevBuf near;               // one byte per core cell
     DevBuf near_ev;            // the near-tie events of the FFT row pass: a 64-bit count, then 3 words per event (sc_get_near_events)
     // sc_settle_exact: slot of every flagged cell (one word per core cell, valid at flagged cells), the work lists, and the

@@ -1014,10 +1014,11 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                                 if (ev) {                    // (before the fold: the id plane still names the holder - this lane's own store)
                                     const unsigned long long slot = atomicAdd(ev_count, 1ull);
                                     if (slot < ev_cap) {
-                                        uint32_t* e = ev + 3 * slot;
+                                        uint32_t* e = ev + SC_EVENT_WORDS * slot;
                                         e[0] = (uint32_t)o;
                                         e[1] = t.id;
                                         e[2] = best_id[o];
+                                        e[3] = __float_as_uint(fmaxf(snr, bs));
                                     }
                                 }
                             }

@@ -178,14 +178,20 @@ struct IdMap {
 template <bool FILL>
 __global__ void __launch_bounds__(256)
 k_st_events(const uint32_t* __restrict__ ev, unsigned long long n_ev, const uint8_t* __restrict__ near, size_t nc,
-            const uint32_t* __restrict__ slot_of,
+            const uint32_t* __restrict__ slot_of, const float* __restrict__ best_snr, float keep,
             const uint32_t* __restrict__ best_id, IdMap map, unsigned* __restrict__ cnt, const unsigned* __restrict__ off,
             int32_t* __restrict__ pair_t, uint32_t* __restrict__ pair_slot) {
     const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= n_ev) return;
-    const uint32_t cell = ev[3 * k];
+    const uint32_t cell = ev[SC_EVENT_WORDS * k];
     if (cell >= nc || !near[cell]) return;         // (an event's cell is flagged by the kernel that lists it: slot_of holds a slot there only)
-    const int32_t ms = map(ev[3 * k + 1]), mh = map(ev[3 * k + 2]), mf = map(best_id[cell]);
+    // An event the search has left behind: the larger of its two float32 scores lies further below the FINAL record than the
+    // window.  With scores off by at most e (window >= 2 e) the float64 argmax scores within 2 e of the final record: neither
+    // template of such an event can be it.  (The first orientations of a search tie among themselves in every cell - on the
+    // carrizo DEM at 2 m five ages are PROPORTIONAL templates at -pi/2: 85 % of all events - long before the record gets
+    // where it ends.)
+    if (__uint_as_float(ev[SC_EVENT_WORDS * k + 3]) < best_snr[cell] * keep) return;
+    const int32_t ms = map(ev[SC_EVENT_WORDS * k + 1]), mh = map(ev[SC_EVENT_WORDS * k + 2]), mf = map(best_id[cell]);
     const int32_t cf = mf >= 0 ? map.cls(mf) : -1;
     const bool a = ms >= 0 && map.cls(ms) != cf, b = mh >= 0 && map.cls(mh) != cf && map.cls(mh) != (ms >= 0 ? map.cls(ms) : -1);
     if (!a && !b) return;
@@ -557,9 +563,9 @@ extern "C" int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long lo
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SC_HIP(ctx, hipMemcpy(&n_ev, ctx->near_ev.p, sizeof(n_ev), hipMemcpyDeviceToHost));
     stats_out[5] = (long long)n_ev;
-    if (n_ev > (ctx->near_ev.cap - 16) / 12)
+    if (n_ev > (ctx->near_ev.cap - 16) / (4 * SC_EVENT_WORDS))
         return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_settle_exact: the event list overflowed (%llu near-ties, room for %llu)",
-                       n_ev, (unsigned long long)((ctx->near_ev.cap - 16) / 12));
+                       n_ev, (unsigned long long)((ctx->near_ev.cap - 16) / (4 * SC_EVENT_WORDS)));
     if (3 * n_ev + nc >= 0xFFFFFFFFull) return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_settle_exact: %llu events", n_ev);
     const uint32_t* ev = (const uint32_t*)((const char*)ctx->near_ev.p + 16);
     const uint8_t* near = (const uint8_t*)ctx->near.p;
@@ -627,7 +633,10 @@ extern "C" int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long lo
     const IdMap map{d_tab, max_id + 1, n, n_twin};
     hipLaunchKernelGGL(k_st_slots, dim3(nblk), dim3(256), 0, ctx->stream, near, tm, (const unsigned*)blk, cell_of, slot_of, cnt);
     const unsigned evb = (unsigned)((n_ev + 255) / 256);
+    // (the window the events were listed with, less a hair for the float32 product)
+    const float keep = (1.f - ctx->near_w_used) * (1.f - 4e-7f);
     hipLaunchKernelGGL(k_st_events<false>, dim3(evb), dim3(256), 0, ctx->stream, ev, n_ev, near, nc, (const uint32_t*)slot_of,
+                       (const float*)ctx->best_snr.p, keep,
                        (const uint32_t*)ctx->best_id.p, map, cnt, (const unsigned*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr);
     // ---- list offsets ------------------------------------------------------------------------------------------
     const unsigned nblk2 = (ns + 1 + ST_CH - 1) / ST_CH;
@@ -660,6 +669,7 @@ extern "C" int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long lo
     hipLaunchKernelGGL(k_st_init_lists, dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, ns, (const uint32_t*)cell_of,
                        (const uint32_t*)ctx->best_id.p, map, (const unsigned*)off, cnt, pair_t, pair_slot);
     hipLaunchKernelGGL(k_st_events<true>, dim3(evb), dim3(256), 0, ctx->stream, ev, n_ev, near, nc, (const uint32_t*)slot_of,
+                       (const float*)ctx->best_snr.p, keep,
                        (const uint32_t*)ctx->best_id.p, map, cnt, (const unsigned*)off, pair_t, pair_slot);
     SC_HIP(ctx, hipGetLastError());
     // ---- float64 scores ------------------------------------------------------------------------------------------
