@@ -361,7 +361,8 @@ int sc_score_pairs_f64(sc_ctx* ctx, const int32_t* cells, const int32_t* templat
  * exact=True on the device (round 6, ABI 8): the reference's fold is an argmax over float64 SNR maps (compare(),
  * core.py:230-240); this call makes the record's (age, orientation) of every near-tie cell that argmax.  After an sc_match
  * with option "near_window" on (either path lists its near-ties since ABI 8): the flagged cells become slots in cell
- * order, every cell's candidates - the record's final holder and the templates its events name - become a list, exactly
+ * order, every cell's candidates - the record's final holder and the templates named by its events (those whose larger score
+ * the final record has left behind by more than the window are dropped: neither template can be the argmax) - become a list, exactly
  * those (cell, template) pairs are scored in float64 (sc_score_pairs_f64's arithmetic, one workgroup per pair; a template
  * named twice in a list, or a list of one template, is not scored), and every cell takes the largest float64 SNR, ties to
  * the earlier template of the hand-over order.  The winner's id goes into the record (amp and snr rounded to float32: what

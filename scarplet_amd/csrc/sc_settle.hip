@@ -3,8 +3,10 @@
 // The reference folds float64 SNR maps (compare(), core.py:230-240: the argmax over templates of float64 numbers); the
 // float32 searches here decide a cell to within their own rounding.  With option "near_window" on, both paths flag the
 // cells where a template scored within the window of the running best and list an event (cell, template scored, holder of
-// the record) per near-tie.  A template further below the record than the window is below it in float64 too, so a flagged
-// cell's float64 argmax is its final holder or a template one of its events names.  This file turns the flags and the
+// the record, the larger of their two scores) per near-tie.  With float32 scores off by at most e and a window of 2 e, the
+// float64 argmax of a cell scores within the window of the record's FINAL holder, hence within the window of whatever held
+// the record when it was scored or displaced: it is the final holder or a template named by an event whose larger score
+// lies within the window of the final record (events the search has left behind are dropped).  This file turns the flags and the
 // events into per-cell candidate lists, scores exactly those (cell, template) pairs with match_template()'s float64
 // arithmetic (core.py:340-377 as the real-space closed form: k_st_score, the same expressions as k_score_f64), takes
 // the argmax in fold order, writes it into the record and keeps the float64 (amp, snr) as patches that sc_get_result
@@ -14,7 +16,8 @@
 // Pipeline (all on the context's stream; three 8-byte read-backs size the next step's buffers):
 //   k_st_flag_count / k_st_scan1 / k_st_slots   flagged cells -> slots, numbered 64 x 64 tile by tile (neighbouring pairs share
 //                                               their curvature neighbourhood in L2), cnt[slot] = 1 (the final holder)
-//   k_st_events<false>                          cnt[slot] += candidates the slot's events add
+//   k_st_events<false>                          cnt[slot] += candidates the slot's events add (events left behind by the final
+//                                               record: dropped - nine in ten on the benchmark search)
 //   k_st_sum / k_st_scan1 / k_st_offsets        exclusive scan -> off[slot]
 //   k_st_init_lists, k_st_events<true>          pair lists: entry 0 the final holder, then the events' templates
 //   k_window_f64, k_curv_planes<double>         (score_prepare_f64); k_st_sums: n and sum(W**2) in a fixed order
