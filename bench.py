@@ -725,16 +725,23 @@ def build_sharding(sh, backend, a, rank, world, device, transport, g, Template, 
     if sh == "orientations":
         om = sd.OrientationMatcher(rank, world, g, device=device, backend=backend, transport=transport)
         mine, sp = om.describe(Template, scales[0], params, angles, a.method, a.group or None)
+        # exact mode: every rank searches with the near-tie window on, keeps its own record beside the folded one, lists what
+        # it knows to lie within the window of the FOLDED record; the lists (a few megabytes) travel through the launcher's
+        # transport and every rank settles the union in float64 (sc_rank_candidates / sc_settle_pairs, dist.py)
+        win = om.m.exact_window_for(om._keep, sp) if a.mode == "exact" else 0.0
+        twin = om.m.end_twins(om._keep, len(params), angles)
 
         def step():
-            om.run(mine, sp)                   # reset, this rank's orientations, fold over RCCL
+            om.run(mine, sp, win, twin)        # reset, this rank's orientations, fold over RCCL (+ the candidates' settle)
 
         def after_warmup():
             om.fold_seconds = 0.0
-        return {"step": step, "after_warmup": after_warmup, "plan": om.m.plan, "ctx": om.m.ctx, "mode": "float32",
+        return {"step": step, "after_warmup": after_warmup, "plan": om.m.plan, "ctx": om.m.ctx, "mode": a.mode,
                 "work": lambda: (int(om.m.plan.nty * om.m.plan.ntx), 0 if mine is None else len(mine)),
-                "part": "orientation grid in %d chunks, whole DEM on every rank, records folded by two all-reduces" % world,
+                "part": "orientation grid in %d chunks, whole DEM on every rank, records folded by two all-reduces%s" % (
+                    world, "; near-tie candidates of all ranks exchanged and settled in float64 on every rank" if win else ""),
                 "extra_seconds": lambda: om.fold_seconds, "gather_seconds": lambda: None,
+                "settle": lambda: getattr(om, "exact_stats", None),
                 "result": lambda: om.result_array()}
     dm = sd.DistMatcher(rank, world, (ny, nx), float(g._georef_info.dx), float(g._georef_info.dy),
                         device=device, backend=backend, transport=transport)
@@ -852,13 +859,16 @@ def run_shardings(a, rank, world, device, dist, transport, pool, g, Template, sc
                                 "note": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice of every rank's communicator "
                                         "(sc_comm_info); nranks 0 = no RCCL communicator (host transport)"}
                 line["gpu_per_rank"] = tels
+                if built.get("settle") and built["settle"]():
+                    line["settle"] = built["settle"]()
                 if works and all(w_ is not None for w_ in works):
                     line["predicted"] = predicted_step(works, built.get("mode", "float32"), ms)
                 line["ipc"] = {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get(IPC_VAR),
                                "attempt": os.environ.get("SCARPLET_BENCH_IPC_ATTEMPT", "launcher's environment")}
                 key = "fold_ms" if sh == "orientations" else "halo_exchange_ms"
                 line[key] = {"min_over_ranks": round(1e3 * min(extra), 3), "max_over_ranks": round(1e3 * max(extra), 3),
-                             "note": "wall time per step inside the collective on a rank; the minimum is the rank that "
+                             "note": "wall time per step inside the collective on a rank (exact mode: plus the candidates' "
+                                     "exchange and the float64 settle of the union); the minimum is the rank that "
                                      "arrived last, i.e. the collective itself" if sh == "orientations" else
                                      "upload of the rank's core, pack, grouped ncclSend/ncclRecv, unpack, per step"}
                 if gath is not None:
@@ -879,8 +889,8 @@ def run_shardings(a, rank, world, device, dist, transport, pool, g, Template, sc
                 runs[sh] = {"error": "%s: %s" % (type(e).__name__, e), "ms_per_step": None}
     if rank != 0:
         return None
-    # the top-level line: the faster sharding among those that ran in the mode asked for (exact: the tiles - the
-    # orientation sharding folds float32 records; its line rides along as the float32 figure)
+    # the top-level line: the faster sharding among those that ran in the mode asked for (both shardings have an exact
+    # mode since ABI 9)
     def rank_key(k):
         ms_ = runs[k]["ms_per_step"]
         in_mode = "error" not in runs[k] and runs[k].get("config", {}).get("mode") == getattr(a, "mode", "float32")

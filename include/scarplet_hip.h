@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 8
+#define SC_ABI_VERSION 9
 
 #define SC_OK               0
 #define SC_ERR_INVALID     -1   /* bad argument                                */
@@ -380,6 +380,35 @@ int sc_score_pairs_f64(sc_ctx* ctx, const int32_t* cells, const int32_t* templat
  * sc_score_cells_f64) and for templates with host-uploaded windows.
  */
 int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long long* stats);
+
+/*
+ * exact=True for an ORIENTATION-SHARDED search (scarplet_amd.dist.OrientationMatcher; the reference's pool over orientations,
+ * core.py:180-183, whose compare() folds float64 maps).  Every rank searched its share of the templates with "near_window"
+ * on and sc_fold_ranks made every record the fold of all - a near-tie between templates of two ranks is in no rank's list.
+ * But a template that can be the float64 argmax scores, in float32, within the window of the FOLDED record, and the rank that
+ * matched it knows: it is named by one of that rank's events whose larger score lies within the window of the folded record,
+ * or it held the rank's own record.  The sequence, the same on every rank:
+ *   sc_match (near_window on) -> sc_snapshot_best -> sc_fold_ranks (or sc_get_best / host fold / sc_set_best)
+ *   -> sc_rank_candidates -> the launcher's transport concatenates the ranks' pair lists, in rank order
+ *   -> sc_settle_pairs with the descriptors of the WHOLE search.
+ * Every rank scores the same pairs with the same float64 arithmetic: the records agree bit for bit without a further
+ * collective, and equal what sc_settle_exact leaves in a single context that searched all the templates wherever the
+ * float64 argmax is concerned (tests/test_gpu_exact.py).
+ */
+/* the record's (snr, id) planes as they stand, kept on the device (call it BEFORE the fold) */
+int sc_snapshot_best(sc_ctx* ctx);
+/* upload a record - core cells, row-major: amplitude, SNR, template id - as this context's running best (the host
+ * backend's fold, or a record saved earlier); patches of an earlier settle are dropped */
+int sc_set_best(sc_ctx* ctx, const float* amp, const float* snr, const uint32_t* id);
+/* this rank's candidates against the folded record: (core cell index, template id) pairs, 2 x uint32 each.  *n_pairs is
+ * the number found; they are copied to `pairs` when capacity (in pairs) holds them - call with capacity 0 to size the
+ * buffer (the list is kept on the device in between).  SC_ERR_UNSUPPORTED when the event list overflowed. */
+int sc_rank_candidates(sc_ctx* ctx, uint32_t* pairs, long long capacity, long long* n_pairs);
+/* settle the union of all ranks' candidates: t[0..n) = the descriptors of the WHOLE search in fold order (they become the
+ * context's template table; nothing is matched), pairs as sc_rank_candidates wrote them (ids = sc_template.id);
+ * n_twin, max_work, stats as sc_settle_exact. */
+int sc_settle_pairs(sc_ctx* ctx, const sc_template* t, int n, const uint32_t* pairs, long long n_pairs, int n_twin,
+                    double max_work, long long* stats);
 
 /* Per-template scalars of the last sc_match / sc_match_template call:
  * n = count(W != 0) + eps (core.py:350) and sum(W**2) (core.py:356). */

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCARPLET_HIP_LIB") or os.path.join(_HERE, "libscarplet_hip.so")
 
 SC_OK = 0
-ABI_VERSION = 8
+ABI_VERSION = 9
 ID_NONE = 0xFFFFFFFF
 COMM_ID_BYTES = 128
 
@@ -107,6 +107,11 @@ SIGNATURES = {
     "sc_get_near_events": (C.c_int, [_P, _up, C.c_longlong, C.POINTER(C.c_longlong)]),
     "sc_score_pairs_f64": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, _dp, _dp]),
     "sc_settle_exact": (C.c_int, [_P, C.c_int, C.c_double, C.POINTER(C.c_longlong)]),
+    "sc_snapshot_best": (C.c_int, [_P]),
+    "sc_set_best": (C.c_int, [_P, _fp, _fp, _up]),
+    "sc_rank_candidates": (C.c_int, [_P, _up, C.c_longlong, C.POINTER(C.c_longlong)]),
+    "sc_settle_pairs": (C.c_int, [_P, C.POINTER(sc_template), C.c_int, _up, C.c_longlong, C.c_int, C.c_double,
+                                  C.POINTER(C.c_longlong)]),
     "sc_get_resolution_stats": (C.c_int, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "sc_get_template_sums": (C.c_int, [_P, C.c_int, _dp, _dp]),
     "sc_profile": (C.c_int, [_P, C.c_int]),
@@ -450,9 +455,51 @@ class Context(object):
         their float64 argmax among the templates their events name.  Returns the counters as a dict."""
         st = (C.c_longlong * 8)()
         self._check(self.lib.sc_settle_exact(self._h, int(n_twin), float(max_work), st), "sc_settle_exact")
+        return self._settle_stats(st)
+
+    @staticmethod
+    def _settle_stats(st):
         return {"flagged_cells": int(st[0]), "pairs_listed": int(st[1]), "float64_pairs": int(st[2]),
                 "float64_cells": int(st[3]), "changed_cells": int(st[4]), "events": int(st[5]),
                 "taps": int(st[7])}
+
+    # ---- exact mode of an orientation-sharded search (include/scarplet_hip.h: sc_settle_pairs) ----
+    def snapshot_best(self):
+        """Keep the record's (snr, id) planes as they stand on the device - before the fold over the ranks."""
+        self._check(self.lib.sc_snapshot_best(self._h), "sc_snapshot_best")
+
+    def set_best(self, amp, snr, idx):
+        """Upload a record (core-shaped float32, float32, uint32) as the running best (sc_set_best)."""
+        h, w = self.core_shape()
+        amp = np.ascontiguousarray(amp, dtype=np.float32)
+        snr = np.ascontiguousarray(snr, dtype=np.float32)
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        if not (amp.shape == snr.shape == idx.shape == (h, w)):
+            raise ValueError("set_best: the record must have the core's shape %r" % ((h, w),))
+        self._check(self.lib.sc_set_best(self._h, _as(amp, _fp), _as(snr, _fp), _as(idx, _up)), "sc_set_best")
+
+    def rank_candidates(self):
+        """This rank's candidates against the folded record: an (n, 2) uint32 array of (core cell index, template id)
+        (sc_rank_candidates: the templates of this rank's events and its own holder that lie within the near-tie window
+        of the record as it stands now)."""
+        n = C.c_longlong(0)
+        self._check(self.lib.sc_rank_candidates(self._h, None, 0, C.byref(n)), "sc_rank_candidates")
+        out = np.empty((n.value, 2), dtype=np.uint32)
+        if n.value:
+            m = C.c_longlong(0)
+            self._check(self.lib.sc_rank_candidates(self._h, _as(out, _up), n.value, C.byref(m)), "sc_rank_candidates")
+            if m.value != n.value:
+                raise ScarpletHipError("sc_rank_candidates: %d pairs, then %d" % (n.value, m.value))
+        return out
+
+    def settle_pairs(self, templates, pairs, n_twin=0, max_work=0.0):
+        """Settle the union of all ranks' candidates with the descriptors of the WHOLE search (sc_settle_pairs); the
+        counters as settle_exact returns them."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        st = (C.c_longlong * 8)()
+        self._check(self.lib.sc_settle_pairs(self._h, templates, len(templates), _as(pairs, _up) if len(pairs) else None,
+                                             len(pairs), int(n_twin), float(max_work), st), "sc_settle_pairs")
+        return self._settle_stats(st)
 
     def comm_destroy(self):
         """Drop this context's RCCL communicator (sc_comm_destroy); nothing to do without one."""

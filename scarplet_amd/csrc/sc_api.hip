@@ -616,6 +616,56 @@ static int check_templates(sc_ctx* ctx, const sc_template* t, int n, const sc_pl
     return SC_OK;
 }
 
+// One descriptor as the device's table entry (offsets into the per-chunk window buffers are match_impl's to fill)
+static void templ_from_descriptor(const sc_ctx* ctx, const sc_template& s, TemplDev& d, double* sums2, double* wl1) {
+    const Geom& g = ctx->g;
+    d.kind = s.kind; d.flags = s.flags;
+    d.cos_a = s.cos_a; d.sin_a = s.sin_a; d.c = s.c; d.d = s.d;
+    d.p0 = s.p0; d.p1 = s.p1;
+    d.ilo = s.ilo; d.ihi = s.ihi; d.jlo = s.jlo; d.jhi = s.jhi;
+    if (s.flags & SC_FLAG_NO_LIMITS) { d.ilo = 0; d.ihi = g.ny - 1; d.jlo = 0; d.jhi = g.nx - 1; }
+    d.pmin = s.pmin; d.pmax = s.pmax; d.qmin = s.qmin; d.qmax = s.qmax;
+    d.id = s.id;
+    d.wh = s.pmax - s.pmin + 1;
+    d.ww = s.qmax - s.qmin + 1;
+    d.win_off = 0;
+    d.mask_lim = nullptr; d.mask_err = nullptr;
+    if (s.kind == SC_KIND_WINDOW) {
+        d.mask_lim = ctx->windows[s.window].mask_lim;
+        d.mask_err = ctx->windows[s.window].mask_err;
+        sums2[0] = s.p0;
+        sums2[1] = s.p1;
+        *wl1 = ctx->windows[s.window].l1;
+    }
+}
+
+// The descriptors of a whole search as the template table the float64 scorer reads, without matching them
+// (sc_settle_pairs: a rank of an orientation-sharded search settles candidates of templates other ranks matched)
+int sc_load_templates(sc_ctx* ctx, const sc_template* t, int n) {
+    sc_plan plan{};
+    plan.method = -1;                            // (neither path's support limits: the float64 scorer has none)
+    int rc = check_templates(ctx, t, n, &plan);
+    if (rc) return rc;
+    if (ctx->async_in_flight) {
+        SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->async_in_flight = false;
+    }
+    std::vector<TemplDev>& h = ctx->h_templ;
+    h.assign(n, TemplDev{});
+    ctx->h_sums.assign(2 * (size_t)n, 0.0);
+    ctx->h_wl1.assign(n, 0.0);
+    ctx->templ_windows = false;
+    for (int j = 0; j < n; ++j) {
+        templ_from_descriptor(ctx, t[j], h[j], &ctx->h_sums[2 * (size_t)j], &ctx->h_wl1[j]);
+        ctx->templ_windows = ctx->templ_windows || t[j].kind == SC_KIND_WINDOW;
+    }
+    if ((rc = sc_ensure(ctx, ctx->templ, sizeof(TemplDev) * n))) return rc;
+    ctx->async_in_flight = true;
+    SC_HIP(ctx, hipMemcpyAsync(ctx->templ.p, h.data(), sizeof(TemplDev) * n, hipMemcpyHostToDevice, ctx->stream));
+    ctx->last_batch = n;
+    return SC_OK;
+}
+
 static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* plan,
                       bool to_maps) {
     if (!ctx || !t || !plan || n <= 0) return SC_ERR_INVALID;
@@ -673,24 +723,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
                t[j].ss == t[i].ss) {
             const sc_template& s = t[j];
             TemplDev& d = h[j];
-            d.kind = s.kind; d.flags = s.flags;
-            d.cos_a = s.cos_a; d.sin_a = s.sin_a; d.c = s.c; d.d = s.d;
-            d.p0 = s.p0; d.p1 = s.p1;
-            d.ilo = s.ilo; d.ihi = s.ihi; d.jlo = s.jlo; d.jhi = s.jhi;
-            if (s.flags & SC_FLAG_NO_LIMITS) { d.ilo = 0; d.ihi = g.ny - 1; d.jlo = 0; d.jhi = g.nx - 1; }
-            d.pmin = s.pmin; d.pmax = s.pmax; d.qmin = s.qmin; d.qmax = s.qmax;
-            d.id = s.id;
-            d.wh = s.pmax - s.pmin + 1;
-            d.ww = s.qmax - s.qmin + 1;
-            d.win_off = 0;
-            d.mask_lim = nullptr; d.mask_err = nullptr;
-            if (s.kind == SC_KIND_WINDOW) {
-                d.mask_lim = ctx->windows[s.window].mask_lim;
-                d.mask_err = ctx->windows[s.window].mask_err;
-                sums[2 * (size_t)j] = s.p0;
-                sums[2 * (size_t)j + 1] = s.p1;
-                wl1[j] = ctx->windows[s.window].l1;
-            }
+            templ_from_descriptor(ctx, s, d, &sums[2 * (size_t)j], &wl1[j]);
             // flip symmetry of the built-in templates (k_split_templ_sym): the same parity
             // for the whole run, and support boxes that map onto themselves
             int pj = s.kind == SC_KIND_SCARP ? 1 : (s.kind == SC_KIND_RICKER ? 2 : 0);

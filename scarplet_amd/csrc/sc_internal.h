@@ -131,6 +131,8 @@ struct sc_ctx {
     // patches - per flagged cell its index and the float64 (amp, snr, id) sc_get_result writes over the converted record;
     // patch_n: how many the current record carries (0 after any sc_match / sc_reset_best)
     DevBuf st_slot, st_work, st_pairs, st_patch, st_spans;
+    DevBuf snap;               // sc_snapshot_best: the record's (snr, id) planes as they stood (before sc_fold_ranks)
+    size_t snap_cells = 0;
     size_t patch_n = 0;
     DevBuf score;              // sc_score_cells_f64: the cell list and the two float64 outputs
     DevBuf score_w;            // ... and the templates' float64 windows (offsets, then the windows)
@@ -193,6 +195,8 @@ void sc_prof_collect(sc_ctx* ctx);
 int sc_launch_result(sc_ctx* ctx, const float* amp, const float* snr, const uint32_t* id, const double* tab_par,
                      const double* tab_ang, int n_ids, size_t n, double* planes);
 // flag plane and event list of option "near_window" (allocated and cleared on first use; sc_reset_best clears them from then on)
+// the descriptors of a search as the device's template table (TemplDev), without matching them: sc_settle_pairs
+int sc_load_templates(sc_ctx* ctx, const sc_template* t, int n);
 int sc_near_buffers(sc_ctx* ctx, unsigned long long** ev_count, uint32_t** ev, unsigned long long* ev_cap);
 // sc_settle.hip: the patches of sc_settle_exact over four converted float64 planes of nc cells each
 int sc_apply_patches(sc_ctx* ctx, const double* tab_par, const double* tab_ang, int n_ids, size_t nc, double* planes);

@@ -548,8 +548,14 @@ int sc_apply_patches(sc_ctx* ctx, const double* tab_par, const double* tab_ang, 
     return SC_OK;
 }
 
+static int settle_impl(sc_ctx* ctx, int n_twin, double max_work, long long* stats_out);
+
 extern "C" int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long long* stats_out) {
     if (!ctx || !stats_out || n_twin < 0) return SC_ERR_INVALID;
+    return settle_impl(ctx, n_twin, max_work, stats_out);
+}
+
+static int settle_impl(sc_ctx* ctx, int n_twin, double max_work, long long* stats_out) {
     for (unsigned k = 0; k < ST_STATS; ++k) stats_out[k] = 0;
     if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
     const int n = ctx->last_batch;
@@ -704,4 +710,156 @@ extern "C" int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long lo
     ctx->patch_n = ns;
     ctx->async_in_flight = false;
     return SC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The settle of an ORIENTATION-SHARDED search (scarplet_amd.dist.OrientationMatcher, exact mode).  Every rank holds the
+// whole DEM and searched its share of the templates with the near-tie window on; sc_fold_ranks has made every rank's
+// record the fold of all of them.  A near-tie between templates of two ranks is in neither rank's list - but every
+// template that can be the float64 argmax scores, in float32, within the window of the FOLDED record, and its rank
+// knows it: it is named by one of the rank's events whose larger score lies within the window of the folded record, or
+// it is the holder of the rank's own record (sc_snapshot_best, taken before the fold) where that lies within the window.
+// sc_rank_candidates lists those (cell, template id) pairs; the ranks exchange their lists (a few megabytes, through the
+// launcher's transport) and EVERY rank settles the union with the whole search's descriptors (sc_settle_pairs): the same
+// pairs, the same float64 scores, the same record on every rank - no further collective.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void __launch_bounds__(256)
+k_rank_pairs_events(const uint32_t* __restrict__ ev, unsigned long long n_ev, const float* __restrict__ best_snr, float keep,
+                    size_t nc, uint32_t* __restrict__ out, unsigned long long cap, unsigned long long* __restrict__ count) {
+    const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_ev) return;
+    const uint32_t cell = ev[SC_EVENT_WORDS * k];
+    if (cell >= nc || __uint_as_float(ev[SC_EVENT_WORDS * k + 3]) < best_snr[cell] * keep) return;
+    for (int w = 1; w <= 2; ++w) {
+        const uint32_t id = ev[SC_EVENT_WORDS * k + w];
+        if (id == SC_ID_NONE) continue;
+        const unsigned long long slot = atomicAdd(count, 1ull);
+        if (slot < cap) { out[2 * slot] = cell; out[2 * slot + 1] = id; }
+    }
+}
+
+// the rank's own holder where the folded record's holder is another template and the two lie within the window
+__global__ void __launch_bounds__(256)
+k_rank_pairs_holders(const float* __restrict__ snap_snr, const uint32_t* __restrict__ snap_id, const float* __restrict__ best_snr,
+                     const uint32_t* __restrict__ best_id, float keep, size_t nc, uint32_t* __restrict__ out,
+                     unsigned long long cap, unsigned long long* __restrict__ count) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nc; i += (size_t)gridDim.x * 256) {
+        const uint32_t id = snap_id[i];
+        if (id == SC_ID_NONE || id == best_id[i]) continue;
+        const float s = snap_snr[i];
+        if (!(s > 0.f) || s < best_snr[i] * keep) continue;
+        const unsigned long long slot = atomicAdd(count, 1ull);
+        if (slot < cap) { out[2 * slot] = (uint32_t)i; out[2 * slot + 1] = id; }
+    }
+}
+
+// the exchanged pairs as events the settle reads: (cell, template, no holder, a score nothing drops)
+__global__ void __launch_bounds__(256)
+k_pairs_to_events(const uint32_t* __restrict__ pairs, unsigned long long n, size_t nc, uint32_t* __restrict__ ev,
+                  uint8_t* __restrict__ near) {
+    const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t cell = pairs[2 * k];
+    ev[SC_EVENT_WORDS * k] = cell;
+    ev[SC_EVENT_WORDS * k + 1] = pairs[2 * k + 1];
+    ev[SC_EVENT_WORDS * k + 2] = SC_ID_NONE;
+    ev[SC_EVENT_WORDS * k + 3] = 0x7F800000u;                               // +inf
+    if (cell < nc) near[cell] = (uint8_t)1;
+}
+
+}  // namespace
+
+extern "C" int sc_set_best(sc_ctx* ctx, const float* amp, const float* snr, const uint32_t* id) {
+    if (!ctx || !amp || !snr || !id) return SC_ERR_INVALID;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
+    SC_HIP(ctx, hipMemcpyAsync(ctx->best_amp.p, amp, sizeof(float) * nc, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(ctx->best_snr.p, snr, sizeof(float) * nc, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(ctx->best_id.p, id, sizeof(uint32_t) * nc, hipMemcpyHostToDevice, ctx->stream));
+    ctx->patch_n = 0;
+    return sc_sync(ctx);
+}
+
+extern "C" int sc_snapshot_best(sc_ctx* ctx) {
+    if (!ctx) return SC_ERR_INVALID;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
+    int rc;
+    if ((rc = sc_ensure(ctx, ctx->snap, 8 * nc))) return rc;
+    SC_HIP(ctx, hipMemcpyAsync(ctx->snap.p, ctx->best_snr.p, 4 * nc, hipMemcpyDeviceToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync((char*)ctx->snap.p + 4 * nc, ctx->best_id.p, 4 * nc, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->snap_cells = nc;
+    return SC_OK;
+}
+
+extern "C" int sc_rank_candidates(sc_ctx* ctx, uint32_t* pairs, long long capacity, long long* n_pairs) {
+    if (!ctx || !n_pairs || capacity < 0 || (capacity > 0 && !pairs)) return SC_ERR_INVALID;
+    *n_pairs = 0;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
+    if (ctx->snap_cells != nc) return sc_fail(ctx, SC_ERR_INVALID, "sc_rank_candidates: no snapshot of this rank's record (sc_snapshot_best)");
+    unsigned long long n_ev = 0;
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->near_ev.p) {
+        SC_HIP(ctx, hipMemcpy(&n_ev, ctx->near_ev.p, sizeof(n_ev), hipMemcpyDeviceToHost));
+        if (n_ev > (ctx->near_ev.cap - 16) / (4 * SC_EVENT_WORDS))
+            return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_rank_candidates: the event list overflowed (%llu near-ties)", n_ev);
+    }
+    const unsigned long long cap = 2 * n_ev + nc;
+    int rc;
+    if ((rc = sc_ensure(ctx, ctx->st_pairs, 16 + 8 * cap))) return rc;
+    unsigned long long* count = (unsigned long long*)ctx->st_pairs.p;
+    uint32_t* out = (uint32_t*)((char*)ctx->st_pairs.p + 16);
+    const float keep = (1.f - ctx->near_w_used) * (1.f - 4e-7f);
+    SC_HIP(ctx, hipMemsetAsync(count, 0, 16, ctx->stream));
+    if (n_ev)
+        hipLaunchKernelGGL(k_rank_pairs_events, dim3((unsigned)((n_ev + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const uint32_t*)((const char*)ctx->near_ev.p + 16), n_ev, (const float*)ctx->best_snr.p, keep, nc, out, cap, count);
+    hipLaunchKernelGGL(k_rank_pairs_holders, dim3((unsigned)std::min<size_t>((nc + 255) / 256, 16384)), dim3(256), 0, ctx->stream,
+                       (const float*)ctx->snap.p, (const uint32_t*)((const char*)ctx->snap.p + 4 * nc), (const float*)ctx->best_snr.p,
+                       (const uint32_t*)ctx->best_id.p, keep, nc, out, cap, count);
+    SC_HIP(ctx, hipGetLastError());
+    unsigned long long n = 0;
+    SC_HIP(ctx, hipMemcpyAsync(&n, count, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_pairs = (long long)n;
+    if (n > cap) return sc_fail(ctx, SC_ERR_INVALID, "sc_rank_candidates: %llu pairs", n);
+    if ((unsigned long long)capacity >= n && n)
+        SC_HIP(ctx, hipMemcpy(pairs, out, 8 * n, hipMemcpyDeviceToHost));
+    return SC_OK;
+}
+
+extern "C" int sc_settle_pairs(sc_ctx* ctx, const sc_template* t, int n, const uint32_t* pairs, long long n_pairs, int n_twin,
+                               double max_work, long long* stats_out) {
+    if (!ctx || !t || n <= 0 || n_pairs < 0 || (n_pairs > 0 && !pairs) || n_twin < 0 || !stats_out) return SC_ERR_INVALID;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = sc_load_templates(ctx, t, n))) return rc;                    // the WHOLE search's descriptors: the scorer's table
+    const size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);
+    unsigned long long* ev_count = nullptr;
+    uint32_t* ev = nullptr;
+    unsigned long long ev_cap = 0;
+    const float w_used = ctx->near_w_used;
+    if ((rc = sc_near_buffers(ctx, &ev_count, &ev, &ev_cap))) return rc;
+    ctx->near_w_used = w_used;                                            // (the window the ranks searched with, not the option as it stands now)
+    if ((unsigned long long)n_pairs > ev_cap) return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_settle_pairs: %lld pairs, room for %llu", n_pairs, ev_cap);
+    SC_HIP(ctx, hipMemsetAsync(ctx->near.p, 0, nc, ctx->stream));
+    const unsigned long long np = (unsigned long long)n_pairs;
+    SC_HIP(ctx, hipMemcpyAsync(ev_count, &np, 8, hipMemcpyHostToDevice, ctx->stream));
+    if (np) {
+        if ((rc = sc_ensure(ctx, ctx->st_pairs, 16 + 8 * np))) return rc;
+        uint32_t* d_pairs = (uint32_t*)((char*)ctx->st_pairs.p + 16);
+        SC_HIP(ctx, hipMemcpyAsync(d_pairs, pairs, 8 * np, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_pairs_to_events, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_pairs, np, nc,
+                           ev, (uint8_t*)ctx->near.p);
+        SC_HIP(ctx, hipGetLastError());
+    }
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));                        // (np is a local; st_pairs is taken again by the settle)
+    return settle_impl(ctx, n_twin, max_work, stats_out);
 }

@@ -440,6 +440,17 @@ def fold_host(results):
     return best
 
 
+def fold_records(parts):
+    """sc_fold_ranks on host records [(amp float32, snr float32, id uint32)]: per cell the greatest SNR, equal SNRs to the
+    smaller id (the earlier template of the fold order), a NaN SNR beats every number; the amplitude follows the winner."""
+    amp, snr, idx = [np.array(a, copy=True) for a in parts[0]]
+    for (a, s, i) in parts[1:]:
+        with np.errstate(invalid="ignore"):
+            take = (s > snr) | ((s == snr) & (i < idx)) | (np.isnan(s) & ~np.isnan(snr))
+        amp[take], snr[take], idx[take] = a[take], s[take], i[take]
+    return amp, snr, idx
+
+
 class OrientationMatcher(object):
     """Per-rank driver of an orientation-sharded search - the reference's own parallelism
     (a pool over orientations, core.py:180-183, folded by compare()) across GPUs.
@@ -497,38 +508,85 @@ class OrientationMatcher(object):
         self._keep = arr                      # the slice borrows its memory
         return mine, sp
 
-    def run(self, mine, sp):
-        """One search step: reset, this rank's templates, fold over the ranks."""
+    def run(self, mine, sp, exact_window=0.0, n_twin=0):
+        """One search step: reset, this rank's templates, fold over the ranks - and, with ``exact_window`` > 0, the
+        float64 settle of the near-ties of the WHOLE search (``n_twin``: Matcher.end_twins of the whole list):
+
+        every rank matches with the near-tie window on and keeps its own record's (snr, id) (sc_snapshot_best); after
+        the fold it lists what it knows to lie within the window of the FOLDED record - the templates of its events and
+        its own holder (sc_rank_candidates: a near-tie between templates of two ranks is in no rank's event list, but
+        each rank knows its side of it); the lists travel through the transport (a few megabytes: rank order, so every
+        rank holds the same union) and every rank scores the union in float64 with the descriptors of the whole grid
+        (sc_settle_pairs).  Same pairs, same arithmetic: the records agree bit for bit on every rank without a further
+        collective, and carry the reference's float64 argmax (compare(), core.py:230-240)."""
         import time
         ctx = self.m.ctx
+        exact = exact_window > 0.0
+        if exact and self.nranks > 1 and self.transport is None:
+            raise ValueError("exact mode over %d ranks needs transport= (the ranks exchange their candidate lists)" % self.nranks)
         ctx.reset_best()
-        if mine is not None:
-            ctx.match(mine, sp)
+        if exact:
+            ctx.set_option("near_window", float(exact_window))
+        try:
+            if mine is not None:
+                ctx.match(mine, sp)
+        finally:
+            if exact:
+                ctx.set_option("near_window", 0.0)
+        if exact:
+            ctx.snapshot_best()
         self._folded = None
         t0 = time.perf_counter()
         if self.backend == "rccl":
             ctx.fold_ranks()
+        elif self.nranks > 1 and exact:
+            # the raw records (12 bytes per cell), folded by sc_fold_ranks' rule on rank 0, back onto every device
+            parts = self.transport.gather(ctx.get_best(), 0)
+            rec = fold_records(parts) if self.rank == 0 else None
+            blob = self.transport.broadcast_bytes(b"".join(a.tobytes() for a in rec) if self.rank == 0 else None)
+            h, w = ctx.core_shape()
+            n = 4 * h * w
+            ctx.set_best(np.frombuffer(blob, np.float32, h * w, 0).reshape(h, w),
+                         np.frombuffer(blob, np.float32, h * w, n).reshape(h, w),
+                         np.frombuffer(blob, np.uint32, h * w, 2 * n).reshape(h, w))
         elif self.nranks > 1:
             parts = self.transport.gather(self.m.result_array(), 0)
             self._folded = fold_host(parts) if self.rank == 0 else None
-        # wall time of the fold on this rank, the wait for slower ranks included (bench.py: fold_ms)
+        self.exact_stats = None
+        if exact:
+            pairs = ctx.rank_candidates() if mine is not None else np.empty((0, 2), np.uint32)
+            if self.nranks > 1:
+                parts = self.transport.gather(pairs, 0)
+                blob = self.transport.broadcast_bytes(np.concatenate(parts).tobytes() if self.rank == 0 else None)
+                pairs = np.frombuffer(blob, np.uint32).reshape(-1, 2)
+            self.exact_stats = ctx.settle_pairs(self._keep, pairs, n_twin, self.m.EXACT_MAX_F64)
+            self.exact_stats["route"] = "device, %d ranks' candidates" % self.nranks
+        # wall time of the fold (and, exact mode, of the candidates' exchange and settle) on this rank, the wait for slower
+        # ranks included (bench.py: fold_ms)
         self.fold_seconds = getattr(self, "fold_seconds", 0.0) + (time.perf_counter() - t0)
+        self._exact_run = exact
 
-    def search(self, Template, scale, params, angles, method="auto", group=None, **kwargs):
+    def search(self, Template, scale, params, angles, method="auto", group=None, exact=None, **kwargs):
+        """``exact`` (default: on for the built-in template classes wherever the ranks can exchange their candidate
+        lists - one rank, or a transport): the float64 argmax of the whole search, as ``scarplet_amd.match`` delivers."""
         if getattr(self.m, "nan_dem", False):      # the reference's all-NaN maps, on every rank
             self.m.search(Template, scale, params, angles, method=method, **kwargs)
             self._nan = True
             return self
         self._nan = False
         mine, sp = self.describe(Template, scale, params, angles, method, group, **kwargs)
-        self.run(mine, sp)
+        arr = self._keep
+        if exact is None:
+            exact = all(int(arr[k].kind) != 2 for k in (0, len(arr) - 1)) and (self.nranks == 1 or self.transport is not None)
+        self.run(mine, sp, self.m.exact_window_for(arr, sp) if exact else 0.0,
+                 self.m.end_twins(arr, len(self.m.params), self.m.angles))
         return self
 
     def result_array(self):
         """(4, ny, nx): amp, age, angle, snr - on every rank with the 'rccl' backend (the fold is
         an all-reduce), on rank 0 only (None elsewhere) with the host backend."""
-        if self.backend == "rccl" or self.nranks == 1 or getattr(self, "_nan", False):
-            return self.m.result_array()
+        if self.backend == "rccl" or self.nranks == 1 or getattr(self, "_nan", False) or getattr(self, "_exact_run", False):
+            return self.m.result_array()         # (exact mode: every rank settled the same record, host backend included)
         return self._folded
 
     def result(self):

@@ -205,7 +205,7 @@ def _orientation_worker(rank, world, port, q):
         m.ctx = _OracleContext(m, z, orc.SCARP, 6)
         m.result_array = lambda: m.ctx.rec
         om = sd.OrientationMatcher(rank, world, None, backend="host", transport=TorchTransport(), matcher=m)
-        om.search(sl.Scarp, 6, ages, angles, method="fft")
+        om.search(sl.Scarp, 6, ages, angles, method="fft", exact=False)
         ok = True
         if rank == 0:
             # one context folding every template in id order (orientation-major), ties to the incumbent
@@ -246,6 +246,215 @@ def test_orientation_sharded_search_folds_over_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(r, True) for r in range(world)], res
+
+
+# ---- exact mode of the orientation sharding: the candidates' exchange and the settle of the union ----------------------
+NONE_ID = 0xFFFFFFFF
+
+
+def _jitter(tid, shape):
+    """A deterministic relative error in [-1, 1] per (template, cell): what stands in for the float32 paths' rounding."""
+    ny, nx = shape
+    c = np.arange(ny * nx, dtype=np.uint64).reshape(ny, nx)
+    h = (c * np.uint64(2654435761) + np.uint64(int(tid) * 40503 + 977)) % np.uint64(10007)
+    return h.astype(np.float64) / 5003.0 - 1.0
+
+
+class _ExactOracleContext(object):
+    """The device side of OrientationMatcher's exact mode on the CPU: float32 scores = the oracle's float64 SNR with a
+    relative error up to `noise` (well above float32 rounding, below half the near-tie window), a float32 record with
+    near-tie events as sc_match lists them (cell, template scored, holder, the larger score), and the calls the ranks make
+    around the fold: snapshot_best, get_best / set_best, rank_candidates, settle_pairs (float64 = the oracle itself)."""
+
+    def __init__(self, m, z, kind, scale, noise):
+        self.m, self.z, self.kind, self.scale, self.noise = m, z, kind, scale, noise
+        self.opt, self.cache, self.patch = {}, {}, {}
+
+    def core_shape(self):
+        return self.z.shape
+
+    def set_option(self, key, value):
+        self.opt[key] = value
+
+    def reset_best(self):
+        self.amp = np.zeros(self.z.shape, np.float32)
+        self.snr = np.zeros(self.z.shape, np.float32)
+        self.idx = np.full(self.z.shape, NONE_ID, np.uint32)
+        self.events, self.patch, self.w_used = [], {}, 0.0
+
+    def _f64(self, tid):
+        if tid not in self.cache:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import scarplet_oracle as orc
+            amp, _, _, snr = orc.match_template(self.z, 1.0, 1.0, self.kind, self.scale, float(self.m._id_par[tid]),
+                                                float(self.m._id_ang[tid]))
+            self.cache[tid] = (amp, snr)
+        return self.cache[tid]
+
+    def match(self, templates, plan, sync=True):
+        w = float(self.opt.get("near_window", 0.0))
+        self.w_used = w
+        for t in templates:
+            tid = int(t.id)
+            a64, s64 = self._f64(tid)
+            s32 = (s64 * (1.0 + self.noise * _jitter(tid, self.z.shape))).astype(np.float32)
+            won = s32 > self.snr
+            if w > 0.0:
+                big, small = np.maximum(s32, self.snr), np.minimum(s32, self.snr)
+                near = (small >= big * np.float32(1.0 - w)) & (self.idx != NONE_ID)
+                for c in np.flatnonzero(near):
+                    self.events.append((int(c), tid, int(self.idx.flat[c]), float(big.flat[c])))
+            self.amp = np.where(won, a64.astype(np.float32), self.amp)
+            self.snr = np.where(won, s32, self.snr)
+            self.idx = np.where(won, np.uint32(tid), self.idx)
+
+    def snapshot_best(self):
+        self.snap = (self.snr.copy(), self.idx.copy())
+
+    def get_best(self):
+        return self.amp.copy(), self.snr.copy(), self.idx.copy()
+
+    def set_best(self, amp, snr, idx):
+        self.amp, self.snr, self.idx, self.patch = np.array(amp), np.array(snr), np.array(idx), {}
+
+    def rank_candidates(self):
+        keep = 1.0 - self.w_used
+        out = []
+        for (c, tid, holder, big) in self.events:
+            if big >= self.snr.flat[c] * keep:
+                out += [(c, tid), (c, holder)]
+        s_snr, s_idx = self.snap
+        mine = (s_idx != NONE_ID) & (s_idx != self.idx) & (s_snr > 0) & (s_snr >= self.snr * np.float32(keep))
+        out += [(int(c), int(s_idx.flat[c])) for c in np.flatnonzero(mine)]
+        return np.array(out, dtype=np.uint32).reshape(-1, 2)
+
+    def settle_pairs(self, templates, pairs, n_twin=0, max_work=0.0):
+        assert len(templates) == len(self.m._id_par)                 # the descriptors of the WHOLE grid
+        lists = {}
+        for c, tid in np.asarray(pairs).reshape(-1, 2):
+            lists.setdefault(int(c), set()).add(int(tid))
+        changed = 0
+        for c, ids in lists.items():
+            ids.add(int(self.idx.flat[c]))
+            best = max(sorted(ids), key=lambda k: (self._f64(k)[1].flat[c], -k))      # float64 argmax, ties to the earlier id
+            changed += best != int(self.idx.flat[c])
+            a64, s64 = self._f64(best)
+            self.idx.flat[c] = best
+            self.amp.flat[c], self.snr.flat[c] = a64.flat[c], s64.flat[c]
+            self.patch[c] = (a64.flat[c], s64.flat[c])
+        return {"flagged_cells": len(lists), "pairs_listed": int(sum(len(v) for v in lists.values())),
+                "float64_pairs": 0, "float64_cells": len(lists), "changed_cells": int(changed), "events": len(pairs), "taps": 0}
+
+    def result_array(self):
+        out = np.stack(sd.record_planes(self.amp, self.snr, self.idx, self.m._id_par, self.m._id_ang))
+        for c, (a, s) in self.patch.items():
+            out[0].flat[c], out[3].flat[c] = a, s
+        return out
+
+
+def _exact_orientation_worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from torch_transport import TorchTransport
+        import scarplet_oracle as orc
+        import scarplet_amd as sl
+        from scarplet_amd.core import Matcher
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+        rng = np.random.default_rng(23)
+        z = (np.cumsum(rng.standard_normal((40, 36)), 1) * 0.05 + rng.standard_normal((40, 36)) * 0.03)
+        # every orientation twice, 2e-4 rad apart: near-ties within the float32 error - and the chunks (contiguous in grid
+        # order) put the two of a pair on DIFFERENT ranks, for 2 ranks and for 3
+        ages, angles = [1.0, 4.0, 16.0], np.array([0.3, -0.8, 0.9, 0.3002, -0.8002, 0.9002])
+        m = object.__new__(Matcher)
+        m.ny, m.nx, m.de, m.core, m.whole = 40, 36, 1.0, (0, 40, 0, 36), True
+        noise = 2.5e-4                                       # (below half the 6e-4 window, as the device's errors are)
+        m.ctx = _ExactOracleContext(m, z, orc.SCARP, 6, noise)
+        m.result_array = lambda: m.ctx.result_array()
+        om = sd.OrientationMatcher(rank, world, None, backend="host", transport=TorchTransport(), matcher=m)
+        om.search(sl.Scarp, 6, ages, angles, method="fft")           # exact by default: a built-in, a transport
+        got = om.result_array()
+        # the reference: compare() over float64 maps in fold order (orientation-major ids), ties to the incumbent
+        want = np.zeros((4, 40, 36))
+        want_id = np.full((40, 36), NONE_ID, np.uint32)
+        k = 0
+        for ang in angles:
+            for age in ages:
+                amp, _, _, snr = orc.match_template(z, 1.0, 1.0, orc.SCARP, 6, age, float(ang))
+                take = snr > want[3]
+                for kk, v in enumerate((amp, age, float(ang), snr)):
+                    want[kk] = np.where(take, v, want[kk])
+                want_id = np.where(take, np.uint32(k), want_id)
+                k += 1
+        st = om.exact_stats
+        checks = {}
+        checks["every cell holds the float64 argmax"] = got is not None and np.array_equal(m.ctx.idx, want_id)
+        checks["age and angle planes"] = np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+        settled = np.zeros(40 * 36, bool)
+        settled[list(m.ctx.patch)] = True
+        settled = settled.reshape(40, 36)
+        checks["settled cells carry float64 (amp, snr)"] = np.array_equal(got[3][settled], want[3][settled]) and \
+            np.array_equal(got[0][settled], want[0][settled])
+        checks["other cells within the float32 error"] = np.allclose(got[3], want[3], rtol=2 * noise, atol=0)
+        checks["the settle changed cells"] = st["changed_cells"] > 0
+        # the float32 fold alone is NOT the float64 argmax on this surface (the test would prove nothing otherwise)
+        m2 = object.__new__(Matcher)
+        m2.ny, m2.nx, m2.de, m2.core, m2.whole = 40, 36, 1.0, (0, 40, 0, 36), True
+        m2.ctx = _ExactOracleContext(m2, z, orc.SCARP, 6, noise)
+        m2.ctx.cache = m.ctx.cache
+        om2 = sd.OrientationMatcher(0, 1, None, backend="host", matcher=m2)
+        mine2, sp2 = om2.describe(sl.Scarp, 6, ages, angles, method="fft")
+        om2.run(mine2, sp2)
+        n_off = int((m2.ctx.idx != want_id).sum())
+        checks["float32 alone is off in >= 10 cells (%d)" % n_off] = n_off >= 10
+        # ... and one rank settling the whole search holds the same record as every rank of the sharded one
+        om2.run(mine2, sp2, m2.exact_window_for(om2._keep, sp2), 0)
+        checks["one rank's settle = the sharded one"] = np.array_equal(m2.ctx.idx, m.ctx.idx)
+        ok = all(checks.values()) or [k_ for k_, v_ in checks.items() if not v_]
+        if rank == 0:
+            print("exact orientation sharding, %d ranks: %s" % (world, st))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, ok))
+    except Exception as e:                       # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exact_orientation_sharding_settles_cross_rank_ties_over_gloo(world):
+    """The N > 1 path of exact mode for the orientation sharding (dist.OrientationMatcher.run), on CPU ranks over gloo: the
+    records are folded through the transport, every rank lists its candidates against the FOLDED record, the lists are
+    exchanged and every rank settles the union - every rank ends with the float64 argmax of the whole search in every cell
+    (every orientation has a near twin on ANOTHER rank: near-ties no rank's event list holds)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exact_orientation_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)], res
+
+
+def test_fold_records_is_the_rule_of_sc_fold_ranks():
+    rng = np.random.default_rng(5)
+    parts = []
+    for r in range(3):
+        snr = rng.integers(0, 4, size=(5, 6)).astype(np.float32)
+        parts.append((snr + 10 * r, snr, rng.permutation(30).reshape(5, 6).astype(np.uint32) + 30 * (2 - r)))
+    parts[1][1][2, 2] = np.nan
+    amp, snr, idx = sd.fold_records(parts)
+    for i in range(5):
+        for j in range(6):
+            if (i, j) == (2, 2):
+                assert np.isnan(snr[i, j]) and idx[i, j] == parts[1][2][i, j]
+                continue
+            r = max(range(3), key=lambda r_: (parts[r_][1][i, j], -int(parts[r_][2][i, j])))
+            assert snr[i, j] == parts[r][1][i, j] and idx[i, j] == parts[r][2][i, j] and amp[i, j] == parts[r][0][i, j]
 
 
 def test_package_imports_no_process_group_library():

@@ -2,6 +2,9 @@
 searched on its own (non-periodic block, window limits in global coordinates)
 and the stitched tiles must reproduce the whole-DEM search.  Also runs the RCCL
 entry points with a single-rank communicator (periodic self-images only)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -10,6 +13,8 @@ import scarplet_amd as sl
 from scarplet_amd import _lib, _plan, dist as sd, synthetic
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P_AMP = orc.PARITY["amp"]
 
 
 def whole_and_tiled(g, Template, scale, params, angles, nranks, method, backend="host"):
@@ -254,3 +259,68 @@ def test_fold_ranks_with_a_one_rank_communicator():
     after = ctx.get_best()
     for a, b in zip(before, after):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def _fold_twin(ang):
+    """the orientation plane with the grid's end twins as one (+pi/2 is -pi/2 for the symmetric built-ins)"""
+    a = np.array(ang, dtype=float)
+    a[np.abs(a - np.pi / 2) < 1e-12] = -np.pi / 2
+    return a
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+@pytest.mark.parametrize("method", ["fft", "direct"])
+def test_exact_orientation_sharding_equals_the_single_context(nranks, method):
+    """Exact mode of the orientation sharding with the REAL device code, the ranks as threads with a context each on this
+    GPU (tools/thread_transport.py, host backend): match with the window on, sc_snapshot_best, the fold (sc_get_best ->
+    fold_records -> sc_set_best), sc_rank_candidates, the exchange, sc_settle_pairs.  Every rank ends with the same record
+    in every bit, and it names the same (age, orientation) in every cell as ONE context searching all the templates with
+    exact=True (sc_settle_exact) - the near-ties between templates of different ranks, which no rank's event list holds,
+    included (a noise-free surface is full of them)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from thread_transport import run_ranks
+    grid = _plan.angle_grid(-np.pi / 2, np.pi / 2)                             # both ends: the twins sit on the first and last rank
+    # every orientation twice, 2e-5 rad apart - near-ties inside the float32 error - and listed so that the contiguous chunks
+    # put the two of a pair on DIFFERENT ranks (2, 3 and 8 of them); the grid's own end twins first and last
+    base = grid[:-1:23]
+    paired = np.concatenate([base, base[1:] + 2e-5, grid[-1:]])
+    cases = [(synthetic.synthetic_scarp(230, seed=4, ny=200), sl.Scarp, orc.SCARP, 14, [1.0, 4.0, 4.0004, 20.0, 100.0], paired),
+             (synthetic.synthetic_scarp(160, seed=2, sigma=0.0), sl.Scarp, orc.SCARP, 10, [1.0, 4.0, 4.05, 20.0], grid[::3]),
+             (synthetic.synthetic_scarp(150, seed=6, ny=140), sl.Ricker, orc.RICKER, 8, [2.0, 4.0, 4.0003], paired)]
+    teeth = 0
+    for (g, Template, kind, scale, params, angles) in cases:
+        single = sl.Matcher(g, ctx=_lib.Context(0))
+        want = np.stack(single.search(Template, scale, params, angles, method=method, exact=True).result())
+        want_rec = [a.copy() for a in single.ctx.get_best()]
+        st1 = dict(single.exact_stats)
+        assert st1.get("route") == "device", st1
+        f32 = np.stack(single.search(Template, scale, params, angles, method=method, exact=False).result())
+
+        def rank_body(rank, transport):
+            m = sl.Matcher(g, ctx=_lib.Context(0))
+            om = sd.OrientationMatcher(rank, nranks, None, backend="host", transport=transport, matcher=m)
+            om.search(Template, scale, params, angles, method=method)           # (exact by default)
+            return [a.copy() for a in m.ctx.get_best()], np.array(om.result_array()), dict(om.exact_stats), method
+
+        outs = run_ranks(nranks, rank_body)
+        rec0, arr0, st, used = outs[0]
+        print("%s %s, %d ranks (%s): one context %s; sharded %s" % (Template.__name__, g._griddata.shape, nranks, used, st1, st))
+        for (rec, arr, st_r, _) in outs[1:]:
+            assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(rec, rec0))
+            assert np.array_equal(arr, arr0, equal_nan=True) and st_r == st
+        # the same (age, orientation) in every cell as the single context's settle (the grid's end twins are one maximum) ...
+        off = (arr0[1] != want[1]) | (_fold_twin(arr0[2]) != _fold_twin(want[2]))
+        assert not off.any(), int(off.sum())
+        # ... (the test has teeth: the float32 fold alone names other templates in some cells)
+        n_f32 = int(((f32[1] != want[1]) | (_fold_twin(f32[2]) != _fold_twin(want[2]))).sum())
+        assert n_f32 == st1["changed_cells"], (n_f32, st1)
+        teeth += n_f32
+        # ... and (amp, snr) within the float32 paths' error of it (a cell settled here and not there carries float64 against
+        # float32 of the same template; twins differ in the amplitude's sign)
+        rtol, afac = orc.snr_tolerance(kind)
+        assert np.allclose(arr0[3], want[3], rtol=rtol, atol=afac * np.nanmax(want[3]), equal_nan=True)
+        same = arr0[2] == want[2]
+        a_tol = P_AMP[0] * np.abs(want[0]) + P_AMP[1] * np.nanmax(np.abs(want[0]))
+        assert (np.abs(arr0[0] - want[0])[same] <= a_tol[same]).all()
+        assert (np.abs(np.abs(arr0[0]) - np.abs(want[0])) <= a_tol).all()
+    assert teeth >= 20, teeth
