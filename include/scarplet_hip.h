@@ -389,8 +389,8 @@ int sc_settle_exact(sc_ctx* ctx, int n_twin, double max_work, long long* stats);
  * matched it knows: it is named by one of that rank's events whose larger score lies within the window of the folded record,
  * or it held the rank's own record.  The sequence, the same on every rank:
  *   sc_match (near_window on) -> sc_snapshot_best -> sc_fold_ranks (or sc_get_best / host fold / sc_set_best)
- *   -> sc_rank_candidates -> the launcher's transport concatenates the ranks' pair lists, in rank order
- *   -> sc_settle_pairs with the descriptors of the WHOLE search.
+ *   -> sc_rank_candidates -> sc_exchange_candidates (RCCL; or the launcher's transport concatenates the ranks' pair
+ *   lists, in rank order) -> sc_settle_pairs with the descriptors of the WHOLE search.
  * Every rank scores the same pairs with the same float64 arithmetic: the records agree bit for bit without a further
  * collective, and equal what sc_settle_exact leaves in a single context that searched all the templates wherever the
  * float64 argmax is concerned (tests/test_gpu_exact.py).
@@ -409,6 +409,12 @@ int sc_rank_candidates(sc_ctx* ctx, uint32_t* pairs, long long capacity, long lo
  * n_twin, max_work, stats as sc_settle_exact. */
 int sc_settle_pairs(sc_ctx* ctx, const sc_template* t, int n, const uint32_t* pairs, long long n_pairs, int n_twin,
                     double max_work, long long* stats);
+/* the exchange on the devices: after sc_rank_candidates (capacity 0 will do: the list stays on the device) every rank's
+ * list becomes one list on every device - two ncclAllGather over RCCL/xGMI: the counts, then slots of the largest count in
+ * rank order, short lists padded with cells no DEM has.  *n_union = pairs in it, padding included; sc_settle_pairs with
+ * pairs == NULL and n_pairs == *n_union settles it.  Collective: all ranks of the communicator call it.  No communicator:
+ * the union is the rank's own list. */
+int sc_exchange_candidates(sc_ctx* ctx, long long* n_union);
 
 /* Per-template scalars of the last sc_match / sc_match_template call:
  * n = count(W != 0) + eps (core.py:350) and sum(W**2) (core.py:356). */

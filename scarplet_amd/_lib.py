@@ -112,6 +112,7 @@ SIGNATURES = {
     "sc_rank_candidates": (C.c_int, [_P, _up, C.c_longlong, C.POINTER(C.c_longlong)]),
     "sc_settle_pairs": (C.c_int, [_P, C.POINTER(sc_template), C.c_int, _up, C.c_longlong, C.c_int, C.c_double,
                                   C.POINTER(C.c_longlong)]),
+    "sc_exchange_candidates": (C.c_int, [_P, C.POINTER(C.c_longlong)]),
     "sc_get_resolution_stats": (C.c_int, [_P, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "sc_get_template_sums": (C.c_int, [_P, C.c_int, _dp, _dp]),
     "sc_profile": (C.c_int, [_P, C.c_int]),
@@ -478,12 +479,15 @@ class Context(object):
             raise ValueError("set_best: the record must have the core's shape %r" % ((h, w),))
         self._check(self.lib.sc_set_best(self._h, _as(amp, _fp), _as(snr, _fp), _as(idx, _up)), "sc_set_best")
 
-    def rank_candidates(self):
+    def rank_candidates(self, fetch=True):
         """This rank's candidates against the folded record: an (n, 2) uint32 array of (core cell index, template id)
         (sc_rank_candidates: the templates of this rank's events and its own holder that lie within the near-tie window
-        of the record as it stands now)."""
+        of the record as it stands now).  ``fetch=False``: the list stays on the device (exchange_candidates), the count
+        is returned."""
         n = C.c_longlong(0)
         self._check(self.lib.sc_rank_candidates(self._h, None, 0, C.byref(n)), "sc_rank_candidates")
+        if not fetch:
+            return n.value
         out = np.empty((n.value, 2), dtype=np.uint32)
         if n.value:
             m = C.c_longlong(0)
@@ -492,13 +496,26 @@ class Context(object):
                 raise ScarpletHipError("sc_rank_candidates: %d pairs, then %d" % (n.value, m.value))
         return out
 
+    def exchange_candidates(self):
+        """All ranks' candidate lists as one list on every device (sc_exchange_candidates: two all-gathers over RCCL);
+        returns its length in pairs, padding included - what settle_pairs(templates, None, ...) then settles."""
+        n = C.c_longlong(0)
+        self._check(self.lib.sc_exchange_candidates(self._h, C.byref(n)), "sc_exchange_candidates")
+        self._exchanged = n.value
+        return n.value
+
     def settle_pairs(self, templates, pairs, n_twin=0, max_work=0.0):
         """Settle the union of all ranks' candidates with the descriptors of the WHOLE search (sc_settle_pairs); the
-        counters as settle_exact returns them."""
-        pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        counters as settle_exact returns them.  ``pairs``: an (n, 2) uint32 array, or None for the list
+        exchange_candidates left on the device."""
         st = (C.c_longlong * 8)()
-        self._check(self.lib.sc_settle_pairs(self._h, templates, len(templates), _as(pairs, _up) if len(pairs) else None,
-                                             len(pairs), int(n_twin), float(max_work), st), "sc_settle_pairs")
+        if pairs is None:
+            ptr, n = None, int(getattr(self, "_exchanged", 0))
+        else:
+            pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+            ptr, n = (_as(pairs, _up) if len(pairs) else None), len(pairs)
+        self._check(self.lib.sc_settle_pairs(self._h, templates, len(templates), ptr, n, int(n_twin), float(max_work), st),
+                    "sc_settle_pairs")
         return self._settle_stats(st)
 
     def comm_destroy(self):

@@ -46,7 +46,7 @@ size_t sc_total_bytes(sc_ctx* c) {
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->norm_part, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
                      &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats, &c->digest, &c->split_s, &c->split_a, &c->split_i,
-                     &c->near, &c->near_ev, &c->score, &c->score_w, &c->score_abc, &c->st_slot, &c->st_work, &c->st_pairs, &c->st_patch, &c->st_spans};
+                     &c->near, &c->near_ev, &c->score, &c->score_w, &c->score_abc, &c->st_slot, &c->st_work, &c->st_pairs, &c->st_patch, &c->st_spans, &c->snap, &c->xch, &c->xch_cnt};
     size_t s = 0;
     for (DevBuf* b : arr) s += b->cap;
     for (auto& w : c->windows) s += (size_t)w.h * w.wd * 5;
@@ -224,7 +224,7 @@ extern "C" void sc_destroy(sc_ctx* c) {
                      &c->map_snr, &c->templ, &c->sums, &c->wl1, &c->norms, &c->norm_part, &c->win_w, &c->win_m,
                      &c->tw_y, &c->tw_x, &c->blk, &c->uc, &c->uc2, &c->vh, &c->wh, &c->mh,
                      &c->yw, &c->ym, &c->tiles, &c->halo_z, &c->halo_stage, &c->res, &c->sib_buf, &c->dwin, &c->spans, &c->res_stats, &c->digest, &c->split_s, &c->split_a, &c->split_i,
-                     &c->near, &c->near_ev, &c->score, &c->score_w, &c->score_abc, &c->st_slot, &c->st_work, &c->st_pairs, &c->st_patch, &c->st_spans};
+                     &c->near, &c->near_ev, &c->score, &c->score_w, &c->score_abc, &c->st_slot, &c->st_work, &c->st_pairs, &c->st_patch, &c->st_spans, &c->snap, &c->xch, &c->xch_cnt};
     for (DevBuf* b : arr) buf_free(*b);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp[k]);
     for (int k = 0; k < 4; ++k) buf_free(c->cmp_in[k]);

@@ -297,3 +297,50 @@ extern "C" int sc_fold_ranks(sc_ctx* ctx) {
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SC_OK;
 }
+
+/*
+ * The ranks' candidate lists of an orientation-sharded exact search (sc_rank_candidates: each left on its device) as one
+ * list on every device.  Two all-gathers over RCCL/xGMI: the counts (one 64-bit word per rank), then slots of the largest
+ * count - in place, every rank's own list already in its slot, the rest of a slot filled with cells no DEM has
+ * (0xFFFFFFFF: sc_settle_pairs leaves them out).  Every rank ends with the same slots in rank order.  Without a
+ * communicator the union is the rank's own list.
+ */
+extern "C" int sc_exchange_candidates(sc_ctx* ctx, long long* n_union) {
+    if (!ctx || !n_union) return SC_ERR_INVALID;
+    *n_union = 0;
+    ctx->xch_n = -1;
+    if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    if (ctx->cand_n < 0) return sc_fail(ctx, SC_ERR_INVALID, "sc_exchange_candidates: no candidate list on the device (sc_rank_candidates)");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    int nr = 1, me = 0;
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    if (comm) {
+        SC_NCCL(ctx, ncclCommCount(comm, &nr));
+        SC_NCCL(ctx, ncclCommUserRank(comm, &me));
+    }
+    const unsigned long long mine = (unsigned long long)ctx->cand_n;
+    std::vector<unsigned long long> counts((size_t)nr, mine);
+    int rc;
+    if (comm) {
+        if ((rc = sc_ensure(ctx, ctx->xch_cnt, 8 * (size_t)(nr + 1)))) return rc;
+        unsigned long long* d_cnt = (unsigned long long*)ctx->xch_cnt.p;
+        SC_HIP(ctx, hipMemcpyAsync(d_cnt + nr, &mine, 8, hipMemcpyHostToDevice, ctx->stream));
+        SC_NCCL(ctx, ncclAllGather(d_cnt + nr, d_cnt, 1, ncclUint64, comm, ctx->stream));
+        SC_HIP(ctx, hipMemcpyAsync(counts.data(), d_cnt, 8 * (size_t)nr, hipMemcpyDeviceToHost, ctx->stream));
+        SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    unsigned long long slot = 0;
+    for (int r = 0; r < nr; ++r) slot = std::max(slot, counts[r]);
+    if (slot == 0) { ctx->xch_n = 0; return SC_OK; }
+    if ((rc = sc_ensure(ctx, ctx->xch, 8 * slot * (size_t)nr))) return rc;
+    uint32_t* all = (uint32_t*)ctx->xch.p;
+    uint32_t* own = all + 2 * slot * (size_t)me;
+    SC_HIP(ctx, hipMemsetAsync(own, 0xFF, 8 * slot, ctx->stream));
+    if (mine)
+        SC_HIP(ctx, hipMemcpyAsync(own, (const char*)ctx->st_pairs.p + 16, 8 * mine, hipMemcpyDeviceToDevice, ctx->stream));
+    if (comm) SC_NCCL(ctx, ncclAllGather(own, all, 2 * slot, ncclUint32, comm, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->xch_n = (long long)(slot * (unsigned long long)nr);
+    *n_union = ctx->xch_n;
+    return SC_OK;
+}

@@ -133,6 +133,9 @@ struct sc_ctx {
     DevBuf st_slot, st_work, st_pairs, st_patch, st_spans;
     DevBuf snap;               // sc_snapshot_best: the record's (snr, id) planes as they stood (before sc_fold_ranks)
     size_t snap_cells = 0;
+    long long cand_n = -1;      // sc_rank_candidates: pairs of the list it left on the device (st_pairs), -1: none
+    DevBuf xch, xch_cnt;        // sc_exchange_candidates: all ranks' lists (slots of equal size, padded with invalid cells), their counts
+    long long xch_n = -1;       // pairs in xch, padding included; -1: nothing exchanged
     size_t patch_n = 0;
     DevBuf score;              // sc_score_cells_f64: the cell list and the two float64 outputs
     DevBuf score_w;            // ... and the templates' float64 windows (offsets, then the windows)

@@ -755,18 +755,22 @@ k_rank_pairs_holders(const float* __restrict__ snap_snr, const uint32_t* __restr
     }
 }
 
-// the exchanged pairs as events the settle reads: (cell, template, no holder, a score nothing drops)
+// the exchanged pairs as events the settle reads: (cell, template, no holder, a score nothing drops).  Appended through the
+// counter (the settle does not depend on the order of its events); the padding of sc_exchange_candidates' slots - cells
+// beyond the core - is left out
 __global__ void __launch_bounds__(256)
 k_pairs_to_events(const uint32_t* __restrict__ pairs, unsigned long long n, size_t nc, uint32_t* __restrict__ ev,
-                  uint8_t* __restrict__ near) {
+                  unsigned long long* __restrict__ ev_count, uint8_t* __restrict__ near) {
     const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
     const uint32_t cell = pairs[2 * k];
-    ev[SC_EVENT_WORDS * k] = cell;
-    ev[SC_EVENT_WORDS * k + 1] = pairs[2 * k + 1];
-    ev[SC_EVENT_WORDS * k + 2] = SC_ID_NONE;
-    ev[SC_EVENT_WORDS * k + 3] = 0x7F800000u;                               // +inf
-    if (cell < nc) near[cell] = (uint8_t)1;
+    if (cell >= nc) return;
+    const unsigned long long slot = atomicAdd(ev_count, 1ull);
+    ev[SC_EVENT_WORDS * slot] = cell;
+    ev[SC_EVENT_WORDS * slot + 1] = pairs[2 * k + 1];
+    ev[SC_EVENT_WORDS * slot + 2] = SC_ID_NONE;
+    ev[SC_EVENT_WORDS * slot + 3] = 0x7F800000u;                            // +inf
+    near[cell] = (uint8_t)1;
 }
 
 }  // namespace
@@ -828,7 +832,9 @@ extern "C" int sc_rank_candidates(sc_ctx* ctx, uint32_t* pairs, long long capaci
     SC_HIP(ctx, hipMemcpyAsync(&n, count, 8, hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *n_pairs = (long long)n;
+    ctx->cand_n = -1;
     if (n > cap) return sc_fail(ctx, SC_ERR_INVALID, "sc_rank_candidates: %llu pairs", n);
+    ctx->cand_n = (long long)n;
     if ((unsigned long long)capacity >= n && n)
         SC_HIP(ctx, hipMemcpy(pairs, out, 8 * n, hipMemcpyDeviceToHost));
     return SC_OK;
@@ -836,8 +842,11 @@ extern "C" int sc_rank_candidates(sc_ctx* ctx, uint32_t* pairs, long long capaci
 
 extern "C" int sc_settle_pairs(sc_ctx* ctx, const sc_template* t, int n, const uint32_t* pairs, long long n_pairs, int n_twin,
                                double max_work, long long* stats_out) {
-    if (!ctx || !t || n <= 0 || n_pairs < 0 || (n_pairs > 0 && !pairs) || n_twin < 0 || !stats_out) return SC_ERR_INVALID;
+    if (!ctx || !t || n <= 0 || n_pairs < 0 || n_twin < 0 || !stats_out) return SC_ERR_INVALID;
     if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
+    const bool from_device = pairs == nullptr && n_pairs > 0;             // what sc_exchange_candidates left on the device
+    if (from_device && n_pairs != ctx->xch_n)
+        return sc_fail(ctx, SC_ERR_INVALID, "sc_settle_pairs: %lld pairs without a host list, %lld exchanged", n_pairs, ctx->xch_n);
     SC_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
     if ((rc = sc_load_templates(ctx, t, n))) return rc;                    // the WHOLE search's descriptors: the scorer's table
@@ -850,16 +859,20 @@ extern "C" int sc_settle_pairs(sc_ctx* ctx, const sc_template* t, int n, const u
     ctx->near_w_used = w_used;                                            // (the window the ranks searched with, not the option as it stands now)
     if ((unsigned long long)n_pairs > ev_cap) return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_settle_pairs: %lld pairs, room for %llu", n_pairs, ev_cap);
     SC_HIP(ctx, hipMemsetAsync(ctx->near.p, 0, nc, ctx->stream));
+    SC_HIP(ctx, hipMemsetAsync(ev_count, 0, 16, ctx->stream));
     const unsigned long long np = (unsigned long long)n_pairs;
-    SC_HIP(ctx, hipMemcpyAsync(ev_count, &np, 8, hipMemcpyHostToDevice, ctx->stream));
     if (np) {
-        if ((rc = sc_ensure(ctx, ctx->st_pairs, 16 + 8 * np))) return rc;
-        uint32_t* d_pairs = (uint32_t*)((char*)ctx->st_pairs.p + 16);
-        SC_HIP(ctx, hipMemcpyAsync(d_pairs, pairs, 8 * np, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_pairs_to_events, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_pairs, np, nc,
-                           ev, (uint8_t*)ctx->near.p);
+        const uint32_t* d_pairs = (const uint32_t*)ctx->xch.p;
+        if (!from_device) {
+            if ((rc = sc_ensure(ctx, ctx->st_pairs, 16 + 8 * np))) return rc;
+            d_pairs = (const uint32_t*)((char*)ctx->st_pairs.p + 16);
+            ctx->cand_n = -1;                                             // (the rank's own list lived there)
+            SC_HIP(ctx, hipMemcpyAsync((void*)d_pairs, pairs, 8 * np, hipMemcpyHostToDevice, ctx->stream));
+        }
+        hipLaunchKernelGGL(k_pairs_to_events, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, d_pairs, np, nc, ev, ev_count,
+                           (uint8_t*)ctx->near.p);
         SC_HIP(ctx, hipGetLastError());
     }
-    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));                        // (np is a local; st_pairs is taken again by the settle)
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));                        // (st_pairs is taken again by the settle)
     return settle_impl(ctx, n_twin, max_work, stats_out);
 }

@@ -515,14 +515,14 @@ class OrientationMatcher(object):
         every rank matches with the near-tie window on and keeps its own record's (snr, id) (sc_snapshot_best); after
         the fold it lists what it knows to lie within the window of the FOLDED record - the templates of its events and
         its own holder (sc_rank_candidates: a near-tie between templates of two ranks is in no rank's event list, but
-        each rank knows its side of it); the lists travel through the transport (a few megabytes: rank order, so every
-        rank holds the same union) and every rank scores the union in float64 with the descriptors of the whole grid
+        each rank knows its side of it); the lists travel between the devices (sc_exchange_candidates: two all-gathers over
+        RCCL) or, host backend, through the transport (a few megabytes; rank order, so every rank holds the same union) and every rank scores the union in float64 with the descriptors of the whole grid
         (sc_settle_pairs).  Same pairs, same arithmetic: the records agree bit for bit on every rank without a further
         collective, and carry the reference's float64 argmax (compare(), core.py:230-240)."""
         import time
         ctx = self.m.ctx
         exact = exact_window > 0.0
-        if exact and self.nranks > 1 and self.transport is None:
+        if exact and self.nranks > 1 and self.backend == "host" and self.transport is None:
             raise ValueError("exact mode over %d ranks needs transport= (the ranks exchange their candidate lists)" % self.nranks)
         ctx.reset_best()
         if exact:
@@ -554,8 +554,14 @@ class OrientationMatcher(object):
             self._folded = fold_host(parts) if self.rank == 0 else None
         self.exact_stats = None
         if exact:
-            pairs = ctx.rank_candidates() if mine is not None else np.empty((0, 2), np.uint32)
-            if self.nranks > 1:
+            if self.backend == "rccl":
+                # on the devices: the list stays where sc_rank_candidates wrote it, two all-gathers make it every rank's
+                ctx.rank_candidates(fetch=False)
+                ctx.exchange_candidates()
+                pairs = None
+            else:
+                pairs = ctx.rank_candidates()            # (a rank without templates: no events, nothing held - empty)
+            if self.nranks > 1 and pairs is not None:
                 parts = self.transport.gather(pairs, 0)
                 blob = self.transport.broadcast_bytes(np.concatenate(parts).tobytes() if self.rank == 0 else None)
                 pairs = np.frombuffer(blob, np.uint32).reshape(-1, 2)
@@ -568,7 +574,7 @@ class OrientationMatcher(object):
 
     def search(self, Template, scale, params, angles, method="auto", group=None, exact=None, **kwargs):
         """``exact`` (default: on for the built-in template classes wherever the ranks can exchange their candidate
-        lists - one rank, or a transport): the float64 argmax of the whole search, as ``scarplet_amd.match`` delivers."""
+        lists - one rank, RCCL, or a transport): the float64 argmax of the whole search, as ``scarplet_amd.match`` delivers."""
         if getattr(self.m, "nan_dem", False):      # the reference's all-NaN maps, on every rank
             self.m.search(Template, scale, params, angles, method=method, **kwargs)
             self._nan = True
@@ -577,7 +583,8 @@ class OrientationMatcher(object):
         mine, sp = self.describe(Template, scale, params, angles, method, group, **kwargs)
         arr = self._keep
         if exact is None:
-            exact = all(int(arr[k].kind) != 2 for k in (0, len(arr) - 1)) and (self.nranks == 1 or self.transport is not None)
+            exact = all(int(arr[k].kind) != 2 for k in (0, len(arr) - 1)) and \
+                (self.nranks == 1 or self.backend == "rccl" or self.transport is not None)
         self.run(mine, sp, self.m.exact_window_for(arr, sp) if exact else 0.0,
                  self.m.end_twins(arr, len(self.m.params), self.m.angles))
         return self

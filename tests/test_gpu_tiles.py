@@ -324,3 +324,44 @@ def test_exact_orientation_sharding_equals_the_single_context(nranks, method):
         assert (np.abs(arr0[0] - want[0])[same] <= a_tol[same]).all()
         assert (np.abs(np.abs(arr0[0]) - np.abs(want[0])) <= a_tol).all()
     assert teeth >= 20, teeth
+
+
+@pytest.mark.parametrize("with_comm", [False, True])
+def test_exact_orientation_exchange_on_the_device(with_comm):
+    """The RCCL form of the exchange on the hardware there is: the candidate list stays on the device, sc_exchange_candidates
+    all-gathers the counts and the padded slots (a one-rank communicator runs both ncclAllGather; without one the union is
+    the rank's own list) and sc_settle_pairs settles the device list - the same record, bit for bit, as the host form of
+    the exchange (ctx.rank_candidates() handed back to sc_settle_pairs) and the same (age, orientation) as
+    sc_settle_exact."""
+    g = synthetic.synthetic_scarp(230, seed=4, ny=200)
+    grid = _plan.angle_grid(-np.pi / 2, np.pi / 2)
+    base = grid[:-1:23]
+    angles = np.concatenate([base, base[1:] + 2e-5, grid[-1:]])
+    params = [1.0, 4.0, 4.0004, 20.0]
+    ctx = _lib.Context(0)
+    om = sd.OrientationMatcher(0, 1, None, matcher=sl.Matcher(g, ctx=ctx))          # backend "rccl"
+    if with_comm:
+        ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+    om.search(sl.Scarp, 14, params, angles, method="fft")
+    st = dict(om.exact_stats)
+    rec = [a.copy() for a in ctx.get_best()]
+    arr = np.array(om.result_array())
+    assert st["changed_cells"] > 20 and st["route"].startswith("device"), st
+    # the host form of the exchange on the same context
+    mine, sp = om.describe(sl.Scarp, 14, params, angles, method="fft")
+    ctx.reset_best()
+    ctx.set_option("near_window", om.m.exact_window_for(om._keep, sp))
+    ctx.match(mine, sp)
+    ctx.set_option("near_window", 0.0)
+    ctx.snapshot_best()
+    ctx.fold_ranks()
+    pairs = ctx.rank_candidates()
+    assert len(pairs) == ctx.rank_candidates(fetch=False) > 0
+    st2 = ctx.settle_pairs(om._keep, pairs, om.m.end_twins(om._keep, len(params), angles), om.m.EXACT_MAX_F64)
+    assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(rec, ctx.get_best()))
+    assert {k: v for k, v in st.items() if k != "route"} == st2
+    # and one context's own settle
+    want = np.stack(sl.Matcher(g, ctx=ctx).search(sl.Scarp, 14, params, angles, method="fft", exact=True).result())
+    assert np.array_equal(arr[1], want[1]) and np.array_equal(_fold_twin(arr[2]), _fold_twin(want[2]))
+    if with_comm:
+        ctx.comm_destroy()
