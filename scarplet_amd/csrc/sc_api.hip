@@ -733,7 +733,7 @@ static int match_impl(sc_ctx* ctx, const sc_template* t, int n, const sc_plan* p
                     d.mask_lim != nullptr || d.mask_err != nullptr;
             ++j;
         }
-        // real-space path: does some template of the run have window rows of 16 taps or more along x
+        // real-space path: does some template of the run have window rows of 16 taps or more along x (SC_DR_SHARE_MIN)
         // (about min(2c / |cos a|, 2d / |sin a|) cells for the built-in rectangles; a window uploaded
         // by the host: unknown, taken as long)?  Decides the kernel form of the run's launch
         // (launch_direct) - per RUN, so that a template's sums do not depend on what it is batched with

@@ -555,6 +555,10 @@ k_direct(const float* __restrict__ curv, Geom g,
 #define SC_DR_VMEMW 1      // the real-space kernel's weights through vector loads (0: scalar loads, rounds 3 - 4a)
 #endif
 #define DR2_WAVES 8
+#ifndef SC_DR_SHARE_MIN
+#define SC_DR_SHARE_MIN 16    // shortest hole-free run (taps) whose T3 takes the shared form (8, the least the end-cell pieces allow, is slower:
+                              // 0.26 against 0.19 ms at 46 taps, 0.56 against 0.50 at 294 - profiles/r06_crossover.txt)
+#endif
 
 // grid = (ceil(wh_max / 4), n_templates), block = 256: one wave per window row.
 // spans[row] = (first group, groups, s, e): taps s .. e of the span (counted from its first group's
@@ -594,8 +598,10 @@ k_direct_prep(const TemplDev* __restrict__ templ, int first, const float* __rest
     }
 }
 
-template <int NB, int RW, bool SHARE>
-__global__ void __launch_bounds__(64 * DR2_WAVES, 2)
+// (W4: built for four waves per SIMD, 128 registers - with a slab of half the LDS two workgroups share a CU, launch_direct;
+//  the shared form then keeps 16 dwords in scratch and is still the faster one on windows that small)
+template <int NB, int RW, bool SHARE, bool W4 = false>
+__global__ void __launch_bounds__(64 * DR2_WAVES, W4 ? 4 : 2)
 k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
           const TemplDev* __restrict__ templ, int first, int n_per, int nb,
           const float2* __restrict__ dwin, const int4* __restrict__ spans,
@@ -604,7 +610,7 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
           float* __restrict__ best_amp, uint32_t* __restrict__ best_id,
           float* __restrict__ map_amp, float* __restrict__ map_snr,
           float near_w, uint8_t* __restrict__ near, unsigned long long* __restrict__ ev_count,
-          uint32_t* __restrict__ ev, unsigned long long ev_cap) {
+          uint32_t* __restrict__ ev, unsigned long long ev_cap, int lds_floats) {
     // near_w > 0 (the host layer's exact mode): a byte per core cell, set where a template scored within near_w
     // (relative) of the cell's running best, equal scores included - the cells whose argmax is decided inside THIS path's
     // own float32 error - and an event (cell, template scored, holder of the record) per near-tie, as the FFT row pass
@@ -661,7 +667,7 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
         // slab column x + b'), rows for template rows [a0, a0 + na): output row r, template
         // row a reads slab row r + (na - 1 - a)
         const int lwp = TXW + P;                                  // a multiple of 4
-        int na_max = DR2_LDS_FLOATS / lwp - (TY - 1);
+        int na_max = lds_floats / lwp - (TY - 1);            // (lds_floats: the slab this launch was given, launch_direct)
         na_max = max(1, min(na_max, wh));
         const int gj_left = j0 - qmax + g.ox;
         for (int a0 = 0; a0 < wh; a0 += na_max) {
@@ -750,8 +756,10 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                 // instead of 16 weighted FMAs), the 3 - 6 cells at either end are read again after the
                 // groups and added to the outputs they belong to - the same addends, no per-cell masks.
                 // Rows with holes (Scarp's xr = 0 column at -pi/2, 0, pi/2; generic windows) and runs
-                // shorter than 16 taps keep the weighted form.
-                const bool shared = SHARE && sp.w >= 0 && sp.w - sp.z >= 15;
+                // shorter than SC_DR_SHARE_MIN taps keep the weighted form.  (From 8 taps on the pieces below tile the run: cells
+                // s .. s + 2 and e + 1 .. e + 3 per output, [s + 3, 4 jlo) and [4 (jhi + 1), e] - at most three cells each - one
+                // by one into the common sum, whole chunks jlo .. jhi in between; below 8 the two short pieces could overlap.)
+                const bool shared = SHARE && sp.w >= 0 && sp.w - sp.z >= SC_DR_SHARE_MIN - 1;
                 if (!shared) {
 #if SC_DR_VMEMW
                   // (the group's four (w, m) pairs through the vector memory path, one group ahead: see the shared form.  While the
@@ -889,7 +897,7 @@ k_direct2(const float* __restrict__ curv0, size_t curv_stride, Geom g,
                         }
                     }
                     // the next row's first loads, under this row's end cells
-                    if (a + 1 < na && sp_next.y > 0 && sp_next.w >= 0 && sp_next.w - sp_next.z >= 15) {
+                    if (a + 1 < na && sp_next.y > 0 && sp_next.w >= 0 && sp_next.w - sp_next.z >= SC_DR_SHARE_MIN - 1) {
                         const float* wvn = reinterpret_cast<const float*>(dw + (size_t)(a0 + a + 1) * P + 4 * sp_next.x) + zlane;
                         pwl = *reinterpret_cast<const f4*>(wvn);
                         pwh = *reinterpret_cast<const f4*>(wvn + 4);
@@ -1377,16 +1385,18 @@ int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_ma
         if (rc) return rc;
     }
     // patch: 512 x 16 cells where that still gives every CU a workgroup, else 256 x 16, else 256 x 8
-    const size_t lds = (size_t)DR2_LDS_FLOATS * sizeof(float);
+    // The slab: all of the LDS (one workgroup per CU) unless the patch selection below gives the launch a smaller one.  Its
+    // size decides only how many template rows are staged at a time, not the order of any sum.
+    size_t lds = (size_t)DR2_LDS_FLOATS * sizeof(float);
     const size_t plane = (size_t)g.ly * g.lx;
     auto wgs = [&](int txw, int ty) { return (long long)((cw + txw - 1) / txw) * ((ch + ty - 1) / ty); };
-#define DR2_LAUNCH(NBV, RWV, SHV)                                                                       \
+#define DR2_LAUNCH(NBV, RWV, SHV, ...)                                                                     \
     {                                                                                              \
-        int rc = sc_lds_attr(ctx, (const void*)k_direct2<NBV, RWV, SHV>, lds);                   \
+        int rc = sc_lds_attr(ctx, (const void*)k_direct2<NBV, RWV, SHV __VA_OPT__(,) __VA_ARGS__>, lds);                   \
         if (rc) return rc;                                                                         \
         dim3 grid((cw + 256 * NBV - 1) / (256 * NBV), (ch + 8 * RWV - 1) / (8 * RWV));            \
         sc_prof_begin(ctx, SC_K_DIRECT);                                                           \
-        hipLaunchKernelGGL((k_direct2<NBV, RWV, SHV>), grid, dim3(64 * DR2_WAVES), lds, ctx->stream, \
+        hipLaunchKernelGGL((k_direct2<NBV, RWV, SHV __VA_OPT__(,) __VA_ARGS__>), grid, dim3(64 * DR2_WAVES), lds, ctx->stream, \
                            (const float*)ctx->curv.p, plane, g, (const TemplDev*)ctx->templ.p, first, n, nb, \
                            (const float2*)ctx->dwin.p, (const int4*)ctx->spans.p,                  \
                            (const double*)ctx->sums.p, (const double*)ctx->xaxis.p,                \
@@ -1394,7 +1404,8 @@ int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_ma
                            (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p,                     \
                            to_maps ? (float*)ctx->map_amp.p : nullptr,                             \
                            to_maps ? (float*)ctx->map_snr.p : nullptr,                             \
-                           near_on ? ctx->near_w : 0.f, near_on ? (uint8_t*)ctx->near.p : nullptr, ev_count, ev, ev_cap); \
+                           near_on ? ctx->near_w : 0.f, near_on ? (uint8_t*)ctx->near.p : nullptr, ev_count, ev, ev_cap, \
+                           (int)(lds / sizeof(float)));                                            \
         sc_prof_end(ctx);                                                                          \
     }
     // (variant 11: T3 in the weighted form on every row; long_runs: some template of the launch has
@@ -1403,7 +1414,16 @@ int launch_direct(sc_ctx* ctx, int first, int n, bool to_maps, int nb, int wh_ma
     const bool share = ctx->variant != 11 && long_runs;
     // (the 512-wide patch needs a slab of 512 + the padded window width cells x 16 rows)
     const bool fits512 = (long long)(512 + ((ww_max + 3) & ~3)) * 16 <= DR2_LDS_FLOATS;
-    if (fits512 && wgs(512, 16) >= 512 && ctx->variant != 16) { if (share) DR2_LAUNCH(2, 2, true) else DR2_LAUNCH(2, 2, false) }
+    // (round 6) windows whose 256 x 16 slab fits half the LDS in one piece - up to about a thousand taps - take that patch
+    // with a slab of their own size: 128 registers and half the LDS are two workgroups per CU, four waves per SIMD, and the
+    // kernel is bound by instruction issue there (-4 .. -25 % against the 512 x 16 patch at two waves per SIMD,
+    // profiles/r06_crossover.txt; option "variant" 19: the whole LDS as before)
+    const long long need256 = (long long)(256 + ((ww_max + 3) & ~3)) * (16 + wh_max - 1);
+    const bool two_wg = need256 <= DR2_LDS_FLOATS / 2 - 256 && wgs(256, 16) >= 256 && ctx->variant != 19;
+    if (two_wg) {
+        lds = (size_t)need256 * sizeof(float);
+        if (share) DR2_LAUNCH(1, 2, true, true) else DR2_LAUNCH(1, 2, false, true)
+    } else if (fits512 && wgs(512, 16) >= 512 && ctx->variant != 16) { if (share) DR2_LAUNCH(2, 2, true) else DR2_LAUNCH(2, 2, false) }
     else if (wgs(256, 16) >= 256) { if (share) DR2_LAUNCH(1, 2, true) else DR2_LAUNCH(1, 2, false) }
     else { if (share) DR2_LAUNCH(1, 1, true) else DR2_LAUNCH(1, 1, false) }
 #undef DR2_LAUNCH

@@ -39,8 +39,13 @@ def kernel_table(src, extra=()):
 def test_real_space_kernel_has_no_scratch():
     t = kernel_table("sc_kernels.hip", ("-fno-slp-vectorize",))
     forms = {k: v for k, v in t.items() if k.startswith("k_direct2<")}
-    assert len(forms) == 6, sorted(forms)
+    assert len(forms) == 8, sorted(forms)
     for name, r in forms.items():
+        if name.endswith(", true>") and name.count(",") == 3:
+            # round 6, windows below about a thousand taps: the 256 x 16 patch built for FOUR waves per SIMD (two workgroups
+            # per CU with a slab of half the LDS); its shared-T3 form keeps 16 dwords in scratch and is still the faster one
+            assert r["vgpr"] <= 128 and r["scratch"] <= 64, (name, r)
+            continue
         assert r["scratch"] == 0, (name, r)
         assert r["vgpr"] <= 256, (name, r)          # two waves per SIMD
 

@@ -14,7 +14,8 @@ if len(sys.argv) > 2:                                   # engine option "variant
     m.ctx.set_option("variant", float(sys.argv[2]))
 angs = _plan.angle_grid()[[30, 90, 150]]
 print("DEM %dx%d; per row: scale, age, taps(n), direct ms/template, fft ms/template, plan" % (n, n))
-for scale in (5, 10, 20, 50, 100):
+SCALES = tuple(int(x) for x in os.environ.get("CROSSOVER_SCALES", "5,10,20,50,100").split(","))
+for scale in SCALES:
     for age in (1.0, 10.0, 100.0, 1000.0):
         row = []
         nn_last = 0
