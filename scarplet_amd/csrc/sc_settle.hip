@@ -283,7 +283,11 @@ __device__ __forceinline__ int wrap1(int x, int n) { return x < 0 ? x + n : (x >
 // One WAVE per list entry (four entries per workgroup: the windows that meet in near-ties are thin - 1 700 taps on average
 // on the C3 search - and a workgroup per pair spent its time starting up and reducing); an entry whose template (or its
 // end twin) the list holds a second time, or whose list names one template only, is marked (snr = -1) and not scored.
-__global__ void __launch_bounds__(256)
+// WPP > 1 (few pairs - a five-scale Channel search settles 350 pairs of 28 000 taps at a time, a wave each took 350 us):
+// WPP waves per entry, a workgroup each; wave w takes every WPP-th row group, the partial sums meet in LDS and are added in
+// wave order.  Which form runs depends on the number of pairs alone: the same bits from run to run.
+template <int WPP>
+__global__ void __launch_bounds__(WPP == 1 ? 256 : 64 * WPP)
 k_st_score(const double* __restrict__ pa, const double* __restrict__ pb, const double* __restrict__ pc, Geom g,
            const TemplDev* __restrict__ templ, const double* __restrict__ sums,
            const double* __restrict__ xaxis, const double* __restrict__ yaxis,
@@ -296,7 +300,9 @@ k_st_score(const double* __restrict__ pa, const double* __restrict__ pb, const d
     // list in order, so that the waves that share an L2 work on neighbouring cells
     const unsigned nb8 = (gridDim.x + 7) / 8;
     const unsigned lb = (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3);
-    const unsigned pos = __builtin_amdgcn_readfirstlane(lb * 4 + (threadIdx.x >> 6));            // (wave-uniform: scalar loads below)
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned pos = WPP == 1 ? lb * 4 + wv : lb;                                            // (wave-uniform: scalar loads below)
+    const int wsel = WPP == 1 ? 0 : wv;                                                           // this wave's share of the rows
     const int lane = threadIdx.x & 63;
     if (pos >= n_pairs) return;
     const uint32_t slot = pair_slot[pos];
@@ -350,7 +356,7 @@ k_st_score(const double* __restrict__ pa, const double* __restrict__ pb, const d
         while ((1 << ls) < ml) ++ls;
         const int R = 64 >> ls, bl = lane & ((1 << ls) - 1);
         constexpr int ROWS = 4;
-        for (int a0 = lane >> ls; a0 < t.wh; a0 += ROWS * R) {
+        for (int a0 = (lane >> ls) + wsel * ROWS * R; a0 < t.wh; a0 += WPP * ROWS * R) {
             int2 sp[ROWS];
             size_t orow[ROWS];
             bool v[ROWS];
@@ -389,7 +395,7 @@ k_st_score(const double* __restrict__ pa, const double* __restrict__ pb, const d
         // in flight (a wide window - a Ricker's support, an old scarp's - is tens of thousands of taps for one wave: row
         // after row with a load chain each it took a third of a millisecond a pair)
         constexpr int ROWS = 4, CH = 2;
-        for (int a0 = 0; a0 < t.wh; a0 += ROWS) {
+        for (int a0 = wsel * ROWS; a0 < t.wh; a0 += WPP * ROWS) {
             int2 sp[ROWS];
             size_t orow[ROWS];
             bool rv[ROWS];
@@ -437,6 +443,14 @@ k_st_score(const double* __restrict__ pa, const double* __restrict__ pb, const d
     for (int sft = 32; sft > 0; sft >>= 1) {
         xc += __shfl_down(xc, sft, 64);
         t3 += __shfl_down(t3, sft, 64);
+    }
+    if constexpr (WPP > 1) {
+        __shared__ double part[2 * WPP];
+        if (lane == 0) { part[2 * wv] = xc; part[2 * wv + 1] = t3; }
+        __syncthreads();
+        if (wv != 0) return;
+        xc = part[0]; t3 = part[1];
+        for (int k = 1; k < WPP; ++k) { xc += part[2 * k]; t3 += part[2 * k + 1]; }
     }
     if (lane == 0) {
         const double n = sums[2 * it] + SC_EPS, ts = sums[2 * it + 1];
@@ -691,11 +705,17 @@ static int settle_impl(sc_ctx* ctx, int n_twin, double max_work, long long* stat
     hipLaunchKernelGGL(k_st_spans, dim3((wh_max + 3) / 4, n), dim3(256), 0, ctx->stream, (const TemplDev*)ctx->templ.p, woff, wbuf,
                        (const unsigned*)soff, (int2*)ctx->st_spans.p, maxlen);
     // (a multiple of eight workgroups: the kernel deals the pair list out over the XCDs in eighths)
-    hipLaunchKernelGGL(k_st_score, dim3((unsigned)(((np + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, ctx->stream, pa, pa + npl, pa + 2 * npl, g,
-                       (const TemplDev*)ctx->templ.p, (const double*)sums64, (const double*)ctx->xaxis.p,
-                       (const double*)ctx->yaxis.p, woff, wbuf, (const unsigned*)soff, (const int2*)ctx->st_spans.p,
-                       (const int*)maxlen, (const unsigned*)off, (const int32_t*)pair_t,
-                       (const uint32_t*)pair_slot, (const uint32_t*)cell_of, map, (unsigned)np, pair_amp, pair_snr);
+#define ST_SCORE(WPPV, BLOCKS, THREADS)                                                                                       \
+    hipLaunchKernelGGL(k_st_score<WPPV>, dim3((unsigned)(((BLOCKS) + 7) / 8 * 8)), dim3(THREADS), 0, ctx->stream, pa, pa + npl, \
+                       pa + 2 * npl, g, (const TemplDev*)ctx->templ.p, (const double*)sums64, (const double*)ctx->xaxis.p,      \
+                       (const double*)ctx->yaxis.p, woff, wbuf, (const unsigned*)soff, (const int2*)ctx->st_spans.p,            \
+                       (const int*)maxlen, (const unsigned*)off, (const int32_t*)pair_t,                                        \
+                       (const uint32_t*)pair_slot, (const uint32_t*)cell_of, map, (unsigned)np, pair_amp, pair_snr)
+    // a wave per pair fills the chip from a few thousand pairs on; shorter lists spread every pair over 4 or 16 waves
+    if (np < 4096 && ctx->variant != 20) ST_SCORE(16, np, 1024);
+    else if (np < 32768 && ctx->variant != 20) ST_SCORE(4, np, 256);
+    else ST_SCORE(1, (np + 3) / 4, 256);
+#undef ST_SCORE
     hipLaunchKernelGGL(k_st_resolve, dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, ns, (const unsigned*)off, (const int32_t*)pair_t,
                        (const double*)pair_amp, (const double*)pair_snr, (const uint32_t*)cell_of, (const TemplDev*)ctx->templ.p,
                        (const double*)sums64, (float*)ctx->best_snr.p, (float*)ctx->best_amp.p, (uint32_t*)ctx->best_id.p, p_amp, p_snr, p_id, stats);
