@@ -412,8 +412,9 @@ int sc_settle_pairs(sc_ctx* ctx, const sc_template* t, int n, const uint32_t* pa
 /* the exchange on the devices: after sc_rank_candidates (capacity 0 will do: the list stays on the device) every rank's
  * list becomes one list on every device - two ncclAllGather over RCCL/xGMI: the counts, then slots of the largest count in
  * rank order, short lists padded with cells no DEM has.  *n_union = pairs in it, padding included; sc_settle_pairs with
- * pairs == NULL and n_pairs == *n_union settles it.  Collective: all ranks of the communicator call it.  No communicator:
- * the union is the rank's own list. */
+ * pairs == NULL and n_pairs == *n_union settles it.  Collective: all ranks of the communicator call it - a rank whose
+ * sc_rank_candidates failed (an overflowed event list) too: it takes part in the counts' all-gather with a marker and every rank
+ * returns SC_ERR_UNSUPPORTED, none is left waiting.  No communicator: the union is the rank's own list. */
 int sc_exchange_candidates(sc_ctx* ctx, long long* n_union);
 
 /* Per-template scalars of the last sc_match / sc_match_template call:

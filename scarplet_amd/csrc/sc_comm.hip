@@ -310,7 +310,10 @@ extern "C" int sc_exchange_candidates(sc_ctx* ctx, long long* n_union) {
     *n_union = 0;
     ctx->xch_n = -1;
     if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
-    if (ctx->cand_n < 0) return sc_fail(ctx, SC_ERR_INVALID, "sc_exchange_candidates: no candidate list on the device (sc_rank_candidates)");
+    // (a rank whose sc_rank_candidates failed - its event list overflowed - still takes part in the counts' all-gather, with a
+    //  count no list can have: every rank then returns the same error instead of one rank leaving the others in a collective)
+    const bool mine_bad = ctx->cand_n < 0;
+    if (mine_bad && !ctx->comm) return sc_fail(ctx, SC_ERR_INVALID, "sc_exchange_candidates: no candidate list on the device (sc_rank_candidates)");
     SC_HIP(ctx, hipSetDevice(ctx->device));
     int nr = 1, me = 0;
     ncclComm_t comm = (ncclComm_t)ctx->comm;
@@ -318,7 +321,7 @@ extern "C" int sc_exchange_candidates(sc_ctx* ctx, long long* n_union) {
         SC_NCCL(ctx, ncclCommCount(comm, &nr));
         SC_NCCL(ctx, ncclCommUserRank(comm, &me));
     }
-    const unsigned long long mine = (unsigned long long)ctx->cand_n;
+    const unsigned long long mine = mine_bad ? ~0ull : (unsigned long long)ctx->cand_n;
     std::vector<unsigned long long> counts((size_t)nr, mine);
     int rc;
     if (comm) {
@@ -330,7 +333,11 @@ extern "C" int sc_exchange_candidates(sc_ctx* ctx, long long* n_union) {
         SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     unsigned long long slot = 0;
-    for (int r = 0; r < nr; ++r) slot = std::max(slot, counts[r]);
+    for (int r = 0; r < nr; ++r) {
+        if (counts[r] == ~0ull)
+            return sc_fail(ctx, SC_ERR_UNSUPPORTED, "sc_exchange_candidates: rank %d has no candidate list (its event list overflowed)", r);
+        slot = std::max(slot, counts[r]);
+    }
     if (slot == 0) { ctx->xch_n = 0; return SC_OK; }
     if ((rc = sc_ensure(ctx, ctx->xch, 8 * slot * (size_t)nr))) return rc;
     uint32_t* all = (uint32_t*)ctx->xch.p;

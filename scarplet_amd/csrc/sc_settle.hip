@@ -831,6 +831,7 @@ extern "C" int sc_snapshot_best(sc_ctx* ctx) {
 extern "C" int sc_rank_candidates(sc_ctx* ctx, uint32_t* pairs, long long capacity, long long* n_pairs) {
     if (!ctx || !n_pairs || capacity < 0 || (capacity > 0 && !pairs)) return SC_ERR_INVALID;
     *n_pairs = 0;
+    ctx->cand_n = -1;                                                     // (until this call has listed them)
     if (!ctx->have_dem) return sc_fail(ctx, SC_ERR_NO_DEM, "no DEM set");
     SC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nc = (size_t)(ctx->g.cy1 - ctx->g.cy0) * (ctx->g.cx1 - ctx->g.cx0);

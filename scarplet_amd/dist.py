@@ -554,17 +554,37 @@ class OrientationMatcher(object):
             self._folded = fold_host(parts) if self.rank == 0 else None
         self.exact_stats = None
         if exact:
+            # (a rank that cannot list its candidates - an overflowed event list - must not leave the others waiting in the
+            #  exchange: it takes part with a marker, and every rank raises the same error)
+            failed = None
             if self.backend == "rccl":
                 # on the devices: the list stays where sc_rank_candidates wrote it, two all-gathers make it every rank's
-                ctx.rank_candidates(fetch=False)
-                ctx.exchange_candidates()
+                try:
+                    ctx.rank_candidates(fetch=False)
+                except _lib.ScarpletHipError as e:
+                    failed = e
+                ctx.exchange_candidates()                 # (raises on every rank when some rank has no list)
+                if failed is not None:
+                    raise failed
                 pairs = None
             else:
-                pairs = ctx.rank_candidates()            # (a rank without templates: no events, nothing held - empty)
-            if self.nranks > 1 and pairs is not None:
-                parts = self.transport.gather(pairs, 0)
-                blob = self.transport.broadcast_bytes(np.concatenate(parts).tobytes() if self.rank == 0 else None)
-                pairs = np.frombuffer(blob, np.uint32).reshape(-1, 2)
+                try:
+                    pairs = ctx.rank_candidates()        # (a rank without templates: no events, nothing held - empty)
+                except _lib.ScarpletHipError as e:
+                    failed, pairs = e, None
+            if self.nranks > 1 and self.backend != "rccl":
+                parts = self.transport.gather(pairs if failed is None else "failed: %s" % failed, 0)
+                if self.rank == 0:
+                    bad = [p_ for p_ in parts if isinstance(p_, str)]
+                    blob = (b"!" + bad[0].encode()) if bad else (b"=" + np.concatenate(parts).tobytes())
+                else:
+                    blob = None
+                blob = self.transport.broadcast_bytes(blob)
+                if blob[:1] == b"!":
+                    raise _lib.ScarpletHipError("exact mode: a rank could not list its candidates (%s)" % blob[1:].decode())
+                pairs = np.frombuffer(blob, np.uint32, offset=1).reshape(-1, 2)
+            elif failed is not None:
+                raise failed
             self.exact_stats = ctx.settle_pairs(self._keep, pairs, n_twin, self.m.EXACT_MAX_F64)
             self.exact_stats["route"] = "device, %d ranks' candidates" % self.nranks
         # wall time of the fold (and, exact mode, of the candidates' exchange and settle) on this rank, the wait for slower

@@ -318,6 +318,9 @@ class _ExactOracleContext(object):
         self.amp, self.snr, self.idx, self.patch = np.array(amp), np.array(snr), np.array(idx), {}
 
     def rank_candidates(self):
+        if getattr(self, "fail", False):                         # (what an overflowed event list answers)
+            from scarplet_amd import _lib
+            raise _lib.ScarpletHipError("sc_rank_candidates: the event list overflowed")
         keep = 1.0 - self.w_used
         out = []
         for (c, tid, holder, big) in self.events:
@@ -411,6 +414,15 @@ def _exact_orientation_worker(rank, world, port, q):
         # ... and one rank settling the whole search holds the same record as every rank of the sharded one
         om2.run(mine2, sp2, m2.exact_window_for(om2._keep, sp2), 0)
         checks["one rank's settle = the sharded one"] = np.array_equal(m2.ctx.idx, m.ctx.idx)
+        ok = all(checks.values()) or [k_ for k_, v_ in checks.items() if not v_]
+        # a rank that cannot list its candidates must not leave the others waiting in the exchange: every rank raises
+        from scarplet_amd import _lib
+        m.ctx.fail = rank == world - 1
+        try:
+            om.search(sl.Scarp, 6, ages, angles, method="fft")
+            checks["a failed rank fails every rank"] = False
+        except _lib.ScarpletHipError as e:
+            checks["a failed rank fails every rank"] = "overflowed" in str(e)
         ok = all(checks.values()) or [k_ for k_, v_ in checks.items() if not v_]
         if rank == 0:
             print("exact orientation sharding, %d ranks: %s" % (world, st))
